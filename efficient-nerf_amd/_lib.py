@@ -1,0 +1,96 @@
+"""ctypes binding of libr2l_hip.so (include/r2l_hip.h).  Fails loudly when absent."""
+import ctypes as C
+import os
+
+PREC_FP16X3 = 0
+PREC_FP16X1 = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libr2l_hip.so')
+
+
+class R2LError(RuntimeError):
+    pass
+
+
+_f = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/r2l_hip.h declares
+SIGNATURES = {
+    'r2l_last_error': (C.c_char_p, []),
+    'r2l_device_count': (C.c_int, []),
+    'r2l_create': (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_double, C.c_float, C.c_float,
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'r2l_destroy': (None, [_vp]),
+    'r2l_load_weights': (C.c_int, [_vp, C.POINTER(_vp), C.c_int]),
+    'r2l_set_precision': (C.c_int, [_vp, C.c_int]),
+    'r2l_render': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'r2l_render_rays': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    'r2l_sample_embed': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'r2l_embed': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'r2l_flops_per_ray': (C.c_longlong, [_vp]),
+    'r2l_weight_image_bytes': (C.c_longlong, [_vp]),
+    'r2l_rays_per_tile': (C.c_int, [_vp]),
+    'r2l_timing_enable': (C.c_int, [_vp, C.c_int]),
+    'r2l_kernel_time_ms': (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
+    'nerf_create': (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_double, C.c_float, C.c_float,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'nerf_destroy': (None, [_vp]),
+    'nerf_load_weights': (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.c_int]),
+    'nerf_render': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'nerf_render_rays': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'nerf_last_extras': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    'nerf_raw2outputs': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'nerf_sample_pdf': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'nerf_merge_sorted': (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises R2LError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise R2LError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'(or `make -C efficient-nerf_amd/csrc`). There is no CPU fallback.')
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 not found
+            raise R2LError(f'cannot load {LIB_PATH}: {e}') from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise R2LError(f'[{rc}] ' + lib().r2l_last_error().decode('utf-8', 'replace'))
+
+
+def dptr(t):
+    """data_ptr of a contiguous float32 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    import torch
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise R2LError(f'expected a contiguous float32 device tensor, got {t.dtype} on {t.device} '
+                       f'(contiguous={t.is_contiguous()})')
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_ptrs(tensors):
+    """float32 contiguous CPU copies + a (void*)[] over them (keep the first alive)."""
+    import torch
+    keep = [t.detach().to('cpu', torch.float32).contiguous() for t in tensors]
+    arr = (C.c_void_p * len(keep))(*[C.c_void_p(t.data_ptr()) for t in keep])
+    return keep, arr

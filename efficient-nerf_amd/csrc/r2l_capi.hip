@@ -1,0 +1,438 @@
+// C-ABI host side for the R2L student: context, host-side weight re-packing into the
+// MFMA-native chunk stream (r2l_common.h), launches.  Declared in include/r2l_hip.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/r2l_hip.h"
+#include "r2l_common.h"
+#include "r2l_kernels.h"
+#include "r2l_host_util.h"
+
+static thread_local std::string g_err;
+
+const char* r2l_last_error(void) { return g_err.c_str(); }
+
+int r2l_set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int r2l_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int r2l_require_gfx950(int* n_cu) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return r2l_set_error(R2L_ENOGPU, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return r2l_set_error(R2L_ENOGPU, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return r2l_set_error(R2L_ENOGPU, "device %d is %s; this library is built for gfx950 only", dev,
+                             prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    return R2L_OK;
+}
+
+// torch.linspace(0, 1, steps) on CPU for float32 (aten RangeFactories: symmetric fill)
+void r2l_linspace01(int steps, float* out) {
+    volatile float step = (1.0f - 0.0f) / (float)(steps - 1);
+    int halfway = steps / 2;
+    for (int i = 0; i < steps; ++i) {
+        volatile float v;
+        if (i < halfway) {
+            volatile float m = step * (float)i;
+            v = 0.0f + m;
+        } else {
+            volatile float m = step * (float)(steps - i - 1);
+            v = 1.0f - m;
+        }
+        out[i] = v;
+    }
+}
+
+// near * (1 - t) + far * t in float32, one rounding per op (model/nerf_raybased.py:90)
+void r2l_z_vals(int steps, float near_, float far_, float* out) {
+    std::vector<float> t(steps);
+    r2l_linspace01(steps, t.data());
+    for (int i = 0; i < steps; ++i) {
+        volatile float a = 1.0f - t[i];
+        volatile float b = near_ * a;
+        volatile float c = far_ * t[i];
+        volatile float z = b + c;
+        out[i] = z;
+    }
+}
+
+// power-of-two scale that brings max|w| into [2^12, 2^13)
+float r2l_pow2_scale(const float* w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        float a = fabsf(w[i]);
+        if (a > m && isfinite(a)) m = a;
+    }
+    if (m == 0.f) return 1.0f;
+    int e;
+    frexpf(m, &e);  // m = f * 2^e, f in [0.5,1)
+    return ldexpf(1.0f, 13 - e);
+}
+
+void r2l_split_f16(float v, _Float16* hi, _Float16* lo) {
+    _Float16 h = (_Float16)v;
+    *hi = h;
+    if (lo) *lo = (_Float16)(v - (float)h);
+}
+
+struct r2l_ctx {
+    int H, W, n_block, use_residual, mode;
+    double focal;
+    float near_, far_;
+    float z[16];
+    float act_scale;
+    int n_cu;
+    bool loaded;
+    std::vector<std::vector<float>> host_w;  // state_dict order
+    char* d_img[2];                           // [mode] packed image
+    size_t img_bytes[2];
+    float* d_scratch;
+    bool timing;
+    std::vector<hipEvent_t> ev;  // pairs
+    int ev_used;
+};
+
+static int np_of(int mode) { return mode == R2L_PREC_FP16X3 ? 2 : 1; }
+
+int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far_, int n_sample, int L,
+               int width, int n_block, int use_residual, int precision_mode) {
+    if (!out) return r2l_set_error(R2L_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_sample != R2L_NSAMPLE || L != R2L_L || width != R2L_WIDTH)
+        return r2l_set_error(R2L_EINVAL,
+                             "unsupported R2L shape n_sample=%d L=%d width=%d (built for n_sample=16, multires=10, "
+                             "netwidth=256)",
+                             n_sample, L, width);
+    if (H <= 0 || W <= 0 || n_block < 0 || !(focal > 0))
+        return r2l_set_error(R2L_EINVAL, "bad geometry H=%d W=%d focal=%g n_block=%d", H, W, focal, n_block);
+    if (precision_mode != R2L_PREC_FP16X3 && precision_mode != R2L_PREC_FP16X1)
+        return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", precision_mode);
+    int n_cu = 0;
+    int rc = r2l_require_gfx950(&n_cu);
+    if (rc) return rc;
+    r2l_ctx* c = new r2l_ctx();
+    c->H = H;
+    c->W = W;
+    c->focal = focal;
+    c->near_ = near_;
+    c->far_ = far_;
+    c->n_block = n_block;
+    c->use_residual = use_residual ? 1 : 0;
+    c->mode = precision_mode;
+    c->act_scale = 16.0f;
+    c->n_cu = n_cu;
+    c->loaded = false;
+    c->d_img[0] = c->d_img[1] = nullptr;
+    c->img_bytes[0] = c->img_bytes[1] = 0;
+    c->d_scratch = nullptr;
+    c->timing = false;
+    c->ev_used = 0;
+    r2l_z_vals(R2L_NSAMPLE, near_, far_, c->z);
+    size_t scr = (size_t)n_cu * R2L_WAVES * 32 * 256 * sizeof(float);
+    hipError_t e = hipMalloc((void**)&c->d_scratch, scr);
+    if (e != hipSuccess) {
+        delete c;
+        return r2l_set_error(R2L_EHIP, "hipMalloc scratch: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return R2L_OK;
+}
+
+void r2l_destroy(r2l_ctx* c) {
+    if (!c) return;
+    for (int m = 0; m < 2; ++m)
+        if (c->d_img[m]) (void)hipFree(c->d_img[m]);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    for (auto& e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+}
+
+// ---- packing ---------------------------------------------------------------------------
+static void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
+    _Float16 hi, lo;
+    r2l_split_f16(v, &hi, np == 2 ? &lo : nullptr);
+    _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(frag * np + 0) * R2L_FRAG_BYTES + lane * 16);
+    ph[j] = hi;
+    if (np == 2) {
+        _Float16* pl = reinterpret_cast<_Float16*>(chunk + (size_t)(frag * np + 1) * R2L_FRAG_BYTES + lane * 16);
+        pl[j] = lo;
+    }
+}
+
+static int build_image(r2l_ctx* c, int mode) {
+    const int np = np_of(mode);
+    const int CH = r2l_chunk_bytes(np);
+    const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
+    const int cpt = r2l_chunks_per_tile(c->n_block);
+    std::vector<char> img((size_t)cpt * CH, 0);
+    auto aux = [&](int chunk) { return reinterpret_cast<float*>(img.data() + (size_t)chunk * CH + AUX); };
+    const float Sa = c->act_scale;
+    // head
+    {
+        const float* Wh = c->host_w[0].data();
+        const float* bh = c->host_w[1].data();
+        const float Sw = r2l_pow2_scale(Wh, (size_t)R2L_WIDTH * R2L_IN);
+        const float S = Sa * Sw;
+        for (int ch = 0; ch < R2L_HEAD_CHUNKS; ++ch) {
+            char* chunk = img.data() + (size_t)ch * CH;
+            for (int ksl = 0; ksl < 2; ++ksl)
+                for (int t = 0; t < R2L_NTILE; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            int col = r2l_head_col(2 * ch + ksl, lane >> 5, j);
+                            float v = col < 0 ? 0.f : Wh[(size_t)(32 * t + (lane & 31)) * R2L_IN + col] * Sw;
+                            put_frag(chunk, np, ksl * 8 + t, lane, j, v);
+                        }
+        }
+        for (int n = 0; n < R2L_WIDTH; ++n) aux(0)[n] = bh[n] * S;
+        aux(R2L_HEAD_CHUNKS - 1)[32] = 1.0f / S;
+    }
+    // body
+    for (int li = 0; li < 2 * c->n_block; ++li) {
+        const float* Wl = c->host_w[2 + 2 * li].data();
+        const float* bl = c->host_w[3 + 2 * li].data();
+        const float Sw = r2l_pow2_scale(Wl, (size_t)R2L_WIDTH * R2L_WIDTH);
+        const float S = Sa * Sw;
+        for (int t = 0; t < R2L_NTILE; ++t) {
+            const int ci = R2L_HEAD_CHUNKS + li * R2L_NTILE + t;
+            char* chunk = img.data() + (size_t)ci * CH;
+            for (int ks = 0; ks < R2L_KSTEPS; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        int k = r2l_kappa(ks, lane >> 5, j);
+                        put_frag(chunk, np, ks, lane, j, Wl[(size_t)(32 * t + (lane & 31)) * R2L_WIDTH + k] * Sw);
+                    }
+            for (int i = 0; i < 32; ++i) aux(ci)[i] = bl[32 * t + i] * S;
+            aux(ci)[32] = 1.0f / S;
+        }
+    }
+    // tail
+    {
+        const int ti = 2 + 4 * c->n_block;
+        const float* Wt = c->host_w[ti].data();
+        const float* bt = c->host_w[ti + 1].data();
+        const float Sw = r2l_pow2_scale(Wt, (size_t)3 * R2L_WIDTH);
+        const float S = Sa * Sw;
+        const int ci = cpt - 1;
+        char* chunk = img.data() + (size_t)ci * CH;
+        for (int ks = 0; ks < R2L_KSTEPS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    int r = lane & 31;
+                    int k = r2l_kappa(ks, lane >> 5, j);
+                    put_frag(chunk, np, ks, lane, j, r < 3 ? Wt[(size_t)r * R2L_WIDTH + k] * Sw : 0.f);
+                }
+        for (int i = 0; i < 3; ++i) aux(ci)[i] = bt[i] * S;
+        aux(ci)[32] = 1.0f / S;
+    }
+    if (c->d_img[mode]) {
+        (void)hipFree(c->d_img[mode]);
+        c->d_img[mode] = nullptr;
+    }
+    hipError_t e = hipMalloc((void**)&c->d_img[mode], img.size());
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc image: %s", hipGetErrorString(e));
+    e = hipMemcpy(c->d_img[mode], img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy image: %s", hipGetErrorString(e));
+    c->img_bytes[mode] = img.size();
+    return R2L_OK;
+}
+
+int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
+    if (!c || !tensors) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    const int expect = 4 + 4 * c->n_block;
+    if (n_tensors != expect)
+        return r2l_set_error(R2L_EINVAL, "expected %d tensors (head, %d ResMLP blocks x 4, tail), got %d", expect,
+                             c->n_block, n_tensors);
+    c->host_w.clear();
+    for (int i = 0; i < n_tensors; ++i) {
+        size_t n;
+        if (i == 0) n = (size_t)R2L_WIDTH * R2L_IN;
+        else if (i == 1) n = R2L_WIDTH;
+        else if (i == expect - 2) n = 3 * R2L_WIDTH;
+        else if (i == expect - 1) n = 3;
+        else n = ((i - 2) % 2 == 0) ? (size_t)R2L_WIDTH * R2L_WIDTH : R2L_WIDTH;
+        if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
+        c->host_w.emplace_back(tensors[i], tensors[i] + n);
+    }
+    for (int m = 0; m < 2; ++m)
+        if (c->d_img[m]) {
+            (void)hipFree(c->d_img[m]);
+            c->d_img[m] = nullptr;
+        }
+    int rc = build_image(c, c->mode);
+    if (rc) return rc;
+    c->loaded = true;
+    return R2L_OK;
+}
+
+int r2l_set_precision(r2l_ctx* c, int mode) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (mode != R2L_PREC_FP16X3 && mode != R2L_PREC_FP16X1) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
+    c->mode = mode;
+    if (c->loaded && !c->d_img[mode]) return build_image(c, mode);
+    return R2L_OK;
+}
+
+// ---- launches --------------------------------------------------------------------------
+static void fill_common(const r2l_ctx* c, R2LParams& p) {
+    memset(&p, 0, sizeof p);
+    memcpy(p.z, c->z, sizeof p.z);
+    p.focal = (float)c->focal;
+    p.half_w = (float)(c->W * .5);
+    p.half_h = (float)(c->H * .5);
+    p.act_scale = c->act_scale;
+    p.W = c->W;
+    p.n_block = c->n_block;
+    p.use_residual = c->use_residual;
+    p.chunks_per_tile = r2l_chunks_per_tile(c->n_block);
+    p.scratch = c->d_scratch;
+}
+
+static int timed_launch(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
+    const int grid = p.n_tiles < c->n_cu ? p.n_tiles : c->n_cu;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        if (c->ev_used + 2 > (int)c->ev.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t e;
+                hipError_t er = hipEventCreate(&e);
+                if (er != hipSuccess) return r2l_set_error(R2L_EHIP, "hipEventCreate: %s", hipGetErrorString(er));
+                c->ev.push_back(e);
+            }
+        }
+        e0 = c->ev[c->ev_used];
+        e1 = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+        (void)hipEventRecord(e0, s);
+    }
+    hipError_t e = r2l_launch_resmlp(p, np_of(c->mode), grid, s);
+    if (c->timing) (void)hipEventRecord(e1, s);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l_resmlp launch: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
+int r2l_render(r2l_ctx* c, const float* c2w, int c2w_on_device, int n_pose, int row_begin, int row_end,
+               float* rgb_out_dev, void* stream) {
+    if (!c || !c2w || !rgb_out_dev) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (!c->loaded) return r2l_set_error(R2L_ESTATE, "r2l_render before r2l_load_weights");
+    if (row_begin < 0 || row_end > c->H || row_begin >= row_end)
+        return r2l_set_error(R2L_EINVAL, "bad row range [%d,%d) for H=%d", row_begin, row_end, c->H);
+    if (n_pose < 1 || (!c2w_on_device && n_pose != 1))
+        return r2l_set_error(R2L_EINVAL, "n_pose=%d (host poses are rendered one per call)", n_pose);
+    const long long rpp = (long long)(row_end - row_begin) * c->W;
+    const long long total = rpp * n_pose;
+    if (total > 0x7fffffffLL) return r2l_set_error(R2L_EINVAL, "too many rays in one call: %lld", total);
+    R2LParams p;
+    fill_common(c, p);
+    p.wimg = c->d_img[c->mode];
+    p.rgb = rgb_out_dev;
+    if (c2w_on_device) p.c2w = c2w;
+    else memcpy(p.c2w_host, c2w, sizeof p.c2w_host);
+    p.pix_begin = row_begin * c->W;
+    p.rays_per_pose = (int)rpp;
+    p.n_rays = (int)total;
+    p.n_tiles = (int)((total + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS);
+    return timed_launch(c, p, (hipStream_t)stream);
+}
+
+int r2l_render_rays(r2l_ctx* c, const float* rays_o_dev, const float* rays_d_dev, int n, float* rgb_out_dev,
+                    void* stream) {
+    if (!c || !rays_o_dev || !rays_d_dev || !rgb_out_dev) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (!c->loaded) return r2l_set_error(R2L_ESTATE, "r2l_render_rays before r2l_load_weights");
+    if (n < 0) return r2l_set_error(R2L_EINVAL, "n=%d", n);
+    if (n == 0) return R2L_OK;
+    R2LParams p;
+    fill_common(c, p);
+    p.wimg = c->d_img[c->mode];
+    p.rgb = rgb_out_dev;
+    p.rays_o = rays_o_dev;
+    p.rays_d = rays_d_dev;
+    p.rays_per_pose = n;
+    p.n_rays = n;
+    p.n_tiles = (n + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    return timed_launch(c, p, (hipStream_t)stream);
+}
+
+int r2l_sample_embed(r2l_ctx* c, const float* c2w_host, int row_begin, int row_end, float* pts_out_dev,
+                     float* emb_out_dev, void* stream) {
+    if (!c || !c2w_host) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (row_begin < 0 || row_end > c->H || row_begin >= row_end)
+        return r2l_set_error(R2L_EINVAL, "bad row range [%d,%d) for H=%d", row_begin, row_end, c->H);
+    R2LParams p;
+    fill_common(c, p);
+    memcpy(p.c2w_host, c2w_host, sizeof p.c2w_host);
+    p.pix_begin = row_begin * c->W;
+    p.rays_per_pose = (row_end - row_begin) * c->W;
+    p.n_rays = p.rays_per_pose;
+    hipError_t e = r2l_launch_sample_embed(p, pts_out_dev, emb_out_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "sample_embed launch: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
+int r2l_embed(const float* x_dev, int n, int dim, int L, float* emb_out_dev, void* stream) {
+    if (!x_dev || !emb_out_dev || n < 0 || dim <= 0 || L <= 0 || L > 16)
+        return r2l_set_error(R2L_EINVAL, "bad argument to r2l_embed");
+    int rc = r2l_require_gfx950(nullptr);
+    if (rc) return rc;
+    if (n == 0) return R2L_OK;
+    hipError_t e = r2l_launch_embed(x_dev, (long long)n * dim, L, emb_out_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "embed launch: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
+long long r2l_flops_per_ray(const r2l_ctx* c) {
+    if (!c) return 0;
+    return 2LL * ((long long)R2L_IN * R2L_WIDTH + 2LL * c->n_block * R2L_WIDTH * R2L_WIDTH + R2L_WIDTH * 3);
+}
+long long r2l_weight_image_bytes(const r2l_ctx* c) { return c ? (long long)c->img_bytes[c->mode] : 0; }
+int r2l_rays_per_tile(const r2l_ctx*) { return R2L_TILE_RAYS; }
+
+int r2l_timing_enable(r2l_ctx* c, int on) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    c->timing = on != 0;
+    return R2L_OK;
+}
+
+int r2l_kernel_time_ms(r2l_ctx* c, double* total_ms, int* n_launches, int reset) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    double tot = 0;
+    for (int i = 0; i + 1 < c->ev_used; i += 2) {
+        hipError_t e = hipEventSynchronize(c->ev[i + 1]);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+        float ms = 0;
+        e = hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipEventElapsedTime: %s", hipGetErrorString(e));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (n_launches) *n_launches = c->ev_used / 2;
+    if (reset) c->ev_used = 0;
+    return R2L_OK;
+}

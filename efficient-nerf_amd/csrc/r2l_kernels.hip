@@ -1,0 +1,504 @@
+// R2L (neural light field) hot path for MI355X / gfx950, hand-written HIP.
+//
+//   r2l_resmlp_kernel<NP>  K1+K2+K3 fused: get_rays + 16-point sampling + sinusoidal
+//                          embedding + 88-layer width-256 residual MLP + sigmoid, one
+//                          persistent workgroup per CU, activations resident in registers,
+//                          weights streamed global -> LDS ring (LDS-DMA) -> MFMA A operand.
+//                          NP = 2: fp16 hi/lo split, 3 MFMA per k-step (fp32-grade result)
+//                          NP = 1: single fp16 pass.
+//   r2l_sample_embed_kernel / r2l_embed_kernel
+//                          stand-alone K1+K2 (PointSampler.sample_test,
+//                          PositionalEmbedder.__call__) for parity tests and the API mirror.
+//
+// Reference semantics restated here (file:line in MingSun-Tse/Efficient-NeRF):
+//   dirs / rays      model/nerf_raybased.py:80-99  == utils/run_nerf_raybased_helpers.py:233-247
+//   points           model/nerf_raybased.py:100-102
+//   embedding        model/nerf_raybased.py:198-208
+//   network          model/nerf_raybased.py:443-465 (ResMLP), :539-544 (NeRF_v3_2.forward)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "r2l_common.h"
+#include "r2l_kernels.h"
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define AS1(p) ((const __attribute__((address_space(1))) void*)(p))
+#define AS3(p) ((__attribute__((address_space(3))) void*)(p))
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+// ------------------------------------------------------------------------------------
+// sin / cos of 2^l * x, l = 0..9, matching sin/cos of the exactly scaled fp32 argument.
+// x/(2 pi) is kept as an unevaluated sum rh + rl (two-float), scaled by the exact power
+// of two, the integer part is removed exactly (v_rndne), and sin(2 pi g) is evaluated on
+// the folded fraction |g'| <= 1/4 with a degree-11 odd polynomial.
+// ------------------------------------------------------------------------------------
+#define R2L_INV2PI_HI 0.15915494f              // fl32(1/(2 pi))
+#define R2L_INV2PI_LO 6.4206382e-09f           // 1/(2 pi) - fl32(1/(2 pi))  (set by host check)
+#define R2L_2PI 6.2831855f
+
+struct Rev {  // x / (2 pi) = rh + rl
+    float rh, rl;
+};
+
+__device__ __forceinline__ Rev to_rev(float x) {
+    Rev r;
+    r.rh = x * R2L_INV2PI_HI;
+    r.rl = fmaf(x, R2L_INV2PI_LO, fmaf(x, R2L_INV2PI_HI, -r.rh));
+    return r;
+}
+
+// sin(th), |th| <= pi/2 (degree-11 odd polynomial)
+__device__ __forceinline__ float sin_poly(float th) {
+    float s = th * th;
+    float p = fmaf(s, -2.5052108e-8f, 2.7557319e-6f);
+    p = fmaf(s, p, -1.9841270e-4f);
+    p = fmaf(s, p, 8.3333333e-3f);
+    p = fmaf(s, p, -1.6666667e-1f);
+    return fmaf(th * s, p, th);
+}
+
+// sin (is_cos = false) or cos (true) of x * 2^l given x/(2 pi) = rh + rl, pow2l = 2^l.
+// rh*2^l is exact, t - rint(t) is exact, so g = frac(x*2^l/(2 pi)) in [-1/2, 1/2] keeps
+// ~2^-26 absolute accuracy; sin folds |g| to [-1/4, 1/4] (sign of g restored on the
+// angle), cos uses cos(2 pi g) = sin(2 pi (1/4 - |g|)).  max |err| 1.8e-7 (tests).
+__device__ __forceinline__ float trig_pow2(Rev r, float pow2l, bool is_cos) {
+    float t = r.rh * pow2l;
+    float u = t - rintf(t);
+    float g = fmaf(r.rl, pow2l, u);
+    float a = fabsf(g);
+    float m = is_cos ? (0.25f - a) : fminf(a, 0.5f - a);
+    float sg = is_cos ? 1.0f : g;
+    return sin_poly(m * copysignf(R2L_2PI, sg));
+}
+
+// camera ray of flat ray index `ray` (model/nerf_raybased.py:84-99).
+__device__ __forceinline__ void make_ray(const R2LParams& p, int ray, float o[3], float d[3]) {
+    if (p.rays_o != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = p.rays_o[(size_t)ray * 3 + k];
+            d[k] = p.rays_d[(size_t)ray * 3 + k];
+        }
+        return;
+    }
+    int pose = ray / p.rays_per_pose;
+    int pix = p.pix_begin + (ray - pose * p.rays_per_pose);
+    int jrow = pix / p.W;
+    int icol = pix - jrow * p.W;
+    float c[12];
+    if (p.c2w != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) c[k] = p.c2w[(size_t)pose * 12 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) c[k] = p.c2w_host[k];
+    }
+    float dx = __fdiv_rn((float)icol - p.half_w, p.focal);
+    float dy = -__fdiv_rn((float)jrow - p.half_h, p.focal);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // torch.sum(dirs[..., None, :] * c2w[:3,:3], -1): products rounded, then summed
+        float s = __fadd_rn(__fmul_rn(dx, c[4 * k + 0]), __fmul_rn(dy, c[4 * k + 1]));
+        d[k] = __fadd_rn(s, __fmul_rn(-1.0f, c[4 * k + 2]));
+        o[k] = c[4 * k + 3];
+    }
+}
+
+__device__ __forceinline__ float sample_pt(float o, float d, float z) {
+    return __fadd_rn(o, __fmul_rn(d, z));  // rays_o + rays_d * z  (two roundings)
+}
+
+// ------------------------------------------------------------------------------------
+// stand-alone K1+K2
+// ------------------------------------------------------------------------------------
+__global__ void r2l_sample_embed_kernel(R2LParams p, float* __restrict__ pts_out,
+                                        float* __restrict__ emb_out) {
+    // one thread per (ray, coordinate): 21 contiguous outputs
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)p.n_rays * R2L_NCOORD;
+    if (gid >= total) return;
+    int ray = (int)(gid / R2L_NCOORD);
+    int c = (int)(gid - (long long)ray * R2L_NCOORD);
+    int s = c / 3, kk = c - 3 * s;
+    float o[3], d[3];
+    make_ray(p, ray, o, d);
+    float ok = kk == 0 ? o[0] : (kk == 1 ? o[1] : o[2]);
+    float dk = kk == 0 ? d[0] : (kk == 1 ? d[1] : d[2]);
+    float x = sample_pt(ok, dk, p.z[s]);
+    if (pts_out) pts_out[gid] = x;
+    if (emb_out) {
+        float* e = emb_out + gid * R2L_EMBED;
+        Rev r = to_rev(x);
+        float pw = 1.0f;
+#pragma unroll
+        for (int l = 0; l < R2L_L; ++l) {
+            e[l] = trig_pow2(r, pw, false);
+            e[R2L_L + l] = trig_pow2(r, pw, true);
+            pw *= 2.0f;
+        }
+        e[2 * R2L_L] = x;
+    }
+}
+
+__global__ void r2l_embed_kernel(const float* __restrict__ x_in, long long total, int L,
+                                 float* __restrict__ emb_out) {
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    float x = x_in[gid];
+    float* e = emb_out + gid * (2 * L + 1);
+    Rev r = to_rev(x);
+    float pw = 1.0f;
+    for (int l = 0; l < L; ++l) {
+        e[l] = trig_pow2(r, pw, false);
+        e[L + l] = trig_pow2(r, pw, true);
+        pw *= 2.0f;
+    }
+    e[2 * L] = x;
+}
+
+// ------------------------------------------------------------------------------------
+// fused persistent kernel
+// ------------------------------------------------------------------------------------
+template <int NP>
+struct KCfg {
+    static constexpr int AUX = R2L_FRAGS * NP * R2L_FRAG_BYTES;  // aux offset in a chunk
+    static constexpr int CH = AUX + R2L_AUX_BYTES;               // chunk bytes
+    static constexpr int NBUF = (NP == 2) ? 4 : 6;               // LDS ring slots
+    static constexpr int D = NBUF - 1;                           // chunks issued ahead
+    static constexpr int P = 4 * NP + 1;                         // LDS-DMA ops / wave / chunk
+    static constexpr int WAIT_MID = (D - 2) * P;                 // certify chunk c+1 at mid-c
+    static constexpr int WAIT_PRO = (D - 1) * P;                 // prologue: certify chunk 0
+    static constexpr int LDS = NBUF * CH;
+};
+
+struct Ring {
+    const char* wimg;   // chunk stream of one ray tile (periodic)
+    int cpt;            // chunks per tile
+    int issue_pos;      // next chunk (position in the tile image) to issue
+    uint32_t issue_off; // LDS byte offset of the slot it goes to
+    uint32_t use_off;   // LDS byte offset of the chunk being consumed
+    int wave, lane;
+};
+
+template <int NP>
+__device__ __forceinline__ void ring_issue(Ring& R) {
+    typedef KCfg<NP> C;
+    const char* src = R.wimg + (size_t)R.issue_pos * C::CH;
+    const uint32_t dst = R.issue_off;
+#pragma unroll
+    for (int q = 0; q < 4 * NP; ++q) {
+        const int off = (R.wave * 4 * NP + q) * R2L_FRAG_BYTES;
+        __builtin_amdgcn_global_load_lds(AS1(src + off + R.lane * 16), AS3(smem + dst + off), 16,
+                                         0, 0);
+    }
+    __builtin_amdgcn_global_load_lds(AS1(src + C::AUX + R.wave * 256 + R.lane * 4),
+                                     AS3(smem + dst + C::AUX + R.wave * 256), 4, 0, 0);
+    R.issue_pos = (R.issue_pos + 1 == R.cpt) ? 0 : R.issue_pos + 1;
+    R.issue_off = (R.issue_off + C::CH == (uint32_t)C::LDS) ? 0u : R.issue_off + C::CH;
+}
+
+#define R2L_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// Mid-chunk rendezvous while consuming chunk c: every wave's LDS-DMA of chunk c+1 has
+// landed (counted vmcnt, then the barrier), every wave is past chunk c-1, so its slot is
+// refilled with chunk c+D.
+template <int NP>
+__device__ __forceinline__ void ring_mid(Ring& R) {
+    R2L_WAIT_VMCNT(KCfg<NP>::WAIT_MID);
+    __builtin_amdgcn_s_barrier();
+    ring_issue<NP>(R);
+}
+
+template <int NP>
+__device__ __forceinline__ void ring_next(Ring& R) {
+    typedef KCfg<NP> C;
+    R.use_off = (R.use_off + C::CH == (uint32_t)C::LDS) ? 0u : R.use_off + C::CH;
+}
+
+template <int NP>
+__device__ __forceinline__ f16x8 lds_frag(uint32_t lane_base, int frag, int part) {
+    return *reinterpret_cast<const f16x8*>(smem + lane_base + (frag * NP + part) * R2L_FRAG_BYTES);
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// split an fp32 activation (already multiplied by act_scale) into fp16 hi (+ lo)
+template <int NP>
+__device__ __forceinline__ void split_store(float a, f16x8& hi, f16x8& lo, int j) {
+    f16 h = (f16)a;
+    hi[j] = h;
+    if (NP == 2) lo[j] = (f16)(a - (float)h);
+}
+
+// one MFMA k-step on one 32x32 output tile
+template <int NP>
+__device__ __forceinline__ f32x16 kstep(uint32_t lane_base, int frag, const f16x8& bh,
+                                        const f16x8& bl, f32x16 acc) {
+    f16x8 ah = lds_frag<NP>(lane_base, frag, 0);
+    acc = MFMA(ah, bh, acc);
+    if (NP == 2) {
+        f16x8 al = lds_frag<NP>(lane_base, frag, 1);
+        acc = MFMA(ah, bl, acc);
+        acc = MFMA(al, bh, acc);
+    }
+    return acc;
+}
+
+// accumulator init = aux[tile_off + 8g + 4h + i] (bias pre-multiplied by the layer scale)
+template <int NP>
+__device__ __forceinline__ f32x16 acc_init(uint32_t slot_off, int tile_off, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(smem + slot_off + KCfg<NP>::AUX +
+                                                  (tile_off + 8 * g + 4 * h) * 4);
+        acc[4 * g + 0] = b[0];
+        acc[4 * g + 1] = b[1];
+        acc[4 * g + 2] = b[2];
+        acc[4 * g + 3] = b[3];
+    }
+    return acc;
+}
+
+template <int NP>
+__device__ __forceinline__ float aux_inv_scale(uint32_t slot_off) {
+    return *reinterpret_cast<const float*>(smem + slot_off + KCfg<NP>::AUX + 32 * 4);
+}
+
+// One body Linear(256,256): in = (Bh,Bl) fragments, out fragments -> (Nh,Nl).
+// SECOND = false: out = relu(W in + b)            (ResMLP body.0 + inact)
+// SECOND = true : x   = x + (W in + b); out = x   (ResMLP body.2 + residual)
+template <int NP, bool SECOND>
+__device__ __forceinline__ void body_layer(Ring& R, const f16x8 (&Bh)[16], const f16x8 (&Bl)[16],
+                                           f16x8 (&Nh)[16], f16x8 (&Nl)[16], f32x16 (&x)[8],
+                                           float act_scale, int h) {
+#pragma unroll
+    for (int t = 0; t < R2L_NTILE; ++t) {
+        const uint32_t slot = R.use_off;
+        const uint32_t lane_base = slot + R.lane * 16;
+        f32x16 acc = acc_init<NP>(slot, 0, h);
+        const float inv = aux_inv_scale<NP>(slot);
+#pragma unroll
+        for (int ks = 0; ks < R2L_KSTEPS; ++ks) {
+            if (ks == R2L_KSTEPS / 2) ring_mid<NP>(R);
+            acc = kstep<NP>(lane_base, ks, Bh[ks], Bl[ks], acc);
+        }
+        ring_next<NP>(R);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            float v;
+            if (!SECOND) {
+                v = fmaxf(acc[reg] * inv, 0.0f);
+            } else {
+                v = fmaf(acc[reg], inv, x[t][reg]);
+                x[t][reg] = v;
+            }
+            split_store<NP>(v * act_scale, Nh[2 * t + (reg >> 3)], Nl[2 * t + (reg >> 3)], reg & 7);
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
+    typedef KCfg<NP> C;
+    Ring R;
+    R.wimg = p.wimg;
+    R.cpt = p.chunks_per_tile;
+    R.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    R.lane = threadIdx.x & 63;
+    R.issue_pos = 0;
+    R.issue_off = 0;
+    R.use_off = 0;
+    const int lane = R.lane;
+    const int h = lane >> 5;
+    const float act_scale = p.act_scale;
+    const bool is_cos = h != 0;
+
+    // prologue: D chunks in flight, chunk 0 certified
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) ring_issue<NP>(R);
+    R2L_WAIT_VMCNT(C::WAIT_PRO);
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 x[8];
+    f16x8 Bh[16], Bl[16], Nh[16], Nl[16];
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const int ray_raw = tile * R2L_TILE_RAYS + R.wave * R2L_RAYS_PER_WAVE + (lane & 31);
+        const bool valid = ray_raw < p.n_rays;
+        const int ray = valid ? ray_raw : p.n_rays - 1;
+        float o[3], d[3];
+        make_ray(p, ray, o, d);
+
+        // ---------------- head: Linear(1008,256) + ReLU, k outer / feature tile inner -------
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = acc_init<NP>(R.use_off, 32 * t, h);
+
+        // phase 1: k-steps 0..47, one coordinate each, frequencies 0..7 (sin | cos by half)
+        for (int sp = 0; sp < 8; ++sp) {
+            const float z0 = p.z[2 * sp], z1 = p.z[2 * sp + 1];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const float xc = sample_pt(o[u % 3], d[u % 3], u < 3 ? z0 : z1);
+                const Rev r = to_rev(xc);
+                f16x8 bh, bl;
+                float pw = 1.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    split_store<NP>(trig_pow2(r, pw, is_cos) * act_scale, bh, bl, j);
+                    pw *= 2.0f;
+                }
+                const uint32_t lane_base = R.use_off + lane * 16;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) x[t] = kstep<NP>(lane_base, (u & 1) * 8 + t, bh, bl, x[t]);
+                if ((u & 1) == 0) ring_mid<NP>(R); else ring_next<NP>(R);
+            }
+        }
+        // phase 2: k-steps 48..59, four coordinates each, frequencies 8, 9
+        for (int it = 0; it < 2; ++it) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                f16x8 bh, bl;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int cc = 4 * u + m;  // coordinate within this group of 24
+                    const float xc = sample_pt(o[cc % 3], d[cc % 3], p.z[8 * it + cc / 3]);
+                    const Rev r = to_rev(xc);
+                    split_store<NP>(trig_pow2(r, 256.0f, is_cos) * act_scale, bh, bl, 2 * m);
+                    split_store<NP>(trig_pow2(r, 512.0f, is_cos) * act_scale, bh, bl, 2 * m + 1);
+                }
+                const uint32_t lane_base = R.use_off + lane * 16;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) x[t] = kstep<NP>(lane_base, (u & 1) * 8 + t, bh, bl, x[t]);
+                if ((u & 1) == 0) ring_mid<NP>(R); else ring_next<NP>(R);
+            }
+        }
+        // phase 3: k-steps 60..62 identity (coordinate 16*(ks-60) + 8h + j), k-step 63 = pad
+        float inv_head;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < 3) {
+                f16x8 bh, bl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c0 = 16 * u + j, c1 = c0 + 8;
+                    const float x0 = sample_pt(o[c0 % 3], d[c0 % 3], p.z[c0 / 3]);
+                    const float x1 = sample_pt(o[c1 % 3], d[c1 % 3], p.z[c1 / 3]);
+                    split_store<NP>((h ? x1 : x0) * act_scale, bh, bl, j);
+                }
+                const uint32_t lane_base = R.use_off + lane * 16;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) x[t] = kstep<NP>(lane_base, (u & 1) * 8 + t, bh, bl, x[t]);
+            }
+            if ((u & 1) == 0) {
+                ring_mid<NP>(R);
+            } else {
+                if (u == 3) inv_head = aux_inv_scale<NP>(R.use_off);
+                ring_next<NP>(R);
+            }
+        }
+        // head epilogue: h0 = relu(acc/scale); keep a copy for the global skip
+        float* scr = p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float v = fmaxf(x[t][reg] * inv_head, 0.0f);
+                x[t][reg] = v;
+                split_store<NP>(v * act_scale, Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
+            }
+            if (p.use_residual) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v4 = {x[t][4 * g], x[t][4 * g + 1], x[t][4 * g + 2], x[t][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(scr + (t * 4 + g) * 256) = v4;
+                }
+            }
+        }
+
+        // ---------------- body: n_block x ResMLP ----------------------------------------
+        for (int blk = 0; blk < p.n_block; ++blk) {
+            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, h);
+            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, h);
+        }
+
+        // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------
+        if (p.use_residual) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(scr + (t * 4 + g) * 256);
+                    x[t][4 * g + 0] += v4[0];
+                    x[t][4 * g + 1] += v4[1];
+                    x[t][4 * g + 2] += v4[2];
+                    x[t][4 * g + 3] += v4[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                split_store<NP>(x[t][reg] * act_scale, Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
+        {
+            const uint32_t slot = R.use_off;
+            const uint32_t lane_base = slot + lane * 16;
+            f32x16 acc = acc_init<NP>(slot, 0, h);
+            const float inv = aux_inv_scale<NP>(slot);
+#pragma unroll
+            for (int ks = 0; ks < R2L_KSTEPS; ++ks) {
+                if (ks == R2L_KSTEPS / 2) ring_mid<NP>(R);
+                acc = kstep<NP>(lane_base, ks, Bh[ks], Bl[ks], acc);
+            }
+            ring_next<NP>(R);
+            if (valid && h == 0) {
+                float* out = p.rgb + (size_t)ray * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) out[k] = 1.0f / (1.0f + expf(-(acc[k] * inv)));
+            }
+        }
+    }
+    // the ring always runs D chunks ahead: drain before the LDS is released
+    R2L_WAIT_VMCNT(0);
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+template <int NP>
+static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(r2l_resmlp_kernel<NP>, dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t r2l_launch_resmlp(const R2LParams& p, int np, int grid, hipStream_t stream) {
+    return np == 2 ? launch_resmlp<2>(p, grid, stream) : launch_resmlp<1>(p, grid, stream);
+}
+
+hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,
+                                   hipStream_t stream) {
+    long long total = (long long)p.n_rays * R2L_NCOORD;
+    int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(r2l_sample_embed_kernel, dim3(grid), dim3(256), 0, stream, p, pts_out, emb_out);
+    return hipGetLastError();
+}
+
+hipError_t r2l_launch_embed(const float* x, long long total, int L, float* emb_out,
+                            hipStream_t stream) {
+    int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(r2l_embed_kernel, dim3(grid), dim3(256), 0, stream, x, total, L, emb_out);
+    return hipGetLastError();
+}

@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's R2L call surface, backed by libr2l_hip.so.
+
+Reference interface mirrored (MingSun-Tse/Efficient-NeRF):
+  PointSampler            model/nerf_raybased.py:76-126
+  PositionalEmbedder      model/nerf_raybased.py:191-208
+  NeRF_v3_2               model/nerf_raybased.py:480-544
+  render_func             main.py:401-404
+  render_path R2L branch  main.py:285-325
+
+The reference evaluates ``model(positional_embedder(point_sampler.sample_test(c2w)))`` as
+three eager stages that materialise [N,48] and [N,1008] tensors.  Here the three calls
+compose lazily: ``sample_test`` returns a ``LazyPoints`` handle, the embedder wraps it,
+and the model launches ONE fused HIP kernel (get_rays + sampling + embedding + ResMLP)
+that writes [N,3].  Calling ``.materialize()`` (or torch ops via ``.tensor``) on the lazy
+handles runs the stand-alone HIP kernels instead, which is what the parity tests do.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, check, current_stream, dptr, lib
+
+
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise R2LError('no HIP device visible to torch: the R2L path has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def _c2w_host(c2w):
+    c = torch.as_tensor(c2w).detach().to('cpu', torch.float32)
+    if c.shape[-2:] == (4, 4):
+        c = c[..., :3, :4]
+    if c.shape != (3, 4):
+        raise R2LError(f'c2w must be [3,4] (or [4,4]); got {tuple(c.shape)}')
+    return c.contiguous()
+
+
+class R2LEngine:
+    """One r2l_ctx: geometry + weights + launches (include/r2l_hip.h)."""
+
+    def __init__(self, H, W, focal, near=2., far=6., n_sample=16, L=10, width=256, n_block=43,
+                 use_residual=True, precision=PREC_FP16X3, device=None):
+        self.device = _dev(device)
+        self.H, self.W, self.focal = int(H), int(W), float(focal)
+        self.n_block = int(n_block)
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().r2l_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
+                                   int(n_sample), int(L), int(width), self.n_block, int(bool(use_residual)),
+                                   int(precision)))
+        self.precision = int(precision)
+        self._loaded = False
+
+    def close(self):
+        if getattr(self, '_ctx', None) and self._ctx.value:
+            lib().r2l_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    __del__ = close
+
+    # -- weights --------------------------------------------------------------------
+    @staticmethod
+    def state_names(n_block):
+        names = ['head.0.weight', 'head.0.bias']
+        for i in range(n_block):
+            for j in (0, 2):
+                names += [f'body.{i}.body.{j}.weight', f'body.{i}.body.{j}.bias']
+        return names + ['tail.0.weight', 'tail.0.bias']
+
+    def load_state_dict(self, state_dict):
+        """state_dict of the reference's NeRF_v3_2 (``module.`` prefixes tolerated,
+        utils/run_nerf_raybased_helpers.py:408-425)."""
+        sd = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        names = self.state_names(self.n_block)
+        missing = [n for n in names if n not in sd]
+        if missing:
+            raise R2LError(f'state_dict lacks {len(missing)} tensors, e.g. {missing[:3]}')
+        shapes = {'head.0.weight': (256, 1008), 'tail.0.weight': (3, 256), 'tail.0.bias': (3,)}
+        for n in names:
+            want = shapes.get(n, (256, 256) if n.endswith('weight') else (256,))
+            if tuple(sd[n].shape) != want:
+                raise R2LError(f'{n}: shape {tuple(sd[n].shape)} != {want}')
+        keep, arr = _lib.host_ptrs([sd[n] for n in names])
+        with torch.cuda.device(self.device):
+            check(lib().r2l_load_weights(self._ctx, arr, len(keep)))
+        self._loaded = True
+        return self
+
+    def set_precision(self, precision):
+        with torch.cuda.device(self.device):
+            check(lib().r2l_set_precision(self._ctx, int(precision)))
+        self.precision = int(precision)
+
+    # -- rendering ------------------------------------------------------------------
+    def _rows(self, rows):
+        r0, r1 = (0, self.H) if rows is None else (int(rows[0]), int(rows[1]))
+        return r0, r1
+
+    def render(self, c2w, rows=None, out=None):
+        """rgb [rows*W, 3] for one pose given on the host (c2w [3,4] or [4,4])."""
+        r0, r1 = self._rows(rows)
+        c = _c2w_host(c2w)
+        n = (r1 - r0) * self.W
+        if out is None:
+            out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().r2l_render(self._ctx, C.c_void_p(c.data_ptr()), 0, 1, r0, r1, dptr(out), current_stream()))
+        return out
+
+    def render_batch(self, c2w_dev, rows=None, out=None):
+        """rgb [P, rows*W, 3] for P poses resident on the device ([P,3,4] f32): one launch."""
+        r0, r1 = self._rows(rows)
+        if c2w_dev.dim() == 2:
+            c2w_dev = c2w_dev[None]
+        if c2w_dev.shape[-2:] != (3, 4):
+            raise R2LError(f'c2w_dev must be [P,3,4]; got {tuple(c2w_dev.shape)}')
+        P = c2w_dev.shape[0]
+        n = (r1 - r0) * self.W
+        if out is None:
+            out = torch.empty((P, n, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().r2l_render(self._ctx, dptr(c2w_dev), 1, P, r0, r1, dptr(out), current_stream()))
+        return out
+
+    def render_rays(self, rays_o, rays_d, out=None):
+        """Given-rays path (main.py:220-230): rays_o, rays_d [n,3] device f32 -> rgb [n,3]."""
+        n = rays_o.shape[0]
+        if out is None:
+            out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().r2l_render_rays(self._ctx, dptr(rays_o), dptr(rays_d), n, dptr(out), current_stream()))
+        return out
+
+    def sample_embed(self, c2w, rows=None, want_pts=True, want_emb=True):
+        r0, r1 = self._rows(rows)
+        c = _c2w_host(c2w)
+        n = (r1 - r0) * self.W
+        pts = torch.empty((n, 48), dtype=torch.float32, device=self.device) if want_pts else None
+        emb = torch.empty((n, 1008), dtype=torch.float32, device=self.device) if want_emb else None
+        with torch.cuda.device(self.device):
+            check(lib().r2l_sample_embed(self._ctx, C.c_void_p(c.data_ptr()), r0, r1, dptr(pts), dptr(emb),
+                                         current_stream()))
+        return pts, emb
+
+    # -- introspection --------------------------------------------------------------
+    @property
+    def flops_per_ray(self):
+        return int(lib().r2l_flops_per_ray(self._ctx))
+
+    @property
+    def weight_image_bytes(self):
+        return int(lib().r2l_weight_image_bytes(self._ctx))
+
+    @property
+    def rays_per_tile(self):
+        return int(lib().r2l_rays_per_tile(self._ctx))
+
+    def timing(self, on=True):
+        check(lib().r2l_timing_enable(self._ctx, int(on)))
+
+    def kernel_time_ms(self, reset=True):
+        tot, n = C.c_double(), C.c_int()
+        check(lib().r2l_kernel_time_ms(self._ctx, C.byref(tot), C.byref(n), int(reset)))
+        return tot.value, n.value
+
+
+# ------------------------------------------------------------------------------------------
+# reference-shaped objects
+# ------------------------------------------------------------------------------------------
+class LazyPoints:
+    """What PointSampler.sample_test / sample_train return: the recipe for [N, 48] points."""
+
+    def __init__(self, sampler, c2w=None, rays=None):
+        self.sampler, self.c2w, self.rays = sampler, c2w, rays
+        n = sampler.H * sampler.W if rays is None else rays[0].shape[0]
+        self.shape = (n, sampler.n_sample * 3)
+
+    def materialize(self):
+        if self.rays is not None:
+            raise R2LError('points of a given-rays bundle are only consumed by the fused kernel')
+        return self.sampler._geometry_engine().sample_embed(self.c2w, want_emb=False)[0]
+
+    tensor = property(materialize)
+
+
+class LazyEmbedding:
+    """What PositionalEmbedder returns for LazyPoints: the recipe for [N, 1008]."""
+
+    def __init__(self, pts, L):
+        self.pts, self.L = pts, L
+        self.shape = (pts.shape[0], pts.shape[1] * (2 * L + 1))
+
+    def materialize(self):
+        if self.pts.rays is not None:
+            raise R2LError('embedding of a given-rays bundle is only consumed by the fused kernel')
+        return self.pts.sampler._geometry_engine().sample_embed(self.pts.c2w, want_pts=False)[1]
+
+    tensor = property(materialize)
+
+
+class PointSampler:
+    """model/nerf_raybased.py:76-126.  Same constructor; sample_test(c2w) and
+    sample_train(rays_o, rays_d, perturb=0) return lazy handles (see module docstring)."""
+
+    def __init__(self, H, W, focal, n_sample, near, far):
+        if n_sample != 16:
+            raise R2LError(f'n_sample_per_ray={n_sample}: the HIP path is built for 16')
+        self.H, self.W, self.focal = int(H), int(W), float(focal)
+        self.n_sample, self.near, self.far = int(n_sample), float(near), float(far)
+        self._geo = None
+
+    def _geometry_engine(self):
+        if self._geo is None:  # weight-less ctx: enough for the stand-alone K1+K2 kernels
+            self._geo = R2LEngine(self.H, self.W, self.focal, self.near, self.far, n_block=0)
+        return self._geo
+
+    def sample_test(self, c2w):  # c2w: [3, 4]
+        return LazyPoints(self, c2w=c2w)
+
+    def sample_train(self, rays_o, rays_d, perturb):
+        if perturb > 0.:
+            raise NotImplementedError('perturb>0 is a training-only path (out of scope)')
+        return LazyPoints(self, rays=(rays_o, rays_d))
+
+
+class PositionalEmbedder:
+    """model/nerf_raybased.py:191-208."""
+
+    def __init__(self, L, include_input=True):
+        if not include_input:
+            raise R2LError('include_input=False is not used by the reference R2L path')
+        self.L = int(L)
+        self.include_input = include_input
+        self.embed_dim = 2 * L + 1
+
+    def __call__(self, x):
+        if isinstance(x, LazyPoints):
+            if self.L != 10:
+                raise R2LError(f'multires={self.L}: the fused HIP path is built for 10')
+            return LazyEmbedding(x, self.L)
+        # plain tensor [n, dim] on the device: stand-alone HIP embedder
+        x = x.contiguous()
+        out = torch.empty((x.shape[0], x.shape[1] * self.embed_dim), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib().r2l_embed(dptr(x), x.shape[0], x.shape[1], self.L, dptr(out), current_stream()))
+        return out
+
+
+class NeRF_v3_2:
+    """model/nerf_raybased.py:480-544 for the `--trial.body_arch resmlp` family at
+    netwidth 256.  ``args`` is the reference's namespace (netdepth, netwidth, use_residual,
+    trial.n_block, ...).  Weights arrive through load_state_dict (the reference's
+    `.tar['network_fn_state_dict']`)."""
+
+    def __init__(self, args, input_dim, output_dim, precision=PREC_FP16X3):
+        D, W = int(args.netdepth), int(args.netwidth)
+        trial = getattr(args, 'trial', None)
+        if W != 256 or input_dim != 1008 or output_dim != 3:
+            raise R2LError(f'unsupported R2L shape W={W} input_dim={input_dim} output_dim={output_dim}')
+        if trial is None or getattr(trial, 'body_arch', 'resmlp') != 'resmlp':
+            raise R2LError('only --trial.ON --trial.body_arch resmlp networks are supported')
+        if getattr(args, 'layerwise_netwidths', '') or getattr(args, 'linear_tail', False):
+            raise R2LError('layerwise_netwidths / linear_tail variants are not supported')
+        if getattr(args, 'act', 'relu').lower() != 'relu' or getattr(trial, 'inact', 'relu').lower() != 'relu' \
+                or getattr(trial, 'outact', 'none').lower() != 'none' \
+                or float(getattr(trial, 'res_scale', 1.)) != 1. or int(getattr(trial, 'n_learnable', 2)) != 2:
+            raise R2LError('only act=relu, trial.inact=relu, trial.outact=none, res_scale=1, n_learnable=2')
+        n_block = int(getattr(trial, 'n_block', -1))
+        self.n_block = n_block if n_block > 0 else (D - 2) // 2
+        self.use_residual = bool(getattr(args, 'use_residual', False))
+        self.input_dim = input_dim
+        self.precision = precision
+        self._state = None
+        self._engines = {}
+
+    def load_state_dict(self, state_dict):
+        self._state = {k: v.detach().to('cpu', torch.float32) for k, v in state_dict.items()}
+        for eng in self._engines.values():
+            eng.load_state_dict(self._state)
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def engine_for(self, sampler):
+        key = (sampler.H, sampler.W, sampler.focal, sampler.near, sampler.far)
+        eng = self._engines.get(key)
+        if eng is None:
+            if self._state is None:
+                raise R2LError('NeRF_v3_2 called before load_state_dict')
+            eng = R2LEngine(sampler.H, sampler.W, sampler.focal, sampler.near, sampler.far,
+                            n_block=self.n_block, use_residual=self.use_residual, precision=self.precision)
+            eng.load_state_dict(self._state)
+            self._engines[key] = eng
+        return eng
+
+    def __call__(self, x):
+        if not isinstance(x, LazyEmbedding):
+            raise R2LError('the HIP NeRF_v3_2 consumes positional_embedder(point_sampler.sample_*(...)) '
+                           'handles; pre-materialised [N,1008] inputs have no kernel (the embedding never '
+                           'touches HBM in the fused path)')
+        pts = x.pts
+        eng = self.engine_for(pts.sampler)
+        if pts.rays is not None:
+            return eng.render_rays(pts.rays[0].contiguous(), pts.rays[1].contiguous())
+        c2w = pts.c2w
+        if torch.is_tensor(c2w) and c2w.is_cuda:
+            return eng.render_batch(c2w[:3, :4].contiguous()[None])[0]
+        return eng.render(c2w)
+
+    forward = __call__
+
+
+def render_func(model, pose, point_sampler, positional_embedder):
+    """main.py:401-404 (the reference's --benchmark unit of work)."""
+    with torch.no_grad():
+        return model(positional_embedder(point_sampler.sample_test(pose)))

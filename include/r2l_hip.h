@@ -1,0 +1,154 @@
+/*
+ * r2l_hip.h — C-ABI of the MI355X (gfx950) renderer for the R2L / NeRF-teacher
+ * ray-batched inference path of MingSun-Tse/Efficient-NeRF.
+ *
+ * The reference has no FFI: its hot path is ordinary Python calls on module-level
+ * globals.  Each entry point below replaces one of those call sites (cited as
+ * reference file:line).  All pointers are plain host or device pointers, sizes are
+ * plain ints, streams are a `hipStream_t` passed as `void*` (0 = default stream).
+ * No torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative R2L_E* code otherwise;
+ *     r2l_last_error() returns a thread-local message for the last failure.
+ *   - "dev" pointers are device memory owned by the caller (a PyTorch-ROCm tensor's
+ *     data_ptr()); the library borrows them for the duration of the stream-ordered
+ *     call and never synchronises the stream.
+ *   - weights are copied / re-packed once into library-owned device memory by the
+ *     *_load_weights calls; tensors are float32, row-major `[out, in]` exactly as in
+ *     the reference's `state_dict` (nn.Linear convention).
+ *   - a context is not re-entrant across threads; use one context per stream.
+ */
+#ifndef R2L_HIP_H
+#define R2L_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R2L_OK 0
+#define R2L_EINVAL -1   /* bad argument / unsupported configuration */
+#define R2L_EHIP -2     /* a HIP runtime call failed (see r2l_last_error) */
+#define R2L_ESTATE -3   /* call order violated (e.g. render before load_weights) */
+#define R2L_ENOGPU -4   /* no gfx950 device visible */
+
+/* precision_mode of the ResMLP / teacher MLP contractions (MFMA fp16 operands,
+ * fp32 accumulate):
+ *   R2L_PREC_FP16X3  hi/lo split of both operands, 3 MFMA passes per k-step
+ *                    (ah*wh + ah*wl + al*wh): L_inf vs the fp32 reference ~1e-6;
+ *   R2L_PREC_FP16X1  single pass on fp16-rounded operands: L_inf ~4e-4, 3x fewer MFMAs. */
+#define R2L_PREC_FP16X3 0
+#define R2L_PREC_FP16X1 1
+
+typedef struct r2l_ctx r2l_ctx;
+typedef struct nerf_ctx nerf_ctx;
+
+const char* r2l_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => every call fails loudly) */
+int r2l_device_count(void);
+
+/* ---------------------------------------------------------------------------------
+ * R2L student (neural light field).  Replaces, under torch.no_grad():
+ *   PointSampler.__init__            model/nerf_raybased.py:78-92   -> r2l_create
+ *   NeRF_v3_2.__init__ + load        model/nerf_raybased.py:483-537,
+ *                                    main.py:482-502                -> r2l_load_weights
+ *   model(positional_embedder(point_sampler.sample_test(c2w)))
+ *                                    main.py:300-309, 401-404       -> r2l_render
+ *   model(positional_embedder(point_sampler.sample_train(o,d,0)))
+ *                                    main.py:220-230                -> r2l_render_rays
+ *   point_sampler.sample_test / positional_embedder alone
+ *                                    model/nerf_raybased.py:94-102,198-208
+ *                                                                   -> r2l_sample_embed
+ * --------------------------------------------------------------------------------- */
+
+/* H, W, focal: image geometry (focal as the Python float the reference passes, it is
+ * rounded to f32 where the reference's tensor ops round it).  n_sample must be 16,
+ * L (multires) 10 and width (netwidth) 256 — the R2L W256 family; n_block is the number
+ * of ResMLP blocks ((netdepth-2)/2 = 43 for D88), any value >= 0.  use_residual = the
+ * --use_residual global skip. */
+int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far_,
+               int n_sample, int L, int width, int n_block, int use_residual,
+               int precision_mode);
+void r2l_destroy(r2l_ctx* ctx);
+
+/* tensors: 4 + 4*n_block HOST pointers in state_dict order:
+ *   head.0.weight[256,1008], head.0.bias[256],
+ *   body.{i}.body.0.weight[256,256], .bias[256], body.{i}.body.2.weight, .bias  (i < n_block),
+ *   tail.0.weight[3,256], tail.0.bias[3]                                            */
+int r2l_load_weights(r2l_ctx* ctx, const float* const* tensors, int n_tensors);
+int r2l_set_precision(r2l_ctx* ctx, int precision_mode);
+
+/* Render rows [row_begin,row_end) of n_pose frames.  c2w: n_pose x [3,4] row-major f32
+ * (the reference's c2w[:3,:4]), on the host if c2w_on_device == 0 (n_pose must be 1) or
+ * in device memory otherwise.  rgb_out_dev: [n_pose, (row_end-row_begin)*W, 3] f32. */
+int r2l_render(r2l_ctx* ctx, const float* c2w, int c2w_on_device, int n_pose,
+               int row_begin, int row_end, float* rgb_out_dev, void* stream);
+
+/* Given-rays variant: rays_o_dev, rays_d_dev [n,3] f32 device; rgb_out_dev [n,3]. */
+int r2l_render_rays(r2l_ctx* ctx, const float* rays_o_dev, const float* rays_d_dev, int n,
+                    float* rgb_out_dev, void* stream);
+
+/* Stand-alone K1+K2 (parity / API mirror of PointSampler.sample_test and
+ * PositionalEmbedder.__call__): either output may be NULL.
+ * pts_out_dev [rows*W, 48], emb_out_dev [rows*W, 1008]; c2w on the host. */
+int r2l_sample_embed(r2l_ctx* ctx, const float* c2w_host, int row_begin, int row_end,
+                     float* pts_out_dev, float* emb_out_dev, void* stream);
+/* PositionalEmbedder on caller-provided points: x_dev [n, dim] -> emb_out_dev [n, dim*21] */
+int r2l_embed(const float* x_dev, int n, int dim, int L, float* emb_out_dev, void* stream);
+
+/* introspection for bench.py / DESIGN.md */
+long long r2l_flops_per_ray(const r2l_ctx* ctx);      /* algorithmic: 2*MACs of the network */
+long long r2l_weight_image_bytes(const r2l_ctx* ctx); /* packed fp16 image streamed per ray tile */
+int r2l_rays_per_tile(const r2l_ctx* ctx);
+/* HIP-event timing of the dominant kernel on the stream it is launched on: when enabled,
+ * every r2l_render* call records start/stop events around its kernel; r2l_kernel_time_ms
+ * synchronises those events and returns the sum and count since the last reset. */
+int r2l_timing_enable(r2l_ctx* ctx, int on);
+int r2l_kernel_time_ms(r2l_ctx* ctx, double* total_ms, int* n_launches, int reset);
+
+/* ---------------------------------------------------------------------------------
+ * NeRF teacher (coarse 64 + fine 128 samples).  Replaces:
+ *   render(H,W,focal,chunk,c2w=...)   main.py:107-186 (c2w path) / create_data.py:824
+ *   render_rays                       main.py:624-756
+ *   run_network + Embedder + NeRF     main.py:65-87, helpers:24-56, model/nerf_raybased.py:377-401
+ *   raw2outputs                       main.py:556-621
+ *   sample_pdf                        utils/run_nerf_raybased_helpers.py:283-330
+ *   sort(cat(z_vals, z_samples))      main.py:730-732
+ * --------------------------------------------------------------------------------- */
+int nerf_create(nerf_ctx** out, int H, int W, double focal, float near_, float far_,
+                int N_samples, int N_importance, int multires, int multires_views,
+                int white_bkgd, int precision_mode);
+void nerf_destroy(nerf_ctx* ctx);
+/* which: 0 = network_fn (coarse), 1 = network_fine.  tensors: 24 HOST pointers in
+ * state_dict order: pts_linears.{0..7}.{weight,bias}, views_linears.0.{weight,bias},
+ * feature_linear.{weight,bias}, alpha_linear.{weight,bias}, rgb_linear.{weight,bias}. */
+int nerf_load_weights(nerf_ctx* ctx, int which, const float* const* tensors, int n_tensors);
+/* rows [row_begin,row_end) of one frame; c2w [3,4] on host.  Outputs are device
+ * pointers, any of disp/acc/depth may be NULL.  rgb [n,3], others [n]. */
+int nerf_render(nerf_ctx* ctx, const float* c2w_host, int row_begin, int row_end,
+                float* rgb_dev, float* disp_dev, float* acc_dev, float* depth_dev, void* stream);
+int nerf_render_rays(nerf_ctx* ctx, const float* rays_o_dev, const float* rays_d_dev, int n,
+                     float* rgb_dev, float* disp_dev, float* acc_dev, float* depth_dev,
+                     void* stream);
+/* coarse-pass by-products of the last nerf_render* call (device pointers owned by ctx,
+ * valid until the next call): rgb0 [n,3], z_samples [n,N_importance], z_vals [n,S0+S1] */
+int nerf_last_extras(nerf_ctx* ctx, const float** rgb0, const float** z_samples,
+                     const float** z_vals, const float** raw_fine);
+
+/* stand-alone scan kernels (all device pointers, f32):
+ * raw [n,S,4], z [n,S], rays_d [n,3] -> rgb [n,3], disp [n], acc [n], weights [n,S], depth [n]
+ * (weights/depth/disp/acc may be NULL). */
+int nerf_raw2outputs(const float* raw, const float* z, const float* rays_d, int n, int S,
+                     int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
+                     float* depth, void* stream);
+/* bins [n,n_bins], weights [n,n_bins-1] -> samples [n,N] (det=True: u = linspace(0,1,N)) */
+int nerf_sample_pdf(const float* bins, const float* weights, int n, int n_bins, int N,
+                    float* samples, void* stream);
+/* a [n,na] and b [n,nb], each row ascending -> out [n,na+nb] ascending */
+int nerf_merge_sorted(const float* a, int na, const float* b, int nb, int n, float* out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R2L_HIP_H */

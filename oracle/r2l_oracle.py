@@ -1,0 +1,380 @@
+"""CPU oracle for the R2L / NeRF-teacher ray-batched inference path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch-CPU fp32 restatement of the
+reference's algorithm (MingSun-Tse/Efficient-NeRF, paths cited per function as
+``file:line`` relative to the reference checkout).  It is the *checker* for the HIP
+path: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  Nothing under ``efficient-nerf_amd/`` imports it and the product
+path never falls back to it.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference's own
+``model/nerf_raybased.py`` and ``utils/run_nerf_raybased_helpers.py`` on CPU, runs them
+on seeded inputs and commits the inputs/outputs under ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` asserts every function here reproduces those vectors
+(bit-exact where the op sequence is the same, which is everywhere except the MLP
+GEMMs whose summation order is the BLAS's).
+
+All tensors are torch.float32 on CPU unless a function says otherwise.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# poses / camera (dataset/load_blender.py:10-28, 82, 106-109, 327-368)
+# --------------------------------------------------------------------------------------
+LEGO_CAMERA_ANGLE_X = 0.6911112070083618  # transforms_*.json of nerf_synthetic/lego
+
+
+def focal_from_angle(W, camera_angle_x=LEGO_CAMERA_ANGLE_X):
+    """dataset/load_blender.py:82  focal = .5 * W / np.tan(.5 * camera_angle_x)."""
+    return .5 * W / np.tan(.5 * camera_angle_x)
+
+
+def pose_spherical(theta, phi, radius):
+    """dataset/load_blender.py:10-28 (trans_t, rot_phi, rot_theta, pose_spherical)."""
+    trans_t = torch.Tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius],
+                            [0, 0, 0, 1]]).float()
+    ph = phi / 180. * np.pi
+    rot_phi = torch.Tensor([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0],
+                            [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]]).float()
+    th = theta / 180. * np.pi
+    rot_theta = torch.Tensor([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0],
+                              [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]]).float()
+    c2w = trans_t
+    c2w = rot_phi @ c2w
+    c2w = rot_theta @ c2w
+    c2w = torch.Tensor([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0],
+                        [0, 0, 0, 1]]) @ c2w
+    return c2w
+
+
+def novel_poses(n_pose, phi=-30., radius=4.):
+    """dataset/load_blender.py:327-333 (get_novel_poses, int case): even thetas."""
+    thetas = np.linspace(-180, 180, n_pose + 1)[:-1]
+    return torch.stack([pose_spherical(t, phi, radius) for t in thetas], 0)
+
+
+def rand_poses(n_pose, seed=0):
+    """dataset/load_blender.py:359-368 (get_rand_pose) driven by one numpy stream."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_pose):
+        theta = -180 + rs.rand() * 360
+        phi = -90 + rs.rand() * 90
+        out.append(pose_spherical(theta, phi, 4))
+    return torch.stack(out, 0)
+
+
+# --------------------------------------------------------------------------------------
+# R2L: PointSampler / PositionalEmbedder / NeRF_v3_2  (model/nerf_raybased.py)
+# --------------------------------------------------------------------------------------
+def camera_dirs(H, W, focal):
+    """model/nerf_raybased.py:80-86 == utils/run_nerf_raybased_helpers.py:233-240.
+
+    dirs[h, w] = ((w - W/2)/focal, -(h - H/2)/focal, -1), no half-pixel offset."""
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H),
+                          indexing='ij')
+    i, j = i.t(), j.t()
+    return torch.stack([(i - W * .5) / focal, -(j - H * .5) / focal,
+                        -torch.ones_like(i)], dim=-1)  # [H, W, 3]
+
+
+def sampler_z_vals(n_sample, near, far):
+    """model/nerf_raybased.py:88-90."""
+    t_vals = torch.linspace(0., 1., steps=n_sample)
+    return near * (1 - t_vals) + far * (t_vals)
+
+
+def rays_from_dirs(dirs, c2w):
+    """model/nerf_raybased.py:95-99 / helpers:243-247: rays_d[k] = sum_j dirs[j]*c2w[k,j]."""
+    rays_d = torch.sum(dirs.unsqueeze(dim=-2) * c2w[:3, :3], dim=-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def get_rays(H, W, focal, c2w):
+    """utils/run_nerf_raybased_helpers.py:231-257 (trans_origin='', focal_scale=1)."""
+    return rays_from_dirs(camera_dirs(H, W, focal), c2w)
+
+
+def sample_test(dirs, z_vals, c2w):
+    """model/nerf_raybased.py:94-102 (PointSampler.sample_test): [H*W, n_sample*3]."""
+    rays_o, rays_d = rays_from_dirs(dirs, c2w)
+    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    return sample_rays(rays_o, rays_d, z_vals)
+
+
+def sample_rays(rays_o, rays_d, z_vals):
+    """model/nerf_raybased.py:114-126 (sample_train, perturb=0) == :100-102."""
+    z = z_vals[None, :].expand(rays_o.shape[0], z_vals.shape[0])
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+    return pts.reshape(pts.shape[0], -1)
+
+
+def positional_embed(x, L=10, include_input=True):
+    """model/nerf_raybased.py:191-208 (PositionalEmbedder.__call__).
+
+    out[r, c*(2L+1) + (l | L+l | 2L)] = (sin(x*2^l) | cos(x*2^l) | x)."""
+    weights = 2**torch.linspace(0, L - 1, steps=L)
+    y = x[..., None] * weights
+    y = torch.cat([torch.sin(y), torch.cos(y)], dim=-1)
+    if include_input:
+        y = torch.cat([y, x.unsqueeze(dim=-1)], dim=-1)
+    return y.reshape(y.shape[0], -1)
+
+
+def r2l_state_names(n_block=43):
+    names = ['head.0.weight', 'head.0.bias']
+    for i in range(n_block):
+        for j in (0, 2):
+            names += [f'body.{i}.body.{j}.weight', f'body.{i}.body.{j}.bias']
+    names += ['tail.0.weight', 'tail.0.bias']
+    return names
+
+
+def make_r2l_state(seed=0, netdepth=88, netwidth=256, input_dim=1008, body_gain=1.0):
+    """Seeded synthetic W{netwidth}D{netdepth} state_dict with nn.Linear default init.
+
+    Reproduces, RNG draw for RNG draw, what ``NeRF_v3_2.__init__`` does under
+    ``torch.manual_seed(seed)`` (model/nerf_raybased.py:483-537): head Linear, then the
+    D-2 plain Linear layers of the first ``body`` list (created and discarded when
+    ``--trial.body_arch resmlp`` replaces it, :503-524), then (D-2)//2 ResMLP blocks of
+    two Linear each (:443-457), then the tail Linear (:534-537)."""
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    D, W = netdepth, netwidth
+    sd = OrderedDict()
+    head = nn.Linear(input_dim, W)
+    sd['head.0.weight'], sd['head.0.bias'] = head.weight.data, head.bias.data
+    for _ in range(1, D - 1):
+        nn.Linear(W, W)  # first body list, discarded (same RNG consumption)
+    n_block = (D - 2) // 2
+    for i in range(n_block):
+        l0, l2 = nn.Linear(W, W), nn.Linear(W, W)
+        sd[f'body.{i}.body.0.weight'], sd[f'body.{i}.body.0.bias'] = l0.weight.data, l0.bias.data
+        sd[f'body.{i}.body.2.weight'], sd[f'body.{i}.body.2.bias'] = l2.weight.data, l2.bias.data
+    tail = nn.Linear(W, 3)
+    sd['tail.0.weight'], sd['tail.0.bias'] = tail.weight.data, tail.bias.data
+    torch.random.set_rng_state(g)
+    if body_gain != 1.0:
+        for k in sd:
+            if k.startswith('body.') and k.endswith('weight'):
+                sd[k] = sd[k] * body_gain
+    return sd
+
+
+def r2l_forward(sd, x, use_residual=True, res_scale=1.0, dtype=torch.float32,
+                return_layers=False):
+    """model/nerf_raybased.py:539-544 (NeRF_v3_2.forward) with ResMLP blocks :461-465.
+
+    head: ReLU(W x + b); body: x = (W2 ReLU(W1 x + b1) + b2)*res_scale + x, no outact;
+    global skip body(x)+x when use_residual; tail: sigmoid(W x + b)."""
+    n_block = sum(1 for k in sd if k.endswith('body.0.weight'))
+    c = lambda t: t.to(dtype)
+    x = c(x)
+    h = F.relu(F.linear(x, c(sd['head.0.weight']), c(sd['head.0.bias'])))
+    layers = [h]
+    h0 = h
+    for i in range(n_block):
+        t = F.relu(F.linear(h, c(sd[f'body.{i}.body.0.weight']), c(sd[f'body.{i}.body.0.bias'])))
+        h = F.linear(t, c(sd[f'body.{i}.body.2.weight']), c(sd[f'body.{i}.body.2.bias'])).mul(res_scale) + h
+        if return_layers:
+            layers.append(h)
+    if use_residual:
+        h = h + h0
+    out = torch.sigmoid(F.linear(h, c(sd['tail.0.weight']), c(sd['tail.0.bias'])))
+    return (out, layers) if return_layers else out
+
+
+def r2l_render(sd, H, W, focal, c2w, near=2., far=6., n_sample=16, L=10, chunk=40000,
+               rows=None, dtype=torch.float32):
+    """main.py:401-404 render_func == main.py:300-309: model(embed(sample_test(c2w)))."""
+    dirs = camera_dirs(H, W, focal)
+    if rows is not None:
+        dirs = dirs[rows[0]:rows[1]]
+    z = sampler_z_vals(n_sample, near, far)
+    pts = sample_test(dirs, z, c2w[:3, :4])
+    outs = []
+    with torch.no_grad():
+        for s in range(0, pts.shape[0], chunk):
+            outs.append(r2l_forward(sd, positional_embed(pts[s:s + chunk], L), dtype=dtype))
+    return torch.cat(outs, 0).float()
+
+
+# --------------------------------------------------------------------------------------
+# NeRF teacher: Embedder / NeRF / run_network / raw2outputs / sample_pdf / render_rays
+# --------------------------------------------------------------------------------------
+def nerf_embed(x, multires):
+    """utils/run_nerf_raybased_helpers.py:24-56: [x, sin(2^0 x), cos(2^0 x), ...]."""
+    freq_bands = 2.**torch.linspace(0., multires - 1, steps=multires)
+    outs = [x]
+    for freq in freq_bands:
+        outs.append(torch.sin(x * freq))
+        outs.append(torch.cos(x * freq))
+    return torch.cat(outs, -1)
+
+
+def teacher_state_names():
+    names = []
+    for i in range(8):
+        names += [f'pts_linears.{i}.weight', f'pts_linears.{i}.bias']
+    names += ['views_linears.0.weight', 'views_linears.0.bias', 'feature_linear.weight',
+              'feature_linear.bias', 'alpha_linear.weight', 'alpha_linear.bias',
+              'rgb_linear.weight', 'rgb_linear.bias']
+    return names
+
+
+def make_teacher_state(seed=0, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,),
+                       sigma_bias_shift=0.5):
+    """Seeded synthetic NeRF(D=8,W=256,use_viewdirs) state_dict, nn.Linear default init,
+    module creation order of model/nerf_raybased.py:357-375."""
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    sd = OrderedDict()
+    lins = [nn.Linear(input_ch, W)] + [
+        nn.Linear(W, W) if i not in skips else nn.Linear(W + input_ch, W) for i in range(D - 1)]
+    views = nn.Linear(input_ch_views + W, W // 2)
+    feature, alpha, rgb = nn.Linear(W, W), nn.Linear(W, 1), nn.Linear(W // 2, 3)
+    for i, l in enumerate(lins):
+        sd[f'pts_linears.{i}.weight'], sd[f'pts_linears.{i}.bias'] = l.weight.data, l.bias.data
+    sd['views_linears.0.weight'], sd['views_linears.0.bias'] = views.weight.data, views.bias.data
+    sd['feature_linear.weight'], sd['feature_linear.bias'] = feature.weight.data, feature.bias.data
+    sd['alpha_linear.weight'], sd['alpha_linear.bias'] = alpha.weight.data, alpha.bias.data + sigma_bias_shift
+    sd['rgb_linear.weight'], sd['rgb_linear.bias'] = rgb.weight.data, rgb.bias.data
+    torch.random.set_rng_state(g)
+    return sd
+
+
+def teacher_forward(sd, x, input_ch=63, skips=(4,), dtype=torch.float32):
+    """model/nerf_raybased.py:377-401 (NeRF.forward, use_viewdirs=True)."""
+    c = lambda t: t.to(dtype)
+    x = c(x)
+    input_pts, input_views = x[..., :input_ch], x[..., input_ch:]
+    h = input_pts
+    for i in range(8):
+        h = F.relu(F.linear(h, c(sd[f'pts_linears.{i}.weight']), c(sd[f'pts_linears.{i}.bias'])))
+        if i in skips:
+            h = torch.cat([input_pts, h], -1)
+    alpha = F.linear(h, c(sd['alpha_linear.weight']), c(sd['alpha_linear.bias']))
+    feature = F.linear(h, c(sd['feature_linear.weight']), c(sd['feature_linear.bias']))
+    h = torch.cat([feature, input_views], -1)
+    h = F.relu(F.linear(h, c(sd['views_linears.0.weight']), c(sd['views_linears.0.bias'])))
+    rgb = F.linear(h, c(sd['rgb_linear.weight']), c(sd['rgb_linear.bias']))
+    return torch.cat([rgb, alpha], -1)
+
+
+def run_network(sd, pts, viewdirs, multires=10, multires_views=4, netchunk=1024 * 64,
+                dtype=torch.float32):
+    """main.py:65-87 (run_network): embed pts + expanded viewdirs, MLP in netchunk slices."""
+    inputs_flat = pts.reshape(-1, 3)
+    embedded = nerf_embed(inputs_flat, multires)
+    input_dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)
+    embedded = torch.cat([embedded, nerf_embed(input_dirs, multires_views)], -1)
+    outs = [teacher_forward(sd, embedded[i:i + netchunk], dtype=dtype)
+            for i in range(0, embedded.shape[0], netchunk)]
+    return torch.cat(outs, 0).reshape(list(pts.shape[:-1]) + [4]).float()
+
+
+def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
+    """main.py:556-621 (raw_noise_std=0): alpha-compositing along the ray."""
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.Tensor([1e10]).expand(dists[..., :1].shape)], -1)
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+    rgb = torch.sigmoid(raw[..., :3])
+    alpha = 1. - torch.exp(-F.relu(raw[..., 3]) * dists)
+    weights = alpha * torch.cumprod(
+        torch.cat([torch.ones((alpha.shape[0], 1)), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+    rgb_map = torch.sum(weights[..., None] * rgb, -2)
+    depth_map = torch.sum(weights * z_vals, -1)
+    disp_map = 1. / torch.max(1e-10 * torch.ones_like(depth_map),
+                              depth_map / torch.sum(weights, -1))
+    acc_map = torch.sum(weights, -1)
+    if white_bkgd:
+        rgb_map = rgb_map + (1. - acc_map[..., None])
+    return rgb_map, disp_map, acc_map, weights, depth_map
+
+
+def sample_pdf(bins, weights, N_samples, det=True):
+    """utils/run_nerf_raybased_helpers.py:283-330 (det=True, pytest=False)."""
+    assert det, 'only the deterministic (perturb==0) test path is on the hot path'
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    u = torch.linspace(0., 1., steps=N_samples)
+    u = u.expand(list(cdf.shape[:-1]) + [N_samples]).contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    inds_g = torch.stack([below, above], -1)
+    matched_shape = [inds_g.shape[0], inds_g.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(matched_shape), 2, inds_g)
+    denom = (cdf_g[..., 1] - cdf_g[..., 0])
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+
+
+def coarse_z_vals(near, far, N_samples, n_rays):
+    """main.py:676-682 (lindisp=False, perturb=0)."""
+    t_vals = torch.linspace(0., 1., steps=N_samples)
+    z_vals = near * (1. - t_vals) + far * (t_vals)
+    return z_vals.expand([n_rays, N_samples])
+
+
+def merge_z(z_vals, z_samples):
+    """main.py:730-732: sort(cat(coarse, fine))."""
+    return torch.sort(torch.cat([z_vals, z_samples], -1), -1)[0]
+
+
+def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=64,
+                N_importance=128, white_bkgd=True, dtype=torch.float32):
+    """main.py:624-756 (render_rays) + main.py:148-157 (viewdirs), perturb=0, no noise."""
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    n = rays_o.shape[0]
+    near_t = near * torch.ones_like(rays_d[..., :1])
+    far_t = far * torch.ones_like(rays_d[..., :1])
+    t_vals = torch.linspace(0., 1., steps=N_samples)
+    z_vals = near_t * (1. - t_vals) + far_t * (t_vals)  # [n, N_samples] (main.py:673-682)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw0 = run_network(sd_coarse, pts, viewdirs, dtype=dtype)
+    rgb0, disp0, acc0, weights0, depth0 = raw2outputs(raw0, z_vals, rays_d, white_bkgd)
+    z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    z_samples = sample_pdf(z_mid, weights0[..., 1:-1], N_importance, det=True)
+    z_all = merge_z(z_vals, z_samples)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
+    raw = run_network(sd_fine, pts, viewdirs, dtype=dtype)
+    rgb, disp, acc, weights, depth = raw2outputs(raw, z_all, rays_d, white_bkgd)
+    return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, rgb0=rgb0,
+                disp0=disp0, acc0=acc0, weights0=weights0, z_samples=z_samples, z_vals=z_all,
+                raw0=raw0, raw=raw, z_std=torch.std(z_samples, dim=-1, unbiased=False))
+
+
+def teacher_render(sd_coarse, sd_fine, H, W, focal, c2w, rows=None, chunk=4096, **kw):
+    """main.py:107-186 (render, c2w given, ndc=False, use_viewdirs=True) over a row range."""
+    rays_o, rays_d = get_rays(H, W, focal, c2w[:3, :4])
+    if rows is not None:
+        rays_o, rays_d = rays_o[rows[0]:rows[1]], rays_d[rows[0]:rows[1]]
+    rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    outs = []
+    with torch.no_grad():
+        for s in range(0, rays_o.shape[0], chunk):
+            outs.append(render_rays(sd_coarse, sd_fine, rays_o[s:s + chunk], rays_d[s:s + chunk], **kw))
+    return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+
+
+# --------------------------------------------------------------------------------------
+# metrics (utils/run_nerf_raybased_helpers.py:19-20)
+# --------------------------------------------------------------------------------------
+def mse2psnr(mse):
+    return -10. * math.log10(max(float(mse), 1e-30))
+
+
+def psnr(a, b):
+    return mse2psnr(torch.mean((a.double() - b.double())**2))
