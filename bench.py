@@ -25,6 +25,18 @@ N_BLOCK = 43  # W256 D88
 PEAK_FP16_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA (guides/MI355X_MICROARCH.md)
 
 
+def cpu_threads():
+    """Host cores this process may use: the scheduler affinity, capped at the GPU box's
+    per-GPU CPU share (16); override with R2L_CPU_THREADS."""
+    if 'R2L_CPU_THREADS' in os.environ:
+        return int(os.environ['R2L_CPU_THREADS'])
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -113,7 +125,7 @@ def main():
         c2w = poses[0]
         gpu = eng.render(c2w, rows=(0, n_cpu_rows)).cpu()
         if not args.no_cpu_baseline and world == 1:
-            torch.set_num_threads(os.cpu_count() or 1)
+            torch.set_num_threads(cpu_threads())
             t1 = time.perf_counter()
             ref = O.r2l_render(sd, H, W, focal, c2w, rows=(0, n_cpu_rows), chunk=16384)
             t_cpu = time.perf_counter() - t1

@@ -300,6 +300,13 @@ int r2l_set_precision(r2l_ctx* c, int mode) {
     return R2L_OK;
 }
 
+int r2l_set_z_vals(r2l_ctx* c, const float* z_host, int n) {
+    if (!c || !z_host) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (n != R2L_NSAMPLE) return r2l_set_error(R2L_EINVAL, "expected %d z values, got %d", R2L_NSAMPLE, n);
+    memcpy(c->z, z_host, sizeof c->z);
+    return R2L_OK;
+}
+
 // ---- launches --------------------------------------------------------------------------
 static void fill_common(const r2l_ctx* c, R2LParams& p) {
     memset(&p, 0, sizeof p);

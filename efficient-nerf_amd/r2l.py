@@ -41,7 +41,7 @@ class R2LEngine:
     """One r2l_ctx: geometry + weights + launches (include/r2l_hip.h)."""
 
     def __init__(self, H, W, focal, near=2., far=6., n_sample=16, L=10, width=256, n_block=43,
-                 use_residual=True, precision=PREC_FP16X3, device=None):
+                 use_residual=True, precision=PREC_FP16X3, device=None, z_vals=None):
         self.device = _dev(device)
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.n_block = int(n_block)
@@ -52,6 +52,17 @@ class R2LEngine:
                                    int(precision)))
         self.precision = int(precision)
         self._loaded = False
+        # model/nerf_raybased.py:88-90, evaluated with the host's torch exactly as the
+        # reference does (torch.linspace's last ulp depends on the CPU vector width)
+        if z_vals is None:
+            t_vals = torch.linspace(0., 1., steps=int(n_sample))
+            z_vals = float(near) * (1 - t_vals) + float(far) * (t_vals)
+        self.set_z_vals(z_vals)
+
+    def set_z_vals(self, z_vals):
+        z = torch.as_tensor(z_vals).detach().to('cpu', torch.float32).contiguous()
+        check(lib().r2l_set_z_vals(self._ctx, C.c_void_p(z.data_ptr()), z.numel()))
+        self.z_vals = z
 
     def close(self):
         if getattr(self, '_ctx', None) and self._ctx.value:

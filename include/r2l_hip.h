@@ -77,6 +77,12 @@ void r2l_destroy(r2l_ctx* ctx);
  *   tail.0.weight[3,256], tail.0.bias[3]                                            */
 int r2l_load_weights(r2l_ctx* ctx, const float* const* tensors, int n_tensors);
 int r2l_set_precision(r2l_ctx* ctx, int precision_mode);
+/* Override PointSampler.z_vals (model/nerf_raybased.py:88-90).  r2l_create fills them with
+ * near*(1-t)+far*t, t = linspace(0,1,n) by the scalar formula; torch.linspace on the CPU is
+ * vector-width dependent in the last ulp (AVX2 vs AVX-512 builds differ), so a front-end
+ * that wants bit-identical points to the reference running on the same host passes the
+ * tensor the reference would have computed.  z_host: n_sample floats on the host. */
+int r2l_set_z_vals(r2l_ctx* ctx, const float* z_host, int n);
 
 /* Render rows [row_begin,row_end) of n_pose frames.  c2w: n_pose x [3,4] row-major f32
  * (the reference's c2w[:3,:4]), on the host if c2w_on_device == 0 (n_pose must be 1) or
