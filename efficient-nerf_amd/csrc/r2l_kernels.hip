@@ -176,6 +176,12 @@ struct KCfg {
     static constexpr int LDS = NBUF * CH;
 };
 
+template <int NP>
+struct AFrag {  // one A (weight) fragment: hi [, lo]
+    f16x8 h, l;
+};
+
+template <int NP>
 struct Ring {
     const char* wimg;   // chunk stream of one ray tile (periodic)
     int cpt;            // chunks per tile
@@ -183,21 +189,26 @@ struct Ring {
     uint32_t issue_off; // LDS byte offset of the slot it goes to
     uint32_t use_off;   // LDS byte offset of the chunk being consumed
     int wave, lane;
+    AFrag<NP> pre;      // fragment 0 of the chunk at use_off, already read from LDS
 };
 
+// LDS-DMA of one chunk with `global_load_lds_dwordx4 v_off, s[base:base+1]` (scalar base +
+// one 32-bit VGPR offset = lane*16, no 64-bit per-lane address math).  MUBUF `... lds`
+// loads are not usable here: their LDS base is M0[15:0] and the ring spans > 64 KiB.
 template <int NP>
-__device__ __forceinline__ void ring_issue(Ring& R) {
+__device__ __forceinline__ void ring_issue(Ring<NP>& R) {
     typedef KCfg<NP> C;
-    const char* src = R.wimg + (size_t)R.issue_pos * C::CH;
-    const uint32_t dst = R.issue_off;
+    const char* src = R.wimg + (size_t)R.issue_pos * C::CH + R.wave * (4 * NP * R2L_FRAG_BYTES);
+    const uint32_t dst = R.issue_off + R.wave * (4 * NP * R2L_FRAG_BYTES);
+    const uint32_t voff = (uint32_t)R.lane * 16u;
 #pragma unroll
     for (int q = 0; q < 4 * NP; ++q) {
-        const int off = (R.wave * 4 * NP + q) * R2L_FRAG_BYTES;
-        __builtin_amdgcn_global_load_lds(AS1(src + off + R.lane * 16), AS3(smem + dst + off), 16,
-                                         0, 0);
+        __builtin_amdgcn_global_load_lds(AS1(src + q * R2L_FRAG_BYTES + voff), AS3(smem + dst + q * R2L_FRAG_BYTES),
+                                         16, 0, 0);
     }
-    __builtin_amdgcn_global_load_lds(AS1(src + C::AUX + R.wave * 256 + R.lane * 4),
-                                     AS3(smem + dst + C::AUX + R.wave * 256), 4, 0, 0);
+    const char* asrc = R.wimg + (size_t)R.issue_pos * C::CH + C::AUX + R.wave * 256;
+    __builtin_amdgcn_global_load_lds(AS1(asrc + (uint32_t)R.lane * 4u), AS3(smem + R.issue_off + C::AUX + R.wave * 256),
+                                     4, 0, 0);
     R.issue_pos = (R.issue_pos + 1 == R.cpt) ? 0 : R.issue_pos + 1;
     R.issue_off = (R.issue_off + C::CH == (uint32_t)C::LDS) ? 0u : R.issue_off + C::CH;
 }
@@ -208,24 +219,44 @@ __device__ __forceinline__ void ring_issue(Ring& R) {
 // landed (counted vmcnt, then the barrier), every wave is past chunk c-1, so its slot is
 // refilled with chunk c+D.
 template <int NP>
-__device__ __forceinline__ void ring_mid(Ring& R) {
+__device__ __forceinline__ void ring_mid(Ring<NP>& R) {
     R2L_WAIT_VMCNT(KCfg<NP>::WAIT_MID);
     __builtin_amdgcn_s_barrier();
     ring_issue<NP>(R);
 }
 
 template <int NP>
-__device__ __forceinline__ void ring_next(Ring& R) {
+__device__ __forceinline__ uint32_t ring_next_off(uint32_t off) {
     typedef KCfg<NP> C;
-    R.use_off = (R.use_off + C::CH == (uint32_t)C::LDS) ? 0u : R.use_off + C::CH;
+    return (off + C::CH == (uint32_t)C::LDS) ? 0u : off + C::CH;
 }
 
 template <int NP>
-__device__ __forceinline__ f16x8 lds_frag(uint32_t lane_base, int frag, int part) {
-    return *reinterpret_cast<const f16x8*>(smem + lane_base + (frag * NP + part) * R2L_FRAG_BYTES);
+__device__ __forceinline__ void ring_next(Ring<NP>& R) {
+    R.use_off = ring_next_off<NP>(R.use_off);
+}
+
+template <int NP>
+__device__ __forceinline__ AFrag<NP> read_frag(uint32_t lane_base, int frag) {
+    AFrag<NP> a;
+    a.h = *reinterpret_cast<const f16x8*>(smem + lane_base + (frag * NP) * R2L_FRAG_BYTES);
+    if (NP == 2) a.l = *reinterpret_cast<const f16x8*>(smem + lane_base + (frag * NP + 1) * R2L_FRAG_BYTES);
+    return a;
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// one k-step on one 32x32 output tile: ah*bh [+ ah*bl + al*bh]
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_step(const AFrag<NP>& a, const f16x8& bh, const f16x8& bl,
+                                            f32x16 acc) {
+    acc = MFMA(a.h, bh, acc);
+    if (NP == 2) {
+        acc = MFMA(a.h, bl, acc);
+        acc = MFMA(a.l, bh, acc);
+    }
+    return acc;
+}
 
 // split an fp32 activation (already multiplied by act_scale) into fp16 hi (+ lo)
 template <int NP>
@@ -233,20 +264,6 @@ __device__ __forceinline__ void split_store(float a, f16x8& hi, f16x8& lo, int j
     f16 h = (f16)a;
     hi[j] = h;
     if (NP == 2) lo[j] = (f16)(a - (float)h);
-}
-
-// one MFMA k-step on one 32x32 output tile
-template <int NP>
-__device__ __forceinline__ f32x16 kstep(uint32_t lane_base, int frag, const f16x8& bh,
-                                        const f16x8& bl, f32x16 acc) {
-    f16x8 ah = lds_frag<NP>(lane_base, frag, 0);
-    acc = MFMA(ah, bh, acc);
-    if (NP == 2) {
-        f16x8 al = lds_frag<NP>(lane_base, frag, 1);
-        acc = MFMA(ah, bl, acc);
-        acc = MFMA(al, bh, acc);
-    }
-    return acc;
 }
 
 // accumulator init = aux[tile_off + 8g + 4h + i] (bias pre-multiplied by the layer scale)
@@ -270,43 +287,84 @@ __device__ __forceinline__ float aux_inv_scale(uint32_t slot_off) {
     return *reinterpret_cast<const float*>(smem + slot_off + KCfg<NP>::AUX + 32 * 4);
 }
 
-// One body Linear(256,256): in = (Bh,Bl) fragments, out fragments -> (Nh,Nl).
-// SECOND = false: out = relu(W in + b)            (ResMLP body.0 + inact)
-// SECOND = true : x   = x + (W in + b); out = x   (ResMLP body.2 + residual)
+// epilogue of one accumulator register of feature tile t:
+// SECOND = false: out = relu(acc/scale)              (ResMLP body.0 + inact)
+// SECOND = true : x = x + acc/scale; out = x         (ResMLP body.2 + residual)
 template <int NP, bool SECOND>
-__device__ __forceinline__ void body_layer(Ring& R, const f16x8 (&Bh)[16], const f16x8 (&Bl)[16],
+__device__ __forceinline__ void epi_reg(const f32x16& acc, float inv, f32x16& xt, f16x8 (&Nh)[16],
+                                        f16x8 (&Nl)[16], int t, int reg, float act_scale) {
+    float v;
+    if (!SECOND) {
+        v = fmaxf(acc[reg] * inv, 0.0f);
+    } else {
+        v = fmaf(acc[reg], inv, xt[reg]);
+        xt[reg] = v;
+    }
+    split_store<NP>(v * act_scale, Nh[2 * t + (reg >> 3)], Nl[2 * t + (reg >> 3)], reg & 7);
+}
+
+// 16 k-steps of one feature tile (one chunk), A fragments prefetched one step ahead (the
+// last step prefetches fragment 0 of the next chunk, certified by this chunk's ring_mid).
+// While the MFMAs of tile t run, the VALU epilogue of tile t-1 (`prev`) is interleaved,
+// one accumulator register per k-step.
+template <int NP, bool SECOND, bool HAVE_PREV>
+__device__ __forceinline__ f32x16 body_tile(Ring<NP>& R, const f16x8 (&Bh)[16], const f16x8 (&Bl)[16],
+                                            f16x8 (&Nh)[16], f16x8 (&Nl)[16], const f32x16& prev,
+                                            float inv, f32x16& xprev, int tprev, float act_scale,
+                                            int h) {
+    const uint32_t slot = R.use_off;
+    const uint32_t lane_base = slot + R.lane * 16;
+    const uint32_t next_base = ring_next_off<NP>(slot) + R.lane * 16;
+    f32x16 acc = acc_init<NP>(slot, 0, h);
+    AFrag<NP> cur = R.pre;
+#pragma unroll
+    for (int ks = 0; ks < R2L_KSTEPS; ++ks) {
+        if (ks == R2L_KSTEPS / 2) ring_mid<NP>(R);
+        AFrag<NP> nxt = (ks + 1 < R2L_KSTEPS) ? read_frag<NP>(lane_base, ks + 1) : read_frag<NP>(next_base, 0);
+        acc = mfma_step<NP>(cur, Bh[ks], Bl[ks], acc);
+        if (HAVE_PREV) epi_reg<NP, SECOND>(prev, inv, xprev, Nh, Nl, tprev, ks, act_scale);
+        cur = nxt;
+    }
+    R.pre = cur;
+    ring_next<NP>(R);
+    return acc;
+}
+
+// One body Linear(256,256): in = (Bh,Bl) fragments, out fragments -> (Nh,Nl).
+template <int NP, bool SECOND>
+__device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[16], const f16x8 (&Bl)[16],
                                            f16x8 (&Nh)[16], f16x8 (&Nl)[16], f32x16 (&x)[8],
                                            float act_scale, int h) {
+    const float inv = aux_inv_scale<NP>(R.use_off);  // same for the 8 chunks of a layer
+    f32x16 prev = body_tile<NP, SECOND, false>(R, Bh, Bl, Nh, Nl, x[0], inv, x[0], 0, act_scale, h);
 #pragma unroll
-    for (int t = 0; t < R2L_NTILE; ++t) {
-        const uint32_t slot = R.use_off;
-        const uint32_t lane_base = slot + R.lane * 16;
-        f32x16 acc = acc_init<NP>(slot, 0, h);
-        const float inv = aux_inv_scale<NP>(slot);
+    for (int t = 1; t < R2L_NTILE; ++t)
+        prev = body_tile<NP, SECOND, true>(R, Bh, Bl, Nh, Nl, prev, inv, x[t - 1], t - 1, act_scale, h);
 #pragma unroll
-        for (int ks = 0; ks < R2L_KSTEPS; ++ks) {
-            if (ks == R2L_KSTEPS / 2) ring_mid<NP>(R);
-            acc = kstep<NP>(lane_base, ks, Bh[ks], Bl[ks], acc);
-        }
-        ring_next<NP>(R);
+    for (int reg = 0; reg < 16; ++reg)
+        epi_reg<NP, SECOND>(prev, inv, x[R2L_NTILE - 1], Nh, Nl, R2L_NTILE - 1, reg, act_scale);
+}
+
+// one head k-step: 8 feature tiles against one generated B fragment (fragments ksl*8 + t)
+template <int NP>
+__device__ __forceinline__ void head_kstep(Ring<NP>& R, int ksl, const f16x8& bh, const f16x8& bl,
+                                           f32x16 (&x)[8]) {
+    const uint32_t lane_base = R.use_off + R.lane * 16;
+    const uint32_t next_base = ring_next_off<NP>(R.use_off) + R.lane * 16;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            float v;
-            if (!SECOND) {
-                v = fmaxf(acc[reg] * inv, 0.0f);
-            } else {
-                v = fmaf(acc[reg], inv, x[t][reg]);
-                x[t][reg] = v;
-            }
-            split_store<NP>(v * act_scale, Nh[2 * t + (reg >> 3)], Nl[2 * t + (reg >> 3)], reg & 7);
-        }
+    for (int t = 0; t < 8; ++t) {
+        const int f = ksl * 8 + t;
+        AFrag<NP> nxt = (f + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, f + 1) : read_frag<NP>(next_base, 0);
+        x[t] = mfma_step<NP>(R.pre, bh, bl, x[t]);
+        R.pre = nxt;
     }
+    if (ksl == 0) ring_mid<NP>(R); else ring_next<NP>(R);
 }
 
 template <int NP>
 __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     typedef KCfg<NP> C;
-    Ring R;
+    Ring<NP> R;
     R.wimg = p.wimg;
     R.cpt = p.chunks_per_tile;
     R.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,11 +377,12 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     const float act_scale = p.act_scale;
     const bool is_cos = h != 0;
 
-    // prologue: D chunks in flight, chunk 0 certified
+    // prologue: D chunks in flight, chunk 0 certified, its fragment 0 in registers
 #pragma unroll
     for (int i = 0; i < C::D; ++i) ring_issue<NP>(R);
     R2L_WAIT_VMCNT(C::WAIT_PRO);
     __builtin_amdgcn_s_barrier();
+    R.pre = read_frag<NP>(lane * 16, 0);
 
     f32x16 x[8];
     f16x8 Bh[16], Bl[16], Nh[16], Nl[16];
@@ -353,10 +412,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                     split_store<NP>(trig_pow2(r, pw, is_cos) * act_scale, bh, bl, j);
                     pw *= 2.0f;
                 }
-                const uint32_t lane_base = R.use_off + lane * 16;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) x[t] = kstep<NP>(lane_base, (u & 1) * 8 + t, bh, bl, x[t]);
-                if ((u & 1) == 0) ring_mid<NP>(R); else ring_next<NP>(R);
+                head_kstep<NP>(R, u & 1, bh, bl, x);
             }
         }
         // phase 2: k-steps 48..59, four coordinates each, frequencies 8, 9
@@ -372,36 +428,27 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                     split_store<NP>(trig_pow2(r, 256.0f, is_cos) * act_scale, bh, bl, 2 * m);
                     split_store<NP>(trig_pow2(r, 512.0f, is_cos) * act_scale, bh, bl, 2 * m + 1);
                 }
-                const uint32_t lane_base = R.use_off + lane * 16;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) x[t] = kstep<NP>(lane_base, (u & 1) * 8 + t, bh, bl, x[t]);
-                if ((u & 1) == 0) ring_mid<NP>(R); else ring_next<NP>(R);
+                head_kstep<NP>(R, u & 1, bh, bl, x);
             }
         }
         // phase 3: k-steps 60..62 identity (coordinate 16*(ks-60) + 8h + j), k-step 63 = pad
-        float inv_head;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (u < 3) {
-                f16x8 bh, bl;
+        for (int u = 0; u < 3; ++u) {
+            f16x8 bh, bl;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c0 = 16 * u + j, c1 = c0 + 8;
-                    const float x0 = sample_pt(o[c0 % 3], d[c0 % 3], p.z[c0 / 3]);
-                    const float x1 = sample_pt(o[c1 % 3], d[c1 % 3], p.z[c1 / 3]);
-                    split_store<NP>((h ? x1 : x0) * act_scale, bh, bl, j);
-                }
-                const uint32_t lane_base = R.use_off + lane * 16;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) x[t] = kstep<NP>(lane_base, (u & 1) * 8 + t, bh, bl, x[t]);
+            for (int j = 0; j < 8; ++j) {
+                const int c0 = 16 * u + j, c1 = c0 + 8;
+                const float x0 = sample_pt(o[c0 % 3], d[c0 % 3], p.z[c0 / 3]);
+                const float x1 = sample_pt(o[c1 % 3], d[c1 % 3], p.z[c1 / 3]);
+                split_store<NP>((h ? x1 : x0) * act_scale, bh, bl, j);
             }
-            if ((u & 1) == 0) {
-                ring_mid<NP>(R);
-            } else {
-                if (u == 3) inv_head = aux_inv_scale<NP>(R.use_off);
-                ring_next<NP>(R);
-            }
+            head_kstep<NP>(R, u & 1, bh, bl, x);
         }
+        // pad k-step 63: no MFMAs; leave the chunk with the next chunk's fragment 0 prefetched
+        const float inv_head = aux_inv_scale<NP>(R.use_off);
+        R.pre = read_frag<NP>(ring_next_off<NP>(R.use_off) + lane * 16, 0);
+        ring_next<NP>(R);
+
         // head epilogue: h0 = relu(acc/scale); keep a copy for the global skip
         float* scr = p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
 #pragma unroll
@@ -447,16 +494,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             for (int reg = 0; reg < 16; ++reg)
                 split_store<NP>(x[t][reg] * act_scale, Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
         {
-            const uint32_t slot = R.use_off;
-            const uint32_t lane_base = slot + lane * 16;
-            f32x16 acc = acc_init<NP>(slot, 0, h);
-            const float inv = aux_inv_scale<NP>(slot);
-#pragma unroll
-            for (int ks = 0; ks < R2L_KSTEPS; ++ks) {
-                if (ks == R2L_KSTEPS / 2) ring_mid<NP>(R);
-                acc = kstep<NP>(lane_base, ks, Bh[ks], Bl[ks], acc);
-            }
-            ring_next<NP>(R);
+            const float inv = aux_inv_scale<NP>(R.use_off);
+            f32x16 acc = body_tile<NP, false, false>(R, Bh, Bl, Nh, Nl, x[0], inv, x[0], 0, act_scale, h);
             if (valid && h == 0) {
                 float* out = p.rgb + (size_t)ray * 3;
 #pragma unroll
