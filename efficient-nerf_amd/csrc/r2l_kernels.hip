@@ -192,84 +192,23 @@ struct Ring {
     AFrag<NP> pre;      // fragment 0 of the chunk at use_off, already read from LDS
 };
 
-// LDS-DMA of one chunk: per wave 4*NP x `global_load_lds_dwordx4` (1 KiB each) + one
-// `global_load_lds_dword` (256 B of the aux block), scalar base + 32-bit lane offset.
-// Issued from ONE inline-asm statement so that hipcc does not see them: with a
-// compiler-visible LDS-DMA permanently in flight (we never drain to vmcnt(0) in the loop)
-// SIInsertWaitcnts keeps "pending FLAT" set and turns every LDS-read wait into
-// lgkmcnt(0), which serialises the A-fragment prefetch.  M0 (the LDS destination base) is
-// saved/restored inside the statement; each M0 write is followed by >= 1 wait state
-// before the DMA that reads it.  Completion is tracked by hand (R2L_WAIT_VMCNT).
-// (MUBUF `... lds` loads are not usable: their LDS base is M0[15:0], the ring is > 64 KiB.)
+// LDS-DMA of one chunk with `global_load_lds_dwordx4 v_off, s[base:base+1]` (scalar base +
+// one 32-bit VGPR offset = lane*16, no 64-bit per-lane address math).  MUBUF `... lds`
+// loads are not usable here: their LDS base is M0[15:0] and the ring spans > 64 KiB.
 template <int NP>
 __device__ __forceinline__ void ring_issue(Ring<NP>& R) {
     typedef KCfg<NP> C;
     const char* src = R.wimg + (size_t)R.issue_pos * C::CH + R.wave * (4 * NP * R2L_FRAG_BYTES);
-    const char* asrc = R.wimg + (size_t)R.issue_pos * C::CH + C::AUX + R.wave * 256;
     const uint32_t dst = R.issue_off + R.wave * (4 * NP * R2L_FRAG_BYTES);
-    const uint32_t adst = R.issue_off + C::AUX + R.wave * 256;
     const uint32_t voff = (uint32_t)R.lane * 16u;
-    const uint32_t voff4 = (uint32_t)R.lane * 4u;
-    uint32_t keep, tv;
-    if (NP == 2) {
-        asm volatile(
-            "s_nop 4\n\t"  // SGPR operands may come from v_readlane/v_readfirstlane: 5 wait states before VMEM reads them
-            "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[dst]\n\t"
-            "v_add_u32 %[tv], 0x400, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[voff], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0x800, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0xc00, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0x1000, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0x1400, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0x1800, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0x1c00, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_mov_b32 m0, %[adst]\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dword %[voff4], %[asrc]\n\t"
-            "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep), [tv] "=&v"(tv)
-            : [dst] "s"(dst), [adst] "s"(adst), [voff] "v"(voff), [voff4] "v"(voff4), [src] "s"(src), [asrc] "s"(asrc)
-            : "memory", "scc");  // s_add_u32 writes SCC
-    } else {
-        asm volatile(
-            "s_nop 4\n\t"  // SGPR operands may come from v_readlane/v_readfirstlane: 5 wait states before VMEM reads them
-            "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[dst]\n\t"
-            "v_add_u32 %[tv], 0x400, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[voff], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0x800, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "v_add_u32 %[tv], 0xc00, %[voff]\n\t"
-            "global_load_lds_dwordx4 %[tv], %[src]\n\t"
-            "s_mov_b32 m0, %[adst]\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dword %[voff4], %[asrc]\n\t"
-            "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep), [tv] "=&v"(tv)
-            : [dst] "s"(dst), [adst] "s"(adst), [voff] "v"(voff), [voff4] "v"(voff4), [src] "s"(src), [asrc] "s"(asrc)
-            : "memory", "scc");  // s_add_u32 writes SCC
+#pragma unroll
+    for (int q = 0; q < 4 * NP; ++q) {
+        __builtin_amdgcn_global_load_lds(AS1(src + q * R2L_FRAG_BYTES + voff), AS3(smem + dst + q * R2L_FRAG_BYTES),
+                                         16, 0, 0);
     }
+    const char* asrc = R.wimg + (size_t)R.issue_pos * C::CH + C::AUX + R.wave * 256;
+    __builtin_amdgcn_global_load_lds(AS1(asrc + (uint32_t)R.lane * 4u), AS3(smem + R.issue_off + C::AUX + R.wave * 256),
+                                     4, 0, 0);
     R.issue_pos = (R.issue_pos + 1 == R.cpt) ? 0 : R.issue_pos + 1;
     R.issue_off = (R.issue_off + C::CH == (uint32_t)C::LDS) ? 0u : R.issue_off + C::CH;
 }
