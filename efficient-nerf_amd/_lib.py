@@ -6,7 +6,7 @@ PREC_FP16X3 = 0
 PREC_FP16X1 = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libr2l_hip.so')
+LIB_PATH = os.environ.get('R2L_LIB_PATH', os.path.join(_HERE, 'libr2l_hip.so'))  # override: ablation builds (tools/)
 
 
 class R2LError(RuntimeError):

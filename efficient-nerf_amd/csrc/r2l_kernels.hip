@@ -220,9 +220,18 @@ __device__ __forceinline__ void ring_issue(Ring<NP>& R) {
 // refilled with chunk c+D.
 template <int NP>
 __device__ __forceinline__ void ring_mid(Ring<NP>& R) {
+#ifdef R2L_ABL_NODMA  // ablation build: no rendezvous, no refill (LDS keeps the prologue's chunks)
+    return;
+#endif
+#ifndef R2L_ABL_NOWAIT
     R2L_WAIT_VMCNT(KCfg<NP>::WAIT_MID);
+#endif
+#ifndef R2L_ABL_NOBARRIER
     __builtin_amdgcn_s_barrier();
+#endif
+#ifndef R2L_ABL_NOISSUE
     ring_issue<NP>(R);
+#endif
 }
 
 template <int NP>
@@ -293,6 +302,10 @@ __device__ __forceinline__ float aux_inv_scale(uint32_t slot_off) {
 template <int NP, bool SECOND>
 __device__ __forceinline__ void epi_reg(const f32x16& acc, float inv, f32x16& xt, f16x8 (&Nh)[16],
                                         f16x8 (&Nl)[16], int t, int reg, float act_scale) {
+#ifdef R2L_ABL_NOEPI  // ablation build: keep the accumulator live, skip the VALU epilogue
+    asm volatile("" ::"v"(acc[reg]));
+    return;
+#endif
     float v;
     if (!SECOND) {
         v = fmaxf(acc[reg] * inv, 0.0f);
@@ -470,8 +483,13 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
+#ifdef R2L_ABL_NOEPI
+            body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, h);
+            body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, h);
+#else
             body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, h);
             body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, h);
+#endif
         }
 
         // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------
