@@ -39,9 +39,15 @@ SIGNATURES = {
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'nerf_destroy': (None, [_vp]),
     'nerf_load_weights': (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.c_int]),
+    'nerf_set_precision': (C.c_int, [_vp, C.c_int]),
+    'nerf_set_sampling': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
+    'nerf_get_rays': (C.c_int, [C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'nerf_run_network': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'nerf_sample_pdf_u': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     'nerf_render': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'nerf_render_rays': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'nerf_last_extras': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    'nerf_copy_extras': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'nerf_raw2outputs': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nerf_sample_pdf': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'nerf_merge_sorted': (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),

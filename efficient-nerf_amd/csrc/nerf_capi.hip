@@ -1,17 +1,477 @@
-// C-ABI host side for the NeRF teacher (include/r2l_hip.h).  WORK IN PROGRESS: entry
-// points fail loudly until the kernels land.
+// C-ABI host side for the NeRF teacher (include/r2l_hip.h): context, host-side packing of
+// the 24 state_dict tensors into the MFMA fragment stream (nerf_common.h), and the
+// coarse -> importance-sample -> fine pipeline of render_rays (main.py:624-756).
 #include <hip/hip_runtime.h>
-#include "../../include/r2l_hip.h"
-#include "r2l_host_util.h"
-#include "nerf_kernels.h"
+#include <math.h>
+#include <string.h>
 
-#define NI(name) return r2l_set_error(R2L_EINVAL, name ": not implemented in this build")
-int nerf_create(nerf_ctx** out, int, int, double, float, float, int, int, int, int, int, int) { if (out) *out = nullptr; NI("nerf_create"); }
-void nerf_destroy(nerf_ctx*) {}
-int nerf_load_weights(nerf_ctx*, int, const float* const*, int) { NI("nerf_load_weights"); }
-int nerf_render(nerf_ctx*, const float*, int, int, float*, float*, float*, float*, void*) { NI("nerf_render"); }
-int nerf_render_rays(nerf_ctx*, const float*, const float*, int, float*, float*, float*, float*, void*) { NI("nerf_render_rays"); }
-int nerf_last_extras(nerf_ctx*, const float**, const float**, const float**, const float**) { NI("nerf_last_extras"); }
-int nerf_raw2outputs(const float*, const float*, const float*, int, int, int, float*, float*, float*, float*, float*, void*) { NI("nerf_raw2outputs"); }
-int nerf_sample_pdf(const float*, const float*, int, int, int, float*, void*) { NI("nerf_sample_pdf"); }
-int nerf_merge_sorted(const float*, int, const float*, int, int, float*, void*) { NI("nerf_merge_sorted"); }
+#include <functional>
+#include <vector>
+
+#include "../../include/r2l_hip.h"
+#include "nerf_common.h"
+#include "nerf_kernels.h"
+#include "r2l_host_util.h"
+
+namespace {
+
+struct PackedNet {
+    char* d_img[2] = {nullptr, nullptr};   // [precision mode]
+    float inv_scale[2][NERF_N_SCALES];
+    std::vector<std::vector<float>> host_w;  // 24 tensors, state_dict order
+    bool loaded = false;
+};
+
+// state_dict order (model/nerf_raybased.py:357-375)
+enum { T_PTS0_W = 0, T_VIEWS_W = 16, T_VIEWS_B = 17, T_FEAT_W = 18, T_FEAT_B = 19, T_ALPHA_W = 20, T_ALPHA_B = 21,
+       T_RGB_W = 22, T_RGB_B = 23 };
+const size_t kTensorNumel[24] = {
+    256 * 63, 256, 256 * 256, 256, 256 * 256, 256, 256 * 256, 256, 256 * 256, 256,  // pts_linears 0..4
+    256 * 319, 256, 256 * 256, 256, 256 * 256, 256,                                    // pts_linears 5..7
+    128 * 283, 128, 256 * 256, 256, 256, 1, 3 * 128, 3};
+
+int np_of(int mode) { return mode == R2L_PREC_FP16X3 ? 2 : 1; }
+
+void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
+    _Float16 hi, lo;
+    r2l_split_f16(v, &hi, np == 2 ? &lo : nullptr);
+    reinterpret_cast<_Float16*>(chunk + (size_t)(frag * np + 0) * R2L_FRAG_BYTES + lane * 16)[j] = hi;
+    if (np == 2) reinterpret_cast<_Float16*>(chunk + (size_t)(frag * np + 1) * R2L_FRAG_BYTES + lane * 16)[j] = lo;
+}
+
+// One layer of the fragment stream.  weight(row, col) returns W[row][col] (0 outside),
+// col_of(ks, h, j) the input column of k-step ks (or -1), bias(row) the bias.
+void pack_layer(std::vector<char>& img, int np, int F0, int KS, int NT, float Sa,
+                const std::function<float(int, int)>& weight, const std::function<int(int, int, int)>& col_of,
+                const std::function<float(int)>& bias, float Sw, float* inv_scale_out) {
+    const int CH = r2l_chunk_bytes(np);
+    const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
+    const float S = Sa * Sw;
+    for (int t = 0; t < NT; ++t) {
+        for (int ks = 0; ks < KS; ++ks) {
+            const int q = F0 + t * KS + ks;
+            char* chunk = img.data() + (size_t)(q / R2L_FRAGS) * CH;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int col = col_of(ks, lane >> 5, j);
+                    const float v = col < 0 ? 0.f : weight(32 * t + (lane & 31), col) * Sw;
+                    put_frag(chunk, np, q % R2L_FRAGS, lane, j, v);
+                }
+        }
+        const int q0 = F0 + t * KS;
+        float* aux = reinterpret_cast<float*>(img.data() + (size_t)(q0 / R2L_FRAGS) * CH + AUX);
+        for (int i = 0; i < 32; ++i) aux[32 * nerf_aux_slot(q0) + i] = bias(32 * t + i) * S;
+    }
+    *inv_scale_out = 1.0f / S;
+}
+
+float max_scale(std::initializer_list<std::pair<const float*, size_t>> ts) {
+    float m = 0.f;
+    for (auto& t : ts)
+        for (size_t i = 0; i < t.second; ++i) {
+            float a = fabsf(t.first[i]);
+            if (a > m && isfinite(a)) m = a;
+        }
+    return r2l_pow2_scale(&m, 1);
+}
+
+}  // namespace
+
+struct nerf_ctx {
+    int H, W, N_samples, N_importance, white_bkgd, mode, n_cu;
+    double focal;
+    float near_, far_, act_scale;
+    std::vector<float> z_coarse, u;  // host copies
+    float *d_zc = nullptr, *d_zmid = nullptr, *d_u = nullptr;
+    PackedNet net[2];
+    // per-call temporaries, grown on demand (sized for `cap` rays)
+    int cap = 0;
+    float *d_rays_o = nullptr, *d_rays_d = nullptr, *d_raw0 = nullptr, *d_w0 = nullptr, *d_zs = nullptr,
+          *d_zall = nullptr, *d_raw = nullptr, *d_rgb0 = nullptr, *d_disp0 = nullptr, *d_acc0 = nullptr;
+};
+
+static void free_tmp(nerf_ctx* c) {
+    float** ps[] = {&c->d_rays_o, &c->d_rays_d, &c->d_raw0, &c->d_w0, &c->d_zs, &c->d_zall, &c->d_raw,
+                    &c->d_rgb0, &c->d_disp0, &c->d_acc0};
+    for (auto p : ps)
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    c->cap = 0;
+}
+
+static int ensure_tmp(nerf_ctx* c, int n) {
+    if (n <= c->cap) return R2L_OK;
+    free_tmp(c);
+    const int S0 = c->N_samples, S1 = c->N_samples + c->N_importance;
+    struct { float** p; size_t numel; } req[] = {
+        {&c->d_rays_o, (size_t)n * 3}, {&c->d_rays_d, (size_t)n * 3}, {&c->d_raw0, (size_t)n * S0 * 4},
+        {&c->d_w0, (size_t)n * S0},    {&c->d_zs, (size_t)n * c->N_importance}, {&c->d_zall, (size_t)n * S1},
+        {&c->d_raw, (size_t)n * S1 * 4}, {&c->d_rgb0, (size_t)n * 3}, {&c->d_disp0, (size_t)n}, {&c->d_acc0, (size_t)n}};
+    for (auto& r : req) {
+        hipError_t e = hipMalloc((void**)r.p, r.numel * sizeof(float));
+        if (e != hipSuccess) {
+            free_tmp(c);
+            return r2l_set_error(R2L_EHIP, "hipMalloc temporaries for %d rays: %s", n, hipGetErrorString(e));
+        }
+    }
+    c->cap = n;
+    return R2L_OK;
+}
+
+static int upload_sampling(nerf_ctx* c) {
+    const int S = c->N_samples;
+    std::vector<float> zmid(S - 1);
+    for (int i = 0; i + 1 < S; ++i) {
+        volatile float s = c->z_coarse[i + 1] + c->z_coarse[i];  // .5 * (z[1:] + z[:-1])  (main.py:722)
+        volatile float m = .5f * s;
+        zmid[i] = m;
+    }
+    struct { float** d; const float* h; size_t n; } up[] = {
+        {&c->d_zc, c->z_coarse.data(), (size_t)S}, {&c->d_zmid, zmid.data(), (size_t)S - 1},
+        {&c->d_u, c->u.data(), (size_t)c->N_importance}};
+    for (auto& x : up) {
+        if (!*x.d) {
+            hipError_t e = hipMalloc((void**)x.d, x.n * sizeof(float));
+            if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc: %s", hipGetErrorString(e));
+        }
+        hipError_t e = hipMemcpy(*x.d, x.h, x.n * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy: %s", hipGetErrorString(e));
+    }
+    return R2L_OK;
+}
+
+int nerf_create(nerf_ctx** out, int H, int W, double focal, float near_, float far_, int N_samples, int N_importance,
+                int multires, int multires_views, int white_bkgd, int precision_mode) {
+    if (!out) return r2l_set_error(R2L_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (multires != 10 || multires_views != 4)
+        return r2l_set_error(R2L_EINVAL, "unsupported embedder multires=%d multires_views=%d (built for 10 / 4)",
+                             multires, multires_views);
+    if (N_samples < 2 || N_samples > 64 || N_importance < 1 || N_samples + N_importance > 256)
+        return r2l_set_error(R2L_EINVAL, "unsupported sampling N_samples=%d N_importance=%d (need 2..64 coarse, total <= 256)",
+                             N_samples, N_importance);
+    if (H <= 0 || W <= 0 || !(focal > 0)) return r2l_set_error(R2L_EINVAL, "bad geometry");
+    if (precision_mode != R2L_PREC_FP16X3 && precision_mode != R2L_PREC_FP16X1)
+        return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", precision_mode);
+    int n_cu = 0;
+    int rc = r2l_require_gfx950(&n_cu);
+    if (rc) return rc;
+    nerf_ctx* c = new nerf_ctx();
+    c->H = H; c->W = W; c->focal = focal; c->near_ = near_; c->far_ = far_;
+    c->N_samples = N_samples; c->N_importance = N_importance; c->white_bkgd = white_bkgd ? 1 : 0;
+    c->mode = precision_mode; c->n_cu = n_cu; c->act_scale = 16.0f;
+    c->z_coarse.resize(N_samples);
+    r2l_z_vals(N_samples, near_, far_, c->z_coarse.data());  // main.py:676-678
+    c->u.resize(N_importance);
+    r2l_linspace01(N_importance, c->u.data());               // helpers:293
+    rc = upload_sampling(c);
+    if (rc) {
+        nerf_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return R2L_OK;
+}
+
+void nerf_destroy(nerf_ctx* c) {
+    if (!c) return;
+    free_tmp(c);
+    for (auto& n : c->net)
+        for (int m = 0; m < 2; ++m)
+            if (n.d_img[m]) (void)hipFree(n.d_img[m]);
+    if (c->d_zc) (void)hipFree(c->d_zc);
+    if (c->d_zmid) (void)hipFree(c->d_zmid);
+    if (c->d_u) (void)hipFree(c->d_u);
+    delete c;
+}
+
+int nerf_set_sampling(nerf_ctx* c, const float* z_coarse_host, int n_z, const float* u_host, int n_u) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (z_coarse_host) {
+        if (n_z != c->N_samples) return r2l_set_error(R2L_EINVAL, "expected %d coarse z values, got %d", c->N_samples, n_z);
+        c->z_coarse.assign(z_coarse_host, z_coarse_host + n_z);
+    }
+    if (u_host) {
+        if (n_u != c->N_importance) return r2l_set_error(R2L_EINVAL, "expected %d u values, got %d", c->N_importance, n_u);
+        c->u.assign(u_host, u_host + n_u);
+    }
+    return upload_sampling(c);
+}
+
+static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
+    const int np = np_of(mode);
+    const int CH = r2l_chunk_bytes(np);
+    std::vector<char> img((size_t)NERF_CHUNKS * CH, 0);
+    const float Sa = c->act_scale;
+    auto& w = net.host_w;
+    float* inv = net.inv_scale[mode];
+    auto mat = [&](int ti, int ncol, int nrow) {
+        const float* p = w[ti].data();
+        return [p, ncol, nrow](int r, int col) -> float { return r < nrow ? p[(size_t)r * ncol + col] : 0.f; };
+    };
+    auto vec = [&](int ti, int nrow) {
+        const float* p = w[ti].data();
+        return [p, nrow](int r) -> float { return r < nrow ? p[r] : 0.f; };
+    };
+    auto kap = [](int ks, int h, int j) { return r2l_kappa(ks, h, j); };
+    // L0
+    pack_layer(img, np, NERF_F0_L0, 4, 8, Sa, mat(0, 63, 256), [](int ks, int h, int j) { return nerf_pts_col(ks, h, j); },
+               vec(1, 256), r2l_pow2_scale(w[0].data(), w[0].size()), &inv[0]);
+    // L1..L4, L6, L7
+    const int plain[6] = {1, 2, 3, 4, 6, 7};
+    for (int li : plain) {
+        const int F0 = li <= 4 ? NERF_F0_L1 + 128 * (li - 1) : NERF_F0_L6 + 128 * (li - 6);
+        pack_layer(img, np, F0, 16, 8, Sa, mat(2 * li, 256, 256), kap, vec(2 * li + 1, 256),
+                   r2l_pow2_scale(w[2 * li].data(), w[2 * li].size()), &inv[li]);
+    }
+    // L5: reference input = cat[input_pts(63), h(256)]  (model/nerf_raybased.py:385)
+    pack_layer(img, np, NERF_F0_L5, 20, 8, Sa, mat(10, 319, 256),
+               [](int ks, int h, int j) {
+                   if (ks < 16) return 63 + r2l_kappa(ks, h, j);
+                   const int cidx = nerf_pts_col(ks - 16, h, j);
+                   return cidx;
+               },
+               vec(11, 256), r2l_pow2_scale(w[10].data(), w[10].size()), &inv[5]);
+    // FA: rows 0..255 feature_linear, row 256 alpha_linear
+    {
+        const float* fw = w[T_FEAT_W].data();
+        const float* aw = w[T_ALPHA_W].data();
+        const float* fb = w[T_FEAT_B].data();
+        const float* ab = w[T_ALPHA_B].data();
+        const float Sw = max_scale({{fw, w[T_FEAT_W].size()}, {aw, w[T_ALPHA_W].size()}});
+        pack_layer(img, np, NERF_F0_FA, 16, 9, Sa,
+                   [=](int r, int col) -> float { return r < 256 ? fw[(size_t)r * 256 + col] : (r == 256 ? aw[col] : 0.f); },
+                   kap, [=](int r) -> float { return r < 256 ? fb[r] : (r == 256 ? ab[0] : 0.f); }, Sw, &inv[8]);
+    }
+    // V: reference input = cat[feature(256), input_views(27)]  (model/nerf_raybased.py:390)
+    pack_layer(img, np, NERF_F0_V, 18, 4, Sa, mat(T_VIEWS_W, 283, 128),
+               [](int ks, int h, int j) {
+                   if (ks < 16) return r2l_kappa(ks, h, j);
+                   const int cidx = nerf_view_col(ks - 16, h, j);
+                   return cidx < 0 ? -1 : 256 + cidx;
+               },
+               vec(T_VIEWS_B, 128), r2l_pow2_scale(w[T_VIEWS_W].data(), w[T_VIEWS_W].size()), &inv[9]);
+    // RGB
+    pack_layer(img, np, NERF_F0_RGB, 8, 1, Sa, mat(T_RGB_W, 128, 3), kap, vec(T_RGB_B, 3),
+               r2l_pow2_scale(w[T_RGB_W].data(), w[T_RGB_W].size()), &inv[10]);
+    if (net.d_img[mode]) {
+        (void)hipFree(net.d_img[mode]);
+        net.d_img[mode] = nullptr;
+    }
+    hipError_t e = hipMalloc((void**)&net.d_img[mode], img.size());
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc image: %s", hipGetErrorString(e));
+    e = hipMemcpy(net.d_img[mode], img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy image: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
+int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n_tensors) {
+    if (!c || !tensors) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (which != 0 && which != 1) return r2l_set_error(R2L_EINVAL, "which=%d (0 coarse, 1 fine)", which);
+    if (n_tensors != 24) return r2l_set_error(R2L_EINVAL, "expected 24 tensors (NeRF D=8 W=256 use_viewdirs), got %d", n_tensors);
+    PackedNet& net = c->net[which];
+    net.host_w.clear();
+    for (int i = 0; i < 24; ++i) {
+        if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
+        net.host_w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
+    }
+    for (int m = 0; m < 2; ++m)
+        if (net.d_img[m]) {
+            (void)hipFree(net.d_img[m]);
+            net.d_img[m] = nullptr;
+        }
+    int rc = build_net(c, net, c->mode);
+    if (rc) return rc;
+    net.loaded = true;
+    return R2L_OK;
+}
+
+int nerf_set_precision(nerf_ctx* c, int mode) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (mode != R2L_PREC_FP16X3 && mode != R2L_PREC_FP16X1) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
+    c->mode = mode;
+    for (auto& n : c->net)
+        if (n.loaded && !n.d_img[mode]) {
+            int rc = build_net(c, n, mode);
+            if (rc) return rc;
+        }
+    return R2L_OK;
+}
+
+static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* rays_d, const float* z, int z_stride,
+                   int S, int n, float* raw, hipStream_t s) {
+    NerfMlpParams p;
+    memset(&p, 0, sizeof p);
+    p.wimg = c->net[which].d_img[c->mode];
+    p.raw = raw;
+    p.rays_o = rays_o;
+    p.rays_d = rays_d;
+    p.z = z;
+    p.z_stride = z_stride;
+    p.S = S;
+    p.n_rays = n;
+    p.n_pts = (long long)n * S;
+    p.n_tiles = (int)((p.n_pts + NERF_TILE_PTS - 1) / NERF_TILE_PTS);
+    p.act_scale = c->act_scale;
+    memcpy(p.inv_scale, c->net[which].inv_scale[c->mode], sizeof p.inv_scale);
+    const int grid = p.n_tiles < c->n_cu ? p.n_tiles : c->n_cu;
+    hipError_t e = nerf_launch_mlp(p, np_of(c->mode), grid, s);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
+#define HIPCHK(call, what)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return r2l_set_error(R2L_EHIP, what ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+// render_rays (main.py:624-756) for n rays already in device memory
+static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d, int n, float* rgb, float* disp,
+                           float* acc, float* depth, hipStream_t s) {
+    const int S0 = c->N_samples, NI = c->N_importance, S1 = S0 + NI;
+    int rc = run_mlp(c, 0, rays_o, rays_d, c->d_zc, 0, S0, n, c->d_raw0, s);  // coarse network_fn
+    if (rc) return rc;
+    HIPCHK(nerf_launch_raw2outputs(c->d_raw0, c->d_zc, 0, rays_d, n, S0, c->white_bkgd, c->d_rgb0, c->d_disp0,
+                                   c->d_acc0, c->d_w0, nullptr, s), "raw2outputs(coarse)");
+    // sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=True)   (main.py:722-728)
+    HIPCHK(nerf_launch_sample_pdf(c->d_zmid, 0, c->d_w0, S0, 1, n, S0 - 1, c->d_u, NI, c->d_zs, s), "sample_pdf");
+    // z_vals = sort(cat(z_vals, z_samples))                                 (main.py:730-732)
+    HIPCHK(nerf_launch_merge(c->d_zc, 0, S0, c->d_zs, NI, n, c->d_zall, s), "merge");
+    rc = run_mlp(c, 1, rays_o, rays_d, c->d_zall, S1, S1, n, c->d_raw, s);   // network_fine
+    if (rc) return rc;
+    HIPCHK(nerf_launch_raw2outputs(c->d_raw, c->d_zall, S1, rays_d, n, S1, c->white_bkgd, rgb, disp, acc, nullptr,
+                                   depth, s), "raw2outputs(fine)");
+    return R2L_OK;
+}
+
+int nerf_render_rays(nerf_ctx* c, const float* rays_o_dev, const float* rays_d_dev, int n, float* rgb_dev,
+                     float* disp_dev, float* acc_dev, float* depth_dev, void* stream) {
+    if (!c || !rays_o_dev || !rays_d_dev || !rgb_dev) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (!c->net[0].loaded || !c->net[1].loaded)
+        return r2l_set_error(R2L_ESTATE, "nerf_render before nerf_load_weights of both networks");
+    if (n < 0) return r2l_set_error(R2L_EINVAL, "n=%d", n);
+    if (n == 0) return R2L_OK;
+    int rc = ensure_tmp(c, n);
+    if (rc) return rc;
+    return render_rays_dev(c, rays_o_dev, rays_d_dev, n, rgb_dev, disp_dev, acc_dev, depth_dev, (hipStream_t)stream);
+}
+
+int nerf_render(nerf_ctx* c, const float* c2w_host, int row_begin, int row_end, float* rgb_dev, float* disp_dev,
+                float* acc_dev, float* depth_dev, void* stream) {
+    if (!c || !c2w_host || !rgb_dev) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (!c->net[0].loaded || !c->net[1].loaded)
+        return r2l_set_error(R2L_ESTATE, "nerf_render before nerf_load_weights of both networks");
+    if (row_begin < 0 || row_end > c->H || row_begin >= row_end)
+        return r2l_set_error(R2L_EINVAL, "bad row range [%d,%d) for H=%d", row_begin, row_end, c->H);
+    const int n = (row_end - row_begin) * c->W;
+    int rc = ensure_tmp(c, n);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(nerf_launch_get_rays(c2w_host, c->W, (float)(c->W * .5), (float)(c->H * .5), (float)c->focal,
+                                row_begin * c->W, n, c->d_rays_o, c->d_rays_d, s), "get_rays");
+    return render_rays_dev(c, c->d_rays_o, c->d_rays_d, n, rgb_dev, disp_dev, acc_dev, depth_dev, s);
+}
+
+int nerf_last_extras(nerf_ctx* c, const float** rgb0, const float** z_samples, const float** z_vals,
+                     const float** raw_fine) {
+    if (!c || c->cap == 0) return r2l_set_error(R2L_ESTATE, "no render has run on this context");
+    if (rgb0) *rgb0 = c->d_rgb0;
+    if (z_samples) *z_samples = c->d_zs;
+    if (z_vals) *z_vals = c->d_zall;
+    if (raw_fine) *raw_fine = c->d_raw;
+    return R2L_OK;
+}
+
+int nerf_copy_extras(nerf_ctx* c, int n, float* rgb0_dev, float* z_samples_dev, float* z_vals_dev, float* raw_dev,
+                      void* stream) {
+    if (!c || c->cap == 0) return r2l_set_error(R2L_ESTATE, "no render has run on this context");
+    if (n < 0 || n > c->cap) return r2l_set_error(R2L_EINVAL, "n=%d exceeds the last render (%d rays)", n, c->cap);
+    const int S1 = c->N_samples + c->N_importance;
+    hipStream_t s = (hipStream_t)stream;
+    struct { float* dst; const float* src; size_t numel; } cp[] = {
+        {rgb0_dev, c->d_rgb0, (size_t)n * 3}, {z_samples_dev, c->d_zs, (size_t)n * c->N_importance},
+        {z_vals_dev, c->d_zall, (size_t)n * S1}, {raw_dev, c->d_raw, (size_t)n * S1 * 4}};
+    for (auto& x : cp)
+        if (x.dst) HIPCHK(hipMemcpyAsync(x.dst, x.src, x.numel * sizeof(float), hipMemcpyDeviceToDevice, s), "copy extras");
+    return R2L_OK;
+}
+
+int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_begin, int row_end, float* rays_o_dev,
+                  float* rays_d_dev, void* stream) {
+    if (!c2w_host || !rays_o_dev || !rays_d_dev || row_begin < 0 || row_end > H || row_begin >= row_end)
+        return r2l_set_error(R2L_EINVAL, "bad argument to nerf_get_rays");
+    int rc = r2l_require_gfx950(nullptr);
+    if (rc) return rc;
+    HIPCHK(nerf_launch_get_rays(c2w_host, W, (float)(W * .5), (float)(H * .5), (float)focal, row_begin * W,
+                                (row_end - row_begin) * W, rays_o_dev, rays_d_dev, (hipStream_t)stream), "get_rays");
+    return R2L_OK;
+}
+
+// run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
+int nerf_run_network(nerf_ctx* c, int which, const float* rays_o_dev, const float* rays_d_dev, const float* z_dev,
+                     int z_stride, int S, int n, float* raw_dev, void* stream) {
+    if (!c || !rays_o_dev || !rays_d_dev || !z_dev || !raw_dev) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (which != 0 && which != 1) return r2l_set_error(R2L_EINVAL, "which=%d", which);
+    if (!c->net[which].loaded) return r2l_set_error(R2L_ESTATE, "network %d not loaded", which);
+    if (S < 1 || n < 0 || (z_stride != 0 && z_stride < S)) return r2l_set_error(R2L_EINVAL, "bad S/n/z_stride");
+    if (n == 0) return R2L_OK;
+    return run_mlp(c, which, rays_o_dev, rays_d_dev, z_dev, z_stride, S, n, raw_dev, (hipStream_t)stream);
+}
+
+int nerf_raw2outputs(const float* raw, const float* z, const float* rays_d, int n, int S, int white_bkgd, float* rgb,
+                     float* disp, float* acc, float* weights, float* depth, void* stream) {
+    if (!raw || !z || !rays_d || n < 0 || S < 1 || S > 256)
+        return r2l_set_error(R2L_EINVAL, "bad argument to nerf_raw2outputs (S must be 1..256)");
+    int rc = r2l_require_gfx950(nullptr);
+    if (rc) return rc;
+    if (n == 0) return R2L_OK;
+    HIPCHK(nerf_launch_raw2outputs(raw, z, S, rays_d, n, S, white_bkgd, rgb, disp, acc, weights, depth,
+                                   (hipStream_t)stream), "raw2outputs");
+    return R2L_OK;
+}
+
+int nerf_sample_pdf(const float* bins, const float* weights, int n, int n_bins, int N, float* samples, void* stream) {
+    if (!bins || !weights || !samples || n < 0 || n_bins < 2 || n_bins > 64 || N < 1)
+        return r2l_set_error(R2L_EINVAL, "bad argument to nerf_sample_pdf (n_bins must be 2..64)");
+    int rc = r2l_require_gfx950(nullptr);
+    if (rc) return rc;
+    if (n == 0) return R2L_OK;
+    // u = torch.linspace(0, 1, N): scalar formula here; contexts carry the caller's tensor
+    std::vector<float> u(N);
+    r2l_linspace01(N, u.data());
+    float* d_u = nullptr;
+    HIPCHK(hipMalloc((void**)&d_u, N * sizeof(float)), "hipMalloc u");
+    hipError_t e = hipMemcpyAsync(d_u, u.data(), N * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);  // u lives on the host stack
+    if (e == hipSuccess)
+        e = nerf_launch_sample_pdf(bins, n_bins, weights, n_bins - 1, 0, n, n_bins, d_u, N, samples, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d_u);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "sample_pdf: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
+int nerf_sample_pdf_u(const float* bins, const float* weights, int n, int n_bins, const float* u_dev, int N,
+                      float* samples, void* stream) {
+    if (!bins || !weights || !samples || !u_dev || n < 0 || n_bins < 2 || n_bins > 64 || N < 1)
+        return r2l_set_error(R2L_EINVAL, "bad argument to nerf_sample_pdf_u (n_bins must be 2..64)");
+    int rc = r2l_require_gfx950(nullptr);
+    if (rc) return rc;
+    if (n == 0) return R2L_OK;
+    HIPCHK(nerf_launch_sample_pdf(bins, n_bins, weights, n_bins - 1, 0, n, n_bins, u_dev, N, samples,
+                                  (hipStream_t)stream), "sample_pdf");
+    return R2L_OK;
+}
+
+int nerf_merge_sorted(const float* a, int na, const float* b, int nb, int n, float* out, void* stream) {
+    if (!a || !b || !out || n < 0 || na < 0 || nb < 0 || na > 256 || nb > 256)
+        return r2l_set_error(R2L_EINVAL, "bad argument to nerf_merge_sorted (row lengths must be <= 256)");
+    int rc = r2l_require_gfx950(nullptr);
+    if (rc) return rc;
+    if (n == 0) return R2L_OK;
+    HIPCHK(nerf_launch_merge(a, na, na, b, nb, n, out, (hipStream_t)stream), "merge");
+    return R2L_OK;
+}

@@ -1,3 +1,37 @@
-// NeRF-teacher kernels: launcher prototypes (filled in by nerf_kernels.hip).
+// NeRF-teacher kernels: parameter blocks + launcher prototypes (nerf_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "nerf_common.h"
+
+struct NerfMlpParams {
+    const char* wimg;       // packed fragment stream of one network (device), mode-specific
+    float* raw;             // [n_pts, 4] out: rgb(3), sigma(1)   (NeRF.forward output order)
+    const float* rays_o;    // [n_rays, 3]
+    const float* rays_d;    // [n_rays, 3]
+    const float* z;         // [n_rays, S] or, when z_stride == 0, one shared row [S]
+    int z_stride;
+    int S;                  // samples per ray
+    int n_rays;
+    long long n_pts;        // n_rays * S
+    int n_tiles;            // ceil(n_pts / 128)
+    float act_scale;
+    float inv_scale[NERF_N_SCALES];  // per layer: 1 / (act_scale * weight_scale)
+};
+
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int np, int grid, hipStream_t stream);
+
+// rays of rows [row_begin,row_end) of one frame (utils/run_nerf_raybased_helpers.py:231-257)
+hipError_t nerf_launch_get_rays(const float* c2w12_host, int W, float half_w, float half_h, float focal,
+                                int pix_begin, int n, float* rays_o, float* rays_d, hipStream_t stream);
+
+// raw [n,S,4], z [n,S] (z_stride 0 = shared row), rays_d [n,3]; any output may be null
+hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_stride, const float* rays_d, int n,
+                                   int S, int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
+                                   float* depth, hipStream_t stream);
+// bins [n,n_bins] (stride 0 = shared), weights [n, w_stride] using columns [w_off, w_off + n_bins - 1)
+hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, int w_off,
+                                  int n, int n_bins, const float* u, int N, float* samples, hipStream_t stream);
+// a [n,na] (stride 0 = shared) and b [n,nb] ascending -> out [n, na+nb] ascending
+hipError_t nerf_launch_merge(const float* a, int a_stride, int na, const float* b, int nb, int n, float* out,
+                             hipStream_t stream);

@@ -1,2 +1,507 @@
-// placeholder translation unit (teacher kernels land here)
+// NeRF teacher hot path for MI355X / gfx950, hand-written HIP.
+//
+//   nerf_mlp_kernel<NP>     K4+K5 fused: point = o + d*z, Embedder(pts, L=10) + Embedder(viewdir,
+//                           L=4), the 8x256 MLP with the skip concat, feature/alpha heads, the
+//                           view branch and the rgb head -> raw[pt] = (rgb, sigma).  Same machine
+//                           as r2l_resmlp_kernel: a wave owns 32 points, activations stay in
+//                           registers as MFMA B fragments, weights stream through the LDS ring.
+//   nerf_raw2outputs_kernel K6: alpha compositing, one wave per ray, prefix product in a wave scan
+//   nerf_sample_pdf_kernel  K7: inverse-CDF sampling, wave prefix sum + per-lane binary search in LDS
+//   nerf_merge_kernel       K8: merge of two sorted rows by rank (merge path), no sort
+//   nerf_get_rays_kernel    get_rays
+//
+// Reference semantics (file:line in MingSun-Tse/Efficient-NeRF):
+//   get_rays        utils/run_nerf_raybased_helpers.py:231-257
+//   viewdirs        main.py:148-157
+//   pts             main.py:701-702 / 733-734
+//   Embedder        utils/run_nerf_raybased_helpers.py:24-56
+//   NeRF.forward    model/nerf_raybased.py:377-401
+//   raw2outputs     main.py:556-621
+//   sample_pdf      utils/run_nerf_raybased_helpers.py:283-330 (det=True)
+//   sort-merge      main.py:730-732
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
 #include "nerf_kernels.h"
+#include "r2l_device.h"
+
+// ====================================================================================
+// MLP
+// ====================================================================================
+enum { EPI_RELU = 0, EPI_LINEAR_ALPHA = 1, EPI_RGB = 2 };
+
+struct MlpOut {
+    float alpha;   // sigma (alpha_linear output), valid in lanes h == 0
+    float rgb[3];  // rgb_linear output, valid in lanes h == 0
+};
+
+// epilogue of accumulator register `reg` of output tile t of a layer
+template <int NP, int EPI, int NT>
+__device__ __forceinline__ void mlp_epi_reg(const f32x16& acc, float inv, f16x8 (&Dh)[16], f16x8 (&Dl)[16],
+                                            int t, int reg, float act_scale, MlpOut& out) {
+    if (EPI == EPI_RGB) {
+        if (reg < 3) out.rgb[reg] = acc[reg] * inv;
+        return;
+    }
+    if (EPI == EPI_LINEAR_ALPHA && t == NT - 1) {  // tile 8 of FA: row 0 = alpha_linear
+        if (reg == 0) out.alpha = acc[0] * inv;
+        return;
+    }
+    float v = acc[reg] * inv;
+    if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
+    split_store<NP>(v * act_scale, Dh[2 * t + (reg >> 3)], Dl[2 * t + (reg >> 3)], reg & 7);
+}
+
+// One Linear layer = fragment run [F0, F0 + NT*KS).  Input fragments: k-steps 0..15 from
+// (Sh,Sl), k-steps 16.. from (Xh,Xl).  Output tiles are written as fragments of (Dh,Dl).
+// The epilogue of tile t-1 is interleaved with the MFMAs of tile t; the last tile's is exposed.
+template <int NP, int KS, int NT, int F0, int EPI>
+__device__ __forceinline__ void mlp_layer(Ring<NP>& R, const f16x8 (&Sh)[16], const f16x8 (&Sl)[16],
+                                          const f16x8 (&Xh)[4], const f16x8 (&Xl)[4], f16x8 (&Dh)[16],
+                                          f16x8 (&Dl)[16], float inv, float act_scale, int h, MlpOut& out) {
+    f32x16 prev;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int q = F0 + t * KS + ks;
+            const int pos = q % R2L_FRAGS;
+            if (ks == 0) acc = acc_init<NP>(R.use_off, 32 * nerf_aux_slot(q), h);
+            AFrag<NP> nxt = (pos + 1 < R2L_FRAGS) ? read_frag<NP>(R.use_off + R.lane * 16, pos + 1)
+                                                  : read_frag<NP>(ring_next_off<NP>(R.use_off) + R.lane * 16, 0);
+            if (ks < 16) acc = mfma_step<NP>(R.pre, Sh[ks < 16 ? ks : 0], Sl[ks < 16 ? ks : 0], acc);
+            else acc = mfma_step<NP>(R.pre, Xh[ks >= 16 ? ks - 16 : 0], Xl[ks >= 16 ? ks - 16 : 0], acc);
+            R.pre = nxt;
+            if (t > 0) {
+#pragma unroll
+                for (int reg = (16 * ks + KS - 1) / KS; reg < (16 * (ks + 1) + KS - 1) / KS && reg < 16; ++reg)
+                    mlp_epi_reg<NP, EPI, NT>(prev, inv, Dh, Dl, t - 1, reg, act_scale, out);
+            }
+            if (pos == R2L_FRAGS / 2 - 1) ring_mid<NP>(R);
+            if (pos == R2L_FRAGS - 1) ring_next<NP>(R);
+        }
+        prev = acc;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) mlp_epi_reg<NP, EPI, NT>(prev, inv, Dh, Dl, NT - 1, reg, act_scale, out);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
+    typedef KCfg<NP> C;
+    Ring<NP> R;
+    R.wimg = p.wimg;
+    R.cpt = NERF_CHUNKS;
+    R.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    R.lane = threadIdx.x & 63;
+    R.issue_pos = 0;
+    R.issue_off = 0;
+    R.use_off = 0;
+    const int lane = R.lane;
+    const int h = lane >> 5;
+    const bool is_cos = h != 0;
+    const float act_scale = p.act_scale;
+
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) ring_issue<NP>(R);
+    R2L_WAIT_VMCNT(C::WAIT_PRO);
+    __builtin_amdgcn_s_barrier();
+    R.pre = read_frag<NP>(lane * 16, 0);
+
+    f16x8 A1h[16], A1l[16], A2h[16], A2l[16];
+    f16x8 Eh[4], El[4], Vh[4], Vl[4];
+#pragma unroll
+    for (int i = 2; i < 4; ++i) {  // unused tail of the 4-wide "extra" operand of the V layer
+        Vh[i] = (f16x8)(f16)0;
+        Vl[i] = (f16x8)(f16)0;
+    }
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const long long pt_raw = (long long)tile * NERF_TILE_PTS + R.wave * NERF_PTS_PER_WAVE + (lane & 31);
+        const bool valid = pt_raw < p.n_pts;
+        const long long pt = valid ? pt_raw : p.n_pts - 1;
+        const int ray = (int)(pt / p.S);
+        const int s = (int)(pt - (long long)ray * p.S);
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = p.rays_o[(size_t)ray * 3 + k];
+            d[k] = p.rays_d[(size_t)ray * 3 + k];
+        }
+        const float z = p.z[(size_t)ray * p.z_stride + s];
+        // viewdirs = rays_d / ||rays_d||  (main.py:154-156)
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(d[0] * d[0], d[1] * d[1]), d[2] * d[2]));
+        Rev rx[3], rv[3];
+        float xs[3], vs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xs[k] = __fadd_rn(o[k], __fmul_rn(d[k], z));  // rays_o + rays_d * z  (main.py:701)
+            vs[k] = __fdiv_rn(d[k], nrm);
+            rx[k] = to_rev(xs[k]);
+            rv[k] = to_rev(vs[k]);
+        }
+        // ---- embedding fragments (nerf_common.h: nerf_pts_col / nerf_view_col) -------------
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            float pw = 1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                split_store<NP>(trig_pow2(rx[e], pw, is_cos) * act_scale, Eh[e], El[e], j);
+                pw *= 2.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            split_store<NP>(trig_pow2(rx[j >> 1], (j & 1) ? 512.0f : 256.0f, is_cos) * act_scale, Eh[3], El[3], j);
+        split_store<NP>((h ? xs[2] : xs[0]) * act_scale, Eh[3], El[3], 6);
+        split_store<NP>((h ? 0.0f : xs[1]) * act_scale, Eh[3], El[3], 7);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            split_store<NP>(trig_pow2(rv[j >> 2], (float)(1 << (j & 3)), is_cos) * act_scale, Vh[0], Vl[0], j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            split_store<NP>(trig_pow2(rv[2], (float)(1 << j), is_cos) * act_scale, Vh[1], Vl[1], j);
+#pragma unroll
+        for (int j = 4; j < 8; ++j)
+            split_store<NP>(((h == 0 && j < 7) ? vs[j - 4] : 0.0f) * act_scale, Vh[1], Vl[1], j);
+
+        MlpOut out;
+        out.alpha = 0.f;
+        out.rgb[0] = out.rgb[1] = out.rgb[2] = 0.f;
+        // L0: E -> A2   (KS = 4: the source operand is E parked in A1[0..3])
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            A1h[e] = Eh[e];
+            A1l[e] = El[e];
+        }
+        mlp_layer<NP, 4, 8, NERF_F0_L0, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, p.inv_scale[0], act_scale, h, out);
+        for (int it = 0; it < 3; ++it) {
+            if (it == 2) {
+                // L5: [h(256) | E] -> A1, then move to A2 so the two-layer body is reused
+                mlp_layer<NP, 20, 8, NERF_F0_L5, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[5], act_scale,
+                                                           h, out);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    A2h[i] = A1h[i];
+                    A2l[i] = A1l[i];
+                }
+            }
+            // (L1,L2) (L3,L4) (L6,L7): the fragment run of the pair is contiguous per iteration
+            const float inva = p.inv_scale[it == 0 ? 1 : (it == 1 ? 3 : 6)];
+            const float invb = p.inv_scale[it == 0 ? 2 : (it == 1 ? 4 : 7)];
+            mlp_layer<NP, 16, 8, NERF_F0_L1, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, inva, act_scale, h, out);
+            mlp_layer<NP, 16, 8, NERF_F0_L1 + 128, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, invb, act_scale, h, out);
+        }
+        // FA: feature_linear | alpha_linear (no activation) -> A1, sigma
+        mlp_layer<NP, 16, 9, NERF_F0_FA, EPI_LINEAR_ALPHA>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[8], act_scale,
+                                                           h, out);
+        // V: [feature | view embedding] -> 128, relu -> A2[0..7]
+        mlp_layer<NP, 18, 4, NERF_F0_V, EPI_RELU>(R, A1h, A1l, Vh, Vl, A2h, A2l, p.inv_scale[9], act_scale, h, out);
+        // RGB: 128 -> 3
+        mlp_layer<NP, 8, 1, NERF_F0_RGB, EPI_RGB>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[10], act_scale, h, out);
+
+        if (valid && h == 0) {
+            f32x4 r4 = {out.rgb[0], out.rgb[1], out.rgb[2], out.alpha};
+            *reinterpret_cast<f32x4*>(p.raw + (size_t)pt * 4) = r4;
+        }
+    }
+    R2L_WAIT_VMCNT(0);
+}
+
+// ====================================================================================
+// get_rays
+// ====================================================================================
+__global__ void nerf_get_rays_kernel(float c00, float c01, float c02, float c03, float c10, float c11, float c12,
+                                     float c13, float c20, float c21, float c22, float c23, int W, float half_w,
+                                     float half_h, float focal, int pix_begin, int n, float* __restrict__ rays_o,
+                                     float* __restrict__ rays_d) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int pix = pix_begin + i;
+    int jrow = pix / W, icol = pix - jrow * W;
+    float dx = __fdiv_rn((float)icol - half_w, focal);
+    float dy = -__fdiv_rn((float)jrow - half_h, focal);
+    const float c[12] = {c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = __fadd_rn(__fmul_rn(dx, c[4 * k + 0]), __fmul_rn(dy, c[4 * k + 1]));
+        rays_d[(size_t)i * 3 + k] = __fadd_rn(s, __fmul_rn(-1.0f, c[4 * k + 2]));
+        rays_o[(size_t)i * 3 + k] = c[4 * k + 3];
+    }
+}
+
+// ====================================================================================
+// wave-level scans (64 lanes)
+// ====================================================================================
+__device__ __forceinline__ double shfl_up_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta, 64);
+    hi = __shfl_up(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+// inclusive product / sum scans across the wave in double precision (torch's CPU cumprod /
+// cumsum accumulate float tensors in double and round each output to float)
+__device__ __forceinline__ double wave_scan_mul(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double u = shfl_up_f64(v, d);
+        if (lane >= d) v *= u;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_scan_add(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double u = shfl_up_f64(v, d);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+    return v;
+}
+
+// ====================================================================================
+// raw2outputs: one wave per ray, C consecutive samples per lane
+// ====================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void nerf_raw2outputs_kernel(const float* __restrict__ raw,
+                                                               const float* __restrict__ z, int z_stride,
+                                                               const float* __restrict__ rays_d, int n, int S,
+                                                               int white_bkgd, float* __restrict__ rgb_map,
+                                                               float* __restrict__ disp_map,
+                                                               float* __restrict__ acc_map,
+                                                               float* __restrict__ weights_out,
+                                                               float* __restrict__ depth_map) {
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (ray >= n) return;
+    const float* zr = z + (size_t)ray * z_stride;
+    const float dx = rays_d[(size_t)ray * 3 + 0], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(dx * dx, dy * dy), dz * dz));  // torch.norm(rays_d, dim=-1)
+    float alpha[C], zi[C], cr[C], cg[C], cb[C];
+    double lp[C];
+    double prod = 1.0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
+        const bool ok = i < S;
+        const int ii = ok ? i : S - 1;
+        const float zc = zr[ii];
+        const float zn = zr[ii + 1 < S ? ii + 1 : S - 1];
+        float dist = (ii < S - 1) ? (zn - zc) : 1e10f;  // dists = cat(z[1:]-z[:-1], 1e10)
+        dist = dist * norm;
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(raw + ((size_t)ray * S + ii) * 4);
+        const float sig = fmaxf(r4[3], 0.0f);                 // F.relu
+        float a = 1.0f - expf(-sig * dist);                   // 1 - exp(-relu(raw) * dists)
+        if (!ok) a = 0.0f;
+        alpha[c] = a;
+        zi[c] = zc;
+        cr[c] = 1.0f / (1.0f + expf(-r4[0]));                 // torch.sigmoid
+        cg[c] = 1.0f / (1.0f + expf(-r4[1]));
+        cb[c] = 1.0f / (1.0f + expf(-r4[2]));
+        lp[c] = prod;                                          // exclusive product inside the lane
+        const float pterm = ok ? ((1.0f - a) + 1e-10f) : 1.0f; // 1 - alpha + 1e-10, float ops
+        prod *= (double)pterm;
+    }
+    const double incl = wave_scan_mul(prod, lane);
+    double excl = shfl_up_f64(incl, 1);
+    if (lane == 0) excl = 1.0;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = lane * C + c;
+        const float T = (float)(excl * lp[c]);  // cumprod accumulated in double, rounded per element
+        const float w = alpha[c] * T;
+        if (i < S) {
+            if (weights_out) weights_out[(size_t)ray * S + i] = w;
+            sr += w * cr[c];
+            sg += w * cg[c];
+            sb += w * cb[c];
+            sd += w * zi[c];
+            sa += w;
+        }
+    }
+    sr = wave_sum(sr);
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    sd = wave_sum(sd);
+    sa = wave_sum(sa);
+    if (lane == 0) {
+        if (white_bkgd) {
+            const float bg = 1.0f - sa;
+            sr += bg;
+            sg += bg;
+            sb += bg;
+        }
+        if (rgb_map) {
+            rgb_map[(size_t)ray * 3 + 0] = sr;
+            rgb_map[(size_t)ray * 3 + 1] = sg;
+            rgb_map[(size_t)ray * 3 + 2] = sb;
+        }
+        if (depth_map) depth_map[ray] = sd;
+        if (acc_map) acc_map[ray] = sa;
+        if (disp_map) {
+            const float q = sd / sa;
+            // torch.max(1e-10, q) propagates NaN (0/0 for empty rays), fmaxf would not
+            const float m = (q != q) ? q : fmaxf(1e-10f, q);
+            disp_map[ray] = 1.0f / m;
+        }
+    }
+}
+
+// ====================================================================================
+// sample_pdf (det=True): one wave per ray, n_bins <= 64
+// ====================================================================================
+__global__ __launch_bounds__(256) void nerf_sample_pdf_kernel(const float* __restrict__ bins, int bins_stride,
+                                                              const float* __restrict__ weights, int w_stride,
+                                                              int w_off, int n, int n_bins,
+                                                              const float* __restrict__ u_arr, int N,
+                                                              float* __restrict__ samples) {
+    __shared__ float s_cdf[4][64];
+    __shared__ float s_bins[4][64];
+    const int wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    const int lane = threadIdx.x & 63;
+    if (ray >= n) return;
+    const int nw = n_bins - 1;
+    float w = 0.0f;
+    if (lane < nw) w = weights[(size_t)ray * w_stride + w_off + lane] + 1e-5f;  // weights + 1e-5
+    const float total = (float)wave_sum_f64((double)w);                          // torch.sum(weights, -1)
+    const float pdf = (lane < nw) ? w / total : 0.0f;
+    const double cs = wave_scan_add((double)pdf, lane);                          // cumsum (double accumulate)
+    if (lane < nw) s_cdf[wv][lane + 1] = (float)cs;
+    if (lane == 63) s_cdf[wv][0] = 0.0f;                                          // cat(zeros, cdf)
+    if (lane < n_bins) s_bins[wv][lane] = bins[(size_t)ray * bins_stride + lane];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int k = lane; k < N; k += 64) {
+        const float u = u_arr[k];
+        int lo = 0, hi = n_bins;  // searchsorted(cdf, u, right=True): first index with cdf > u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cdf[wv][mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < n_bins - 1 ? lo : n_bins - 1;
+        const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
+        const float b0 = s_bins[wv][below], b1 = s_bins[wv][above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (u - c0) / denom;
+        samples[(size_t)ray * N + k] = b0 + t * (b1 - b0);
+    }
+}
+
+// ====================================================================================
+// merge of two ascending rows (the reference sorts the concatenation): one wave per ray
+// ====================================================================================
+__global__ __launch_bounds__(256) void nerf_merge_kernel(const float* __restrict__ a, int a_stride, int na,
+                                                         const float* __restrict__ b, int nb, int n,
+                                                         float* __restrict__ out) {
+    __shared__ float s_a[4][256];
+    __shared__ float s_b[4][256];
+    const int wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    const int lane = threadIdx.x & 63;
+    if (ray >= n) return;
+    for (int i = lane; i < na; i += 64) s_a[wv][i] = a[(size_t)ray * a_stride + i];
+    for (int i = lane; i < nb; i += 64) s_b[wv][i] = b[(size_t)ray * nb + i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float* o = out + (size_t)ray * (na + nb);
+    for (int i = lane; i < na; i += 64) {  // rank of a[i] = i + #{b < a[i]}
+        const float v = s_a[wv][i];
+        int lo = 0, hi = nb;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_b[wv][mid] < v) lo = mid + 1; else hi = mid;
+        }
+        o[i + lo] = v;
+    }
+    for (int j = lane; j < nb; j += 64) {  // rank of b[j] = j + #{a <= b[j]}
+        const float v = s_b[wv][j];
+        int lo = 0, hi = na;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_a[wv][mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        o[j + lo] = v;
+    }
+}
+
+// ====================================================================================
+// launchers
+// ====================================================================================
+template <int NP>
+static hipError_t launch_mlp(const NerfMlpParams& p, int grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp_kernel<NP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nerf_mlp_kernel<NP>, dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int np, int grid, hipStream_t stream) {
+    return np == 2 ? launch_mlp<2>(p, grid, stream) : launch_mlp<1>(p, grid, stream);
+}
+
+hipError_t nerf_launch_get_rays(const float* c, int W, float half_w, float half_h, float focal, int pix_begin,
+                                int n, float* rays_o, float* rays_d, hipStream_t stream) {
+    hipLaunchKernelGGL(nerf_get_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, c[0], c[1], c[2], c[3],
+                       c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], W, half_w, half_h, focal, pix_begin, n,
+                       rays_o, rays_d);
+    return hipGetLastError();
+}
+
+hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_stride, const float* rays_d, int n,
+                                   int S, int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
+                                   float* depth, hipStream_t stream) {
+    const dim3 grid((n + 3) / 4), block(256);
+    const int C = (S + 63) / 64;
+#define R2O(c)                                                                                              \
+    hipLaunchKernelGGL(nerf_raw2outputs_kernel<c>, grid, block, 0, stream, raw, z, z_stride, rays_d, n, S, \
+                       white_bkgd, rgb, disp, acc, weights, depth)
+    switch (C) {
+        case 1: R2O(1); break;
+        case 2: R2O(2); break;
+        case 3: R2O(3); break;
+        case 4: R2O(4); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef R2O
+    return hipGetLastError();
+}
+
+hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, int w_off,
+                                  int n, int n_bins, const float* u, int N, float* samples, hipStream_t stream) {
+    if (n_bins < 2 || n_bins > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nerf_sample_pdf_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, bins, bins_stride, weights,
+                       w_stride, w_off, n, n_bins, u, N, samples);
+    return hipGetLastError();
+}
+
+hipError_t nerf_launch_merge(const float* a, int a_stride, int na, const float* b, int nb, int n, float* out,
+                             hipStream_t stream) {
+    if (na > 256 || nb > 256 || na < 0 || nb < 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nerf_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, a, a_stride, na, b, nb, n, out);
+    return hipGetLastError();
+}

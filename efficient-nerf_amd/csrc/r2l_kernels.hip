@@ -21,60 +21,7 @@
 #include "r2l_common.h"
 #include "r2l_kernels.h"
 
-typedef _Float16 f16;
-typedef f16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define AS1(p) ((const __attribute__((address_space(1))) void*)(p))
-#define AS3(p) ((__attribute__((address_space(3))) void*)(p))
-
-extern __shared__ __attribute__((aligned(16))) char smem[];
-
-// ------------------------------------------------------------------------------------
-// sin / cos of 2^l * x, l = 0..9, matching sin/cos of the exactly scaled fp32 argument.
-// x/(2 pi) is kept as an unevaluated sum rh + rl (two-float), scaled by the exact power
-// of two, the integer part is removed exactly (v_rndne), and sin(2 pi g) is evaluated on
-// the folded fraction |g'| <= 1/4 with a degree-11 odd polynomial.
-// ------------------------------------------------------------------------------------
-#define R2L_INV2PI_HI 0.15915494f              // fl32(1/(2 pi))
-#define R2L_INV2PI_LO 6.4206382e-09f           // 1/(2 pi) - fl32(1/(2 pi))  (set by host check)
-#define R2L_2PI 6.2831855f
-
-struct Rev {  // x / (2 pi) = rh + rl
-    float rh, rl;
-};
-
-__device__ __forceinline__ Rev to_rev(float x) {
-    Rev r;
-    r.rh = x * R2L_INV2PI_HI;
-    r.rl = fmaf(x, R2L_INV2PI_LO, fmaf(x, R2L_INV2PI_HI, -r.rh));
-    return r;
-}
-
-// sin(th), |th| <= pi/2 (degree-11 odd polynomial)
-__device__ __forceinline__ float sin_poly(float th) {
-    float s = th * th;
-    float p = fmaf(s, -2.5052108e-8f, 2.7557319e-6f);
-    p = fmaf(s, p, -1.9841270e-4f);
-    p = fmaf(s, p, 8.3333333e-3f);
-    p = fmaf(s, p, -1.6666667e-1f);
-    return fmaf(th * s, p, th);
-}
-
-// sin (is_cos = false) or cos (true) of x * 2^l given x/(2 pi) = rh + rl, pow2l = 2^l.
-// rh*2^l is exact, t - rint(t) is exact, so g = frac(x*2^l/(2 pi)) in [-1/2, 1/2] keeps
-// ~2^-26 absolute accuracy; sin folds |g| to [-1/4, 1/4] (sign of g restored on the
-// angle), cos uses cos(2 pi g) = sin(2 pi (1/4 - |g|)).  max |err| 1.8e-7 (tests).
-__device__ __forceinline__ float trig_pow2(Rev r, float pow2l, bool is_cos) {
-    float t = r.rh * pow2l;
-    float u = t - rintf(t);
-    float g = fmaf(r.rl, pow2l, u);
-    float a = fabsf(g);
-    float m = is_cos ? (0.25f - a) : fminf(a, 0.5f - a);
-    float sg = is_cos ? 1.0f : g;
-    return sin_poly(m * copysignf(R2L_2PI, sg));
-}
+#include "r2l_device.h"
 
 // camera ray of flat ray index `ray` (model/nerf_raybased.py:84-99).
 __device__ __forceinline__ void make_ray(const R2LParams& p, int ray, float o[3], float d[3]) {
@@ -164,138 +111,6 @@ __global__ void r2l_embed_kernel(const float* __restrict__ x_in, long long total
 // ------------------------------------------------------------------------------------
 // fused persistent kernel
 // ------------------------------------------------------------------------------------
-template <int NP>
-struct KCfg {
-    static constexpr int AUX = R2L_FRAGS * NP * R2L_FRAG_BYTES;  // aux offset in a chunk
-    static constexpr int CH = AUX + R2L_AUX_BYTES;               // chunk bytes
-    static constexpr int NBUF = (NP == 2) ? 4 : 6;               // LDS ring slots
-    static constexpr int D = NBUF - 1;                           // chunks issued ahead
-    static constexpr int P = 4 * NP + 1;                         // LDS-DMA ops / wave / chunk
-    static constexpr int WAIT_MID = (D - 2) * P;                 // certify chunk c+1 at mid-c
-    static constexpr int WAIT_PRO = (D - 1) * P;                 // prologue: certify chunk 0
-    static constexpr int LDS = NBUF * CH;
-};
-
-template <int NP>
-struct AFrag {  // one A (weight) fragment: hi [, lo]
-    f16x8 h, l;
-};
-
-template <int NP>
-struct Ring {
-    const char* wimg;   // chunk stream of one ray tile (periodic)
-    int cpt;            // chunks per tile
-    int issue_pos;      // next chunk (position in the tile image) to issue
-    uint32_t issue_off; // LDS byte offset of the slot it goes to
-    uint32_t use_off;   // LDS byte offset of the chunk being consumed
-    int wave, lane;
-    AFrag<NP> pre;      // fragment 0 of the chunk at use_off, already read from LDS
-};
-
-// LDS-DMA of one chunk with `global_load_lds_dwordx4 v_off, s[base:base+1]` (scalar base +
-// one 32-bit VGPR offset = lane*16, no 64-bit per-lane address math).  MUBUF `... lds`
-// loads are not usable here: their LDS base is M0[15:0] and the ring spans > 64 KiB.
-template <int NP>
-__device__ __forceinline__ void ring_issue(Ring<NP>& R) {
-    typedef KCfg<NP> C;
-    const char* src = R.wimg + (size_t)R.issue_pos * C::CH + R.wave * (4 * NP * R2L_FRAG_BYTES);
-    const uint32_t dst = R.issue_off + R.wave * (4 * NP * R2L_FRAG_BYTES);
-    const uint32_t voff = (uint32_t)R.lane * 16u;
-#pragma unroll
-    for (int q = 0; q < 4 * NP; ++q) {
-        __builtin_amdgcn_global_load_lds(AS1(src + q * R2L_FRAG_BYTES + voff), AS3(smem + dst + q * R2L_FRAG_BYTES),
-                                         16, 0, 0);
-    }
-    const char* asrc = R.wimg + (size_t)R.issue_pos * C::CH + C::AUX + R.wave * 256;
-    __builtin_amdgcn_global_load_lds(AS1(asrc + (uint32_t)R.lane * 4u), AS3(smem + R.issue_off + C::AUX + R.wave * 256),
-                                     4, 0, 0);
-    R.issue_pos = (R.issue_pos + 1 == R.cpt) ? 0 : R.issue_pos + 1;
-    R.issue_off = (R.issue_off + C::CH == (uint32_t)C::LDS) ? 0u : R.issue_off + C::CH;
-}
-
-#define R2L_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
-// Mid-chunk rendezvous while consuming chunk c: every wave's LDS-DMA of chunk c+1 has
-// landed (counted vmcnt, then the barrier), every wave is past chunk c-1, so its slot is
-// refilled with chunk c+D.
-template <int NP>
-__device__ __forceinline__ void ring_mid(Ring<NP>& R) {
-#ifdef R2L_ABL_NODMA  // ablation build: no rendezvous, no refill (LDS keeps the prologue's chunks)
-    return;
-#endif
-#ifndef R2L_ABL_NOWAIT
-    R2L_WAIT_VMCNT(KCfg<NP>::WAIT_MID);
-#endif
-#ifndef R2L_ABL_NOBARRIER
-    __builtin_amdgcn_s_barrier();
-#endif
-#ifndef R2L_ABL_NOISSUE
-    ring_issue<NP>(R);
-#endif
-}
-
-template <int NP>
-__device__ __forceinline__ uint32_t ring_next_off(uint32_t off) {
-    typedef KCfg<NP> C;
-    return (off + C::CH == (uint32_t)C::LDS) ? 0u : off + C::CH;
-}
-
-template <int NP>
-__device__ __forceinline__ void ring_next(Ring<NP>& R) {
-    R.use_off = ring_next_off<NP>(R.use_off);
-}
-
-template <int NP>
-__device__ __forceinline__ AFrag<NP> read_frag(uint32_t lane_base, int frag) {
-    AFrag<NP> a;
-    a.h = *reinterpret_cast<const f16x8*>(smem + lane_base + (frag * NP) * R2L_FRAG_BYTES);
-    if (NP == 2) a.l = *reinterpret_cast<const f16x8*>(smem + lane_base + (frag * NP + 1) * R2L_FRAG_BYTES);
-    return a;
-}
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-
-// one k-step on one 32x32 output tile: ah*bh [+ ah*bl + al*bh]
-template <int NP>
-__device__ __forceinline__ f32x16 mfma_step(const AFrag<NP>& a, const f16x8& bh, const f16x8& bl,
-                                            f32x16 acc) {
-    acc = MFMA(a.h, bh, acc);
-    if (NP == 2) {
-        acc = MFMA(a.h, bl, acc);
-        acc = MFMA(a.l, bh, acc);
-    }
-    return acc;
-}
-
-// split an fp32 activation (already multiplied by act_scale) into fp16 hi (+ lo)
-template <int NP>
-__device__ __forceinline__ void split_store(float a, f16x8& hi, f16x8& lo, int j) {
-    f16 h = (f16)a;
-    hi[j] = h;
-    if (NP == 2) lo[j] = (f16)(a - (float)h);
-}
-
-// accumulator init = aux[tile_off + 8g + 4h + i] (bias pre-multiplied by the layer scale)
-template <int NP>
-__device__ __forceinline__ f32x16 acc_init(uint32_t slot_off, int tile_off, int h) {
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 b = *reinterpret_cast<const f32x4*>(smem + slot_off + KCfg<NP>::AUX +
-                                                  (tile_off + 8 * g + 4 * h) * 4);
-        acc[4 * g + 0] = b[0];
-        acc[4 * g + 1] = b[1];
-        acc[4 * g + 2] = b[2];
-        acc[4 * g + 3] = b[3];
-    }
-    return acc;
-}
-
-template <int NP>
-__device__ __forceinline__ float aux_inv_scale(uint32_t slot_off) {
-    return *reinterpret_cast<const float*>(smem + slot_off + KCfg<NP>::AUX + 32 * 4);
-}
-
 // epilogue of one accumulator register of feature tile t:
 // SECOND = false: out = relu(acc/scale)              (ResMLP body.0 + inact)
 // SECOND = true : x = x + acc/scale; out = x         (ResMLP body.2 + residual)

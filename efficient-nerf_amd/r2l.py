@@ -65,7 +65,7 @@ class R2LEngine:
         self.z_vals = z
 
     def close(self):
-        if getattr(self, '_ctx', None) and self._ctx.value:
+        if getattr(self, '_ctx', None) and self._ctx.value and _lib._lib is not None:
             lib().r2l_destroy(self._ctx)
             self._ctx = C.c_void_p()
 

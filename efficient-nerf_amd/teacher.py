@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's NeRF-teacher call surface, backed by libr2l_hip.so.
+
+Reference interface mirrored (MingSun-Tse/Efficient-NeRF):
+  get_rays                 utils/run_nerf_raybased_helpers.py:231-257
+  raw2outputs              main.py:556-621  (== helpers:77-144, model/nerf_raybased.py:226-295)
+  sample_pdf               utils/run_nerf_raybased_helpers.py:283-330
+  render / render_rays     main.py:107-186, 624-756   (and utils/create_data.py:80-176, 405-544)
+  create_nerf's networks   main.py:425-453 (NeRF D=8 W=256, skips=[4], use_viewdirs)
+
+Same names and argument meaning; tensors are float32 on the HIP device; errors raise
+R2LError.  No CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, check, current_stream, dptr, lib
+from .r2l import _c2w_host, _dev
+
+
+def _f32(t, device):
+    return torch.as_tensor(t).to(device=device, dtype=torch.float32).contiguous()
+
+
+def get_rays(H, W, focal, c2w, trans_origin='', focal_scale=1, rows=None, device=None):
+    """helpers:231-257 (trans_origin='' only).  Returns rays_o, rays_d [rows, W, 3]."""
+    if trans_origin:
+        raise NotImplementedError('trans_origin variants are ablation paths (out of scope)')
+    dev = _dev(device)
+    focal = float(focal) * focal_scale
+    r0, r1 = (0, H) if rows is None else rows
+    c = _c2w_host(c2w)
+    n = (r1 - r0) * W
+    ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().nerf_get_rays(int(H), int(W), focal, C.c_void_p(c.data_ptr()), r0, r1, dptr(ro), dptr(rd),
+                                  current_stream()))
+    return ro.view(r1 - r0, W, 3), rd.view(r1 - r0, W, 3)
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, verbose=False):
+    """main.py:556-621.  raw [n,S,4], z_vals [n,S], rays_d [n,3] ->
+    rgb_map [n,3], disp_map [n], acc_map [n], weights [n,S], depth_map [n]."""
+    if raw_noise_std > 0.:
+        raise NotImplementedError('raw_noise_std > 0 is a training-only path (out of scope)')
+    dev = raw.device
+    raw, rays_d = _f32(raw, dev), _f32(rays_d, dev)
+    n, S = raw.shape[0], raw.shape[1]
+    z_vals = _f32(z_vals.expand(n, S) if z_vals.dim() == 2 else z_vals, dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp, acc, depth = (torch.empty((n,), dtype=torch.float32, device=dev) for _ in range(3))
+    weights = torch.empty((n, S), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().nerf_raw2outputs(dptr(raw), dptr(z_vals), dptr(rays_d), n, S, int(bool(white_bkgd)), dptr(rgb),
+                                     dptr(disp), dptr(acc), dptr(weights), dptr(depth), current_stream()))
+    return rgb, disp, acc, weights, depth
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
+    """helpers:283-330 with det=True (the perturb==0 test path).  bins [n,B], weights
+    [n,B-1] -> samples [n,N_samples].  `u` defaults to torch.linspace(0,1,N_samples)
+    evaluated on the host exactly as the reference does."""
+    if not det:
+        raise NotImplementedError('det=False draws torch.rand samples: training-only path (out of scope)')
+    dev = bins.device
+    bins, weights = _f32(bins, dev), _f32(weights, dev)
+    n, B = bins.shape
+    if weights.shape != (n, B - 1):
+        raise R2LError(f'weights must be [n, {B - 1}]; got {tuple(weights.shape)}')
+    if u is None:
+        u = torch.linspace(0., 1., steps=N_samples)
+    u = _f32(u, dev)
+    out = torch.empty((n, N_samples), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().nerf_sample_pdf_u(dptr(bins), dptr(weights), n, B, dptr(u), N_samples, dptr(out),
+                                      current_stream()))
+    return out
+
+
+def merge_sorted(z_vals, z_samples):
+    """main.py:730-732: torch.sort(torch.cat([z_vals, z_samples], -1), -1)[0] for rows that
+    are each already ascending."""
+    dev = z_samples.device
+    z_samples = _f32(z_samples, dev)
+    n = z_samples.shape[0]
+    z_vals = _f32(z_vals.expand(n, z_vals.shape[-1]), dev)
+    out = torch.empty((n, z_vals.shape[1] + z_samples.shape[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().nerf_merge_sorted(dptr(z_vals), z_vals.shape[1], dptr(z_samples), z_samples.shape[1], n,
+                                      dptr(out), current_stream()))
+    return out
+
+
+class NeRFEngine:
+    """One nerf_ctx: coarse + fine NeRF(D=8, W=256, use_viewdirs) and the render_rays
+    pipeline (include/r2l_hip.h)."""
+
+    STATE_NAMES = [f'pts_linears.{i}.{k}' for i in range(8) for k in ('weight', 'bias')] + [
+        'views_linears.0.weight', 'views_linears.0.bias', 'feature_linear.weight', 'feature_linear.bias',
+        'alpha_linear.weight', 'alpha_linear.bias', 'rgb_linear.weight', 'rgb_linear.bias']
+
+    def __init__(self, H, W, focal, near=2., far=6., N_samples=64, N_importance=128, multires=10, multires_views=4,
+                 white_bkgd=True, precision=PREC_FP16X3, device=None, z_coarse=None, u=None):
+        self.device = _dev(device)
+        self.H, self.W, self.focal = int(H), int(W), float(focal)
+        self.N_samples, self.N_importance = int(N_samples), int(N_importance)
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().nerf_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
+                                    self.N_samples, self.N_importance, int(multires), int(multires_views),
+                                    int(bool(white_bkgd)), int(precision)))
+        # main.py:676-678 / helpers:293 evaluated with the host's torch, as the reference does
+        if z_coarse is None:
+            t_vals = torch.linspace(0., 1., steps=self.N_samples)
+            z_coarse = float(near) * (1. - t_vals) + float(far) * (t_vals)
+        if u is None:
+            u = torch.linspace(0., 1., steps=self.N_importance)
+        self.set_sampling(z_coarse, u)
+
+    def set_sampling(self, z_coarse, u):
+        z = torch.as_tensor(z_coarse).detach().to('cpu', torch.float32).contiguous()
+        uu = torch.as_tensor(u).detach().to('cpu', torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            check(lib().nerf_set_sampling(self._ctx, C.c_void_p(z.data_ptr()), z.numel(), C.c_void_p(uu.data_ptr()),
+                                          uu.numel()))
+        self.z_coarse, self.u = z, uu
+
+    def close(self):
+        if getattr(self, '_ctx', None) and self._ctx.value and _lib._lib is not None:
+            lib().nerf_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    __del__ = close
+
+    def _load(self, which, state_dict):
+        sd = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        missing = [n for n in self.STATE_NAMES if n not in sd]
+        if missing:
+            raise R2LError(f'teacher state_dict lacks {missing[:3]} ...')
+        keep, arr = _lib.host_ptrs([sd[n] for n in self.STATE_NAMES])
+        want = {'pts_linears.0.weight': (256, 63), 'pts_linears.5.weight': (256, 319),
+                'views_linears.0.weight': (128, 283), 'alpha_linear.weight': (1, 256), 'rgb_linear.weight': (3, 128)}
+        for n, t in zip(self.STATE_NAMES, keep):
+            exp = want.get(n)
+            if exp is None:
+                exp = (256, 256) if n.endswith('weight') else ((128,) if n.startswith('views') else
+                                                                 (1,) if n.startswith('alpha') else
+                                                                 (3,) if n.startswith('rgb') else (256,))
+            if tuple(t.shape) != exp:
+                raise R2LError(f'{n}: shape {tuple(t.shape)} != {exp}')
+        with torch.cuda.device(self.device):
+            check(lib().nerf_load_weights(self._ctx, which, arr, len(keep)))
+
+    def load_state_dicts(self, network_fn_state_dict, network_fine_state_dict):
+        """The `.tar`'s 'network_fn_state_dict' / 'network_fine_state_dict' (main.py:1516-1542)."""
+        self._load(0, network_fn_state_dict)
+        self._load(1, network_fine_state_dict)
+        return self
+
+    def set_precision(self, precision):
+        with torch.cuda.device(self.device):
+            check(lib().nerf_set_precision(self._ctx, int(precision)))
+
+    def _outs(self, n):
+        dev = self.device
+        return (torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+                torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev))
+
+    def _extras(self, n):
+        S1 = self.N_samples + self.N_importance
+        dev = self.device
+        rgb0 = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        zs = torch.empty((n, self.N_importance), dtype=torch.float32, device=dev)
+        zv = torch.empty((n, S1), dtype=torch.float32, device=dev)
+        raw = torch.empty((n, S1, 4), dtype=torch.float32, device=dev)
+        check(lib().nerf_copy_extras(self._ctx, n, dptr(rgb0), dptr(zs), dptr(zv), dptr(raw), current_stream()))
+        return {'rgb0': rgb0, 'z_samples': zs, 'z_vals': zv, 'raw': raw}
+
+    def render(self, c2w, rows=None, extras=False):
+        """render(H, W, focal, c2w=c2w[:3,:4]) of main.py:107-186 for rows [r0,r1):
+        dict(rgb_map [n,3], disp_map [n], acc_map [n], depth_map [n])."""
+        r0, r1 = (0, self.H) if rows is None else (int(rows[0]), int(rows[1]))
+        c = _c2w_host(c2w)
+        n = (r1 - r0) * self.W
+        rgb, disp, acc, depth = self._outs(n)
+        with torch.cuda.device(self.device):
+            check(lib().nerf_render(self._ctx, C.c_void_p(c.data_ptr()), r0, r1, dptr(rgb), dptr(disp), dptr(acc),
+                                    dptr(depth), current_stream()))
+            ret = {'rgb_map': rgb, 'disp_map': disp, 'acc_map': acc, 'depth_map': depth}
+            if extras:
+                ret.update(self._extras(n))
+        return ret
+
+    def render_rays(self, rays_o, rays_d, extras=False):
+        """render(..., rays=(rays_o, rays_d)) / render_rays of main.py:624-756."""
+        rays_o, rays_d = _f32(rays_o, self.device).view(-1, 3), _f32(rays_d, self.device).view(-1, 3)
+        n = rays_o.shape[0]
+        rgb, disp, acc, depth = self._outs(n)
+        with torch.cuda.device(self.device):
+            check(lib().nerf_render_rays(self._ctx, dptr(rays_o), dptr(rays_d), n, dptr(rgb), dptr(disp), dptr(acc),
+                                         dptr(depth), current_stream()))
+            ret = {'rgb_map': rgb, 'disp_map': disp, 'acc_map': acc, 'depth_map': depth}
+            if extras:
+                ret.update(self._extras(n))
+        return ret
+
+    def run_network(self, which, rays_o, rays_d, z_vals):
+        """network_query_fn(pts, viewdirs, network) of main.py:447-453 with
+        pts = rays_o + rays_d * z_vals: raw [n,S,4]."""
+        rays_o, rays_d = _f32(rays_o, self.device), _f32(rays_d, self.device)
+        n = rays_o.shape[0]
+        z = _f32(z_vals, self.device)
+        shared = z.dim() == 1
+        S = z.shape[-1]
+        raw = torch.empty((n, S, 4), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().nerf_run_network(self._ctx, int(which), dptr(rays_o), dptr(rays_d), dptr(z), 0 if shared else S,
+                                         S, n, dptr(raw), current_stream()))
+        return raw
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=False, near=2., far=6., use_viewdirs=True,
+           engine=None, **kwargs):
+    """main.py:107-186 call shape: returns [rgb_map, disp_map, acc_map, extras_dict] reshaped
+    to the ray batch.  `engine` is the NeRFEngine holding network_fn / network_fine (the
+    reference passes them through **kwargs).  `chunk` does not affect results (main.py:124)."""
+    if ndc:
+        raise NotImplementedError('NDC rays (LLFF) are a next-row item, not built yet')
+    if not use_viewdirs:
+        raise R2LError('the teacher path is built for use_viewdirs=True networks')
+    if engine is None:
+        raise R2LError('pass engine=NeRFEngine(...) (holds the coarse/fine networks)')
+    if c2w is not None:
+        out = engine.render(c2w)
+        sh = (engine.H, engine.W)
+    else:
+        rays_o, rays_d = rays
+        sh = tuple(rays_d.shape[:-1])
+        out = engine.render_rays(rays_o, rays_d)
+    rgb = out['rgb_map'].view(*sh, 3)
+    disp, acc = out['disp_map'].view(*sh), out['acc_map'].view(*sh)
+    return [rgb, disp, acc, {'depth_map': out['depth_map'].view(*sh)}]

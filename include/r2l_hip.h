@@ -129,6 +129,12 @@ void nerf_destroy(nerf_ctx* ctx);
  * state_dict order: pts_linears.{0..7}.{weight,bias}, views_linears.0.{weight,bias},
  * feature_linear.{weight,bias}, alpha_linear.{weight,bias}, rgb_linear.{weight,bias}. */
 int nerf_load_weights(nerf_ctx* ctx, int which, const float* const* tensors, int n_tensors);
+int nerf_set_precision(nerf_ctx* ctx, int precision_mode);
+/* Override the coarse depths z_vals[N_samples] (main.py:676-678) and/or the inverse-CDF
+ * abscissae u[N_importance] = torch.linspace(0,1,N) (helpers:293) with the tensors the
+ * reference computes on this host (torch.linspace's last ulp is CPU-vector-width dependent;
+ * nerf_create fills both with the scalar formula).  Either pointer may be NULL. */
+int nerf_set_sampling(nerf_ctx* ctx, const float* z_coarse_host, int n_z, const float* u_host, int n_u);
 /* rows [row_begin,row_end) of one frame; c2w [3,4] on host.  Outputs are device
  * pointers, any of disp/acc/depth may be NULL.  rgb [n,3], others [n]. */
 int nerf_render(nerf_ctx* ctx, const float* c2w_host, int row_begin, int row_end,
@@ -140,6 +146,20 @@ int nerf_render_rays(nerf_ctx* ctx, const float* rays_o_dev, const float* rays_d
  * valid until the next call): rgb0 [n,3], z_samples [n,N_importance], z_vals [n,S0+S1] */
 int nerf_last_extras(nerf_ctx* ctx, const float** rgb0, const float** z_samples,
                      const float** z_vals, const float** raw_fine);
+/* stream-ordered device-to-device copies of those by-products for the first n rays of the
+ * last call into caller tensors (any may be NULL): rgb0 [n,3], z_samples [n,N_importance],
+ * z_vals [n,S0+S1], raw_fine [n,S0+S1,4] */
+int nerf_copy_extras(nerf_ctx* ctx, int n, float* rgb0_dev, float* z_samples_dev, float* z_vals_dev,
+                     float* raw_dev, void* stream);
+
+/* get_rays (utils/run_nerf_raybased_helpers.py:231-257) for rows [row_begin,row_end):
+ * rays_o_dev, rays_d_dev [rows*W, 3]; c2w [3,4] on the host. */
+int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_begin, int row_end,
+                  float* rays_o_dev, float* rays_d_dev, void* stream);
+/* run_network (main.py:65-87): points o + d*z for z_dev [n,S] (z_stride = S) or one shared
+ * row (z_stride = 0), both embedders, network `which` -> raw_dev [n,S,4] = (rgb, sigma). */
+int nerf_run_network(nerf_ctx* ctx, int which, const float* rays_o_dev, const float* rays_d_dev,
+                     const float* z_dev, int z_stride, int S, int n, float* raw_dev, void* stream);
 
 /* stand-alone scan kernels (all device pointers, f32):
  * raw [n,S,4], z [n,S], rays_d [n,3] -> rgb [n,3], disp [n], acc [n], weights [n,S], depth [n]
@@ -150,6 +170,9 @@ int nerf_raw2outputs(const float* raw, const float* z, const float* rays_d, int 
 /* bins [n,n_bins], weights [n,n_bins-1] -> samples [n,N] (det=True: u = linspace(0,1,N)) */
 int nerf_sample_pdf(const float* bins, const float* weights, int n, int n_bins, int N,
                     float* samples, void* stream);
+/* same with caller-provided u_dev [N] (device), fully stream-ordered */
+int nerf_sample_pdf_u(const float* bins, const float* weights, int n, int n_bins,
+                      const float* u_dev, int N, float* samples, void* stream);
 /* a [n,na] and b [n,nb], each row ascending -> out [n,na+nb] ascending */
 int nerf_merge_sorted(const float* a, int na, const float* b, int nb, int n, float* out,
                       void* stream);
