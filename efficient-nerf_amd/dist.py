@@ -50,8 +50,9 @@ def gather_rows(local, H, W, world, group=None):
     if local.shape[1] != mx:
         pad = torch.zeros((F, mx - local.shape[1], Cc), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 1)
-    out = torch.empty((world, F, mx, Cc), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    out = torch.empty((world * F, mx, Cc), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)  # concatenation along dim 0
+    out = out.view(world, F, mx, Cc)
     if all(s == mx for s in sizes):
         return out.permute(1, 0, 2, 3).reshape(F, world * mx, Cc)
     return torch.cat([out[r, :, :sizes[r]] for r in range(world)], 1)

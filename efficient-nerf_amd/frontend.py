@@ -1,0 +1,369 @@
+"""Thin front-end keeping the reference's command line, `configs/*.txt` format and `.tar`
+checkpoint schema for the render-only path:
+
+    python main.py --model_name R2L --config configs/lego_noview.txt --n_sample_per_ray 16 \\
+        --netwidth 256 --netdepth 88 --use_residual --trial.ON --trial.body_arch resmlp \\
+        --pretrained_ckpt R2L_Blender_Models/lego.tar --render_only --render_test --testskip 1
+    python main.py --model_name nerf --config configs/lego.txt --pretrained_ckpt NeRF_Blender_Models/lego.tar \\
+        --render_only --render_test --testskip 1
+
+Reference pieces restated (file:line in MingSun-Tse/Efficient-NeRF):
+  flags / config file      option.py:6-358  (ConfigArgParse-style `key = value`, `#` comments)
+  transforms_*.json rule   dataset/load_blender.py:39-82, 106-109
+  checkpoint schema        main.py:1516-1542 (save_ckpt), main.py:482-502 (load)
+  render_path loop         main.py:189-398 (R2L branch :285-325, nerf branch :276-283)
+  PSNR                     utils/run_nerf_raybased_helpers.py:19-20
+
+Everything computational goes through the HIP library; this module is plumbing.  With
+several processes (torchrun) the rows of each frame are sharded across ranks and assembled
+with one all-gather (dist.py).  Images on disk (PNG GT, `imageio` writes) are a next-row
+item: without `imageio` GT images are not read and renders are saved as .npy / PNG.
+"""
+import argparse
+import io
+import json
+import math
+import os
+import pickle
+import struct
+import sys
+import time
+import types
+import zlib
+
+import numpy as np
+import torch
+
+# ----------------------------------------------------------------------------------------
+# flags (subset of option.py that the render-only hot path reads; same names, same defaults)
+# ----------------------------------------------------------------------------------------
+_BOOL = 'store_true'
+FLAGS = [
+    ('--config', dict(type=str, default=None)), ('--expname', dict(type=str, default=None)),
+    ('--basedir', dict(type=str, default='./logs/')), ('--datadir', dict(type=str, default='./data/llff/fern')),
+    ('--netdepth', dict(type=int, default=8)), ('--netwidth', dict(type=int, default=256)),
+    ('--netdepth_fine', dict(type=int, default=8)), ('--netwidth_fine', dict(type=int, default=256)),
+    ('--chunk', dict(type=int, default=1024 * 32)), ('--netchunk', dict(type=int, default=1024 * 64)),
+    ('--N_samples', dict(type=int, default=64)), ('--N_importance', dict(type=int, default=0)),
+    ('--perturb', dict(type=float, default=1.)), ('--perturb_test', dict(type=float, default=0.)),
+    ('--use_viewdirs', dict(action=_BOOL)), ('--i_embed', dict(type=int, default=0)),
+    ('--multires', dict(type=int, default=10)), ('--multires_views', dict(type=int, default=4)),
+    ('--raw_noise_std', dict(type=float, default=0.)), ('--render_only', dict(action=_BOOL)),
+    ('--render_test', dict(action=_BOOL)), ('--render_factor', dict(type=int, default=0)),
+    ('--dataset_type', dict(type=str, default='llff')), ('--testskip', dict(type=int, default=8)),
+    ('--white_bkgd', dict(action=_BOOL)), ('--half_res', dict(action=_BOOL)), ('--no_ndc', dict(action=_BOOL)),
+    ('--lindisp', dict(action=_BOOL)), ('--model_name', dict(type=str, default='nerf')),
+    ('--n_sample_per_ray', dict(type=int, default=192)), ('--pretrained_ckpt', dict(type=str, default='')),
+    ('--n_pose_video', dict(type=str, default='20,4,1')), ('--video_tag', dict(type=str, default='')),
+    ('--use_residual', dict(action=_BOOL)), ('--linear_tail', dict(action=_BOOL)),
+    ('--layerwise_netwidths', dict(type=str, default='')), ('--act', dict(type=str, default='relu')),
+    ('--focal_scale', dict(type=float, default=1.)), ('--given_render_path_rays', dict(type=str, default='')),
+    ('--learn_depth', dict(action=_BOOL)), ('--plucker', dict(action=_BOOL)), ('--benchmark', dict(action=_BOOL)),
+    ('--trial.ON', dict(action=_BOOL)), ('--trial.body_arch', dict(type=str, default='mlp')),
+    ('--trial.res_scale', dict(type=float, default=1.)), ('--trial.n_learnable', dict(type=int, default=2)),
+    ('--trial.inact', dict(type=str, default='relu')), ('--trial.outact', dict(type=str, default='none')),
+    ('--trial.n_block', dict(type=int, default=-1)), ('--trial.near', dict(type=float, default=-1)),
+    ('--trial.far', dict(type=float, default=-1)),
+    # accepted and ignored (logging / training plumbing of the reference command lines)
+    ('--project', dict(type=str, default='')), ('--screen', dict(action=_BOOL)), ('--cache_ignore', dict(type=str, default='')),
+    ('--debug', dict(action=_BOOL)), ('--no_batching', dict(action=_BOOL)), ('--lrate_decay', dict(type=int, default=250)),
+    ('--N_rand', dict(type=int, default=4096)), ('--precrop_iters', dict(type=int, default=0)),
+    ('--precrop_frac', dict(type=float, default=.5)), ('--no_reload', dict(action=_BOOL)),
+    # this front-end's own knobs
+    ('--precision', dict(type=str, default='fp16x3', choices=['fp16x3', 'fp16x1'])),
+    ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
+    ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
+]
+
+
+def parse_config_file(path):
+    """`key = value` lines, `#` comments (also trailing), blank lines; booleans as
+    True/False (configs/lego_noview.txt:6-19).  Returns an ordered list of (key, value)."""
+    items = []
+    with open(path) as f:
+        for ln, line in enumerate(f, 1):
+            line = line.split('#', 1)[0].strip()
+            if not line:
+                continue
+            if '=' not in line:
+                raise ValueError(f'{path}:{ln}: expected `key = value`, got {line!r}')
+            k, v = (x.strip() for x in line.split('=', 1))
+            items.append((k, v))
+    return items
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog='main.py', description=__doc__.split('\n\n')[0])
+    for name, kw in FLAGS:
+        p.add_argument(name, **kw)
+    return p
+
+
+def parse_args(argv=None):
+    """Command line wins over the config file, as with ConfigArgParse (option.py:6).  Dotted
+    flags become a nested namespace (`args.trial.body_arch`), option.py:335-358, 386."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    p = build_parser()
+    pre, _ = p.parse_known_args(argv)
+    cfg_argv = []
+    if pre.config:
+        known = {n for n, _ in FLAGS}
+        for k, v in parse_config_file(pre.config):
+            flag = '--' + k
+            if flag not in known:
+                continue  # training-only keys of the reference's configs
+            kw = dict(FLAGS)[flag]
+            if kw.get('action') == _BOOL:
+                if v.lower() in ('true', '1', 'yes'):
+                    cfg_argv.append(flag)
+            else:
+                cfg_argv += [flag, v]
+    args = p.parse_args(cfg_argv + argv)
+    trial = types.SimpleNamespace()
+    for k in list(vars(args)):
+        if k.startswith('trial.'):
+            setattr(trial, k.split('.', 1)[1], getattr(args, k))
+            delattr(args, k)
+    args.trial = trial
+    return args
+
+
+# ----------------------------------------------------------------------------------------
+# checkpoint (.tar) reader
+# ----------------------------------------------------------------------------------------
+class _Stub:
+    """Stands in for classes of the reference that are pickled into checkpoints but not
+    importable here (model.nerf_raybased.NeRF_v3_2 / ResMLP, utils.EmptyClass, smilelogging
+    namespaces ...).  Keeps whatever state the pickle carries."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {'_state': state})
+
+    def __call__(self, *a, **k):  # pickled lambdas / functions reduce to calls
+        return _Stub()
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    _FOREIGN = ('model', 'utils', 'smilelogging', 'option', '__main__', 'dataset', 'main')
+
+    def find_class(self, module, name):
+        root = module.split('.', 1)[0]
+        if root in self._FOREIGN:
+            return type(name, (_Stub,), {'__module__': module})
+        return super().find_class(module, name)
+
+
+_pickle_mod = types.ModuleType('r2l_tolerant_pickle')
+_pickle_mod.Unpickler = _TolerantUnpickler
+_pickle_mod.load = lambda f, **kw: _TolerantUnpickler(f, **kw).load()
+_pickle_mod.__dict__.update({k: getattr(pickle, k) for k in ('dump', 'dumps', 'loads', 'Pickler', 'HIGHEST_PROTOCOL')})
+
+
+def strip_module_prefix(sd):
+    """utils/run_nerf_raybased_helpers.py:408-425 (undataparallel)."""
+    return {(k.split('module.', 1)[1] if k.startswith('module.') else k): v for k, v in sd.items()}
+
+
+def load_checkpoint(path):
+    """torch.load of a reference `.tar` with map_location='cpu' (the reference relies on the
+    saving device being present, main.py:483).  Returns the dict; `*_state_dict` entries are
+    plain tensors with `module.` prefixes removed; the pickled `network_fn` object (R2L
+    checkpoints, main.py:1534-1536) is tolerated and only mined for its state if the
+    state_dict entry is missing."""
+    ckpt = torch.load(path, map_location='cpu', pickle_module=_pickle_mod, weights_only=False)
+    if not isinstance(ckpt, dict):
+        raise ValueError(f'{path}: expected a dict checkpoint, got {type(ckpt).__name__}')
+    for k in list(ckpt):
+        if k.endswith('_state_dict') and k != 'optimizer_state_dict' and isinstance(ckpt[k], dict):
+            ckpt[k] = strip_module_prefix(ckpt[k])
+    if 'network_fn_state_dict' not in ckpt:
+        raise KeyError(f"{path}: no 'network_fn_state_dict' (keys: {sorted(ckpt)})")
+    return ckpt
+
+
+def save_checkpoint(path, network_fn_state_dict, network_fine_state_dict=None, global_step=0):
+    """Writes the reference's schema (main.py:1516-1542) without the pickled module."""
+    to_save = {'global_step': global_step, 'best_psnr': 0, 'best_psnr_step': 0,
+               'network_fn_state_dict': dict(network_fn_state_dict), 'optimizer_state_dict': {}}
+    if network_fine_state_dict is not None:
+        to_save['network_fine_state_dict'] = dict(network_fine_state_dict)
+    torch.save(to_save, path)
+    return path
+
+
+# ----------------------------------------------------------------------------------------
+# poses / camera
+# ----------------------------------------------------------------------------------------
+def pose_spherical(theta, phi, radius):
+    """dataset/load_blender.py:10-28."""
+    t = torch.Tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]]).float()
+    ph, th = phi / 180. * np.pi, theta / 180. * np.pi
+    rp = torch.Tensor([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0],
+                       [0, 0, 0, 1]]).float()
+    rt = torch.Tensor([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0],
+                       [0, 0, 0, 1]]).float()
+    return torch.Tensor([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]) @ (rt @ (rp @ t))
+
+
+LEGO_CAMERA_ANGLE_X = 0.6911112070083618
+
+
+def load_test_poses(args):
+    """Test-split poses + intrinsics.  With a Blender datadir: transforms_test.json
+    (load_blender.py:39-82: frames[::testskip], focal = .5*W/tan(.5*camera_angle_x), half_res
+    halves H, W, focal :106-109).  Without data (offline): `--synthetic_poses N` evenly spaced
+    pose_spherical(theta, -30, 4) views with the lego intrinsics."""
+    tf = os.path.join(args.datadir, 'transforms_test.json')
+    if args.synthetic_poses <= 0 and os.path.exists(tf):
+        with open(tf) as fp:
+            meta = json.load(fp)
+        skip = 1 if args.testskip == 0 else args.testskip
+        frames = meta['frames'][::skip]
+        poses = torch.tensor(np.array([f['transform_matrix'] for f in frames]).astype(np.float32))
+        H = W = args.H or 800
+        angle = float(meta['camera_angle_x'])
+    else:
+        n = args.synthetic_poses or 4
+        thetas = np.linspace(-180, 180, n + 1)[:-1]
+        poses = torch.stack([pose_spherical(t, -30., 4.) for t in thetas], 0)
+        H = W = args.H or 800
+        angle = LEGO_CAMERA_ANGLE_X
+    if args.W:
+        W = args.W
+    focal = .5 * W / np.tan(.5 * angle)
+    if args.half_res:
+        H, W, focal = H // 2, W // 2, focal / 2.
+    return poses, (H, W, focal)
+
+
+# ----------------------------------------------------------------------------------------
+# output helpers
+# ----------------------------------------------------------------------------------------
+def to8b(x):
+    return (255 * np.clip(np.asarray(x), 0, 1)).astype(np.uint8)
+
+
+def write_png(path, rgb8):
+    """Minimal RGB8 PNG writer (imageio is not a dependency here)."""
+    h, w, _ = rgb8.shape
+    raw = b''.join(b'\x00' + rgb8[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        c = struct.pack('>I', len(data)) + tag + data
+        return c + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+
+    with open(path, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2, 0, 0, 0)) +
+                chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
+
+
+def mse2psnr(mse):
+    return -10. * math.log10(max(float(mse), 1e-30))
+
+
+# ----------------------------------------------------------------------------------------
+# render_path
+# ----------------------------------------------------------------------------------------
+def build_engine(args, hwf, ckpt):
+    from . import NeRFEngine, PREC_FP16X1, PREC_FP16X3, R2LEngine, R2LError
+    H, W, focal = hwf
+    prec = PREC_FP16X3 if args.precision == 'fp16x3' else PREC_FP16X1
+    near, far = 2., 6.  # main.py:930-931 (blender)
+    if args.trial.near > 0:
+        near = args.trial.near
+    if args.trial.far > 0:
+        far = args.trial.far
+    if args.dataset_type != 'blender':
+        raise R2LError(f'dataset_type={args.dataset_type}: only the blender (non-NDC) path is built')
+    if args.model_name in ('R2L', 'nerf_v3.2'):
+        if args.plucker or args.learn_depth or args.linear_tail or args.layerwise_netwidths:
+            raise R2LError('plucker / learn_depth / linear_tail / layerwise_netwidths variants are not built')
+        if not args.trial.ON or args.trial.body_arch != 'resmlp':
+            raise R2LError('R2L rendering needs --trial.ON --trial.body_arch resmlp (README.md:51)')
+        n_block = args.trial.n_block if args.trial.n_block > 0 else (args.netdepth - 2) // 2
+        eng = R2LEngine(H, W, focal, near, far, n_sample=args.n_sample_per_ray, L=args.multires,
+                        width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec)
+        eng.load_state_dict(ckpt['network_fn_state_dict'])
+        return 'R2L', eng
+    if args.model_name == 'nerf':
+        if not args.use_viewdirs or args.N_importance <= 0:
+            raise R2LError('the teacher path is built for use_viewdirs=True, N_importance>0 (configs/lego.txt)')
+        if 'network_fine_state_dict' not in ckpt:
+            raise KeyError("checkpoint lacks 'network_fine_state_dict'")
+        eng = NeRFEngine(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance,
+                         multires=args.multires, multires_views=args.multires_views, white_bkgd=args.white_bkgd,
+                         precision=prec)
+        eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
+        return 'nerf', eng
+    raise R2LError(f'model_name={args.model_name} is not a render path of this build')
+
+
+def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=print):
+    """main.py:189-398 for the R2L and nerf branches: per-pose render, per-frame timing lines,
+    PSNR when GT is given.  Rows of each frame are sharded over the ranks of torch.distributed
+    (if initialised) and assembled with one all-gather."""
+    from . import dist as D
+    import torch.distributed as tdist
+    H, W, focal = hwf
+    world = tdist.get_world_size() if tdist.is_initialized() else 1
+    rank = tdist.get_rank() if tdist.is_initialized() else 0
+    r0, r1 = D.row_shard(H, rank, world)
+    rgbs, psnrs = [], []
+    for i, c2w in enumerate(render_poses):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        if kind == 'R2L':
+            local = eng.render(c2w[:3, :4], rows=(r0, r1))
+        else:
+            local = eng.render(c2w[:3, :4], rows=(r0, r1))['rgb_map']
+        rgb = D.gather_rows(local[None], H, W, world)[0].view(H, W, 3)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f'[#{i}] frame, rendering done, time for this frame: {time.time() - t0:.4f}s')
+        rgbs.append(rgb)
+        if gt_imgs is not None:
+            psnrs.append(mse2psnr(torch.mean((rgb - gt_imgs[i].to(rgb.device)) ** 2)))
+        if savedir is not None and rank == 0:
+            write_png(os.path.join(savedir, f'{i:03d}.png'), to8b(rgb.cpu().numpy()))
+    rgbs = torch.stack(rgbs, 0)
+    misc = {}
+    if gt_imgs is not None:
+        misc['test_psnr'] = mse2psnr(torch.mean((rgbs - gt_imgs.to(rgbs.device)) ** 2))
+        misc['test_psnr_v2'] = float(np.mean(psnrs))
+    return rgbs, misc
+
+
+def main(argv=None):
+    from . import dist as D
+    args = parse_args(argv)
+    if not args.render_only:
+        raise SystemExit('this front-end implements the --render_only path (training is out of scope)')
+    if not args.pretrained_ckpt:
+        raise SystemExit('--pretrained_ckpt is required with --render_only')
+    rank, local_rank, world = D.init()
+    torch.cuda.set_device(local_rank)
+    log = print if rank == 0 else (lambda *a, **k: None)
+    ckpt = load_checkpoint(args.pretrained_ckpt)
+    log(f'Load pretrained ckpt successfully: "{args.pretrained_ckpt}".')
+    poses, hwf = load_test_poses(args)
+    kind, eng = build_engine(args, hwf, ckpt)
+    outdir = args.outdir or os.path.join(args.basedir, args.expname or 'render', 'gen_img')
+    if rank == 0:
+        os.makedirs(outdir, exist_ok=True)
+    log('RENDER ONLY')
+    t_ = time.time()
+    with torch.no_grad():
+        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=None, savedir=outdir, log=log)
+    dt = time.time() - t_
+    if rank == 0:
+        np.save(os.path.join(outdir, 'rgbs.npy'), rgbs.cpu().numpy())
+        H, W, _ = hwf
+        log(f'Rendered {len(poses)} view(s) {H}x{W} on {world} GPU(s) in {dt:.2f}s '
+            f'({len(poses) * H * W / dt:.3e} rays/s incl. host I/O)')
+        if 'test_psnr' in misc:
+            log(f"[TEST] TestPSNR {misc['test_psnr']:.4f} TestPSNRv2 {misc['test_psnr_v2']:.4f}")
+        log(f'Save renders: "{outdir}"')
+    return 0

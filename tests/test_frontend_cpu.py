@@ -1,0 +1,149 @@
+"""CPU: host logic of the front-end (flag/config parsing, .tar checkpoint schema incl. the
+pickled-module case, pose/intrinsics rule, PNG writer).  No GPU calls."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def fe(pkg):
+    from efficient_nerf_amd import frontend
+    return frontend
+
+
+README_R2L = ('--model_name R2L --config configs/lego_noview.txt --n_sample_per_ray 16 --netwidth 256 --netdepth 88 '
+              '--use_residual --cache_ignore data --trial.ON --trial.body_arch resmlp --pretrained_ckpt X.tar '
+              '--render_only --render_test --testskip 1 --screen --project Test__R2L_W256D88__blender_lego')
+README_NERF = ('--model_name nerf --config configs/lego.txt --pretrained_ckpt Y.tar --render_only --render_test '
+               '--testskip 1 --screen --project Test__NeRF__blender_lego')
+
+
+def test_readme_command_lines_parse(fe):
+    os.chdir(ROOT)
+    a = fe.parse_args(README_R2L.split())
+    assert (a.model_name, a.netdepth, a.netwidth, a.n_sample_per_ray) == ('R2L', 88, 256, 16)
+    assert a.use_residual and a.render_only and a.render_test and a.testskip == 1
+    assert a.trial.ON and a.trial.body_arch == 'resmlp' and a.trial.n_block == -1 and a.trial.res_scale == 1.
+    assert a.white_bkgd and a.half_res and not a.use_viewdirs and a.dataset_type == 'blender'  # from the config
+    assert a.N_samples == 64 and a.N_importance == 128 and a.multires == 10
+    b = fe.parse_args(README_NERF.split())
+    assert b.model_name == 'nerf' and b.use_viewdirs and b.N_importance == 128 and b.netdepth == 8
+    c = fe.parse_args((README_R2L.replace('lego_noview.txt', 'lego_noview_800x800.txt')).split())
+    assert not c.half_res
+
+
+def test_config_parser_rules(fe, tmp_path):
+    p = tmp_path / 'c.txt'
+    p.write_text('# comment\nexpname = x y\n\nwhite_bkgd = True # trailing\nhalf_res = False\nN_samples=32\nunknown_key = 5\n')
+    assert fe.parse_config_file(str(p)) == [('expname', 'x y'), ('white_bkgd', 'True'), ('half_res', 'False'),
+                                            ('N_samples', '32'), ('unknown_key', '5')]
+    a = fe.parse_args(['--config', str(p), '--N_samples', '48'])
+    assert a.white_bkgd and not a.half_res and a.N_samples == 48  # command line wins
+    (tmp_path / 'bad.txt').write_text('no equals sign\n')
+    with pytest.raises(ValueError):
+        fe.parse_config_file(str(tmp_path / 'bad.txt'))
+
+
+def test_checkpoint_roundtrip_and_module_prefix(fe, tmp_path):
+    sd = O.make_r2l_state(seed=2, netdepth=4)
+    path = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(path, {'module.' + k: v for k, v in sd.items()})
+    ck = fe.load_checkpoint(path)
+    assert set(ck) >= {'global_step', 'best_psnr', 'network_fn_state_dict', 'optimizer_state_dict'}
+    assert list(ck['network_fn_state_dict']) == list(sd)
+    assert all(torch.equal(ck['network_fn_state_dict'][k], sd[k]) for k in sd)
+    t0, t1 = O.make_teacher_state(1), O.make_teacher_state(2)
+    fe.save_checkpoint(str(tmp_path / 'nerf.tar'), t0, t1)
+    ck = fe.load_checkpoint(str(tmp_path / 'nerf.tar'))
+    assert all(torch.equal(ck['network_fine_state_dict'][k], t1[k]) for k in t1)
+    torch.save({'foo': 1}, str(tmp_path / 'bad.tar'))
+    with pytest.raises(KeyError):
+        fe.load_checkpoint(str(tmp_path / 'bad.tar'))
+
+
+def test_checkpoint_with_pickled_reference_module(fe, tmp_path):
+    """Released R2L checkpoints carry `network_fn` = the whole pickled module whose classes
+    live in model.nerf_raybased / utils / smilelogging (main.py:1534-1536).  Emulate that
+    layout with throw-away modules of those names, then load with none of them importable."""
+    names = ['model', 'model.nerf_raybased', 'utils', 'smilelogging']
+    saved = {n: sys.modules.get(n) for n in names}
+    try:
+        for n in names:
+            sys.modules[n] = types.ModuleType(n)
+        mod = sys.modules['model.nerf_raybased']
+
+        class ResMLP(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.body = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.ReLU(True), torch.nn.Linear(4, 4))
+
+        class NeRF_v3_2(torch.nn.Module):
+            def __init__(self, args):
+                super().__init__()
+                self.args = args
+                self.head = torch.nn.Sequential(torch.nn.Linear(8, 4), torch.nn.ReLU(True))
+                self.body = torch.nn.Sequential(ResMLP())
+
+        class EmptyClass:
+            pass
+
+        for cls, m in ((ResMLP, 'model.nerf_raybased'), (NeRF_v3_2, 'model.nerf_raybased'), (EmptyClass, 'utils')):
+            cls.__module__ = m
+            cls.__qualname__ = cls.__name__
+            setattr(sys.modules[m], cls.__name__, cls)
+        ns = EmptyClass()
+        ns.netdepth = 88
+        net = NeRF_v3_2(ns)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        path = str(tmp_path / 'with_module.tar')
+        torch.save({'global_step': 7, 'network_fn_state_dict': net.state_dict(), 'optimizer_state_dict': {},
+                    'network_fn': net}, path)
+    finally:
+        for n in names:
+            if saved[n] is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = saved[n]
+    assert 'model.nerf_raybased' not in sys.modules or not hasattr(sys.modules['model.nerf_raybased'], 'NeRF_v3_2')
+    ck = fe.load_checkpoint(path)
+    assert ck['global_step'] == 7 and 'network_fn' in ck
+    assert all(torch.equal(ck['network_fn_state_dict'][k], sd[k]) for k in sd)
+
+
+def test_poses_and_intrinsics(fe, tmp_path):
+    a = fe.parse_args(['--config', os.path.join(ROOT, 'configs', 'lego_noview.txt'), '--synthetic_poses', '5'])
+    poses, (H, W, focal) = fe.load_test_poses(a)
+    assert poses.shape == (5, 4, 4) and (H, W) == (400, 400)
+    assert abs(focal - O.focal_from_angle(400)) < 1e-9
+    assert torch.equal(poses, O.novel_poses(5))
+    # transforms_test.json rule (load_blender.py:50-82)
+    d = tmp_path / 'scene'
+    d.mkdir()
+    frames = [{'file_path': f'./test/r_{i}', 'transform_matrix': O.pose_spherical(10. * i, -30., 4.).tolist()} for i in range(10)]
+    import json
+    (d / 'transforms_test.json').write_text(json.dumps({'camera_angle_x': 0.6911112070083618, 'frames': frames}))
+    b = fe.parse_args(['--datadir', str(d), '--testskip', '4', '--dataset_type', 'blender'])
+    poses, (H, W, focal) = fe.load_test_poses(b)
+    assert poses.shape == (3, 4, 4) and (H, W) == (800, 800) and abs(focal - 1111.1110311937682) < 1e-6
+
+
+def test_png_writer(fe, tmp_path):
+    img = (np.random.RandomState(0).rand(5, 7, 3) * 255).astype(np.uint8)
+    p = str(tmp_path / 'a.png')
+    fe.write_png(p, img)
+    data = open(p, 'rb').read()
+    assert data[:8] == b'\x89PNG\r\n\x1a\n' and b'IHDR' in data and b'IEND' in data
+    import struct, zlib
+    i = data.index(b'IDAT')
+    n = struct.unpack('>I', data[i - 4:i])[0]
+    raw = zlib.decompress(data[i + 4:i + 4 + n])
+    rows = [raw[y * (1 + 7 * 3) + 1:(y + 1) * (1 + 7 * 3)] for y in range(5)]
+    assert b''.join(rows) == img.tobytes()

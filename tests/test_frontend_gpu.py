@@ -1,0 +1,62 @@
+"""GPU: the reference's command line end to end on synthetic checkpoints (R2L and teacher),
+renders compared with the CPU oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_main(args, cwd=ROOT):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py')] + args, cwd=cwd, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_r2l_render_only_cli(pkg, tmp_path):
+    from efficient_nerf_amd import frontend as fe
+    sd = O.make_r2l_state(seed=4, netdepth=6)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    out = str(tmp_path / 'out')
+    log = run_main(['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16',
+                    '--netwidth', '256', '--netdepth', '6', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp',
+                    '--pretrained_ckpt', ck, '--render_only', '--render_test', '--testskip', '1', '--screen',
+                    '--synthetic_poses', '2', '--H', '64', '--outdir', out])
+    assert 'RENDER ONLY' in log and 'Load pretrained ckpt successfully' in log
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    H = 32  # half_res of --H 64
+    assert rgbs.shape == (2, H, H, 3) and os.path.exists(os.path.join(out, '001.png'))
+    focal = O.focal_from_angle(64) / 2.
+    for i, c2w in enumerate(O.novel_poses(2)):
+        ref = O.r2l_render(sd, H, H, focal, c2w).view(H, H, 3).numpy()
+        assert np.abs(rgbs[i] - ref).max() <= 1e-4
+
+
+def test_teacher_render_only_cli(pkg, tmp_path):
+    from efficient_nerf_amd import frontend as fe
+    t0, t1 = O.make_teacher_state(1), O.make_teacher_state(2)
+    ck = str(tmp_path / 'nerf.tar')
+    fe.save_checkpoint(ck, t0, t1)
+    out = str(tmp_path / 'out')
+    run_main(['--model_name', 'nerf', '--config', 'configs/lego.txt', '--pretrained_ckpt', ck, '--render_only',
+              '--render_test', '--testskip', '1', '--synthetic_poses', '1', '--H', '16', '--outdir', out])
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    H = 8
+    assert rgbs.shape == (1, H, H, 3)
+    ref = O.teacher_render(t0, t1, H, H, O.focal_from_angle(16) / 2., O.novel_poses(1)[0], white_bkgd=True)
+    assert np.abs(rgbs[0].reshape(-1, 3) - ref['rgb_map'].numpy()).max() <= 1e-4
+
+
+def test_cli_rejects_unsupported(pkg, tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--model_name', 'R2L'], cwd=ROOT,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and 'render_only' in (r.stdout + r.stderr)
