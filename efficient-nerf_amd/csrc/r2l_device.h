@@ -21,7 +21,7 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 // sin / cos of 2^l * x, l = 0..9, matching sin/cos of the exactly scaled fp32 argument.
 // x/(2 pi) is kept as an unevaluated sum rh + rl (two-float), scaled by the exact power
 // of two, the integer part is removed exactly (v_rndne), and sin(2 pi g) is evaluated on
-// the folded fraction |g'| <= 1/4 with a degree-11 odd polynomial.
+// the folded fraction |g'| <= 1/4 by v_sin_f32.
 // ------------------------------------------------------------------------------------
 #define R2L_INV2PI_HI 0.15915494f              // fl32(1/(2 pi))
 #define R2L_INV2PI_LO 6.4206382e-09f           // 1/(2 pi) - fl32(1/(2 pi))  (set by host check)
@@ -38,20 +38,11 @@ __device__ __forceinline__ Rev to_rev(float x) {
     return r;
 }
 
-// sin(th), |th| <= pi/2 (degree-11 odd polynomial)
-__device__ __forceinline__ float sin_poly(float th) {
-    float s = th * th;
-    float p = fmaf(s, -2.5052108e-8f, 2.7557319e-6f);
-    p = fmaf(s, p, -1.9841270e-4f);
-    p = fmaf(s, p, 8.3333333e-3f);
-    p = fmaf(s, p, -1.6666667e-1f);
-    return fmaf(th * s, p, th);
-}
-
 // sin (is_cos = false) or cos (true) of x * 2^l given x/(2 pi) = rh + rl, pow2l = 2^l.
 // rh*2^l is exact, t - rint(t) is exact, so g = frac(x*2^l/(2 pi)) in [-1/2, 1/2] keeps
 // ~2^-26 absolute accuracy; sin folds |g| to [-1/4, 1/4] (sign of g restored on the
-// angle), cos uses cos(2 pi g) = sin(2 pi (1/4 - |g|)).  max |err| 1.8e-7 (tests).
+// angle), cos uses cos(2 pi g) = sin(2 pi (1/4 - |g|)).  The folded turn fraction goes to
+// v_sin_f32 (sin(2 pi x), |err| <= 1.1e-7 on [-1/4, 1/4], measured: tools/vsin_test.hip).
 __device__ __forceinline__ float trig_pow2(Rev r, float pow2l, bool is_cos) {
     float t = r.rh * pow2l;
     float u = t - rintf(t);
@@ -59,7 +50,8 @@ __device__ __forceinline__ float trig_pow2(Rev r, float pow2l, bool is_cos) {
     float a = fabsf(g);
     float m = is_cos ? (0.25f - a) : fminf(a, 0.5f - a);
     float sg = is_cos ? 1.0f : g;
-    return sin_poly(m * copysignf(R2L_2PI, sg));
+    // m * sign(sg): flip m's sign bit by sg's (m itself may be negative and must stay so)
+    return __builtin_amdgcn_sinf(__uint_as_float(__float_as_uint(m) ^ (__float_as_uint(sg) & 0x80000000u)));
 }
 
 // ------------------------------------------------------------------------------------

@@ -121,14 +121,14 @@ __device__ __forceinline__ void epi_reg(const f32x16& acc, float inv, f32x16& xt
     asm volatile("" ::"v"(acc[reg]));
     return;
 #endif
-    float v;
+    float v;  // activation * act_scale (`inv` = act_scale / layer scale)
     if (!SECOND) {
         v = fmaxf(acc[reg] * inv, 0.0f);
     } else {
         v = fmaf(acc[reg], inv, xt[reg]);
         xt[reg] = v;
     }
-    split_store<NP>(v * act_scale, Nh[2 * t + (reg >> 3)], Nl[2 * t + (reg >> 3)], reg & 7);
+    split_store<NP>(v, Nh[2 * t + (reg >> 3)], Nl[2 * t + (reg >> 3)], reg & 7);
 }
 
 // 16 k-steps of one feature tile (one chunk), A fragments prefetched one step ahead (the
@@ -163,7 +163,8 @@ template <int NP, bool SECOND>
 __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[16], const f16x8 (&Bl)[16],
                                            f16x8 (&Nh)[16], f16x8 (&Nl)[16], f32x16 (&x)[8],
                                            float act_scale, int h) {
-    const float inv = aux_inv_scale<NP>(R.use_off);  // same for the 8 chunks of a layer
+    // activations (x, h0, B fragments) live multiplied by act_scale: `inv` only removes the weight scale
+    const float inv = aux_inv_scale<NP>(R.use_off) * act_scale;  // same for the 8 chunks of a layer
     f32x16 prev = body_tile<NP, SECOND, false>(R, Bh, Bl, Nh, Nl, x[0], inv, x[0], 0, act_scale, h);
 #pragma unroll
     for (int t = 1; t < R2L_NTILE; ++t)
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             head_kstep<NP>(R, u & 1, bh, bl, x);
         }
         // pad k-step 63: no MFMAs; leave the chunk with the next chunk's fragment 0 prefetched
-        const float inv_head = aux_inv_scale<NP>(R.use_off);
+        const float inv_head = aux_inv_scale<NP>(R.use_off) * act_scale;  // h0, x: scaled domain
         R.pre = read_frag<NP>(ring_next_off<NP>(R.use_off) + lane * 16, 0);
         ring_next<NP>(R);
 
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             for (int reg = 0; reg < 16; ++reg) {
                 float v = fmaxf(x[t][reg] * inv_head, 0.0f);
                 x[t][reg] = v;
-                split_store<NP>(v * act_scale, Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
+                split_store<NP>(v, Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
             }
             if (p.use_residual) {
 #pragma unroll
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
-                split_store<NP>(x[t][reg] * act_scale, Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
+                split_store<NP>(x[t][reg], Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
         {
             const float inv = aux_inv_scale<NP>(R.use_off);
             f32x16 acc = body_tile<NP, false, false>(R, Bh, Bl, Nh, Nl, x[0], inv, x[0], 0, act_scale, h);
