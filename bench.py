@@ -45,7 +45,8 @@ def main():
     ap.add_argument('--precision', choices=['fp16x3', 'fp16x1'], default='fp16x3',
                     help='fp16x3 meets the <=1e-4 L_inf contract (default); fp16x1 is the fast mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-rays', type=int, default=65536)
+    ap.add_argument('--cpu-rays', type=int, default=H * W,
+                    help='rays of one frame the CPU oracle renders for the baseline / parity check')
     args = ap.parse_args()
 
     import torch
@@ -123,7 +124,8 @@ def main():
         # parity on the bounded CPU sample + CPU baseline (same box, same run)
         n_cpu_rows = max(1, min(H, args.cpu_rays // W))
         c2w = poses[0]
-        gpu = eng.render(c2w, rows=(0, n_cpu_rows)).cpu()
+        # same full-frame launch as the timed ones (keeps rocprof's per-kernel average clean)
+        gpu = eng.render(c2w).cpu()[:n_cpu_rows * W]
         if not args.no_cpu_baseline and world == 1:
             torch.set_num_threads(cpu_threads())
             t1 = time.perf_counter()
