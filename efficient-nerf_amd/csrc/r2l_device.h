@@ -146,7 +146,19 @@ __device__ __forceinline__ AFrag<NP> read_frag(uint32_t lane_base, int frag) {
     return a;
 }
 
+#ifdef R2L_ABL_MFMA16  // timing-only ablation: same FLOPs on the 16x16x32 shape (results are garbage)
+__device__ __forceinline__ f32x16 mfma16_pair(f16x8 a, f16x8 b, f32x16 c) {
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+}
+#define MFMA(a, b, c) mfma16_pair((a), (b), (c))
+#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#endif
 
 // one k-step on one 32x32 output tile: ah*bh [+ ah*bl + al*bh]
 template <int NP>
