@@ -30,6 +30,7 @@ SIGNATURES = {
     'r2l_render_rays': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     'r2l_sample_embed': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     'r2l_embed': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'r2l_debug_pack_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_longlong]),
     'r2l_flops_per_ray': (C.c_longlong, [_vp]),
     'r2l_weight_image_bytes': (C.c_longlong, [_vp]),
     'r2l_rays_per_tile': (C.c_int, [_vp]),

@@ -186,12 +186,30 @@ static void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
     }
 }
 
+static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img);
+
 static int build_image(r2l_ctx* c, int mode) {
+    std::vector<char> img;
+    pack_image_host(c, mode, img);
+    if (c->d_img[mode]) {
+        (void)hipFree(c->d_img[mode]);
+        c->d_img[mode] = nullptr;
+    }
+    hipError_t e = hipMalloc((void**)&c->d_img[mode], img.size());
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc image: %s", hipGetErrorString(e));
+    e = hipMemcpy(c->d_img[mode], img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy image: %s", hipGetErrorString(e));
+    c->img_bytes[mode] = img.size();
+    return R2L_OK;
+}
+
+// host-only: the packed chunk stream of r2l_common.h (no GPU needed; also behind r2l_debug_pack_host)
+static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) {
     const int np = np_of(mode);
     const int CH = r2l_chunk_bytes(np);
     const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
     const int cpt = r2l_chunks_per_tile(c->n_block);
-    std::vector<char> img((size_t)cpt * CH, 0);
+    img.assign((size_t)cpt * CH, 0);
     auto aux = [&](int chunk) { return reinterpret_cast<float*>(img.data() + (size_t)chunk * CH + AUX); };
     const float Sa = c->act_scale;
     // head
@@ -252,16 +270,6 @@ static int build_image(r2l_ctx* c, int mode) {
         for (int i = 0; i < 3; ++i) aux(ci)[i] = bt[i] * S;
         aux(ci)[32] = 1.0f / S;
     }
-    if (c->d_img[mode]) {
-        (void)hipFree(c->d_img[mode]);
-        c->d_img[mode] = nullptr;
-    }
-    hipError_t e = hipMalloc((void**)&c->d_img[mode], img.size());
-    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc image: %s", hipGetErrorString(e));
-    e = hipMemcpy(c->d_img[mode], img.data(), img.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy image: %s", hipGetErrorString(e));
-    c->img_bytes[mode] = img.size();
-    return R2L_OK;
 }
 
 int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
@@ -290,6 +298,30 @@ int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
     if (rc) return rc;
     c->loaded = true;
     return R2L_OK;
+}
+
+// Host-only packing for tests (no GPU): tensors in state_dict order -> chunk stream bytes.
+// Returns the byte count (or a negative code); copies min(count, cap) bytes into out.
+long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_block, int precision_mode, char* out,
+                              long long cap) {
+    if (!tensors || n_tensors != 4 + 4 * n_block || n_block < 0) return r2l_set_error(R2L_EINVAL, "bad tensor list");
+    if (precision_mode != R2L_PREC_FP16X3 && precision_mode != R2L_PREC_FP16X1) return r2l_set_error(R2L_EINVAL, "bad mode");
+    r2l_ctx c;
+    c.n_block = n_block;
+    c.act_scale = 16.0f;
+    for (int i = 0; i < n_tensors; ++i) {
+        size_t n;
+        if (i == 0) n = (size_t)R2L_WIDTH * R2L_IN;
+        else if (i == 1) n = R2L_WIDTH;
+        else if (i == n_tensors - 2) n = 3 * R2L_WIDTH;
+        else if (i == n_tensors - 1) n = 3;
+        else n = ((i - 2) % 2 == 0) ? (size_t)R2L_WIDTH * R2L_WIDTH : R2L_WIDTH;
+        c.host_w.emplace_back(tensors[i], tensors[i] + n);
+    }
+    std::vector<char> img;
+    pack_image_host(&c, precision_mode, img);
+    if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
+    return (long long)img.size();
 }
 
 int r2l_set_precision(r2l_ctx* c, int mode) {

@@ -102,6 +102,12 @@ int r2l_sample_embed(r2l_ctx* ctx, const float* c2w_host, int row_begin, int row
 /* PositionalEmbedder on caller-provided points: x_dev [n, dim] -> emb_out_dev [n, dim*21] */
 int r2l_embed(const float* x_dev, int n, int dim, int L, float* emb_out_dev, void* stream);
 
+/* Host-only (no GPU): pack state_dict tensors into the MFMA chunk stream that
+ * r2l_load_weights uploads (csrc/r2l_common.h); for the CPU tests of the host logic.
+ * Returns the image size in bytes (negative on error), copies at most cap bytes to out. */
+long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_block,
+                              int precision_mode, char* out, long long cap);
+
 /* introspection for bench.py / DESIGN.md */
 long long r2l_flops_per_ray(const r2l_ctx* ctx);      /* algorithmic: 2*MACs of the network */
 long long r2l_weight_image_bytes(const r2l_ctx* ctx); /* packed fp16 image streamed per ray tile */

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Development bench (GPU box): NeRF teacher coarse+fine render of one 400x400 frame
+(BASELINE.json config 3): rays/s and algorithmic TFLOP/s (303,824,896 FLOP/ray)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import _pkg  # noqa: E402
+
+_pkg.load()
+from efficient_nerf_amd import NeRFEngine, PREC_FP16X1, PREC_FP16X3  # noqa: E402
+from oracle import r2l_oracle as O  # noqa: E402
+
+H = W = int(os.environ.get('T_H', 400))
+REP = int(os.environ.get('T_REP', 3))
+FLOP_PER_RAY = 2 * 593408 * 256
+for prec, name in ((PREC_FP16X3, 'fp16x3'), (PREC_FP16X1, 'fp16x1')):
+    eng = NeRFEngine(H, W, O.focal_from_angle(W), precision=prec).load_state_dicts(O.make_teacher_state(1),
+                                                                                  O.make_teacher_state(2))
+    poses = O.novel_poses(4)
+    eng.render(poses[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(REP):
+        out = eng.render(poses[i % 4])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / REP
+    passes = 3 if name == 'fp16x3' else 1
+    print(f'teacher {name} {H}x{W}: {dt*1e3:.1f} ms/frame, {H*W/dt:.3e} rays/s, algorithmic {FLOP_PER_RAY*H*W/dt/1e12:.0f} TFLOP/s '
+          f'(executed {FLOP_PER_RAY*H*W*passes/dt/1e12:.0f})', flush=True)
+    eng.close()
