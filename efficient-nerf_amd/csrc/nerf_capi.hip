@@ -39,28 +39,29 @@ void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
     if (np == 2) reinterpret_cast<_Float16*>(chunk + (size_t)(frag * np + 1) * R2L_FRAG_BYTES + lane * 16)[j] = lo;
 }
 
-// One layer of the fragment stream.  weight(row, col) returns W[row][col] (0 outside),
-// col_of(ks, h, j) the input column of k-step ks (or -1), bias(row) the bias.
-void pack_layer(std::vector<char>& img, int np, int F0, int KS, int NT, float Sa,
+// One layer of the fragment stream: RT row tiles (16 outputs) x KS k-steps (32 inputs).
+// weight(row, col) returns W[row][col] (0 outside), col_of(s, q, j) the input column of element
+// j of lane quarter q of k-step s (or -1), bias(row) the bias.
+void pack_layer(std::vector<char>& img, int np, int F0, int KS, int RT, float Sa,
                 const std::function<float(int, int)>& weight, const std::function<int(int, int, int)>& col_of,
                 const std::function<float(int)>& bias, float Sw, float* inv_scale_out) {
     const int CH = r2l_chunk_bytes(np);
     const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
     const float S = Sa * Sw;
-    for (int t = 0; t < NT; ++t) {
+    for (int u = 0; u < RT; ++u) {
         for (int ks = 0; ks < KS; ++ks) {
-            const int q = F0 + t * KS + ks;
-            char* chunk = img.data() + (size_t)(q / R2L_FRAGS) * CH;
+            const int fq = F0 + u * KS + ks;
+            char* chunk = img.data() + (size_t)(fq / R2L_FRAGS) * CH;
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                    const int col = col_of(ks, lane >> 5, j);
-                    const float v = col < 0 ? 0.f : weight(32 * t + (lane & 31), col) * Sw;
-                    put_frag(chunk, np, q % R2L_FRAGS, lane, j, v);
+                    const int col = col_of(ks, lane >> 4, j);
+                    const float v = col < 0 ? 0.f : weight(16 * u + (lane & 15), col) * Sw;
+                    put_frag(chunk, np, fq % R2L_FRAGS, lane, j, v);
                 }
         }
-        const int q0 = F0 + t * KS;
+        const int q0 = F0 + u * KS;
         float* aux = reinterpret_cast<float*>(img.data() + (size_t)(q0 / R2L_FRAGS) * CH + AUX);
-        for (int i = 0; i < 32; ++i) aux[32 * nerf_aux_slot(q0) + i] = bias(32 * t + i) * S;
+        for (int i = 0; i < 16; ++i) aux[16 * nerf_aux_slot(q0) + i] = bias(16 * u + i) * S;
     }
     *inv_scale_out = 1.0f / S;
 }
@@ -217,44 +218,43 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
     };
     auto kap = [](int ks, int h, int j) { return r2l_kappa(ks, h, j); };
     // L0
-    pack_layer(img, np, NERF_F0_L0, 4, 8, Sa, mat(0, 63, 256), [](int ks, int h, int j) { return nerf_pts_col(ks, h, j); },
+    pack_layer(img, np, NERF_F0_L0, 2, 16, Sa, mat(0, 63, 256), [](int ks, int q, int j) { return nerf_pts_col(ks, q, j); },
                vec(1, 256), r2l_pow2_scale(w[0].data(), w[0].size()), &inv[0]);
     // L1..L4, L6, L7
     const int plain[6] = {1, 2, 3, 4, 6, 7};
     for (int li : plain) {
         const int F0 = li <= 4 ? NERF_F0_L1 + 128 * (li - 1) : NERF_F0_L6 + 128 * (li - 6);
-        pack_layer(img, np, F0, 16, 8, Sa, mat(2 * li, 256, 256), kap, vec(2 * li + 1, 256),
+        pack_layer(img, np, F0, 8, 16, Sa, mat(2 * li, 256, 256), kap, vec(2 * li + 1, 256),
                    r2l_pow2_scale(w[2 * li].data(), w[2 * li].size()), &inv[li]);
     }
     // L5: reference input = cat[input_pts(63), h(256)]  (model/nerf_raybased.py:385)
-    pack_layer(img, np, NERF_F0_L5, 20, 8, Sa, mat(10, 319, 256),
-               [](int ks, int h, int j) {
-                   if (ks < 16) return 63 + r2l_kappa(ks, h, j);
-                   const int cidx = nerf_pts_col(ks - 16, h, j);
-                   return cidx;
+    pack_layer(img, np, NERF_F0_L5, 10, 16, Sa, mat(10, 319, 256),
+               [](int ks, int q, int j) {
+                   if (ks < 8) return 63 + r2l_kappa(ks, q, j);
+                   return nerf_pts_col(ks - 8, q, j);
                },
                vec(11, 256), r2l_pow2_scale(w[10].data(), w[10].size()), &inv[5]);
-    // FA: rows 0..255 feature_linear, row 256 alpha_linear
+    // FA: rows 0..255 feature_linear, row 256 alpha_linear (row tile 16, row 0)
     {
         const float* fw = w[T_FEAT_W].data();
         const float* aw = w[T_ALPHA_W].data();
         const float* fb = w[T_FEAT_B].data();
         const float* ab = w[T_ALPHA_B].data();
         const float Sw = max_scale({{fw, w[T_FEAT_W].size()}, {aw, w[T_ALPHA_W].size()}});
-        pack_layer(img, np, NERF_F0_FA, 16, 9, Sa,
+        pack_layer(img, np, NERF_F0_FA, 8, 17, Sa,
                    [=](int r, int col) -> float { return r < 256 ? fw[(size_t)r * 256 + col] : (r == 256 ? aw[col] : 0.f); },
                    kap, [=](int r) -> float { return r < 256 ? fb[r] : (r == 256 ? ab[0] : 0.f); }, Sw, &inv[8]);
     }
     // V: reference input = cat[feature(256), input_views(27)]  (model/nerf_raybased.py:390)
-    pack_layer(img, np, NERF_F0_V, 18, 4, Sa, mat(T_VIEWS_W, 283, 128),
-               [](int ks, int h, int j) {
-                   if (ks < 16) return r2l_kappa(ks, h, j);
-                   const int cidx = nerf_view_col(ks - 16, h, j);
+    pack_layer(img, np, NERF_F0_V, 9, 8, Sa, mat(T_VIEWS_W, 283, 128),
+               [](int ks, int q, int j) {
+                   if (ks < 8) return r2l_kappa(ks, q, j);
+                   const int cidx = nerf_view_col(q, j);
                    return cidx < 0 ? -1 : 256 + cidx;
                },
                vec(T_VIEWS_B, 128), r2l_pow2_scale(w[T_VIEWS_W].data(), w[T_VIEWS_W].size()), &inv[9]);
     // RGB
-    pack_layer(img, np, NERF_F0_RGB, 8, 1, Sa, mat(T_RGB_W, 128, 3), kap, vec(T_RGB_B, 3),
+    pack_layer(img, np, NERF_F0_RGB, 4, 1, Sa, mat(T_RGB_W, 128, 3), kap, vec(T_RGB_B, 3),
                r2l_pow2_scale(w[T_RGB_W].data(), w[T_RGB_W].size()), &inv[10]);
     if (net.d_img[mode]) {
         (void)hipFree(net.d_img[mode]);

@@ -30,61 +30,68 @@
 // ====================================================================================
 enum { EPI_RELU = 0, EPI_LINEAR_ALPHA = 1, EPI_RGB = 2 };
 
-struct MlpOut {
-    float alpha;   // sigma (alpha_linear output), valid in lanes h == 0
-    float rgb[3];  // rgb_linear output, valid in lanes h == 0
+struct MlpOut {       // valid in the quarter-0 lanes (q == 0), one value per column tile
+    float alpha[2];   // sigma (alpha_linear output)
+    float rgb[2][3];  // rgb_linear output
 };
 
-// epilogue of accumulator register `reg` of output tile t of a layer
-template <int NP, int EPI, int NT>
-__device__ __forceinline__ void mlp_epi_reg(const f32x16& acc, float inv, f16x8 (&Dh)[16], f16x8 (&Dl)[16],
-                                            int t, int reg, float act_scale, MlpOut& out) {
+// epilogue of accumulator register r of row tile u, column tile c, of a layer with RT row tiles
+template <int NP, int EPI, int RT>
+__device__ __forceinline__ void mlp_epi_reg(const f32x4& acc, float inv, f16x8 (&Dh)[8][2], f16x8 (&Dl)[8][2],
+                                            int u, int c, int r, float act_scale, MlpOut& out) {
     if (EPI == EPI_RGB) {
-        if (reg < 3) out.rgb[reg] = acc[reg] * inv;
+        if (r < 3) out.rgb[c][r] = acc[r] * inv;
         return;
     }
-    if (EPI == EPI_LINEAR_ALPHA && t == NT - 1) {  // tile 8 of FA: row 0 = alpha_linear
-        if (reg == 0) out.alpha = acc[0] * inv;
+    if (EPI == EPI_LINEAR_ALPHA && u == RT - 1) {  // row tile 16 of FA: row 0 = alpha_linear
+        if (r == 0) out.alpha[c] = acc[0] * inv;
         return;
     }
-    float v = acc[reg] * inv;
+    float v = acc[r] * inv;
     if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
-    split_store<NP>(v * act_scale, Dh[2 * t + (reg >> 3)], Dl[2 * t + (reg >> 3)], reg & 7);
+    split_store<NP>(v * act_scale, Dh[(u >> 1) & 7][c], Dl[(u >> 1) & 7][c], 4 * (u & 1) + r);
 }
 
-// One Linear layer = fragment run [F0, F0 + NT*KS).  Input fragments: k-steps 0..15 from
-// (Sh,Sl), k-steps 16.. from (Xh,Xl).  Output tiles are written as fragments of (Dh,Dl).
-// The epilogue of tile t-1 is interleaved with the MFMAs of tile t; the last tile's is exposed.
-template <int NP, int KS, int NT, int F0, int EPI>
-__device__ __forceinline__ void mlp_layer(Ring<NP>& R, const f16x8 (&Sh)[16], const f16x8 (&Sl)[16],
-                                          const f16x8 (&Xh)[4], const f16x8 (&Xl)[4], f16x8 (&Dh)[16],
-                                          f16x8 (&Dl)[16], float inv, float act_scale, int h, MlpOut& out) {
-    f32x16 prev;
+// One Linear layer = fragment run [F0, F0 + RT*KS).  Input fragments: k-steps 0..7 from
+// (Sh,Sl), k-steps 8.. from (Xh,Xl).  Output row tiles are written as fragments of (Dh,Dl).
+// The epilogue of row tile u-1 is interleaved with the MFMAs of row tile u; the last one's is
+// exposed.
+template <int NP, int KS, int RT, int F0, int EPI>
+__device__ __forceinline__ void mlp_layer(Ring<NP>& R, const f16x8 (&Sh)[8][2], const f16x8 (&Sl)[8][2],
+                                          const f16x8 (&Xh)[2][2], const f16x8 (&Xl)[2][2], f16x8 (&Dh)[8][2],
+                                          f16x8 (&Dl)[8][2], float inv, float act_scale, int q, MlpOut& out) {
+    f32x4 acc[2], prev[2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x16 acc;
+    for (int u = 0; u < RT; ++u) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int q = F0 + t * KS + ks;
-            const int pos = q % R2L_FRAGS;
-            if (ks == 0) acc = acc_init<NP>(R.use_off, 32 * nerf_aux_slot(q), h);
+        for (int s = 0; s < KS; ++s) {
+            const int fq = F0 + u * KS + s;
+            const int pos = fq % R2L_FRAGS;
+            if (s == 0) {
+                acc[0] = acc_init<NP>(R.use_off, 16 * nerf_aux_slot(fq), q);
+                acc[1] = acc[0];
+            }
             AFrag<NP> nxt = (pos + 1 < R2L_FRAGS) ? read_frag<NP>(R.use_off + R.lane * 16, pos + 1)
                                                   : read_frag<NP>(ring_next_off<NP>(R.use_off) + R.lane * 16, 0);
-            if (ks < 16) acc = mfma_step<NP>(R.pre, Sh[ks < 16 ? ks : 0], Sl[ks < 16 ? ks : 0], acc);
-            else acc = mfma_step<NP>(R.pre, Xh[ks >= 16 ? ks - 16 : 0], Xl[ks >= 16 ? ks - 16 : 0], acc);
-            R.pre = nxt;
-            if (t > 0) {
 #pragma unroll
-                for (int reg = (16 * ks + KS - 1) / KS; reg < (16 * (ks + 1) + KS - 1) / KS && reg < 16; ++reg)
-                    mlp_epi_reg<NP, EPI, NT>(prev, inv, Dh, Dl, t - 1, reg, act_scale, out);
+            for (int c = 0; c < 2; ++c) {
+                if (s < 8) acc[c] = mfma_step<NP>(R.pre, Sh[s < 8 ? s : 0][c], Sl[s < 8 ? s : 0][c], acc[c]);
+                else acc[c] = mfma_step<NP>(R.pre, Xh[s >= 8 ? s - 8 : 0][c], Xl[s >= 8 ? s - 8 : 0][c], acc[c]);
+            }
+            R.pre = nxt;
+            if (u > 0) {
+#pragma unroll
+                for (int i = (8 * s + KS - 1) / KS; i < (8 * (s + 1) + KS - 1) / KS && i < 8; ++i)
+                    mlp_epi_reg<NP, EPI, RT>(prev[i >> 2], inv, Dh, Dl, u - 1, i >> 2, i & 3, act_scale, out);
             }
             if (pos == R2L_FRAGS / 2 - 1) ring_mid<NP>(R);
             if (pos == R2L_FRAGS - 1) ring_next<NP>(R);
         }
-        prev = acc;
+        prev[0] = acc[0];
+        prev[1] = acc[1];
     }
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) mlp_epi_reg<NP, EPI, NT>(prev, inv, Dh, Dl, NT - 1, reg, act_scale, out);
+    for (int i = 0; i < 8; ++i) mlp_epi_reg<NP, EPI, RT>(prev[i >> 2], inv, Dh, Dl, RT - 1, i >> 2, i & 3, act_scale, out);
 }
 
 template <int NP>
@@ -99,8 +106,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
     R.issue_off = 0;
     R.use_off = 0;
     const int lane = R.lane;
-    const int h = lane >> 5;
-    const bool is_cos = h != 0;
+    const int q = lane >> 4;
     const float act_scale = p.act_scale;
 
 #pragma unroll
@@ -109,101 +115,129 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
     __builtin_amdgcn_s_barrier();
     R.pre = read_frag<NP>(lane * 16, 0);
 
-    f16x8 A1h[16], A1l[16], A2h[16], A2l[16];
-    f16x8 Eh[4], El[4], Vh[4], Vl[4];
+    f16x8 A1h[8][2], A1l[8][2], A2h[8][2], A2l[8][2];
+    f16x8 Eh[2][2], El[2][2], Vh[2][2], Vl[2][2];
 #pragma unroll
-    for (int i = 2; i < 4; ++i) {  // unused tail of the 4-wide "extra" operand of the V layer
-        Vh[i] = (f16x8)(f16)0;
-        Vl[i] = (f16x8)(f16)0;
+    for (int c = 0; c < 2; ++c) {  // unused second slot of the "extra" operand of the V layer
+        Vh[1][c] = (f16x8)(f16)0;
+        Vl[1][c] = (f16x8)(f16)0;
     }
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        const long long pt_raw = (long long)tile * NERF_TILE_PTS + R.wave * NERF_PTS_PER_WAVE + (lane & 31);
-        const bool valid = pt_raw < p.n_pts;
-        const long long pt = valid ? pt_raw : p.n_pts - 1;
-        const int ray = (int)(pt / p.S);
-        const int s = (int)(pt - (long long)ray * p.S);
-        float o[3], d[3];
+        long long pt[2];
+        bool valid[2];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            o[k] = p.rays_o[(size_t)ray * 3 + k];
-            d[k] = p.rays_d[(size_t)ray * 3 + k];
-        }
-        const float z = p.z[(size_t)ray * p.z_stride + s];
-        // viewdirs = rays_d / ||rays_d||  (main.py:154-156)
-        const float nrm = sqrtf(__fadd_rn(__fadd_rn(d[0] * d[0], d[1] * d[1]), d[2] * d[2]));
-        Rev rx[3], rv[3];
-        float xs[3], vs[3];
+        for (int c = 0; c < 2; ++c) {  // a lane serves point (lane & 15) of both column tiles
+            const long long pt_raw = (long long)tile * NERF_TILE_PTS + R.wave * NERF_PTS_PER_WAVE + c * 16 + (lane & 15);
+            valid[c] = pt_raw < p.n_pts;
+            pt[c] = valid[c] ? pt_raw : p.n_pts - 1;
+            const int ray = (int)(pt[c] / p.S);
+            const int smp = (int)(pt[c] - (long long)ray * p.S);
+            float o[3], d[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            xs[k] = __fadd_rn(o[k], __fmul_rn(d[k], z));  // rays_o + rays_d * z  (main.py:701)
-            vs[k] = __fdiv_rn(d[k], nrm);
-            rx[k] = to_rev(xs[k]);
-            rv[k] = to_rev(vs[k]);
-        }
-        // ---- embedding fragments (nerf_common.h: nerf_pts_col / nerf_view_col) -------------
+            for (int k = 0; k < 3; ++k) {
+                o[k] = p.rays_o[(size_t)ray * 3 + k];
+                d[k] = p.rays_d[(size_t)ray * 3 + k];
+            }
+            const float z = p.z[(size_t)ray * p.z_stride + smp];
+            // viewdirs = rays_d / ||rays_d||  (main.py:154-156)
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(d[0] * d[0], d[1] * d[1]), d[2] * d[2]));
+            float xs[3], vs[3];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            float pw = 1.0f;
+            for (int k = 0; k < 3; ++k) {
+                xs[k] = __fadd_rn(o[k], __fmul_rn(d[k], z));  // rays_o + rays_d * z  (main.py:701)
+                vs[k] = __fdiv_rn(d[k], nrm);
+            }
+            // ---- embedding fragments (nerf_common.h: nerf_pts_col / nerf_view_col) ---------
+            {   // E step 0: coordinate q>>1, frequencies 0..7, sin|cos by q&1
+                const Rev r = to_rev((q & 2) ? xs[1] : xs[0]);
+                float pw = 1.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                split_store<NP>(trig_pow2(rx[e], pw, is_cos) * act_scale, Eh[e], El[e], j);
-                pw *= 2.0f;
+                for (int j = 0; j < 8; ++j) {
+                    split_store<NP>(trig_pow2(r, pw, (q & 1) != 0) * act_scale, Eh[0][c], El[0][c], j);
+                    pw *= 2.0f;
+                }
+            }
+            {   // E step 1: q<2: coordinate 2 frequencies 0..7; q>=2: frequencies 8,9 of all three + identity
+                const Rev r2 = to_rev(xs[2]);
+                const Rev r0 = to_rev(xs[0]);
+                const Rev r1 = to_rev(xs[1]);
+                float pw = 1.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float lo_q = trig_pow2(r2, pw, (q & 1) != 0);          // q < 2
+                    float hi_q;                                                   // q >= 2
+                    if (j < 6) hi_q = trig_pow2(j < 2 ? r0 : (j < 4 ? r1 : r2), (j & 1) ? 512.0f : 256.0f, q == 3);
+                    else if (j == 6) hi_q = (q == 3) ? xs[2] : xs[0];
+                    else hi_q = (q == 3) ? 0.0f : xs[1];
+                    split_store<NP>(((q & 2) ? hi_q : lo_q) * act_scale, Eh[1][c], El[1][c], j);
+                    pw *= 2.0f;
+                }
+            }
+            {   // view step: q<3: component q, frequencies j&3, sin|cos by j>>2; q=3: identity
+                const Rev rv = to_rev(q == 0 ? vs[0] : (q == 1 ? vs[1] : vs[2]));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = trig_pow2(rv, (float)(1 << (j & 3)), (j >> 2) != 0);
+                    const float idv = j < 3 ? vs[j < 3 ? j : 0] : 0.0f;
+                    split_store<NP>(((q == 3) ? idv : t) * act_scale, Vh[0][c], Vl[0][c], j);
+                }
             }
         }
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-            split_store<NP>(trig_pow2(rx[j >> 1], (j & 1) ? 512.0f : 256.0f, is_cos) * act_scale, Eh[3], El[3], j);
-        split_store<NP>((h ? xs[2] : xs[0]) * act_scale, Eh[3], El[3], 6);
-        split_store<NP>((h ? 0.0f : xs[1]) * act_scale, Eh[3], El[3], 7);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            split_store<NP>(trig_pow2(rv[j >> 2], (float)(1 << (j & 3)), is_cos) * act_scale, Vh[0], Vl[0], j);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            split_store<NP>(trig_pow2(rv[2], (float)(1 << j), is_cos) * act_scale, Vh[1], Vl[1], j);
-#pragma unroll
-        for (int j = 4; j < 8; ++j)
-            split_store<NP>(((h == 0 && j < 7) ? vs[j - 4] : 0.0f) * act_scale, Vh[1], Vl[1], j);
 
         MlpOut out;
-        out.alpha = 0.f;
-        out.rgb[0] = out.rgb[1] = out.rgb[2] = 0.f;
-        // L0: E -> A2   (KS = 4: the source operand is E parked in A1[0..3])
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            A1h[e] = Eh[e];
-            A1l[e] = El[e];
+        for (int c = 0; c < 2; ++c) {
+            out.alpha[c] = 0.f;
+            out.rgb[c][0] = out.rgb[c][1] = out.rgb[c][2] = 0.f;
         }
-        mlp_layer<NP, 4, 8, NERF_F0_L0, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, p.inv_scale[0], act_scale, h, out);
+        // L0: E -> A2   (KS = 2: the source operand is E parked in A1[0..1])
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                A1h[e][c] = Eh[e][c];
+                A1l[e][c] = El[e][c];
+            }
+        mlp_layer<NP, 2, 16, NERF_F0_L0, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, p.inv_scale[0], act_scale, q, out);
         for (int it = 0; it < 3; ++it) {
             if (it == 2) {
                 // L5: [h(256) | E] -> A1, then move to A2 so the two-layer body is reused
-                mlp_layer<NP, 20, 8, NERF_F0_L5, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[5], act_scale,
-                                                           h, out);
+                mlp_layer<NP, 10, 16, NERF_F0_L5, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[5], act_scale,
+                                                            q, out);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    A2h[i] = A1h[i];
-                    A2l[i] = A1l[i];
-                }
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        A2h[i][c] = A1h[i][c];
+                        A2l[i][c] = A1l[i][c];
+                    }
             }
             // (L1,L2) (L3,L4) (L6,L7): the fragment run of the pair is contiguous per iteration
             const float inva = p.inv_scale[it == 0 ? 1 : (it == 1 ? 3 : 6)];
             const float invb = p.inv_scale[it == 0 ? 2 : (it == 1 ? 4 : 7)];
-            mlp_layer<NP, 16, 8, NERF_F0_L1, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, inva, act_scale, h, out);
-            mlp_layer<NP, 16, 8, NERF_F0_L1 + 128, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, invb, act_scale, h, out);
+            mlp_layer<NP, 8, 16, NERF_F0_L1, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, inva, act_scale, q, out);
+            mlp_layer<NP, 8, 16, NERF_F0_L1 + 128, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, invb, act_scale, q, out);
         }
         // FA: feature_linear | alpha_linear (no activation) -> A1, sigma
-        mlp_layer<NP, 16, 9, NERF_F0_FA, EPI_LINEAR_ALPHA>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[8], act_scale,
-                                                           h, out);
-        // V: [feature | view embedding] -> 128, relu -> A2[0..7]
-        mlp_layer<NP, 18, 4, NERF_F0_V, EPI_RELU>(R, A1h, A1l, Vh, Vl, A2h, A2l, p.inv_scale[9], act_scale, h, out);
-        // RGB: 128 -> 3
-        mlp_layer<NP, 8, 1, NERF_F0_RGB, EPI_RGB>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[10], act_scale, h, out);
+        mlp_layer<NP, 8, 17, NERF_F0_FA, EPI_LINEAR_ALPHA>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[8], act_scale,
+                                                           q, out);
+        // V: [feature | view embedding] -> 128, relu -> A2[0..3]
+        mlp_layer<NP, 9, 8, NERF_F0_V, EPI_RELU>(R, A1h, A1l, Vh, Vl, A2h, A2l, p.inv_scale[9], act_scale, q, out);
+        // RGB: 128 -> 3 (4 k-steps), then leave the half-used last chunk
+        mlp_layer<NP, 4, 1, NERF_F0_RGB, EPI_RGB>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[10], act_scale, q, out);
+        ring_mid<NP>(R);
+        R.pre = read_frag<NP>(ring_next_off<NP>(R.use_off) + lane * 16, 0);
+        ring_next<NP>(R);
 
-        if (valid && h == 0) {
-            f32x4 r4 = {out.rgb[0], out.rgb[1], out.rgb[2], out.alpha};
-            *reinterpret_cast<f32x4*>(p.raw + (size_t)pt * 4) = r4;
+        if (q == 0) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (valid[c]) {
+                    f32x4 r4 = {out.rgb[c][0], out.rgb[c][1], out.rgb[c][2], out.alpha[c]};
+                    *reinterpret_cast<f32x4*>(p.raw + (size_t)pt[c] * 4) = r4;
+                }
+            }
         }
     }
     R2L_WAIT_VMCNT(0);

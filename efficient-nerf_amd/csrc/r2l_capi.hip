@@ -212,7 +212,7 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
     img.assign((size_t)cpt * CH, 0);
     auto aux = [&](int chunk) { return reinterpret_cast<float*>(img.data() + (size_t)chunk * CH + AUX); };
     const float Sa = c->act_scale;
-    // head
+    // head: chunk = k-step s, fragment = row tile u
     {
         const float* Wh = c->host_w[0].data();
         const float* bh = c->host_w[1].data();
@@ -220,38 +220,39 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
         const float S = Sa * Sw;
         for (int ch = 0; ch < R2L_HEAD_CHUNKS; ++ch) {
             char* chunk = img.data() + (size_t)ch * CH;
-            for (int ksl = 0; ksl < 2; ++ksl)
-                for (int t = 0; t < R2L_NTILE; ++t)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            int col = r2l_head_col(2 * ch + ksl, lane >> 5, j);
-                            float v = col < 0 ? 0.f : Wh[(size_t)(32 * t + (lane & 31)) * R2L_IN + col] * Sw;
-                            put_frag(chunk, np, ksl * 8 + t, lane, j, v);
-                        }
+            for (int u = 0; u < R2L_RTILES; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        int col = r2l_head_col(ch, lane >> 4, j);
+                        float v = col < 0 ? 0.f : Wh[(size_t)(16 * u + (lane & 15)) * R2L_IN + col] * Sw;
+                        put_frag(chunk, np, u, lane, j, v);
+                    }
         }
         for (int n = 0; n < R2L_WIDTH; ++n) aux(0)[n] = bh[n] * S;
         aux(R2L_HEAD_CHUNKS - 1)[32] = 1.0f / S;
     }
-    // body
+    // body: chunk m of a layer = row tiles 2m, 2m+1; fragment = (u&1)*8 + k-step
     for (int li = 0; li < 2 * c->n_block; ++li) {
         const float* Wl = c->host_w[2 + 2 * li].data();
         const float* bl = c->host_w[3 + 2 * li].data();
         const float Sw = r2l_pow2_scale(Wl, (size_t)R2L_WIDTH * R2L_WIDTH);
         const float S = Sa * Sw;
-        for (int t = 0; t < R2L_NTILE; ++t) {
-            const int ci = R2L_HEAD_CHUNKS + li * R2L_NTILE + t;
+        for (int m = 0; m < R2L_RTILES / 2; ++m) {
+            const int ci = R2L_HEAD_CHUNKS + li * (R2L_RTILES / 2) + m;
             char* chunk = img.data() + (size_t)ci * CH;
-            for (int ks = 0; ks < R2L_KSTEPS; ++ks)
+            for (int f = 0; f < R2L_FRAGS; ++f) {
+                const int u = 2 * m + (f >> 3), ks = f & 7;
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        int k = r2l_kappa(ks, lane >> 5, j);
-                        put_frag(chunk, np, ks, lane, j, Wl[(size_t)(32 * t + (lane & 31)) * R2L_WIDTH + k] * Sw);
+                        int k = r2l_kappa(ks, lane >> 4, j);
+                        put_frag(chunk, np, f, lane, j, Wl[(size_t)(16 * u + (lane & 15)) * R2L_WIDTH + k] * Sw);
                     }
-            for (int i = 0; i < 32; ++i) aux(ci)[i] = bl[32 * t + i] * S;
+            }
+            for (int i = 0; i < 32; ++i) aux(ci)[i] = bl[32 * m + i] * S;
             aux(ci)[32] = 1.0f / S;
         }
     }
-    // tail
+    // tail: row tile 0 (fragments 0..7), rows 0..2 real
     {
         const int ti = 2 + 4 * c->n_block;
         const float* Wt = c->host_w[ti].data();
@@ -263,8 +264,8 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
         for (int ks = 0; ks < R2L_KSTEPS; ++ks)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                    int r = lane & 31;
-                    int k = r2l_kappa(ks, lane >> 5, j);
+                    int r = lane & 15;
+                    int k = r2l_kappa(ks, lane >> 4, j);
                     put_frag(chunk, np, ks, lane, j, r < 3 ? Wt[(size_t)r * R2L_WIDTH + k] * Sw : 0.f);
                 }
         for (int i = 0; i < 3; ++i) aux(ci)[i] = bt[i] * S;

@@ -2,32 +2,34 @@
 // image ("chunk stream") layout and the index maps both sides must agree on.
 //
 // Geometry (see DESIGN.md "K3"):
-//   * one wave64 owns 32 rays; its activations never leave registers.  A layer is
-//     Y^T[256 x 32] = W[256 x K] * X^T[K x 32] on v_mfma_f32_32x32x16_f16: W fragments are
-//     the A operand (streamed through LDS, shared by the 4 waves of the workgroup), X^T
-//     fragments the B operand (registers).  The 32x32 f32 result of output-feature tile t
-//     has its ray on the lane and its 16 features in registers, which is exactly the B
-//     fragment pair of k-steps 2t, 2t+1 of the next layer up to a fixed permutation of k
-//     inside each 32-feature group; that permutation is applied to W on the host (kappa).
+//   * one wave64 owns 32 rays = 2 column tiles of 16; its activations never leave
+//     registers.  A layer is Y^T[256 x 32] = W[256 x K] * X^T[K x 32] on
+//     v_mfma_f32_16x16x32_f16: W fragments (16 output features x 32 inputs, 1 KiB) are the A
+//     operand, streamed through LDS and shared by the 4 waves of the workgroup; X^T
+//     fragments the B operand (registers).  The 16x16 f32 result of row tile u has its ray
+//     on lane&15 and features 16u + 4*(lane>>4) + reg in its 4 registers; two consecutive
+//     row tiles (2s, 2s+1) are exactly the B fragment of k-step s of the next layer up to a
+//     fixed permutation of k inside each 32-feature group, applied to W on the host (kappa).
 //   * the weight image is a sequence of equal-size chunks: FRAGS=16 fragments of 1 KiB
 //     (64 lanes x 8 f16), NP parts each (hi [, lo]), plus a 1 KiB aux block (f32).
-//       head  : 32 chunks; chunk c = k-steps 2c,2c+1 x 8 feature tiles (frag = ksl*8 + t)
-//       body  : per layer 8 chunks; chunk t = feature tile t x 16 k-steps (frag = ks)
-//       tail  : 1 chunk; rows 0..2 of tile 0 real, rest zero
-//     aux (floats): body/tail [0..31] = bias*scale of the tile, [32] = 1/scale;
+//       head  : 32 chunks; chunk c = k-step c (32 inputs) x 16 row tiles (frag = u)
+//       body  : per layer 8 chunks; chunk m = row tiles 2m, 2m+1 x 8 k-steps (frag = (u&1)*8 + s)
+//       tail  : 1 chunk; rows 0..2 of row tile 0 real (frags 0..7), rest zero
+//     aux (floats): body/tail [0..31] = bias*scale of the chunk's 32 features, [32] = 1/scale;
 //                   head chunk 0 [0..255] = bias*scale, head chunk 31 [32] = 1/scale.
 #pragma once
 #include <stdint.h>
 
 #define R2L_WIDTH 256
-#define R2L_NTILE 8          // 256 / 32 output-feature tiles
-#define R2L_KSTEPS 16        // 256 / 16 k-steps per body layer
+#define R2L_RTILES 16        // 256 / 16 output-feature (row) tiles
+#define R2L_KSTEPS 8         // 256 / 32 k-steps per body layer
+#define R2L_CTILES 2         // 16-ray column tiles per wave
 #define R2L_NSAMPLE 16
 #define R2L_NCOORD 48        // 16 samples x 3
 #define R2L_L 10
 #define R2L_EMBED 21         // 2L+1
 #define R2L_IN 1008          // 48*21
-#define R2L_HEAD_KSTEPS 64   // 63 real k-steps + 1 zero pad
+#define R2L_HEAD_KSTEPS 32   // 1008 -> 1024 inputs / 32
 #define R2L_HEAD_CHUNKS 32
 #define R2L_FRAGS 16
 #define R2L_FRAG_BYTES 1024
@@ -43,25 +45,24 @@
 #endif
 
 R2L_HD int r2l_chunk_bytes(int np) { return (R2L_FRAGS * np) * R2L_FRAG_BYTES + R2L_AUX_BYTES; }
-R2L_HD int r2l_chunks_per_tile(int n_block) { return R2L_HEAD_CHUNKS + 2 * n_block * R2L_NTILE + 1; }
+R2L_HD int r2l_chunks_per_tile(int n_block) { return R2L_HEAD_CHUNKS + 2 * n_block * (R2L_RTILES / 2) + 1; }
 
-// Input feature (0..255) that element j (0..7) of lane-half h (0..1) of body k-step ks
-// (0..15) multiplies: the D-layout of v_mfma_f32_32x32x16 (row = (reg&3) + 8*(reg>>2) +
-// 4*(lane>>5)) read back as a B fragment (reg = 8*(ks&1) + j of feature tile ks>>1).
-R2L_HD int r2l_kappa(int ks, int h, int j) {
-    return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
-}
+// Input feature (0..255) that element j (0..7) of lane quarter q (= lane>>4, 0..3) of body
+// k-step s (0..7) multiplies: the D layout of v_mfma_f32_16x16x32 (row = 4*(lane>>4) + reg)
+// read back as a B fragment: elements 0..3 = registers of row tile 2s, 4..7 = of row tile 2s+1.
+R2L_HD int r2l_kappa(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
 
-// Column of head.0.weight (0..1007, or -1 = zero pad) that element j of lane-half h of
-// head k-step ks (0..63) multiplies.  Reference embedding order per coordinate c is
+// Column of head.0.weight (0..1007, or -1 = zero pad) that element j of lane quarter q of
+// head k-step s (0..31) multiplies.  Reference embedding order per coordinate c is
 // [sin(2^l x) l=0..9, cos(2^l x) l=0..9, x]  (model/nerf_raybased.py:198-208).
-//   ks 0..47  : coordinate ks, frequency l=j; h=0 sin, h=1 cos
-//   ks 48..59 : coordinate 4*(ks-48)+(j>>1), frequency 8+(j&1); h=0 sin, h=1 cos
-//   ks 60..62 : identity of coordinate 16*(ks-60)+8h+j
-//   ks 63     : pad
-R2L_HD int r2l_head_col(int ks, int h, int j) {
-    if (ks < 48) return ks * R2L_EMBED + (h ? R2L_L : 0) + j;
-    if (ks < 60) return (4 * (ks - 48) + (j >> 1)) * R2L_EMBED + (h ? R2L_L : 0) + 8 + (j & 1);
-    if (ks < 63) return (16 * (ks - 60) + 8 * h + j) * R2L_EMBED + 2 * R2L_L;
+//   s 0..23  : coordinate 2s + (q>>1), frequency l=j; q&1 = 0 sin, 1 cos
+//   s 24..29 : coordinate 8(s-24) + 2q + (j>>2), frequency 8 + (j&1); (j>>1)&1 = 0 sin, 1 cos
+//   s 30     : identity of coordinate 8q + j
+//   s 31     : identity of coordinate 32 + 8q + j for q < 2, pad for q >= 2
+R2L_HD int r2l_head_col(int s, int q, int j) {
+    if (s < 24) return (2 * s + (q >> 1)) * R2L_EMBED + ((q & 1) ? R2L_L : 0) + j;
+    if (s < 30) return (8 * (s - 24) + 2 * q + (j >> 2)) * R2L_EMBED + (((j >> 1) & 1) ? R2L_L : 0) + 8 + (j & 1);
+    if (s == 30) return (8 * q + j) * R2L_EMBED + 2 * R2L_L;
+    if (q < 2) return (32 + 8 * q + j) * R2L_EMBED + 2 * R2L_L;
     return -1;
 }

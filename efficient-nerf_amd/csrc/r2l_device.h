@@ -146,24 +146,11 @@ __device__ __forceinline__ AFrag<NP> read_frag(uint32_t lane_base, int frag) {
     return a;
 }
 
-#ifdef R2L_ABL_MFMA16  // timing-only ablation: same FLOPs on the 16x16x32 shape (results are garbage)
-__device__ __forceinline__ f32x16 mfma16_pair(f16x8 a, f16x8 b, f32x16 c) {
-    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
-    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
-    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
-    return c;
-}
-#define MFMA(a, b, c) mfma16_pair((a), (b), (c))
-#else
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-#endif
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
-// one k-step on one 32x32 output tile: ah*bh [+ ah*bl + al*bh]
+// one k-step (32 inputs) on one 16x16 output tile: ah*bh [+ ah*bl + al*bh]
 template <int NP>
-__device__ __forceinline__ f32x16 mfma_step(const AFrag<NP>& a, const f16x8& bh, const f16x8& bl,
-                                            f32x16 acc) {
+__device__ __forceinline__ f32x4 mfma_step(const AFrag<NP>& a, const f16x8& bh, const f16x8& bl, f32x4 acc) {
     acc = MFMA(a.h, bh, acc);
     if (NP == 2) {
         acc = MFMA(a.h, bl, acc);
@@ -180,20 +167,11 @@ __device__ __forceinline__ void split_store(float a, f16x8& hi, f16x8& lo, int j
     if (NP == 2) lo[j] = (f16)(a - (float)h);
 }
 
-// accumulator init = aux[tile_off + 8g + 4h + i] (bias pre-multiplied by the layer scale)
+// accumulator init of one row tile = aux[feat_off + 4q + i], i = 0..3 (bias pre-multiplied by
+// the layer scale); the same for both column tiles
 template <int NP>
-__device__ __forceinline__ f32x16 acc_init(uint32_t slot_off, int tile_off, int h) {
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 b = *reinterpret_cast<const f32x4*>(smem + slot_off + KCfg<NP>::AUX +
-                                                  (tile_off + 8 * g + 4 * h) * 4);
-        acc[4 * g + 0] = b[0];
-        acc[4 * g + 1] = b[1];
-        acc[4 * g + 2] = b[2];
-        acc[4 * g + 3] = b[3];
-    }
-    return acc;
+__device__ __forceinline__ f32x4 acc_init(uint32_t slot_off, int feat_off, int q) {
+    return *reinterpret_cast<const f32x4*>(smem + slot_off + KCfg<NP>::AUX + (feat_off + 4 * q) * 4);
 }
 
 template <int NP>

@@ -111,83 +111,94 @@ __global__ void r2l_embed_kernel(const float* __restrict__ x_in, long long total
 // ------------------------------------------------------------------------------------
 // fused persistent kernel
 // ------------------------------------------------------------------------------------
-// epilogue of one accumulator register of feature tile t:
+// epilogue of accumulator register r of row tile u (one column tile); activations are kept
+// multiplied by act_scale (`inv` = act_scale / layer scale):
 // SECOND = false: out = relu(acc/scale)              (ResMLP body.0 + inact)
 // SECOND = true : x = x + acc/scale; out = x         (ResMLP body.2 + residual)
 template <int NP, bool SECOND>
-__device__ __forceinline__ void epi_reg(const f32x16& acc, float inv, f32x16& xt, f16x8 (&Nh)[16],
-                                        f16x8 (&Nl)[16], int t, int reg, float act_scale) {
+__device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, f32x4& xu, f16x8& nh, f16x8& nl, int u,
+                                        int r) {
 #ifdef R2L_ABL_NOEPI  // ablation build: keep the accumulator live, skip the VALU epilogue
-    asm volatile("" ::"v"(acc[reg]));
+    asm volatile("" ::"v"(acc[r]));
     return;
 #endif
-    float v;  // activation * act_scale (`inv` = act_scale / layer scale)
+    float v;
     if (!SECOND) {
-        v = fmaxf(acc[reg] * inv, 0.0f);
+        v = fmaxf(acc[r] * inv, 0.0f);
     } else {
-        v = fmaf(acc[reg], inv, xt[reg]);
-        xt[reg] = v;
+        v = fmaf(acc[r], inv, xu[r]);
+        xu[r] = v;
     }
-    split_store<NP>(v, Nh[2 * t + (reg >> 3)], Nl[2 * t + (reg >> 3)], reg & 7);
+    split_store<NP>(v, nh, nl, 4 * (u & 1) + r);
 }
 
-// 16 k-steps of one feature tile (one chunk), A fragments prefetched one step ahead (the
-// last step prefetches fragment 0 of the next chunk, certified by this chunk's ring_mid).
-// While the MFMAs of tile t run, the VALU epilogue of tile t-1 (`prev`) is interleaved,
-// one accumulator register per k-step.
+// One row tile (16 output features) of a body layer: 8 k-steps x 2 column tiles.  A
+// fragments are read one step ahead (the chunk's last step prefetches fragment 0 of the next
+// chunk, certified by this chunk's ring_mid).  The 8 accumulator values of the previous row
+// tile get their VALU epilogue interleaved, one per k-step.
 template <int NP, bool SECOND, bool HAVE_PREV>
-__device__ __forceinline__ f32x16 body_tile(Ring<NP>& R, const f16x8 (&Bh)[16], const f16x8 (&Bl)[16],
-                                            f16x8 (&Nh)[16], f16x8 (&Nl)[16], const f32x16& prev,
-                                            float inv, f32x16& xprev, int tprev, float act_scale,
-                                            int h) {
+__device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
+                                           f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
+                                           const f32x4 (&prev)[2], float inv, f32x4 (&xprev)[2], int uprev, int q) {
     const uint32_t slot = R.use_off;
     const uint32_t lane_base = slot + R.lane * 16;
     const uint32_t next_base = ring_next_off<NP>(slot) + R.lane * 16;
-    f32x16 acc = acc_init<NP>(slot, 0, h);
-    AFrag<NP> cur = R.pre;
+    acc[0] = acc_init<NP>(slot, 16 * upos, q);
+    acc[1] = acc[0];
 #pragma unroll
-    for (int ks = 0; ks < R2L_KSTEPS; ++ks) {
-        if (ks == R2L_KSTEPS / 2) ring_mid<NP>(R);
-        AFrag<NP> nxt = (ks + 1 < R2L_KSTEPS) ? read_frag<NP>(lane_base, ks + 1) : read_frag<NP>(next_base, 0);
-        acc = mfma_step<NP>(cur, Bh[ks], Bl[ks], acc);
-        if (HAVE_PREV) epi_reg<NP, SECOND>(prev, inv, xprev, Nh, Nl, tprev, ks, act_scale);
-        cur = nxt;
+    for (int s = 0; s < R2L_KSTEPS; ++s) {
+        const int f = upos * R2L_KSTEPS + s;
+        if (f == R2L_FRAGS / 2) ring_mid<NP>(R);
+        AFrag<NP> nxt = (f + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, f + 1) : read_frag<NP>(next_base, 0);
+        acc[0] = mfma_step<NP>(R.pre, Bh[s][0], Bl[s][0], acc[0]);
+        acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
+        if (HAVE_PREV)
+            epi_reg<NP, SECOND>(prev[s >> 2], inv, xprev[s >> 2], Nh[uprev >> 1][s >> 2], Nl[uprev >> 1][s >> 2], uprev,
+                                s & 3);
+        R.pre = nxt;
     }
-    R.pre = cur;
-    ring_next<NP>(R);
-    return acc;
+    if (upos == 1) ring_next<NP>(R);
 }
 
 // One body Linear(256,256): in = (Bh,Bl) fragments, out fragments -> (Nh,Nl).
 template <int NP, bool SECOND>
-__device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[16], const f16x8 (&Bl)[16],
-                                           f16x8 (&Nh)[16], f16x8 (&Nl)[16], f32x16 (&x)[8],
-                                           float act_scale, int h) {
-    // activations (x, h0, B fragments) live multiplied by act_scale: `inv` only removes the weight scale
+__device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
+                                           f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&x)[16][2],
+                                           float act_scale, int q) {
     const float inv = aux_inv_scale<NP>(R.use_off) * act_scale;  // same for the 8 chunks of a layer
-    f32x16 prev = body_tile<NP, SECOND, false>(R, Bh, Bl, Nh, Nl, x[0], inv, x[0], 0, act_scale, h);
+    f32x4 acc[2], prev[2];
+    body_rtile<NP, SECOND, false>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, x[0], 0, q);
 #pragma unroll
-    for (int t = 1; t < R2L_NTILE; ++t)
-        prev = body_tile<NP, SECOND, true>(R, Bh, Bl, Nh, Nl, prev, inv, x[t - 1], t - 1, act_scale, h);
+    for (int u = 1; u < R2L_RTILES; ++u) {
+        prev[0] = acc[0];
+        prev[1] = acc[1];
+        body_rtile<NP, SECOND, true>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, x[u - 1], u - 1, q);
+    }
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-        epi_reg<NP, SECOND>(prev, inv, x[R2L_NTILE - 1], Nh, Nl, R2L_NTILE - 1, reg, act_scale);
+    for (int i = 0; i < 8; ++i)
+        epi_reg<NP, SECOND>(acc[i >> 2], inv, x[R2L_RTILES - 1][i >> 2], Nh[(R2L_RTILES - 1) >> 1][i >> 2],
+                            Nl[(R2L_RTILES - 1) >> 1][i >> 2], R2L_RTILES - 1, i & 3);
 }
 
-// one head k-step: 8 feature tiles against one generated B fragment (fragments ksl*8 + t)
+// one head k-step (one chunk): 16 row tiles against the generated B fragments of both column tiles
 template <int NP>
-__device__ __forceinline__ void head_kstep(Ring<NP>& R, int ksl, const f16x8& bh, const f16x8& bl,
-                                           f32x16 (&x)[8]) {
+__device__ __forceinline__ void head_step(Ring<NP>& R, const f16x8 (&bh)[2], const f16x8 (&bl)[2],
+                                          f32x4 (&x)[16][2]) {
     const uint32_t lane_base = R.use_off + R.lane * 16;
     const uint32_t next_base = ring_next_off<NP>(R.use_off) + R.lane * 16;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int f = ksl * 8 + t;
-        AFrag<NP> nxt = (f + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, f + 1) : read_frag<NP>(next_base, 0);
-        x[t] = mfma_step<NP>(R.pre, bh, bl, x[t]);
+    for (int u = 0; u < R2L_RTILES; ++u) {
+        if (u == R2L_FRAGS / 2) ring_mid<NP>(R);
+        AFrag<NP> nxt = (u + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, u + 1) : read_frag<NP>(next_base, 0);
+        x[u][0] = mfma_step<NP>(R.pre, bh[0], bl[0], x[u][0]);
+        x[u][1] = mfma_step<NP>(R.pre, bh[1], bl[1], x[u][1]);
         R.pre = nxt;
     }
-    if (ksl == 0) ring_mid<NP>(R); else ring_next<NP>(R);
+    ring_next<NP>(R);
+}
+
+__device__ __forceinline__ float sel4(int q, float a, float b, float c, float d) {
+    return (q & 2) ? ((q & 1) ? d : c) : ((q & 1) ? b : a);
 }
 
 template <int NP>
@@ -202,9 +213,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     R.issue_off = 0;
     R.use_off = 0;
     const int lane = R.lane;
-    const int h = lane >> 5;
+    const int q = lane >> 4;
     const float act_scale = p.act_scale;
-    const bool is_cos = h != 0;
 
     // prologue: D chunks in flight, chunk 0 certified, its fragment 0 in registers
 #pragma unroll
@@ -213,127 +223,169 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     __builtin_amdgcn_s_barrier();
     R.pre = read_frag<NP>(lane * 16, 0);
 
-    f32x16 x[8];
-    f16x8 Bh[16], Bl[16], Nh[16], Nl[16];
+    f32x4 x[16][2];
+    f16x8 Bh[8][2], Bl[8][2], Nh[8][2], Nl[8][2];
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        const int ray_raw = tile * R2L_TILE_RAYS + R.wave * R2L_RAYS_PER_WAVE + (lane & 31);
-        const bool valid = ray_raw < p.n_rays;
-        const int ray = valid ? ray_raw : p.n_rays - 1;
-        float o[3], d[3];
-        make_ray(p, ray, o, d);
-
-        // ---------------- head: Linear(1008,256) + ReLU, k outer / feature tile inner -------
+        // a lane serves ray (lane & 15) of both column tiles
+        float o[2][3], d[2][3];
+        int ray[2];
+        bool valid[2];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = acc_init<NP>(R.use_off, 32 * t, h);
+        for (int c = 0; c < 2; ++c) {
+            const int ray_raw = tile * R2L_TILE_RAYS + R.wave * R2L_RAYS_PER_WAVE + c * 16 + (lane & 15);
+            valid[c] = ray_raw < p.n_rays;
+            ray[c] = valid[c] ? ray_raw : p.n_rays - 1;
+            make_ray(p, ray[c], o[c], d[c]);
+        }
 
-        // phase 1: k-steps 0..47, one coordinate each, frequencies 0..7 (sin | cos by half)
+        // ---------------- head: Linear(1008,256) + ReLU, k outer / row tile inner ------------
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            x[u][0] = acc_init<NP>(R.use_off, 16 * u, q);
+            x[u][1] = x[u][0];
+        }
+        // phase 1: k-steps 0..23: coordinates 2s, 2s+1 (by q>>1), frequencies 0..7, sin|cos by q&1
         for (int sp = 0; sp < 8; ++sp) {
             const float z0 = p.z[2 * sp], z1 = p.z[2 * sp + 1];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const float xc = sample_pt(o[u % 3], d[u % 3], u < 3 ? z0 : z1);
-                const Rev r = to_rev(xc);
-                f16x8 bh, bl;
-                float pw = 1.0f;
+            for (int u3 = 0; u3 < 3; ++u3) {
+                const int ca = 2 * u3, cb = 2 * u3 + 1;  // coordinates inside this pair of samples
+                f16x8 bh[2], bl[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    split_store<NP>(trig_pow2(r, pw, is_cos) * act_scale, bh, bl, j);
-                    pw *= 2.0f;
+                for (int c = 0; c < 2; ++c) {
+                    const float xa = sample_pt(o[c][ca % 3], d[c][ca % 3], ca < 3 ? z0 : z1);
+                    const float xb = sample_pt(o[c][cb % 3], d[c][cb % 3], cb < 3 ? z0 : z1);
+                    const Rev r = to_rev((q & 2) ? xb : xa);
+                    float pw = 1.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        split_store<NP>(trig_pow2(r, pw, (q & 1) != 0) * act_scale, bh[c], bl[c], j);
+                        pw *= 2.0f;
+                    }
                 }
-                head_kstep<NP>(R, u & 1, bh, bl, x);
+                head_step<NP>(R, bh, bl, x);
             }
         }
-        // phase 2: k-steps 48..59, four coordinates each, frequencies 8, 9
+        // phase 2: k-steps 24..29: coordinates 8(s-24) + 2q + (j>>2), frequencies 8, 9
         for (int it = 0; it < 2; ++it) {
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                f16x8 bh, bl;
+            for (int u3 = 0; u3 < 3; ++u3) {
+                f16x8 bh[2], bl[2];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int cc = 4 * u + m;  // coordinate within this group of 24
-                    const float xc = sample_pt(o[cc % 3], d[cc % 3], p.z[8 * it + cc / 3]);
-                    const Rev r = to_rev(xc);
-                    split_store<NP>(trig_pow2(r, 256.0f, is_cos) * act_scale, bh, bl, 2 * m);
-                    split_store<NP>(trig_pow2(r, 512.0f, is_cos) * act_scale, bh, bl, 2 * m + 1);
+                for (int c = 0; c < 2; ++c) {
+                    float pt[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int cc = 8 * u3 + m;  // coordinate inside this group of 24
+                        pt[m] = sample_pt(o[c][cc % 3], d[c][cc % 3], p.z[8 * it + cc / 3]);
+                    }
+                    const Rev r0 = to_rev(sel4(q, pt[0], pt[2], pt[4], pt[6]));
+                    const Rev r1 = to_rev(sel4(q, pt[1], pt[3], pt[5], pt[7]));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        split_store<NP>(trig_pow2((j >> 2) ? r1 : r0, (j & 1) ? 512.0f : 256.0f, ((j >> 1) & 1) != 0) *
+                                            act_scale,
+                                        bh[c], bl[c], j);
                 }
-                head_kstep<NP>(R, u & 1, bh, bl, x);
+                head_step<NP>(R, bh, bl, x);
             }
         }
-        // phase 3: k-steps 60..62 identity (coordinate 16*(ks-60) + 8h + j), k-step 63 = pad
+        // phase 3: k-steps 30, 31: identity of coordinate 8q + j (+32; quarters 2, 3 of step 31 pad)
+        float inv_head = 0.f;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            f16x8 bh, bl;
+        for (int s3 = 0; s3 < 2; ++s3) {
+            f16x8 bh[2], bl[2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c0 = 16 * u + j, c1 = c0 + 8;
-                const float x0 = sample_pt(o[c0 % 3], d[c0 % 3], p.z[c0 / 3]);
-                const float x1 = sample_pt(o[c1 % 3], d[c1 % 3], p.z[c1 / 3]);
-                split_store<NP>((h ? x1 : x0) * act_scale, bh, bl, j);
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v;
+                    if (s3 == 0) {
+                        const int c0 = j, c1 = 8 + j, c2 = 16 + j, c3 = 24 + j;
+                        v = sel4(q, sample_pt(o[c][c0 % 3], d[c][c0 % 3], p.z[c0 / 3]),
+                                 sample_pt(o[c][c1 % 3], d[c][c1 % 3], p.z[c1 / 3]),
+                                 sample_pt(o[c][c2 % 3], d[c][c2 % 3], p.z[c2 / 3]),
+                                 sample_pt(o[c][c3 % 3], d[c][c3 % 3], p.z[c3 / 3]));
+                    } else {
+                        const int c0 = 32 + j, c1 = 40 + j;
+                        v = sel4(q, sample_pt(o[c][c0 % 3], d[c][c0 % 3], p.z[c0 / 3]),
+                                 sample_pt(o[c][c1 % 3], d[c][c1 % 3], p.z[c1 / 3]), 0.0f, 0.0f);
+                    }
+                    split_store<NP>(v * act_scale, bh[c], bl[c], j);
+                }
             }
-            head_kstep<NP>(R, u & 1, bh, bl, x);
+            if (s3 == 1) inv_head = aux_inv_scale<NP>(R.use_off) * act_scale;  // chunk 31's aux
+            head_step<NP>(R, bh, bl, x);
         }
-        // pad k-step 63: no MFMAs; leave the chunk with the next chunk's fragment 0 prefetched
-        const float inv_head = aux_inv_scale<NP>(R.use_off) * act_scale;  // h0, x: scaled domain
-        R.pre = read_frag<NP>(ring_next_off<NP>(R.use_off) + lane * 16, 0);
-        ring_next<NP>(R);
 
-        // head epilogue: h0 = relu(acc/scale); keep a copy for the global skip
+        // head epilogue: h0 = relu(acc/scale) (scaled domain); keep a copy for the global skip
         float* scr = p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int u = 0; u < 16; ++u) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                float v = fmaxf(x[t][reg] * inv_head, 0.0f);
-                x[t][reg] = v;
-                split_store<NP>(v, Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
-            }
-            if (p.use_residual) {
+            for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v4 = {x[t][4 * g], x[t][4 * g + 1], x[t][4 * g + 2], x[t][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(scr + (t * 4 + g) * 256) = v4;
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(x[u][c][r] * inv_head, 0.0f);
+                    x[u][c][r] = v;
+                    split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
+                if (p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
             }
         }
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
 #ifdef R2L_ABL_NOEPI
-            body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, h);
-            body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, h);
+            body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, q);
+            body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, q);
 #else
-            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, h);
-            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, h);
+            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, q);
+            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, q);
 #endif
         }
 
         // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------
-        if (p.use_residual) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+        for (int u = 0; u < 16; ++u) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v4 = *reinterpret_cast<const f32x4*>(scr + (t * 4 + g) * 256);
-                    x[t][4 * g + 0] += v4[0];
-                    x[t][4 * g + 1] += v4[1];
-                    x[t][4 * g + 2] += v4[2];
-                    x[t][4 * g + 3] += v4[3];
+            for (int c = 0; c < 2; ++c) {
+                if (p.use_residual) {
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(scr + (u * 2 + c) * 256);
+                    x[u][c] = x[u][c] + h0;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split_store<NP>(x[u][c][r], Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
             }
         }
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                split_store<NP>(x[t][reg], Bh[2 * t + (reg >> 3)], Bl[2 * t + (reg >> 3)], reg & 7);
         {
-            const float inv = aux_inv_scale<NP>(R.use_off);
-            f32x16 acc = body_tile<NP, false, false>(R, Bh, Bl, Nh, Nl, x[0], inv, x[0], 0, act_scale, h);
-            if (valid && h == 0) {
-                float* out = p.rgb + (size_t)ray * 3;
+            // tail chunk: row tile 0 only (fragments 0..7 real), then leave the chunk
+            const uint32_t slot = R.use_off;
+            const uint32_t lane_base = slot + lane * 16;
+            const float inv = aux_inv_scale<NP>(slot);
+            f32x4 acc[2];
+            acc[0] = acc_init<NP>(slot, 0, q);
+            acc[1] = acc[0];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) out[k] = 1.0f / (1.0f + expf(-(acc[k] * inv)));
+            for (int s = 0; s < R2L_KSTEPS; ++s) {
+                AFrag<NP> nxt = read_frag<NP>(lane_base, s + 1);  // s = 7 reads the unused fragment 8
+                acc[0] = mfma_step<NP>(R.pre, Bh[s][0], Bl[s][0], acc[0]);
+                acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
+                R.pre = nxt;
+            }
+            ring_mid<NP>(R);
+            R.pre = read_frag<NP>(ring_next_off<NP>(slot) + lane * 16, 0);
+            ring_next<NP>(R);
+            if (q == 0) {  // rows 0..2 of the tile = rgb, in the quarter-0 lanes
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (valid[c]) {
+                        float* out = p.rgb + (size_t)ray[c] * 3;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) out[k] = 1.0f / (1.0f + expf(-(acc[c][k] * inv)));
+                    }
+                }
             }
         }
     }

@@ -12,25 +12,25 @@ from oracle import r2l_oracle as O
 FRAG, AUXB, FRAGS = 1024, 1024, 16
 
 
-def kappa(ks, h, j):
-    return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3)
+def kappa(s, q, j):
+    return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3)
 
 
-def head_col(ks, h, j):
-    if ks < 48:
-        return ks * 21 + (10 if h else 0) + j
-    if ks < 60:
-        return (4 * (ks - 48) + (j >> 1)) * 21 + (10 if h else 0) + 8 + (j & 1)
-    if ks < 63:
-        return (16 * (ks - 60) + 8 * h + j) * 21 + 20
-    return -1
+def head_col(s, q, j):
+    if s < 24:
+        return (2 * s + (q >> 1)) * 21 + (10 if q & 1 else 0) + j
+    if s < 30:
+        return (8 * (s - 24) + 2 * q + (j >> 2)) * 21 + (10 if (j >> 1) & 1 else 0) + 8 + (j & 1)
+    if s == 30:
+        return (8 * q + j) * 21 + 20
+    return (32 + 8 * q + j) * 21 + 20 if q < 2 else -1
 
 
 def test_index_maps_are_bijections():
-    for ks_pair in range(8):  # every 32-feature group is covered exactly once by two k-steps
-        got = sorted(kappa(2 * ks_pair + s, h, j) for s in (0, 1) for h in (0, 1) for j in range(8))
-        assert got == list(range(32 * ks_pair, 32 * ks_pair + 32))
-    cols = [head_col(ks, h, j) for ks in range(64) for h in (0, 1) for j in range(8)]
+    for s in range(8):  # every 32-feature group is covered exactly once by one k-step
+        got = sorted(kappa(s, q, j) for q in range(4) for j in range(8))
+        assert got == list(range(32 * s, 32 * s + 32))
+    cols = [head_col(s, q, j) for s in range(32) for q in range(4) for j in range(8)]
     real = sorted(c for c in cols if c >= 0)
     assert real == list(range(1008)) and cols.count(-1) == 16
 
@@ -70,45 +70,47 @@ def test_packed_stream_decodes_to_weights(pkg, built_lib, mode, np_):
 
     tol = 2.0 ** -21 if np_ == 2 else 2.0 ** -11  # relative to the scaled max (|w|*S in [2^12, 2^13))
 
-    # body layers: chunk = feature tile t, frag = k-step
+    # body layers: chunk m = row tiles 2m, 2m+1; frag = (u&1)*8 + k-step
     for li in range(2 * n_block):
         Wl = sd[O.r2l_state_names(n_block)[2 + 2 * li]].double().numpy()
         bl = sd[O.r2l_state_names(n_block)[3 + 2 * li]].double().numpy()
-        for t in range(8):
-            ci = 32 + li * 8 + t
+        for m in range(8):
+            ci = 32 + li * 8 + m
             a = aux(ci)
             inv = float(a[32])
             S = 1.0 / inv
             assert S == 2.0 ** round(np.log2(S))  # power of two
-            np.testing.assert_allclose(a[:32] * inv, bl[32 * t:32 * t + 32], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(a[:32] * inv, bl[32 * m:32 * m + 32], rtol=1e-6, atol=1e-9)
             Sw = S / 16.0
             assert 2 ** 12 <= np.abs(Wl).max() * Sw < 2 ** 13
-            for ks in (0, 7, 15):
-                v = value(ci, ks)
+            for f in (0, 7, 9, 15):
+                u, ks = 2 * m + (f >> 3), f & 7
+                v = value(ci, f)
                 for lane in (0, 17, 33, 63):
-                    want = np.array([Wl[32 * t + (lane & 31), kappa(ks, lane >> 5, j)] for j in range(8)]) * Sw
+                    want = np.array([Wl[16 * u + (lane & 15), kappa(ks, lane >> 4, j)] for j in range(8)]) * Sw
                     assert np.abs(v[lane] - want).max() <= tol * 2 ** 13
-    # head: chunk c = k-steps 2c, 2c+1; frag = ksl*8 + t
+    # head: chunk = k-step; frag = row tile u
     Wh = sd['head.0.weight'].double().numpy()
     inv = float(aux(31)[32])
     Sw = 1.0 / inv / 16.0
     np.testing.assert_allclose(aux(0)[:256] * inv, sd['head.0.bias'].double().numpy(), rtol=1e-6, atol=1e-9)
-    for ks in (0, 47, 48, 59, 60, 62, 63):
-        for t in (0, 5):
-            v = value(ks // 2, (ks & 1) * 8 + t)
-            for lane in (3, 40):
-                want = np.array([0.0 if head_col(ks, lane >> 5, j) < 0 else
-                                 Wh[32 * t + (lane & 31), head_col(ks, lane >> 5, j)] for j in range(8)]) * Sw
+    for ks in (0, 23, 24, 29, 30, 31):
+        for u in (0, 5, 15):
+            v = value(ks, u)
+            for lane in (3, 20, 40, 57):
+                want = np.array([0.0 if head_col(ks, lane >> 4, j) < 0 else
+                                 Wh[16 * u + (lane & 15), head_col(ks, lane >> 4, j)] for j in range(8)]) * Sw
                 assert np.abs(v[lane] - want).max() <= tol * 2 ** 13
-    # tail: rows 0..2 real, the rest zero
+    # tail: rows 0..2 of row tile 0 real (frags 0..7), the rest zero
     Wt = sd['tail.0.weight'].double().numpy()
     inv = float(aux(cpt - 1)[32])
     Sw = 1.0 / inv / 16.0
     v = value(cpt - 1, 4)
-    for lane in (0, 2, 34):
-        want = np.array([Wt[lane & 31, kappa(4, lane >> 5, j)] for j in range(8)]) * Sw
+    for lane in (0, 2, 18, 50):
+        want = np.array([Wt[lane & 15, kappa(4, lane >> 4, j)] for j in range(8)]) * Sw
         assert np.abs(v[lane] - want).max() <= tol * 2 ** 13
-    assert np.abs(v[3:32]).max() == 0 and np.abs(v[35:]).max() == 0
+    assert np.abs(v[3:16]).max() == 0 and np.abs(v[19:32]).max() == 0
+    assert np.abs(value(cpt - 1, 9)).max() == 0
 
 
 def test_pack_rejects_bad_input(pkg, built_lib):
