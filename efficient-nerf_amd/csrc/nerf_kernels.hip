@@ -67,6 +67,7 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const f16x8 (&Sh)[8][2], 
         for (int s = 0; s < KS; ++s) {
             const int fq = F0 + u * KS + s;
             const int pos = fq % R2L_FRAGS;
+            ring_step<NP>(R, pos);  // pos == 8: rendezvous; pos >= 8: one refill piece per step
             if (s == 0) {
                 acc[0] = acc_init<NP>(R.use_off, 16 * nerf_aux_slot(fq), q);
                 acc[1] = acc[0];
@@ -84,7 +85,6 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const f16x8 (&Sh)[8][2], 
                 for (int i = (8 * s + KS - 1) / KS; i < (8 * (s + 1) + KS - 1) / KS && i < 8; ++i)
                     mlp_epi_reg<NP, EPI, RT>(prev[i >> 2], inv, Dh, Dl, u - 1, i >> 2, i & 3, act_scale, out);
             }
-            if (pos == R2L_FRAGS / 2 - 1) ring_mid<NP>(R);
             if (pos == R2L_FRAGS - 1) ring_next<NP>(R);
         }
         prev[0] = acc[0];

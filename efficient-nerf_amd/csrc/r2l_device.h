@@ -85,34 +85,50 @@ struct Ring {
     AFrag<NP> pre;      // fragment 0 of the chunk at use_off, already read from LDS
 };
 
-// LDS-DMA of one chunk with `global_load_lds_dwordx4 v_off, s[base:base+1]` (scalar base +
-// one 32-bit VGPR offset = lane*16, no 64-bit per-lane address math).  MUBUF `... lds`
-// loads are not usable here: their LDS base is M0[15:0] and the ring spans > 64 KiB.
+// LDS-DMA of one chunk: per wave 4*NP pieces of 1 KiB (`global_load_lds_dwordx4`, 16 B/lane) +
+// one 256 B piece of the aux block (`global_load_lds_dword`).  The instruction's immediate
+// offset is added to the global AND the LDS address, so one (global, LDS) base pair serves four
+// consecutive pieces.  MUBUF `... lds` loads are not usable here: their LDS base is M0[15:0]
+// and the ring spans > 64 KiB.
 template <int NP>
-__device__ __forceinline__ void ring_issue(Ring<NP>& R) {
+__device__ __forceinline__ void ring_issue_piece(Ring<NP>& R, int piece) {
     typedef KCfg<NP> C;
-    const char* src = R.wimg + (size_t)R.issue_pos * C::CH + R.wave * (4 * NP * R2L_FRAG_BYTES);
+    const char* src = R.wimg + (size_t)R.issue_pos * C::CH + R.wave * (4 * NP * R2L_FRAG_BYTES) + (uint32_t)R.lane * 16u;
     const uint32_t dst = R.issue_off + R.wave * (4 * NP * R2L_FRAG_BYTES);
-    const uint32_t voff = (uint32_t)R.lane * 16u;
-#pragma unroll
-    for (int q = 0; q < 4 * NP; ++q) {
-        __builtin_amdgcn_global_load_lds(AS1(src + q * R2L_FRAG_BYTES + voff), AS3(smem + dst + q * R2L_FRAG_BYTES),
-                                         16, 0, 0);
+    const int last = (NP == 2) ? 7 : 4;
+    switch (piece) {
+        case 0: __builtin_amdgcn_global_load_lds(AS1(src), AS3(smem + dst), 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds(AS1(src), AS3(smem + dst), 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds(AS1(src), AS3(smem + dst), 16, 2048, 0); break;
+        case 3: __builtin_amdgcn_global_load_lds(AS1(src), AS3(smem + dst), 16, 3072, 0); break;
+        case 4: if (NP == 2) __builtin_amdgcn_global_load_lds(AS1(src + 4096), AS3(smem + dst + 4096), 16, 0, 0); break;
+        case 5: if (NP == 2) __builtin_amdgcn_global_load_lds(AS1(src + 4096), AS3(smem + dst + 4096), 16, 1024, 0); break;
+        case 6: if (NP == 2) __builtin_amdgcn_global_load_lds(AS1(src + 4096), AS3(smem + dst + 4096), 16, 2048, 0); break;
+        case 7: if (NP == 2) __builtin_amdgcn_global_load_lds(AS1(src + 4096), AS3(smem + dst + 4096), 16, 3072, 0); break;
+        default: break;
     }
-    const char* asrc = R.wimg + (size_t)R.issue_pos * C::CH + C::AUX + R.wave * 256;
-    __builtin_amdgcn_global_load_lds(AS1(asrc + (uint32_t)R.lane * 4u), AS3(smem + R.issue_off + C::AUX + R.wave * 256),
-                                     4, 0, 0);
-    R.issue_pos = (R.issue_pos + 1 == R.cpt) ? 0 : R.issue_pos + 1;
-    R.issue_off = (R.issue_off + C::CH == (uint32_t)C::LDS) ? 0u : R.issue_off + C::CH;
+    if (piece == last) {  // the aux block rides with the last piece, then the ring advances
+        const char* asrc = R.wimg + (size_t)R.issue_pos * C::CH + C::AUX + R.wave * 256;
+        __builtin_amdgcn_global_load_lds(AS1(asrc + (uint32_t)R.lane * 4u), AS3(smem + R.issue_off + C::AUX + R.wave * 256),
+                                         4, 0, 0);
+        R.issue_pos = (R.issue_pos + 1 == R.cpt) ? 0 : R.issue_pos + 1;
+        R.issue_off = (R.issue_off + C::CH == (uint32_t)C::LDS) ? 0u : R.issue_off + C::CH;
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void ring_issue(Ring<NP>& R) {  // all pieces at once (prologue, chunk tails)
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) ring_issue_piece<NP>(R, piece);
 }
 
 #define R2L_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // Mid-chunk rendezvous while consuming chunk c: every wave's LDS-DMA of chunk c+1 has
-// landed (counted vmcnt, then the barrier), every wave is past chunk c-1, so its slot is
-// refilled with chunk c+D.
+// landed (counted vmcnt, then the barrier), every wave is past chunk c-1, so its slot may be
+// refilled with chunk c+D: by ring_issue_piece over the following k-steps, or at once (ring_mid).
 template <int NP>
-__device__ __forceinline__ void ring_mid(Ring<NP>& R) {
+__device__ __forceinline__ void ring_sync(Ring<NP>& R) {
 #ifdef R2L_ABL_NODMA  // ablation build: no rendezvous, no refill (LDS keeps the prologue's chunks)
     return;
 #endif
@@ -122,7 +138,24 @@ __device__ __forceinline__ void ring_mid(Ring<NP>& R) {
 #ifndef R2L_ABL_NOBARRIER
     __builtin_amdgcn_s_barrier();
 #endif
-#ifndef R2L_ABL_NOISSUE
+}
+
+// fragment position f (0..15) inside a chunk: rendezvous + refill at 8.  (Spreading the
+// refill over positions 8..15, one piece per k-step, measured 8 % SLOWER than the burst.)
+template <int NP>
+__device__ __forceinline__ void ring_step(Ring<NP>& R, int f) {
+    if (f == R2L_FRAGS / 2) {
+        ring_sync<NP>(R);
+#if !defined(R2L_ABL_NOISSUE) && !defined(R2L_ABL_NODMA)
+        ring_issue<NP>(R);
+#endif
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void ring_mid(Ring<NP>& R) {
+    ring_sync<NP>(R);
+#if !defined(R2L_ABL_NOISSUE) && !defined(R2L_ABL_NODMA)
     ring_issue<NP>(R);
 #endif
 }
@@ -164,7 +197,7 @@ template <int NP>
 __device__ __forceinline__ void split_store(float a, f16x8& hi, f16x8& lo, int j) {
     f16 h = (f16)a;
     hi[j] = h;
-    if (NP == 2) lo[j] = (f16)(a - (float)h);
+    if (NP == 2) lo[j] = (f16)fmaf((float)h, -1.0f, a);  // a - hi, fma-shaped so it can become v_fma_mix*_f16
 }
 
 // accumulator init of one row tile = aux[feat_off + 4q + i], i = 0..3 (bias pre-multiplied by

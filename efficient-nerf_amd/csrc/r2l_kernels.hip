@@ -148,7 +148,7 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
 #pragma unroll
     for (int s = 0; s < R2L_KSTEPS; ++s) {
         const int f = upos * R2L_KSTEPS + s;
-        if (f == R2L_FRAGS / 2) ring_mid<NP>(R);
+        ring_step<NP>(R, f);  // f == 8: rendezvous; f >= 8: one refill piece per step
         AFrag<NP> nxt = (f + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, f + 1) : read_frag<NP>(next_base, 0);
         acc[0] = mfma_step<NP>(R.pre, Bh[s][0], Bl[s][0], acc[0]);
         acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
@@ -188,7 +188,7 @@ __device__ __forceinline__ void head_step(Ring<NP>& R, const f16x8 (&bh)[2], con
     const uint32_t next_base = ring_next_off<NP>(R.use_off) + R.lane * 16;
 #pragma unroll
     for (int u = 0; u < R2L_RTILES; ++u) {
-        if (u == R2L_FRAGS / 2) ring_mid<NP>(R);
+        ring_step<NP>(R, u);
         AFrag<NP> nxt = (u + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, u + 1) : read_frag<NP>(next_base, 0);
         x[u][0] = mfma_step<NP>(R.pre, bh[0], bl[0], x[u][0]);
         x[u][1] = mfma_step<NP>(R.pre, bh[1], bl[1], x[u][1]);
