@@ -114,6 +114,7 @@ struct r2l_ctx {
     char* d_img[2];                           // [mode] packed image
     size_t img_bytes[2];
     float* d_scratch;
+    float* d_z;  // device copy of z
     bool timing;
     std::vector<hipEvent_t> ev;  // pairs
     int ev_used;
@@ -152,6 +153,7 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
     c->d_img[0] = c->d_img[1] = nullptr;
     c->img_bytes[0] = c->img_bytes[1] = 0;
     c->d_scratch = nullptr;
+    c->d_z = nullptr;
     c->timing = false;
     c->ev_used = 0;
     r2l_z_vals(R2L_NSAMPLE, near_, far_, c->z);
@@ -160,6 +162,12 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
     if (e != hipSuccess) {
         delete c;
         return r2l_set_error(R2L_EHIP, "hipMalloc scratch: %s", hipGetErrorString(e));
+    }
+    e = hipMalloc((void**)&c->d_z, sizeof c->z);
+    if (e == hipSuccess) e = hipMemcpy(c->d_z, c->z, sizeof c->z, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        r2l_destroy(c);
+        return r2l_set_error(R2L_EHIP, "hipMalloc/hipMemcpy z_vals: %s", hipGetErrorString(e));
     }
     *out = c;
     return R2L_OK;
@@ -170,6 +178,7 @@ void r2l_destroy(r2l_ctx* c) {
     for (int m = 0; m < 2; ++m)
         if (c->d_img[m]) (void)hipFree(c->d_img[m]);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_z) (void)hipFree(c->d_z);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
 }
@@ -337,13 +346,15 @@ int r2l_set_z_vals(r2l_ctx* c, const float* z_host, int n) {
     if (!c || !z_host) return r2l_set_error(R2L_EINVAL, "NULL argument");
     if (n != R2L_NSAMPLE) return r2l_set_error(R2L_EINVAL, "expected %d z values, got %d", R2L_NSAMPLE, n);
     memcpy(c->z, z_host, sizeof c->z);
+    hipError_t e = hipMemcpy(c->d_z, c->z, sizeof c->z, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy z_vals: %s", hipGetErrorString(e));
     return R2L_OK;
 }
 
 // ---- launches --------------------------------------------------------------------------
 static void fill_common(const r2l_ctx* c, R2LParams& p) {
     memset(&p, 0, sizeof p);
-    memcpy(p.z, c->z, sizeof p.z);
+    p.z = c->d_z;
     p.focal = (float)c->focal;
     p.half_w = (float)(c->W * .5);
     p.half_h = (float)(c->H * .5);

@@ -10,7 +10,8 @@ struct R2LParams {
     const float* rays_d;
     float* scratch;        // [grid, 4 waves, 32, 64 lanes, 4] f32: head output kept for the global skip
     float c2w_host[12];
-    float z[16];           // PointSampler.z_vals (model/nerf_raybased.py:88-90)
+    const float* z;        // device [16]: PointSampler.z_vals (model/nerf_raybased.py:88-90); a pointer, not an
+                           // array: dynamic indexing into a by-value kernarg array spills the struct to scratch
     float focal, half_w, half_h, act_scale;
     int W, pix_begin, rays_per_pose, n_rays, n_tiles, n_block, use_residual, chunks_per_tile;
 };

@@ -23,37 +23,46 @@
 
 #include "r2l_device.h"
 
-// camera ray of flat ray index `ray` (model/nerf_raybased.py:84-99).
-__device__ __forceinline__ void make_ray(const R2LParams& p, int ray, float o[3], float d[3]) {
+// camera ray of flat ray index `ray` (model/nerf_raybased.py:84-99), returned by value with
+// scalar members so it lives in registers (arrays handed around by pointer ended up in scratch,
+// and every scratch reload drains the LDS-DMA ring with a vmcnt(0)).
+struct Ray6 {
+    float ox, oy, oz, dx, dy, dz;
+    __device__ __forceinline__ float o(int k) const { return k == 0 ? ox : (k == 1 ? oy : oz); }
+    __device__ __forceinline__ float d(int k) const { return k == 0 ? dx : (k == 1 ? dy : dz); }
+};
+
+__device__ __forceinline__ Ray6 make_ray(const R2LParams& p, int ray) {
+    Ray6 r;
     if (p.rays_o != nullptr) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            o[k] = p.rays_o[(size_t)ray * 3 + k];
-            d[k] = p.rays_d[(size_t)ray * 3 + k];
-        }
-        return;
+        const float* po = p.rays_o + (size_t)ray * 3;
+        const float* pd = p.rays_d + (size_t)ray * 3;
+        r.ox = po[0]; r.oy = po[1]; r.oz = po[2];
+        r.dx = pd[0]; r.dy = pd[1]; r.dz = pd[2];
+        return r;
     }
-    int pose = ray / p.rays_per_pose;
-    int pix = p.pix_begin + (ray - pose * p.rays_per_pose);
-    int jrow = pix / p.W;
-    int icol = pix - jrow * p.W;
-    float c[12];
+    const int pose = ray / p.rays_per_pose;
+    const int pix = p.pix_begin + (ray - pose * p.rays_per_pose);
+    const int jrow = pix / p.W;
+    const int icol = pix - jrow * p.W;
+    float c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11;
     if (p.c2w != nullptr) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) c[k] = p.c2w[(size_t)pose * 12 + k];
+        const float* c = p.c2w + (size_t)pose * 12;
+        c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+        c6 = c[6]; c7 = c[7]; c8 = c[8]; c9 = c[9]; c10 = c[10]; c11 = c[11];
     } else {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) c[k] = p.c2w_host[k];
+        c0 = p.c2w_host[0]; c1 = p.c2w_host[1]; c2 = p.c2w_host[2]; c3 = p.c2w_host[3];
+        c4 = p.c2w_host[4]; c5 = p.c2w_host[5]; c6 = p.c2w_host[6]; c7 = p.c2w_host[7];
+        c8 = p.c2w_host[8]; c9 = p.c2w_host[9]; c10 = p.c2w_host[10]; c11 = p.c2w_host[11];
     }
-    float dx = __fdiv_rn((float)icol - p.half_w, p.focal);
-    float dy = -__fdiv_rn((float)jrow - p.half_h, p.focal);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        // torch.sum(dirs[..., None, :] * c2w[:3,:3], -1): products rounded, then summed
-        float s = __fadd_rn(__fmul_rn(dx, c[4 * k + 0]), __fmul_rn(dy, c[4 * k + 1]));
-        d[k] = __fadd_rn(s, __fmul_rn(-1.0f, c[4 * k + 2]));
-        o[k] = c[4 * k + 3];
-    }
+    const float dx = __fdiv_rn((float)icol - p.half_w, p.focal);
+    const float dy = -__fdiv_rn((float)jrow - p.half_h, p.focal);
+    // torch.sum(dirs[..., None, :] * c2w[:3,:3], -1): products rounded, then summed left to right
+    r.dx = __fadd_rn(__fadd_rn(__fmul_rn(dx, c0), __fmul_rn(dy, c1)), __fmul_rn(-1.0f, c2));
+    r.dy = __fadd_rn(__fadd_rn(__fmul_rn(dx, c4), __fmul_rn(dy, c5)), __fmul_rn(-1.0f, c6));
+    r.dz = __fadd_rn(__fadd_rn(__fmul_rn(dx, c8), __fmul_rn(dy, c9)), __fmul_rn(-1.0f, c10));
+    r.ox = c3; r.oy = c7; r.oz = c11;
+    return r;
 }
 
 __device__ __forceinline__ float sample_pt(float o, float d, float z) {
@@ -72,11 +81,8 @@ __global__ void r2l_sample_embed_kernel(R2LParams p, float* __restrict__ pts_out
     int ray = (int)(gid / R2L_NCOORD);
     int c = (int)(gid - (long long)ray * R2L_NCOORD);
     int s = c / 3, kk = c - 3 * s;
-    float o[3], d[3];
-    make_ray(p, ray, o, d);
-    float ok = kk == 0 ? o[0] : (kk == 1 ? o[1] : o[2]);
-    float dk = kk == 0 ? d[0] : (kk == 1 ? d[1] : d[2]);
-    float x = sample_pt(ok, dk, p.z[s]);
+    const Ray6 r6 = make_ray(p, ray);
+    float x = sample_pt(r6.o(kk), r6.d(kk), p.z[s]);
     if (pts_out) pts_out[gid] = x;
     if (emb_out) {
         float* e = emb_out + gid * R2L_EMBED;
@@ -180,22 +186,24 @@ __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2],
                             Nl[(R2L_RTILES - 1) >> 1][i >> 2], R2L_RTILES - 1, i & 3);
 }
 
-// one head k-step (one chunk): 16 row tiles against the generated B fragments of both column tiles
-template <int NP>
-__device__ __forceinline__ void head_step(Ring<NP>& R, const f16x8 (&bh)[2], const f16x8 (&bl)[2],
-                                          f32x4 (&x)[16][2]) {
-    const uint32_t lane_base = R.use_off + R.lane * 16;
-    const uint32_t next_base = ring_next_off<NP>(R.use_off) + R.lane * 16;
-#pragma unroll
-    for (int u = 0; u < R2L_RTILES; ++u) {
-        ring_step<NP>(R, u);
-        AFrag<NP> nxt = (u + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, u + 1) : read_frag<NP>(next_base, 0);
-        x[u][0] = mfma_step<NP>(R.pre, bh[0], bl[0], x[u][0]);
-        x[u][1] = mfma_step<NP>(R.pre, bh[1], bl[1], x[u][1]);
-        R.pre = nxt;
-    }
-    ring_next<NP>(R);
-}
+// one head k-step (one chunk): 16 row tiles against the generated B fragments of both column
+// tiles.  GEN is a statement using `i` (0..15), expanded between the MFMA groups: it produces
+// element (i>>3, i&7) of the NEXT k-step's fragments, so the embedding VALU work runs under this
+// step's MFMAs.  (A macro, not a functor: arrays captured by a lambda ended up in scratch.)
+#define R2L_HEAD_STEP(BH, BL, ...)                                                                      \
+    do {                                                                                               \
+        const uint32_t lane_base_ = R.use_off + R.lane * 16;                                           \
+        const uint32_t next_base_ = ring_next_off<NP>(R.use_off) + R.lane * 16;                        \
+        _Pragma("unroll") for (int i = 0; i < R2L_RTILES; ++i) {                                       \
+            ring_step<NP>(R, i);                                                                       \
+            AFrag<NP> nxt_ = (i + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base_, i + 1) : read_frag<NP>(next_base_, 0); \
+            x[i][0] = mfma_step<NP>(R.pre, (BH)[0], (BL)[0], x[i][0]);                                 \
+            x[i][1] = mfma_step<NP>(R.pre, (BH)[1], (BL)[1], x[i][1]);                                 \
+            R.pre = nxt_;                                                                              \
+            __VA_ARGS__;                                                                               \
+        }                                                                                              \
+        ring_next<NP>(R);                                                                              \
+    } while (0)
 
 __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d) {
     return (q & 2) ? ((q & 1) ? d : c) : ((q & 1) ? b : a);
@@ -215,6 +223,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     const int lane = R.lane;
     const int q = lane >> 4;
     const float act_scale = p.act_scale;
+    // read-only, wave-uniform: constant address space => scalar loads (s_load), no vmcnt traffic
+    const __attribute__((address_space(4))) float* zc = (const __attribute__((address_space(4))) float*)p.z;
 
     // prologue: D chunks in flight, chunk 0 certified, its fragment 0 in registers
 #pragma unroll
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // a lane serves ray (lane & 15) of both column tiles
-        float o[2][3], d[2][3];
+        Ray6 rr[2];
         int ray[2];
         bool valid[2];
 #pragma unroll
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             const int ray_raw = tile * R2L_TILE_RAYS + R.wave * R2L_RAYS_PER_WAVE + c * 16 + (lane & 15);
             valid[c] = ray_raw < p.n_rays;
             ray[c] = valid[c] ? ray_raw : p.n_rays - 1;
-            make_ray(p, ray[c], o[c], d[c]);
+            rr[c] = make_ray(p, ray[c]);
         }
 
         // ---------------- head: Linear(1008,256) + ReLU, k outer / row tile inner ------------
@@ -245,50 +255,78 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             x[u][0] = acc_init<NP>(R.use_off, 16 * u, q);
             x[u][1] = x[u][0];
         }
-        // phase 1: k-steps 0..23: coordinates 2s, 2s+1 (by q>>1), frequencies 0..7, sin|cos by q&1
+        // phase 1: k-steps 0..23: coordinates 2s, 2s+1 (by q>>1), frequencies 0..7, sin|cos by q&1.
+        // Three steps (= two samples) per iteration; inside it the fragments of step u3+1 are
+        // generated under the MFMAs of step u3.
+        const bool is_cos1 = (q & 1) != 0;
         for (int sp = 0; sp < 8; ++sp) {
-            const float z0 = p.z[2 * sp], z1 = p.z[2 * sp + 1];
+            const float z0 = zc[2 * sp], z1 = zc[2 * sp + 1];
+            float xsel[3][2];
 #pragma unroll
             for (int u3 = 0; u3 < 3; ++u3) {
                 const int ca = 2 * u3, cb = 2 * u3 + 1;  // coordinates inside this pair of samples
-                f16x8 bh[2], bl[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const float xa = sample_pt(o[c][ca % 3], d[c][ca % 3], ca < 3 ? z0 : z1);
-                    const float xb = sample_pt(o[c][cb % 3], d[c][cb % 3], cb < 3 ? z0 : z1);
-                    const Rev r = to_rev((q & 2) ? xb : xa);
-                    float pw = 1.0f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        split_store<NP>(trig_pow2(r, pw, (q & 1) != 0) * act_scale, bh[c], bl[c], j);
-                        pw *= 2.0f;
-                    }
+                    const float xa = sample_pt(rr[c].o(ca % 3), rr[c].d(ca % 3), ca < 3 ? z0 : z1);
+                    const float xb = sample_pt(rr[c].o(cb % 3), rr[c].d(cb % 3), cb < 3 ? z0 : z1);
+                    xsel[u3][c] = (q & 2) ? xb : xa;
                 }
-                head_step<NP>(R, bh, bl, x);
             }
-        }
-        // phase 2: k-steps 24..29: coordinates 8(s-24) + 2q + (j>>2), frequencies 8, 9
-        for (int it = 0; it < 2; ++it) {
+            f16x8 bh[2][2], bl[2][2];  // [buffer][column tile]
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const Rev r = to_rev(xsel[0][c]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    split_store<NP>(trig_pow2(r, (float)(1 << j), is_cos1) * act_scale, bh[0][c], bl[0][c], j);
+            }
 #pragma unroll
             for (int u3 = 0; u3 < 3; ++u3) {
-                f16x8 bh[2], bl[2];
+                Rev rn[2];
+                R2L_HEAD_STEP(bh[u3 & 1], bl[u3 & 1], {
+                    if (u3 < 2) {
+                        const int c = i >> 3, j = i & 7;
+                        if (j == 0) rn[c] = to_rev(xsel[u3 < 2 ? u3 + 1 : 0][c]);
+                        split_store<NP>(trig_pow2(rn[c], (float)(1 << j), is_cos1) * act_scale, bh[(u3 & 1) ^ 1][c],
+                                        bl[(u3 & 1) ^ 1][c], j);
+                    }
+                });
+            }
+        }
+        // phase 2: k-steps 24..29: coordinates 8(s-24) + 2q + (j>>2), frequencies 8, 9; same pipelining
+        for (int it = 0; it < 2; ++it) {
+            Rev r01[3][2][2];  // [step][column tile][coordinate of the pair]
+#pragma unroll
+            for (int u3 = 0; u3 < 3; ++u3) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     float pt[8];
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
                         const int cc = 8 * u3 + m;  // coordinate inside this group of 24
-                        pt[m] = sample_pt(o[c][cc % 3], d[c][cc % 3], p.z[8 * it + cc / 3]);
+                        pt[m] = sample_pt(rr[c].o(cc % 3), rr[c].d(cc % 3), zc[8 * it + cc / 3]);
                     }
-                    const Rev r0 = to_rev(sel4(q, pt[0], pt[2], pt[4], pt[6]));
-                    const Rev r1 = to_rev(sel4(q, pt[1], pt[3], pt[5], pt[7]));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        split_store<NP>(trig_pow2((j >> 2) ? r1 : r0, (j & 1) ? 512.0f : 256.0f, ((j >> 1) & 1) != 0) *
-                                            act_scale,
-                                        bh[c], bl[c], j);
+                    r01[u3][c][0] = to_rev(sel4(q, pt[0], pt[2], pt[4], pt[6]));
+                    r01[u3][c][1] = to_rev(sel4(q, pt[1], pt[3], pt[5], pt[7]));
                 }
-                head_step<NP>(R, bh, bl, x);
+            }
+            f16x8 bh[2][2], bl[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    split_store<NP>(trig_pow2(r01[0][c][j >> 2], (j & 1) ? 512.0f : 256.0f, ((j >> 1) & 1) != 0) * act_scale,
+                                    bh[0][c], bl[0][c], j);
+#pragma unroll
+            for (int u3 = 0; u3 < 3; ++u3) {
+                R2L_HEAD_STEP(bh[u3 & 1], bl[u3 & 1], {
+                    if (u3 < 2) {
+                        const int c = i >> 3, j = i & 7;
+                        split_store<NP>(trig_pow2(r01[u3 < 2 ? u3 + 1 : 0][c][j >> 2], (j & 1) ? 512.0f : 256.0f,
+                                                  ((j >> 1) & 1) != 0) * act_scale,
+                                        bh[(u3 & 1) ^ 1][c], bl[(u3 & 1) ^ 1][c], j);
+                    }
+                });
             }
         }
         // phase 3: k-steps 30, 31: identity of coordinate 8q + j (+32; quarters 2, 3 of step 31 pad)
@@ -303,20 +341,20 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                     float v;
                     if (s3 == 0) {
                         const int c0 = j, c1 = 8 + j, c2 = 16 + j, c3 = 24 + j;
-                        v = sel4(q, sample_pt(o[c][c0 % 3], d[c][c0 % 3], p.z[c0 / 3]),
-                                 sample_pt(o[c][c1 % 3], d[c][c1 % 3], p.z[c1 / 3]),
-                                 sample_pt(o[c][c2 % 3], d[c][c2 % 3], p.z[c2 / 3]),
-                                 sample_pt(o[c][c3 % 3], d[c][c3 % 3], p.z[c3 / 3]));
+                        v = sel4(q, sample_pt(rr[c].o(c0 % 3), rr[c].d(c0 % 3), zc[c0 / 3]),
+                                 sample_pt(rr[c].o(c1 % 3), rr[c].d(c1 % 3), zc[c1 / 3]),
+                                 sample_pt(rr[c].o(c2 % 3), rr[c].d(c2 % 3), zc[c2 / 3]),
+                                 sample_pt(rr[c].o(c3 % 3), rr[c].d(c3 % 3), zc[c3 / 3]));
                     } else {
                         const int c0 = 32 + j, c1 = 40 + j;
-                        v = sel4(q, sample_pt(o[c][c0 % 3], d[c][c0 % 3], p.z[c0 / 3]),
-                                 sample_pt(o[c][c1 % 3], d[c][c1 % 3], p.z[c1 / 3]), 0.0f, 0.0f);
+                        v = sel4(q, sample_pt(rr[c].o(c0 % 3), rr[c].d(c0 % 3), zc[c0 / 3]),
+                                 sample_pt(rr[c].o(c1 % 3), rr[c].d(c1 % 3), zc[c1 / 3]), 0.0f, 0.0f);
                     }
                     split_store<NP>(v * act_scale, bh[c], bl[c], j);
                 }
             }
             if (s3 == 1) inv_head = aux_inv_scale<NP>(R.use_off) * act_scale;  // chunk 31's aux
-            head_step<NP>(R, bh, bl, x);
+            R2L_HEAD_STEP(bh, bl, {});
         }
 
         // head epilogue: h0 = relu(acc/scale) (scaled domain); keep a copy for the global skip
