@@ -40,18 +40,14 @@ __device__ __forceinline__ Rev to_rev(float x) {
 
 // sin (is_cos = false) or cos (true) of x * 2^l given x/(2 pi) = rh + rl, pow2l = 2^l.
 // rh*2^l is exact, t - rint(t) is exact, so g = frac(x*2^l/(2 pi)) in [-1/2, 1/2] keeps
-// ~2^-26 absolute accuracy; sin folds |g| to [-1/4, 1/4] (sign of g restored on the
-// angle), cos uses cos(2 pi g) = sin(2 pi (1/4 - |g|)).  The folded turn fraction goes to
-// v_sin_f32 (sin(2 pi x), |err| <= 1.1e-7 on [-1/4, 1/4], measured: tools/vsin_test.hip).
+// ~2^-26 absolute accuracy; cos uses cos(2 pi g) = sin(2 pi (1/4 - |g|)).  The turn fraction
+// goes to v_sin_f32 (sin(2 pi x), |err| <= 1.3e-7 on [-1, 1], measured: tools/vsin_test.hip).
 __device__ __forceinline__ float trig_pow2(Rev r, float pow2l, bool is_cos) {
     float t = r.rh * pow2l;
     float u = t - rintf(t);
-    float g = fmaf(r.rl, pow2l, u);
-    float a = fabsf(g);
-    float m = is_cos ? (0.25f - a) : fminf(a, 0.5f - a);
-    float sg = is_cos ? 1.0f : g;
-    // m * sign(sg): flip m's sign bit by sg's (m itself may be negative and must stay so)
-    return __builtin_amdgcn_sinf(__uint_as_float(__float_as_uint(m) ^ (__float_as_uint(sg) & 0x80000000u)));
+    float g = fmaf(r.rl, pow2l, u);                  // frac(x*2^l/(2 pi)) in [-1/2, 1/2]
+    float arg = is_cos ? (0.25f - fabsf(g)) : g;     // cos(2 pi g) = sin(2 pi (1/4 - |g|)), exact fold
+    return __builtin_amdgcn_sinf(arg);               // v_sin_f32 reduces |arg| <= 1/2 itself
 }
 
 // ------------------------------------------------------------------------------------

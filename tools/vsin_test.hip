@@ -10,7 +10,7 @@ __global__ void k(const float* x, float* y, int n) {
 int main() {
     const int n = 1 << 22;
     std::vector<float> x(n), y(n);
-    for (int i = 0; i < n; ++i) x[i] = -0.25f + 0.5f * (float)i / (float)(n - 1);
+    for (int i = 0; i < n; ++i) x[i] = -1.0f + 2.0f * (float)i / (float)(n - 1);
     float *dx, *dy;
     hipMalloc(&dx, n * 4); hipMalloc(&dy, n * 4);
     hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice);
@@ -21,6 +21,6 @@ int main() {
         double e = fabs((double)y[i] - sin(2 * M_PI * (double)x[i]));
         if (e > worst) { worst = e; wx = x[i]; }
     }
-    printf("v_sin_f32 max abs err on [-0.25,0.25]: %.3e at x=%.6f\n", worst, wx);
+    printf("v_sin_f32 max abs err on [-1,1]: %.3e at x=%.6f\n", worst, wx);
     return 0;
 }
