@@ -37,6 +37,19 @@ def cpu_threads():
     return max(1, min(n, 16))
 
 
+def measured_traffic(precision):
+    """HBM-side bytes per launch from the newest committed PMC pass (profiles/rNN_traffic.json;
+    counters cannot be collected from inside the timed process), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_traffic.json')))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get(precision, {}).get('bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -45,6 +58,7 @@ def main():
     ap.add_argument('--precision', choices=['fp16x3', 'fp16x1'], default='fp16x3',
                     help='fp16x3 meets the <=1e-4 L_inf contract (default); fp16x1 is the fast mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-teacher', action='store_true', help='skip the secondary teacher measurement')
     ap.add_argument('--cpu-rays', type=int, default=H * W,
                     help='rays of one frame the CPU oracle renders for the baseline / parity check')
     args = ap.parse_args()
@@ -113,7 +127,7 @@ def main():
                    'H': H, 'W': W, 'rays_per_gpu_per_step': rows * W * world, 'frames_per_step': world,
                    'precision': args.precision, 'parallelism': 'ray-shard x%d' % world},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP16_TFLOPS, 'traffic': None,
+                     'frac': achieved / PEAK_FP16_TFLOPS, 'traffic': measured_traffic(args.precision),
                      'kernel': 'r2l_resmlp_kernel<%d>' % (2 if passes == 3 else 1),
                      'avg_kernel_ms': avg_kernel_s * 1e3, 'launches': n_launch,
                      'algorithmic_flops_per_ray': flops_per_ray, 'executed_mfma_passes': passes,
@@ -138,6 +152,23 @@ def main():
                                              % (n_cpu_rows * W, n_cpu_rows, t_cpu)}
             out['parity'] = {'linf_vs_cpu_oracle': err, 'psnr_vs_cpu_oracle_db': O.psnr(gpu, ref),
                              'rays_checked': n_cpu_rows * W, 'tolerance': 1e-4}
+        if not args.no_teacher and world == 1:
+            # secondary, outside the timed region: NeRF teacher coarse+fine (BASELINE config 3)
+            from efficient_nerf_amd import NeRFEngine
+            th = 400
+            teng = NeRFEngine(th, th, O.focal_from_angle(th), precision=prec).load_state_dicts(
+                O.make_teacher_state(1), O.make_teacher_state(2))
+            teng.render(poses[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(3):
+                teng.render(poses[i + 1])
+            torch.cuda.synchronize()
+            tdt = (time.perf_counter() - t1) / 3
+            out['teacher'] = {'workload': 'NeRF teacher lego 400x400 coarse 64 + fine 128', 'rays_per_s': th * th / tdt,
+                              'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': 2 * 593408 * 256 * th * th / tdt / 1e12,
+                              'precision': args.precision}
+            teng.close()
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
