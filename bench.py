@@ -55,7 +55,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--precision', choices=['fp16x3', 'fp16x1'], default='fp16x3',
+    ap.add_argument('--precision', choices=['fp16x3', 'fp16x1', 'fp16_fp8'], default='fp16x3',
                     help='fp16x3 meets the <=1e-4 L_inf contract (default); fp16x1 is the fast mode')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-teacher', action='store_true', help='skip the secondary teacher measurement')
@@ -66,7 +66,7 @@ def main():
     import torch
     import _pkg
     _pkg.load()
-    from efficient_nerf_amd import R2LEngine, PREC_FP16X1, PREC_FP16X3, dist as D
+    from efficient_nerf_amd import R2LEngine, PRECISIONS, dist as D
     from oracle import r2l_oracle as O
 
     rank, local_rank, world = D.init()
@@ -77,7 +77,7 @@ def main():
 
     focal = O.focal_from_angle(W)
     sd = O.make_r2l_state(seed=0)  # synthetic weights, reference init (nn.Linear default)
-    prec = PREC_FP16X3 if args.precision == 'fp16x3' else PREC_FP16X1
+    prec = PRECISIONS[args.precision]
     eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True, precision=prec).load_state_dict(sd)
 
     total_steps = args.steps + args.warmup
@@ -116,7 +116,7 @@ def main():
     flops_per_ray = eng.flops_per_ray
     avg_kernel_s = kern_ms / max(n_launch, 1) / 1e3
     achieved = flops_per_ray * rays_per_launch / avg_kernel_s / 1e12
-    passes = 3 if args.precision == 'fp16x3' else 1
+    passes = {'fp16x3': 3, 'fp16x1': 1, 'fp16_fp8': 2}[args.precision]  # fp16-MFMA pass equivalents per k-step
 
     out = {
         'metric': 'rays/sec at 800x800 (R2L W256D88)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
@@ -128,7 +128,8 @@ def main():
                    'precision': args.precision, 'parallelism': 'ray-shard x%d' % world},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP16_TFLOPS, 'traffic': measured_traffic(args.precision),
-                     'kernel': 'r2l_resmlp_kernel<%d>' % (2 if passes == 3 else 1),
+                     'kernel': {'fp16x3': 'r2l_resmlp_kernel<2, false>', 'fp16x1': 'r2l_resmlp_kernel<1, false>',
+                                'fp16_fp8': 'r2l_resmlp_kernel<2, true>'}[args.precision],
                      'avg_kernel_ms': avg_kernel_s * 1e3, 'launches': n_launch,
                      'algorithmic_flops_per_ray': flops_per_ray, 'executed_mfma_passes': passes,
                      'executed_frac': achieved * passes / PEAK_FP16_TFLOPS},

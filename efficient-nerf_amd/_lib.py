@@ -4,6 +4,8 @@ import os
 
 PREC_FP16X3 = 0
 PREC_FP16X1 = 1
+PREC_FP16_FP8 = 2  # R2L only: fp16 main pass + fp8 correction terms
+PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('R2L_LIB_PATH', os.path.join(_HERE, 'libr2l_hip.so'))  # override: ablation builds (tools/)

@@ -102,6 +102,25 @@ void r2l_split_f16(float v, _Float16* hi, _Float16* lo) {
     if (lo) *lo = (_Float16)(v - (float)h);
 }
 
+// OCP e4m3fn (bias 7, 3 mantissa bits, max 448, no inf), round to nearest even, saturating
+unsigned char r2l_f32_to_e4m3(float v) {
+    const unsigned char sgn = signbit(v) ? 0x80 : 0;
+    const float a = fabsf(v);
+    if (!(a == a)) return 0x7f;
+    if (a >= 464.0f) return sgn | 0x7e;
+    int e;
+    frexpf(a, &e);
+    const int E = e - 1;  // a = 1.x * 2^E
+    if (a == 0.f || E < -6) return sgn | (unsigned char)nearbyintf(ldexpf(a, 9));  // subnormal step 2^-9 (8 -> min normal)
+    int qn = (int)nearbyintf(ldexpf(a, 3 - E));  // 8..16
+    int EE = E;
+    if (qn == 16) {
+        qn = 8;
+        ++EE;
+    }
+    return sgn | (unsigned char)(((EE + 7) << 3) | (qn - 8));
+}
+
 struct r2l_ctx {
     int H, W, n_block, use_residual, mode;
     double focal;
@@ -111,8 +130,8 @@ struct r2l_ctx {
     int n_cu;
     bool loaded;
     std::vector<std::vector<float>> host_w;  // state_dict order
-    char* d_img[2];                           // [mode] packed image
-    size_t img_bytes[2];
+    char* d_img[3];                           // [mode] packed image
+    size_t img_bytes[3];
     float* d_scratch;
     float* d_z;  // device copy of z
     bool timing;
@@ -120,7 +139,8 @@ struct r2l_ctx {
     int ev_used;
 };
 
-static int np_of(int mode) { return mode == R2L_PREC_FP16X3 ? 2 : 1; }
+static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
+static bool mode_ok(int mode) { return mode == R2L_PREC_FP16X3 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16_FP8; }
 
 int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far_, int n_sample, int L,
                int width, int n_block, int use_residual, int precision_mode) {
@@ -133,8 +153,7 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
                              n_sample, L, width);
     if (H <= 0 || W <= 0 || n_block < 0 || !(focal > 0))
         return r2l_set_error(R2L_EINVAL, "bad geometry H=%d W=%d focal=%g n_block=%d", H, W, focal, n_block);
-    if (precision_mode != R2L_PREC_FP16X3 && precision_mode != R2L_PREC_FP16X1)
-        return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", precision_mode);
+    if (!mode_ok(precision_mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", precision_mode);
     int n_cu = 0;
     int rc = r2l_require_gfx950(&n_cu);
     if (rc) return rc;
@@ -150,8 +169,8 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
     c->act_scale = 16.0f;
     c->n_cu = n_cu;
     c->loaded = false;
-    c->d_img[0] = c->d_img[1] = nullptr;
-    c->img_bytes[0] = c->img_bytes[1] = 0;
+    c->d_img[0] = c->d_img[1] = c->d_img[2] = nullptr;
+    c->img_bytes[0] = c->img_bytes[1] = c->img_bytes[2] = 0;
     c->d_scratch = nullptr;
     c->d_z = nullptr;
     c->timing = false;
@@ -175,7 +194,7 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
 
 void r2l_destroy(r2l_ctx* c) {
     if (!c) return;
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 3; ++m)
         if (c->d_img[m]) (void)hipFree(c->d_img[m]);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_z) (void)hipFree(c->d_z);
@@ -256,6 +275,18 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
                         int k = r2l_kappa(ks, lane >> 4, j);
                         put_frag(chunk, np, f, lane, j, Wl[(size_t)(16 * u + (lane & 15)) * R2L_WIDTH + k] * Sw);
                     }
+                if (mode != R2L_PREC_FP16_FP8) continue;
+                // piece 2f+1: e4m3 operand bytes of the two correction terms (r2l_common.h)
+                const int term = ks >> 2, t = (ks >> 1) & 1, half = ks & 1;
+                for (int lane = 0; lane < 64; ++lane) {
+                    unsigned char* pb = reinterpret_cast<unsigned char*>(chunk + (size_t)(2 * f + 1) * R2L_FRAG_BYTES + lane * 16);
+                    for (int i = 0; i < 16; ++i) {
+                        const int k = r2l_mix_feat(t, lane >> 4, 16 * half + i);
+                        const float w = Wl[(size_t)(16 * u + (lane & 15)) * R2L_WIDTH + k] * Sw;
+                        const float hi = (float)(_Float16)w;
+                        pb[i] = r2l_f32_to_e4m3(term == 0 ? ldexpf(w - hi, R2L_MIX_WL_SHIFT) : ldexpf(w, -R2L_MIX_W_SHIFT));
+                    }
+                }
             }
             for (int i = 0; i < 32; ++i) aux(ci)[i] = bl[32 * m + i] * S;
             aux(ci)[32] = 1.0f / S;
@@ -299,7 +330,7 @@ int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
         if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
         c->host_w.emplace_back(tensors[i], tensors[i] + n);
     }
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 3; ++m)
         if (c->d_img[m]) {
             (void)hipFree(c->d_img[m]);
             c->d_img[m] = nullptr;
@@ -315,7 +346,7 @@ int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
 long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_block, int precision_mode, char* out,
                               long long cap) {
     if (!tensors || n_tensors != 4 + 4 * n_block || n_block < 0) return r2l_set_error(R2L_EINVAL, "bad tensor list");
-    if (precision_mode != R2L_PREC_FP16X3 && precision_mode != R2L_PREC_FP16X1) return r2l_set_error(R2L_EINVAL, "bad mode");
+    if (!mode_ok(precision_mode)) return r2l_set_error(R2L_EINVAL, "bad mode");
     r2l_ctx c;
     c.n_block = n_block;
     c.act_scale = 16.0f;
@@ -336,7 +367,7 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
 
 int r2l_set_precision(r2l_ctx* c, int mode) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
-    if (mode != R2L_PREC_FP16X3 && mode != R2L_PREC_FP16X1) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
+    if (!mode_ok(mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
     c->mode = mode;
     if (c->loaded && !c->d_img[mode]) return build_image(c, mode);
     return R2L_OK;
@@ -383,7 +414,7 @@ static int timed_launch(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         c->ev_used += 2;
         (void)hipEventRecord(e0, s);
     }
-    hipError_t e = r2l_launch_resmlp(p, np_of(c->mode), grid, s);
+    hipError_t e = r2l_launch_resmlp(p, c->mode, grid, s);
     if (c->timing) (void)hipEventRecord(e1, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l_resmlp launch: %s", hipGetErrorString(e));
     return R2L_OK;

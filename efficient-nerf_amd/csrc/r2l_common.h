@@ -44,6 +44,16 @@
 #define R2L_HD inline
 #endif
 
+// FP16_FP8 mode, body chunks only (head and tail keep the hi|lo fp16 layout): piece 2f = the fp16 hi
+// fragment f = (u&1)*8 + s as above; piece 2f+1 = 16 bytes/lane of e4m3 operand of
+// v_mfma_scale_f32_16x16x128_f8f6f4 for row tile u: s>>2 = term (0: (w - hi(w)) * 2^7 against the e5m2
+// activations, 1: w * 2^-5 against the e5m2 activation residuals), (s>>1)&1 = K-step t of 128 inputs,
+// s&1 = which 16 of the lane's 32 bytes.  Element j (0..31) of lane quarter q of K-step t multiplies
+// input feature r2l_mix_feat(t, q, j): the 4 accumulator registers of row tile 8t + (j>>2).
+#define R2L_MIX_WL_SHIFT 7    // (w*S - hi) * 2^7  : |.| <= 256
+#define R2L_MIX_W_SHIFT 5     // (w*S) * 2^-5      : |.| <  256
+R2L_HD int r2l_mix_feat(int t, int q, int j) { return 16 * (8 * t + (j >> 2)) + 4 * q + (j & 3); }
+
 R2L_HD int r2l_chunk_bytes(int np) { return (R2L_FRAGS * np) * R2L_FRAG_BYTES + R2L_AUX_BYTES; }
 R2L_HD int r2l_chunks_per_tile(int n_block) { return R2L_HEAD_CHUNKS + 2 * n_block * (R2L_RTILES / 2) + 1; }
 

@@ -11,6 +11,8 @@ typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define AS1(p) ((const __attribute__((address_space(1))) void*)(p))
 #define AS3(p) ((__attribute__((address_space(3))) void*)(p))
@@ -241,6 +243,13 @@ __device__ __forceinline__ AFrag<NP> read_frag(uint32_t lane_base, int frag) {
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// v_mfma_scale_f32_16x16x128_f8f6f4: A = weights e4m3 (cbsz 0), B = activations e5m2 (blgp 1); the E8M0
+// scale of A (lane-uniform, byte 0) undoes the host's power-of-two shift of the packed weights.
+#define MFMA8(a, b, c, scale_a) \
+    __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4((a), (b), (c), 0, 1, 0, (scale_a), 0, 0x7f7f7f7f)
+#define R2L_MIX_SCALE_WL (0x01010101 * (127 - R2L_MIX_WL_SHIFT))  // products with (w - hi) * 2^7
+#define R2L_MIX_SCALE_W (0x01010101 * (127 + R2L_MIX_W_SHIFT))    // products with w * 2^-5
 
 // one k-step (32 inputs) on one 16x16 output tile: ah*bh [+ ah*bl + al*bh]
 template <int NP>

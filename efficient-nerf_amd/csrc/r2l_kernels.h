@@ -16,7 +16,7 @@ struct R2LParams {
     int W, pix_begin, rays_per_pose, n_rays, n_tiles, n_block, use_residual, chunks_per_tile;
 };
 
-hipError_t r2l_launch_resmlp(const R2LParams& p, int np, int grid, hipStream_t stream);
+hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,
                                    hipStream_t stream);
 hipError_t r2l_launch_embed(const float* x, long long total, int L, float* emb_out,

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/r2l_hip.h"
 #include "r2l_common.h"
 #include "r2l_kernels.h"
 
@@ -186,6 +187,106 @@ __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2],
                             Nl[(R2L_RTILES - 1) >> 1][i >> 2], R2L_RTILES - 1, i & 3);
 }
 
+// ---- FP16_FP8 body: fp16 main pass + two fp8 correction terms ---------------------------------
+// Two consecutive accumulator values (registers 2*PAIR, 2*PAIR+1 of row tile u, one column tile):
+// fp16 hi into the next layer's fp16 fragment, e5m2 of the value and of its fp16 residual into byte
+// pair PAIR of register u&7 of the next layer's fp8 K-step u>>3.
+template <bool SECOND, int PAIR>
+__device__ __forceinline__ void epi_pair_mix(const f32x4& acc, float inv, f32x4& xu, f16x8& nh, i32x8& na, i32x8& nr,
+                                             int u) {
+    float v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = 2 * PAIR + k;
+        if (!SECOND) {
+            v[k] = fmaxf(acc[r] * inv, 0.0f);
+        } else {
+            v[k] = fmaf(acc[r], inv, xu[r]);
+            xu[r] = v[k];
+        }
+    }
+    const f16 h0 = (f16)v[0], h1 = (f16)v[1];
+    nh[4 * (u & 1) + 2 * PAIR] = h0;
+    nh[4 * (u & 1) + 2 * PAIR + 1] = h1;
+    const float l0 = fmaf((float)h0, -1.0f, v[0]), l1 = fmaf((float)h1, -1.0f, v[1]);
+    na[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], na[u & 7], PAIR != 0);
+    nr[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(l0, l1, nr[u & 7], PAIR != 0);
+}
+
+template <bool SECOND>
+__device__ __forceinline__ void epi_tile_mix(const f32x4& acc, float inv, f32x4& xu, f16x8& nh, i32x8& na, i32x8& nr, int u) {
+    epi_pair_mix<SECOND, 0>(acc, inv, xu, nh, na, nr, u);
+    epi_pair_mix<SECOND, 1>(acc, inv, xu, nh, na, nr, u);
+}
+
+// One row tile of a body layer in FP16_FP8 mode: per k-step s one fp16 MFMA per column tile; the
+// chunk's odd pieces are the 16-byte halves of the e4m3 operands, so every second step one fp8
+// K=128 MFMA per column tile follows (steps 1, 3: w_lo x activations; 5, 7: w x activation residuals).
+template <bool SECOND, bool HAVE_PREV>
+__device__ __forceinline__ void body_rtile_mix(Ring<2>& R, int upos, const f16x8 (&Bh)[8][2], const i32x8 (&Ba)[2][2],
+                                               const i32x8 (&Br)[2][2], f16x8 (&Nh)[8][2], i32x8 (&Na)[2][2],
+                                               i32x8 (&Nr)[2][2], f32x4 (&acc)[2], const f32x4 (&prev)[2], float inv,
+                                               f32x4 (&xprev)[2], int uprev, int q) {
+    const uint32_t slot = R.use_off;
+    const uint32_t lane_base = slot + R.lane * 16;
+    const uint32_t next_base = ring_next_off<2>(slot) + R.lane * 16;
+    acc[0] = acc_init<2>(slot, 16 * upos, q);
+    acc[1] = acc[0];
+    i32x8 a8;
+#pragma unroll
+    for (int s = 0; s < R2L_KSTEPS; ++s) {
+        const int f = upos * R2L_KSTEPS + s;
+        ring_step<2>(R, f);
+        // fp16 fragment one step ahead (R.pre.h); the two 16-byte halves of an e4m3 operand at even s
+        const f16x8 nxt = (f + 1 < R2L_FRAGS)
+                              ? *reinterpret_cast<const f16x8*>(smem + lane_base + (2 * (f + 1)) * R2L_FRAG_BYTES)
+                              : *reinterpret_cast<const f16x8*>(smem + next_base);
+        if ((s & 1) == 0) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(smem + lane_base + (2 * f + 1) * R2L_FRAG_BYTES);
+            const i32x4 hi = *reinterpret_cast<const i32x4*>(smem + lane_base + (2 * f + 3) * R2L_FRAG_BYTES);
+            a8 = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        acc[0] = MFMA(R.pre.h, Bh[s][0], acc[0]);
+        acc[1] = MFMA(R.pre.h, Bh[s][1], acc[1]);
+        if (s & 1) {
+            const int t = (s >> 1) & 1;
+            if (s < 4) {
+                acc[0] = MFMA8(a8, Ba[t][0], acc[0], R2L_MIX_SCALE_WL);
+                acc[1] = MFMA8(a8, Ba[t][1], acc[1], R2L_MIX_SCALE_WL);
+            } else {
+                acc[0] = MFMA8(a8, Br[t][0], acc[0], R2L_MIX_SCALE_W);
+                acc[1] = MFMA8(a8, Br[t][1], acc[1], R2L_MIX_SCALE_W);
+            }
+            if (HAVE_PREV) {
+                const int c = s >> 2;
+                if (((s >> 1) & 1) == 0)
+                    epi_pair_mix<SECOND, 0>(prev[c], inv, xprev[c], Nh[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
+                else
+                    epi_pair_mix<SECOND, 1>(prev[c], inv, xprev[c], Nh[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
+            }
+        }
+        R.pre.h = nxt;
+    }
+    if (upos == 1) ring_next<2>(R);
+}
+
+template <bool SECOND>
+__device__ __forceinline__ void body_layer_mix(Ring<2>& R, const f16x8 (&Bh)[8][2], const i32x8 (&Ba)[2][2],
+                                               const i32x8 (&Br)[2][2], f16x8 (&Nh)[8][2], i32x8 (&Na)[2][2],
+                                               i32x8 (&Nr)[2][2], f32x4 (&x)[16][2], float act_scale, int q) {
+    const float inv = aux_inv_scale<2>(R.use_off) * act_scale;
+    f32x4 accA[2], accB[2];  // alternate between row tiles: the idle one is being drained by the epilogue
+    body_rtile_mix<SECOND, false>(R, 0, Bh, Ba, Br, Nh, Na, Nr, accA, accB, inv, x[0], 0, q);
+#pragma unroll
+    for (int u = 1; u < R2L_RTILES; ++u) {
+        if (u & 1) body_rtile_mix<SECOND, true>(R, 1, Bh, Ba, Br, Nh, Na, Nr, accB, accA, inv, x[u - 1], u - 1, q);
+        else body_rtile_mix<SECOND, true>(R, 0, Bh, Ba, Br, Nh, Na, Nr, accA, accB, inv, x[u - 1], u - 1, q);
+    }
+    const int ul = R2L_RTILES - 1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) epi_tile_mix<SECOND>(accB[c], inv, x[ul][c], Nh[ul >> 1][c], Na[ul >> 3][c], Nr[ul >> 3][c], ul);
+}
+
 // one head k-step (one chunk): 16 row tiles against the generated B fragments of both column
 // tiles.  GEN is a statement using `i` (0..15), expanded between the MFMA groups: it produces
 // element (i>>3, i&7) of the NEXT k-step's fragments, so the embedding VALU work runs under this
@@ -209,8 +310,9 @@ __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d)
     return (q & 2) ? ((q & 1) ? d : c) : ((q & 1) ? b : a);
 }
 
-template <int NP>
+template <int NP, bool MIX>
 __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
+    static_assert(!MIX || NP == 2, "FP16_FP8 uses the two-part chunk");
     typedef KCfg<NP> C;
     Ring<NP> R;
     R.wimg = p.wimg;
@@ -234,7 +336,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     R.pre = read_frag<NP>(lane * 16, 0);
 
     f32x4 x[16][2];
-    f16x8 Bh[8][2], Bl[8][2], Nh[8][2], Nl[8][2];
+    f16x8 Bh[8][2], Bl[8][2], Nh[8][2], Nl[8][2];   // fp16 fragments (Bl / Nl: lo parts; in MIX only for the tail)
+    i32x8 Ba[2][2], Br[2][2], Na[2][2], Nr[2][2];   // MIX: e5m2 activations / activation residuals, K-step x column tile
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // a lane serves ray (lane & 15) of both column tiles
@@ -367,7 +470,11 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(x[u][c][r] * inv_head, 0.0f);
                     x[u][c][r] = v;
-                    split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
+                    if (!MIX) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
+                }
+                if (MIX) {  // the accumulator already holds relu(.) in the scaled domain: identity epilogue
+                    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    epi_tile_mix<true>(zero, 0.0f, x[u][c], Bh[u >> 1][c], Ba[u >> 3][c], Br[u >> 3][c], u);
                 }
                 if (p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
             }
@@ -379,8 +486,13 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, q);
             body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, q);
 #else
-            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, q);
-            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, q);
+            if constexpr (MIX) {
+                body_layer_mix<false>(R, Bh, Ba, Br, Nh, Na, Nr, x, act_scale, q);
+                body_layer_mix<true>(R, Nh, Na, Nr, Bh, Ba, Br, x, act_scale, q);
+            } else {
+                body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, q);
+                body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, q);
+            }
 #endif
         }
 
@@ -402,6 +514,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             const uint32_t slot = R.use_off;
             const uint32_t lane_base = slot + lane * 16;
             const float inv = aux_inv_scale<NP>(slot);
+            if (MIX) R.pre = read_frag<NP>(lane_base, 0);  // the body's prefetch carried only the hi part
             f32x4 acc[2];
             acc[0] = acc_init<NP>(slot, 0, q);
             acc[1] = acc[0];
@@ -434,21 +547,22 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
-template <int NP>
+template <int NP, bool MIX>
 static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP, MIX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(r2l_resmlp_kernel<NP>, dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    hipLaunchKernelGGL((r2l_resmlp_kernel<NP, MIX>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
     return hipGetLastError();
 }
 
-hipError_t r2l_launch_resmlp(const R2LParams& p, int np, int grid, hipStream_t stream) {
-    return np == 2 ? launch_resmlp<2>(p, grid, stream) : launch_resmlp<1>(p, grid, stream);
+hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream) {
+    if (mode == R2L_PREC_FP16_FP8) return launch_resmlp<2, true>(p, grid, stream);
+    return mode == R2L_PREC_FP16X3 ? launch_resmlp<2, false>(p, grid, stream) : launch_resmlp<1, false>(p, grid, stream);
 }
 
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,

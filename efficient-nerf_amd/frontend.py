@@ -70,7 +70,7 @@ FLAGS = [
     ('--N_rand', dict(type=int, default=4096)), ('--precrop_iters', dict(type=int, default=0)),
     ('--precrop_frac', dict(type=float, default=.5)), ('--no_reload', dict(action=_BOOL)),
     # this front-end's own knobs
-    ('--precision', dict(type=str, default='fp16x3', choices=['fp16x3', 'fp16x1'])),
+    ('--precision', dict(type=str, default='fp16x3', choices=['fp16x3', 'fp16x1', 'fp16_fp8'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
 ]
@@ -268,9 +268,9 @@ def mse2psnr(mse):
 # render_path
 # ----------------------------------------------------------------------------------------
 def build_engine(args, hwf, ckpt):
-    from . import NeRFEngine, PREC_FP16X1, PREC_FP16X3, R2LEngine, R2LError
+    from . import NeRFEngine, PRECISIONS, R2LEngine, R2LError
     H, W, focal = hwf
-    prec = PREC_FP16X3 if args.precision == 'fp16x3' else PREC_FP16X1
+    prec = PRECISIONS[args.precision]
     near, far = 2., 6.  # main.py:930-931 (blender)
     if args.trial.near > 0:
         near = args.trial.near

@@ -117,6 +117,37 @@ def test_render_fp16x1_mode(g, engines, pkg):
     assert np.abs(rgb[idx].cpu().numpy() - g['rgb_400_0']).max() <= TOL_X3
 
 
+def test_render_fp16_fp8_mode(g, engines, pkg):
+    """fp16 main pass + the two fp8 correction terms (2 pass-equivalents): still inside the 1e-4
+    contract against the reference golden, with margin; small nets and the stress weights too."""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3, R2LEngine
+    eng = engines[400]
+    idx = T(g['idx_400']).cuda()
+    eng.set_precision(PREC_FP16_FP8)
+    try:
+        worst = 0.
+        for p in range(4):
+            rgb = eng.render(T(g['poses'][p]))
+            worst = max(worst, np.abs(rgb[idx].cpu().numpy() - g[f'rgb_400_{p}']).max())
+        print(f'fp16_fp8 L_inf vs reference golden: {worst:.3e}')
+        assert worst <= 6e-5 < TOL_X3
+    finally:
+        eng.set_precision(PREC_FP16X3)
+    H = 40
+    focal = O.focal_from_angle(H)
+    for n_block, use_residual, gain in ((1, False, 1.0), (5, True, 1.3)):
+        sd = O.make_r2l_state(seed=5, netdepth=2 + 2 * n_block, body_gain=gain)
+        e2 = R2LEngine(H, H, focal, n_block=n_block, use_residual=use_residual, precision=PREC_FP16_FP8).load_state_dict(sd)
+        c2w = O.rand_poses(2, seed=11)[1]
+        rgb = e2.render(c2w).cpu()
+        pts = O.sample_test(O.camera_dirs(H, H, focal), O.sampler_z_vals(16, 2., 6.), c2w[:3, :4])
+        ref = O.r2l_forward(sd, O.positional_embed(pts, 10), use_residual=use_residual)
+        err = (rgb - ref).abs().max().item()
+        print(f'fp16_fp8 n_block={n_block} gain={gain}: L_inf {err:.3e}')
+        assert err <= TOL_X3
+        e2.close()
+
+
 def test_row_ranges_batches_and_given_rays_agree(g, engines):
     """Row sharding (the multi-GPU split), device-resident pose batches and the given-rays
     entry point all reproduce the whole-frame render bit-for-bit."""

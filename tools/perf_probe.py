@@ -35,13 +35,13 @@ def time_engine(n_block, prec):
 
 if __name__ == '__main__':
     blocks = [int(x) for x in os.environ.get('PROBE_BLOCKS', '0,11,43').split(',')]
-    for prec, name in ((PREC_FP16X3, 'fp16x3'), (PREC_FP16X1, 'fp16x1')):
+    for prec, name in ((PREC_FP16X3, 'fp16x3'), (2, 'fp16_fp8'), (PREC_FP16X1, 'fp16x1')):
         res = {nb: time_engine(nb, prec) for nb in blocks}
         line = ' '.join(f'nb={nb}:{ms:.3f}ms' for nb, ms in res.items())
         nb0, nb1 = blocks[0], blocks[-1]
         per_block = (res[nb1] - res[nb0]) / max(nb1 - nb0, 1)
         rays = H * W
-        passes = 3 if name == 'fp16x3' else 1
+        passes = {'fp16x3': 3, 'fp16_fp8': 2, 'fp16x1': 1}[name]
         body_tf = 2 * 2 * 65536 * rays / (per_block * 1e-3) / 1e12 * passes
         head_tf = 2 * (1008 * 256 + 768) * rays / (res[nb0] * 1e-3) / 1e12 * passes if nb0 == 0 else float('nan')
         print(f'{name} {H}x{W}: {line} | per-block {per_block*1e3:.1f} us (executed {body_tf:.0f} TF/s) | '
