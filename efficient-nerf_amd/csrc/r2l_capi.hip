@@ -390,6 +390,7 @@ static void fill_common(const r2l_ctx* c, R2LParams& p) {
     p.half_w = (float)(c->W * .5);
     p.half_h = (float)(c->H * .5);
     p.act_scale = c->act_scale;
+    p.neg1 = -1.0f;
     p.W = c->W;
     p.n_block = c->n_block;
     p.use_residual = c->use_residual;

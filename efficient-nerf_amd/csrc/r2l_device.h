@@ -205,6 +205,8 @@ __device__ __forceinline__ void ring_sync(Ring<NP>& R) {
 
 // fragment position f (0..15) inside a chunk: rendezvous + refill at 8.  (Spreading the
 // refill over positions 8..15, one piece per k-step, measured 8 % SLOWER than the burst.)
+// (Staggering the refill burst by wave -- positions 8, 10, 12, 14 -- changes nothing: the issue cost is
+// per wave, not contention between the four waves.)
 template <int NP>
 __device__ __forceinline__ void ring_step(Ring<NP>& R, int f) {
     if (f == R2L_FRAGS / 2) {
@@ -268,6 +270,34 @@ __device__ __forceinline__ void split_store(float a, f16x8& hi, f16x8& lo, int j
     f16 h = (f16)a;
     hi[j] = h;
     if (NP == 2) lo[j] = (f16)fmaf((float)h, -1.0f, a);  // a - hi, fma-shaped so it can become v_fma_mix*_f16
+}
+
+// ---- pairwise forms (two consecutive accumulator registers -> one dword of a fragment) ----
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f16x2 pack_hi(float v0, float v1) {  // v_cvt_pk_f16_f32 (round to nearest even)
+    return __builtin_convertvector(f32x2{v0, v1}, f16x2);
+}
+// Residuals v - (float)hi are written fma((float)hi, neg1, v) with neg1 = -1.0f arriving as a kernel
+// argument: a compile-time -1 folds into cvt + sub (2 VALU), the opaque multiplier selects
+// v_fma_mix_f32 / v_fma_mixlo|hi_f16, which read the f16 half directly (1 VALU) and stay exact.
+__device__ __forceinline__ uint32_t pack_lo(f16x2 h, float v0, float v1, float neg1) {
+    const f16x2 l = {(f16)fmaf((float)h[0], neg1, v0), (f16)fmaf((float)h[1], neg1, v1)};
+    return __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ f16x2 get_pair(const f16x8& f, int idx) { return f16x2{f[2 * idx], f[2 * idx + 1]}; }
+__device__ __forceinline__ void set_dword(f16x8& f, int idx, uint32_t w) {
+    i32x4 t = __builtin_bit_cast(i32x4, f);
+    t[idx] = (int)w;
+    f = __builtin_bit_cast(f16x8, t);
+}
+// split two activations into dword `idx` of the hi (and lo) fragment
+template <int NP>
+__device__ __forceinline__ void split_store2(float v0, float v1, f16x8& hi, f16x8& lo, int idx, float neg1) {
+    const f16x2 h = pack_hi(v0, v1);
+    set_dword(hi, idx, __builtin_bit_cast(uint32_t, h));
+    if (NP == 2) set_dword(lo, idx, pack_lo(h, v0, v1, neg1));
 }
 
 // accumulator init of one row tile = aux[feat_off + 4q + i], i = 0..3 (bias pre-multiplied by

@@ -13,6 +13,7 @@ struct R2LParams {
     const float* z;        // device [16]: PointSampler.z_vals (model/nerf_raybased.py:88-90); a pointer, not an
                            // array: dynamic indexing into a by-value kernarg array spills the struct to scratch
     float focal, half_w, half_h, act_scale;
+    float neg1;  // -1.0f (kept opaque to the compiler: selects v_fma_mix for the hi/lo residuals)
     int W, pix_begin, rays_per_pose, n_rays, n_tiles, n_block, use_residual, chunks_per_tile;
 };
 

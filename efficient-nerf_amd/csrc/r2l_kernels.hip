@@ -123,20 +123,24 @@ __global__ void r2l_embed_kernel(const float* __restrict__ x_in, long long total
 // SECOND = false: out = relu(acc/scale)              (ResMLP body.0 + inact)
 // SECOND = true : x = x + acc/scale; out = x         (ResMLP body.2 + residual)
 template <int NP, bool SECOND>
-__device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, f32x4& xu, f16x8& nh, f16x8& nl, int u,
+__device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1, f32x4& xu, f16x8& nh, f16x8& nl, int u,
                                         int r) {
 #ifdef R2L_ABL_NOEPI  // ablation build: keep the accumulator live, skip the VALU epilogue
-    asm volatile("" ::"v"(acc[r]));
+    asm volatile("" ::"v"(acc[2 * r]), "v"(acc[2 * r + 1]));
     return;
 #endif
-    float v;
-    if (!SECOND) {
-        v = fmaxf(acc[r] * inv, 0.0f);
-    } else {
-        v = fmaf(acc[r], inv, xu[r]);
-        xu[r] = v;
+    // r = pair index (0, 1): registers 2r, 2r+1 -> dword 2(u&1) + r of the fragments
+    float v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!SECOND) {
+            v[k] = fmaxf(acc[2 * r + k] * inv, 0.0f);
+        } else {
+            v[k] = fmaf(acc[2 * r + k], inv, xu[2 * r + k]);
+            xu[2 * r + k] = v[k];
+        }
     }
-    split_store<NP>(v, nh, nl, 4 * (u & 1) + r);
+    split_store2<NP>(v[0], v[1], nh, nl, 2 * (u & 1) + r, neg1);
 }
 
 // One row tile (16 output features) of a body layer: 8 k-steps x 2 column tiles.  A
@@ -146,7 +150,7 @@ __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, f32x4& xu, 
 template <int NP, bool SECOND, bool HAVE_PREV>
 __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
-                                           const f32x4 (&prev)[2], float inv, f32x4 (&xprev)[2], int uprev, int q) {
+                                           const f32x4 (&prev)[2], float inv, float neg1, f32x4 (&xprev)[2], int uprev, int q) {
     const uint32_t slot = R.use_off;
     const uint32_t lane_base = slot + R.lane * 16;
     const uint32_t next_base = ring_next_off<NP>(slot) + R.lane * 16;
@@ -159,9 +163,9 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
         AFrag<NP> nxt = (f + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, f + 1) : read_frag<NP>(next_base, 0);
         acc[0] = mfma_step<NP>(R.pre, Bh[s][0], Bl[s][0], acc[0]);
         acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
-        if (HAVE_PREV)
-            epi_reg<NP, SECOND>(prev[s >> 2], inv, xprev[s >> 2], Nh[uprev >> 1][s >> 2], Nl[uprev >> 1][s >> 2], uprev,
-                                s & 3);
+        if (HAVE_PREV && (s & 1))
+            epi_reg<NP, SECOND>(prev[s >> 2], inv, neg1, xprev[s >> 2], Nh[uprev >> 1][s >> 2], Nl[uprev >> 1][s >> 2], uprev,
+                                (s >> 1) & 1);
         R.pre = nxt;
     }
     if (upos == 1) ring_next<NP>(R);
@@ -171,52 +175,56 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
 template <int NP, bool SECOND>
 __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&x)[16][2],
-                                           float act_scale, int q) {
+                                           float act_scale, float neg1, int q) {
     const float inv = aux_inv_scale<NP>(R.use_off) * act_scale;  // same for the 8 chunks of a layer
     f32x4 acc[2], prev[2];
-    body_rtile<NP, SECOND, false>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, x[0], 0, q);
+    body_rtile<NP, SECOND, false>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[0], 0, q);
 #pragma unroll
     for (int u = 1; u < R2L_RTILES; ++u) {
         prev[0] = acc[0];
         prev[1] = acc[1];
-        body_rtile<NP, SECOND, true>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, x[u - 1], u - 1, q);
+        body_rtile<NP, SECOND, true>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[u - 1], u - 1, q);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        epi_reg<NP, SECOND>(acc[i >> 2], inv, x[R2L_RTILES - 1][i >> 2], Nh[(R2L_RTILES - 1) >> 1][i >> 2],
-                            Nl[(R2L_RTILES - 1) >> 1][i >> 2], R2L_RTILES - 1, i & 3);
+    for (int i = 0; i < 4; ++i)
+        epi_reg<NP, SECOND>(acc[i >> 1], inv, neg1, x[R2L_RTILES - 1][i >> 1], Nh[(R2L_RTILES - 1) >> 1][i >> 1],
+                            Nl[(R2L_RTILES - 1) >> 1][i >> 1], R2L_RTILES - 1, i & 1);
 }
 
 // ---- FP16_FP8 body: fp16 main pass + two fp8 correction terms ---------------------------------
+// In this mode the residual stream x has no fp32 copy: it lives as the fp16 pair (hi, lo) of the
+// block-input fragments (|x - hi - lo| <= 2^-22 |x|), which frees 64 registers per lane.
 // Two consecutive accumulator values (registers 2*PAIR, 2*PAIR+1 of row tile u, one column tile):
-// fp16 hi into the next layer's fp16 fragment, e5m2 of the value and of its fp16 residual into byte
-// pair PAIR of register u&7 of the next layer's fp8 K-step u>>3.
+//   SECOND = false: v = relu(acc/scale)
+//   SECOND = true : v = (hi + lo) + acc/scale, the fragments updated in place (+ the fp16 lo)
+// written as fp16 hi, e5m2 of the value and e5m2 of its fp16 residual (byte pair PAIR of register
+// u&7 of the next layer's fp8 K-step u>>3).
 template <bool SECOND, int PAIR>
-__device__ __forceinline__ void epi_pair_mix(const f32x4& acc, float inv, f32x4& xu, f16x8& nh, i32x8& na, i32x8& nr,
-                                             int u) {
+__device__ __forceinline__ void epi_pair_mix(const f32x4& acc, float inv, float neg1, f16x8& nh, f16x8& nl, i32x8& na,
+                                             i32x8& nr, int u) {
+    const int idx = 2 * (u & 1) + PAIR;
     float v[2];
+    if (!SECOND) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int r = 2 * PAIR + k;
-        if (!SECOND) {
-            v[k] = fmaxf(acc[r] * inv, 0.0f);
-        } else {
-            v[k] = fmaf(acc[r], inv, xu[r]);
-            xu[r] = v[k];
-        }
+        for (int k = 0; k < 2; ++k) v[k] = fmaxf(acc[2 * PAIR + k] * inv, 0.0f);
+    } else {
+        const f16x2 ho = get_pair(nh, idx), lo = get_pair(nl, idx);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) v[k] = fmaf(acc[2 * PAIR + k], inv, (float)ho[k]) + (float)lo[k];
     }
-    const f16 h0 = (f16)v[0], h1 = (f16)v[1];
-    nh[4 * (u & 1) + 2 * PAIR] = h0;
-    nh[4 * (u & 1) + 2 * PAIR + 1] = h1;
-    const float l0 = fmaf((float)h0, -1.0f, v[0]), l1 = fmaf((float)h1, -1.0f, v[1]);
+    const f16x2 h = pack_hi(v[0], v[1]);
+    set_dword(nh, idx, __builtin_bit_cast(uint32_t, h));
+    const float l0 = fmaf((float)h[0], neg1, v[0]), l1 = fmaf((float)h[1], neg1, v[1]);
+    if (SECOND) set_dword(nl, idx, __builtin_bit_cast(uint32_t, pack_hi(l0, l1)));
     na[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], na[u & 7], PAIR != 0);
     nr[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(l0, l1, nr[u & 7], PAIR != 0);
 }
 
 template <bool SECOND>
-__device__ __forceinline__ void epi_tile_mix(const f32x4& acc, float inv, f32x4& xu, f16x8& nh, i32x8& na, i32x8& nr, int u) {
-    epi_pair_mix<SECOND, 0>(acc, inv, xu, nh, na, nr, u);
-    epi_pair_mix<SECOND, 1>(acc, inv, xu, nh, na, nr, u);
+__device__ __forceinline__ void epi_tile_mix(const f32x4& acc, float inv, float neg1, f16x8& nh, f16x8& nl, i32x8& na,
+                                             i32x8& nr, int u) {
+    epi_pair_mix<SECOND, 0>(acc, inv, neg1, nh, nl, na, nr, u);
+    epi_pair_mix<SECOND, 1>(acc, inv, neg1, nh, nl, na, nr, u);
 }
 
 // One row tile of a body layer in FP16_FP8 mode: per k-step s one fp16 MFMA per column tile; the
@@ -225,8 +233,8 @@ __device__ __forceinline__ void epi_tile_mix(const f32x4& acc, float inv, f32x4&
 template <bool SECOND, bool HAVE_PREV>
 __device__ __forceinline__ void body_rtile_mix(Ring<2>& R, int upos, const f16x8 (&Bh)[8][2], const i32x8 (&Ba)[2][2],
                                                const i32x8 (&Br)[2][2], f16x8 (&Nh)[8][2], i32x8 (&Na)[2][2],
-                                               i32x8 (&Nr)[2][2], f32x4 (&acc)[2], const f32x4 (&prev)[2], float inv,
-                                               f32x4 (&xprev)[2], int uprev, int q) {
+                                               i32x8 (&Nr)[2][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
+                                               const f32x4 (&prev)[2], float inv, float neg1, int uprev, int q) {
     const uint32_t slot = R.use_off;
     const uint32_t lane_base = slot + R.lane * 16;
     const uint32_t next_base = ring_next_off<2>(slot) + R.lane * 16;
@@ -260,9 +268,9 @@ __device__ __forceinline__ void body_rtile_mix(Ring<2>& R, int upos, const f16x8
             if (HAVE_PREV) {
                 const int c = s >> 2;
                 if (((s >> 1) & 1) == 0)
-                    epi_pair_mix<SECOND, 0>(prev[c], inv, xprev[c], Nh[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
+                    epi_pair_mix<SECOND, 0>(prev[c], inv, neg1, Nh[uprev >> 1][c], Nl[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
                 else
-                    epi_pair_mix<SECOND, 1>(prev[c], inv, xprev[c], Nh[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
+                    epi_pair_mix<SECOND, 1>(prev[c], inv, neg1, Nh[uprev >> 1][c], Nl[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
             }
         }
         R.pre.h = nxt;
@@ -273,18 +281,18 @@ __device__ __forceinline__ void body_rtile_mix(Ring<2>& R, int upos, const f16x8
 template <bool SECOND>
 __device__ __forceinline__ void body_layer_mix(Ring<2>& R, const f16x8 (&Bh)[8][2], const i32x8 (&Ba)[2][2],
                                                const i32x8 (&Br)[2][2], f16x8 (&Nh)[8][2], i32x8 (&Na)[2][2],
-                                               i32x8 (&Nr)[2][2], f32x4 (&x)[16][2], float act_scale, int q) {
+                                               i32x8 (&Nr)[2][2], f16x8 (&Nl)[8][2], float act_scale, float neg1, int q) {
     const float inv = aux_inv_scale<2>(R.use_off) * act_scale;
     f32x4 accA[2], accB[2];  // alternate between row tiles: the idle one is being drained by the epilogue
-    body_rtile_mix<SECOND, false>(R, 0, Bh, Ba, Br, Nh, Na, Nr, accA, accB, inv, x[0], 0, q);
+    body_rtile_mix<SECOND, false>(R, 0, Bh, Ba, Br, Nh, Na, Nr, Nl, accA, accB, inv, neg1, 0, q);
 #pragma unroll
     for (int u = 1; u < R2L_RTILES; ++u) {
-        if (u & 1) body_rtile_mix<SECOND, true>(R, 1, Bh, Ba, Br, Nh, Na, Nr, accB, accA, inv, x[u - 1], u - 1, q);
-        else body_rtile_mix<SECOND, true>(R, 0, Bh, Ba, Br, Nh, Na, Nr, accA, accB, inv, x[u - 1], u - 1, q);
+        if (u & 1) body_rtile_mix<SECOND, true>(R, 1, Bh, Ba, Br, Nh, Na, Nr, Nl, accB, accA, inv, neg1, u - 1, q);
+        else body_rtile_mix<SECOND, true>(R, 0, Bh, Ba, Br, Nh, Na, Nr, Nl, accA, accB, inv, neg1, u - 1, q);
     }
     const int ul = R2L_RTILES - 1;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) epi_tile_mix<SECOND>(accB[c], inv, x[ul][c], Nh[ul >> 1][c], Na[ul >> 3][c], Nr[ul >> 3][c], ul);
+    for (int c = 0; c < 2; ++c) epi_tile_mix<SECOND>(accB[c], inv, neg1, Nh[ul >> 1][c], Nl[ul >> 1][c], Na[ul >> 3][c], Nr[ul >> 3][c], ul);
 }
 
 // one head k-step (one chunk): 16 row tiles against the generated B fragments of both column
@@ -325,6 +333,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     const int lane = R.lane;
     const int q = lane >> 4;
     const float act_scale = p.act_scale;
+    const float neg1 = p.neg1;  // -1.0f, opaque to the compiler (r2l_device.h pack_lo)
     // read-only, wave-uniform: constant address space => scalar loads (s_load), no vmcnt traffic
     const __attribute__((address_space(4))) float* zc = (const __attribute__((address_space(4))) float*)p.z;
 
@@ -472,9 +481,12 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                     x[u][c][r] = v;
                     if (!MIX) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
-                if (MIX) {  // the accumulator already holds relu(.) in the scaled domain: identity epilogue
-                    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    epi_tile_mix<true>(zero, 0.0f, x[u][c], Bh[u >> 1][c], Ba[u >> 3][c], Br[u >> 3][c], u);
+                if (MIX) {  // x[u][c] already holds relu(.) in the scaled domain: split it (inv = 1, no relu needed)
+                    set_dword(Bh[u >> 1][c], 2 * (u & 1), 0u);
+                    set_dword(Bh[u >> 1][c], 2 * (u & 1) + 1, 0u);
+                    set_dword(Bl[u >> 1][c], 2 * (u & 1), 0u);
+                    set_dword(Bl[u >> 1][c], 2 * (u & 1) + 1, 0u);
+                    epi_tile_mix<true>(x[u][c], 1.0f, neg1, Bh[u >> 1][c], Bl[u >> 1][c], Ba[u >> 3][c], Br[u >> 3][c], u);
                 }
                 if (p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
             }
@@ -483,15 +495,15 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
 #ifdef R2L_ABL_NOEPI
-            body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, q);
-            body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, q);
+            body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
+            body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
 #else
             if constexpr (MIX) {
-                body_layer_mix<false>(R, Bh, Ba, Br, Nh, Na, Nr, x, act_scale, q);
-                body_layer_mix<true>(R, Nh, Na, Nr, Bh, Ba, Br, x, act_scale, q);
+                body_layer_mix<false>(R, Bh, Ba, Br, Nh, Na, Nr, Nl, act_scale, neg1, q);  // Nl unused (SECOND = false)
+                body_layer_mix<true>(R, Nh, Na, Nr, Bh, Ba, Br, Bl, act_scale, neg1, q);   // x += ..., in place
             } else {
-                body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, q);
-                body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, q);
+                body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q);
+                body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q);
             }
 #endif
         }
@@ -501,6 +513,11 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
         for (int u = 0; u < 16; ++u) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+                if (MIX) {  // the residual stream lives in the fragments (hi + lo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        x[u][c][r] = (float)Bh[u >> 1][c][4 * (u & 1) + r] + (float)Bl[u >> 1][c][4 * (u & 1) + r];
+                }
                 if (p.use_residual) {
                     const f32x4 h0 = *reinterpret_cast<const f32x4*>(scr + (u * 2 + c) * 256);
                     x[u][c] = x[u][c] + h0;
