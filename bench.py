@@ -55,8 +55,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--precision', choices=['fp16x3', 'fp16x1', 'fp16_fp8'], default='fp16x3',
-                    help='fp16x3 meets the <=1e-4 L_inf contract (default); fp16x1 is the fast mode')
+    ap.add_argument('--precision', choices=['fp16x3', 'fp16x1', 'fp16_fp8'], default='fp16_fp8',
+                    help='fp16_fp8 (default) and fp16x3 meet the <=1e-4 L_inf contract (measured 2e-5 / 6e-7, '
+                         'checked in this run against the CPU oracle); fp16x1 (3.5e-4) does not')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-teacher', action='store_true', help='skip the secondary teacher measurement')
     ap.add_argument('--cpu-rays', type=int, default=H * W,
@@ -121,7 +122,9 @@ def main():
     out = {
         'metric': 'rays/sec at 800x800 (R2L W256D88)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16 (MFMA fp16 operands, fp32 accumulate; %s)' % args.precision,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp16x3': 'f16 (3 fp16 MFMA passes on hi/lo-split operands, fp32 accumulate)',
+                                                                                     'fp16x1': 'f16 (1 fp16 MFMA pass, fp32 accumulate)',
+                                                                                     'fp16_fp8': 'f16+f8 (1 fp16 MFMA pass + both hi/lo correction terms on the block-scaled fp8 MFMA, fp32 accumulate)'}[args.precision],
         'data': 'synthetic (seeded nn.Linear-init W256D88 weights, pose_spherical test poses, lego intrinsics)',
         'config': {'workload': 'R2L W256D88 lego_noview_800x800 test views, rows sharded across %d GPU(s) + all-gather' % world,
                    'H': H, 'W': W, 'rays_per_gpu_per_step': rows * W * world, 'frames_per_step': world,
@@ -152,12 +155,13 @@ def main():
                                    'sample': '%d rays (rows 0..%d of one 800x800 frame), PyTorch-CPU fp32 eager restatement, %.1f s'
                                              % (n_cpu_rows * W, n_cpu_rows, t_cpu)}
             out['parity'] = {'linf_vs_cpu_oracle': err, 'psnr_vs_cpu_oracle_db': O.psnr(gpu, ref),
-                             'rays_checked': n_cpu_rows * W, 'tolerance': 1e-4}
+                             'rays_checked': n_cpu_rows * W, 'tolerance': 1e-4, 'within_tolerance': bool(err <= 1e-4)}
         if not args.no_teacher and world == 1:
             # secondary, outside the timed region: NeRF teacher coarse+fine (BASELINE config 3)
             from efficient_nerf_amd import NeRFEngine
             th = 400
-            teng = NeRFEngine(th, th, O.focal_from_angle(th), precision=prec).load_state_dicts(
+            tprec = 'fp16x3' if args.precision == 'fp16_fp8' else args.precision  # the teacher kernel has no fp8 mode yet
+            teng = NeRFEngine(th, th, O.focal_from_angle(th), precision=PRECISIONS[tprec]).load_state_dicts(
                 O.make_teacher_state(1), O.make_teacher_state(2))
             teng.render(poses[0])
             torch.cuda.synchronize()
@@ -168,7 +172,7 @@ def main():
             tdt = (time.perf_counter() - t1) / 3
             out['teacher'] = {'workload': 'NeRF teacher lego 400x400 coarse 64 + fine 128', 'rays_per_s': th * th / tdt,
                               'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': 2 * 593408 * 256 * th * th / tdt / 1e12,
-                              'precision': args.precision}
+                              'precision': tprec}
             teng.close()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -202,6 +202,10 @@ __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2],
 template <bool SECOND, int PAIR>
 __device__ __forceinline__ void epi_pair_mix(const f32x4& acc, float inv, float neg1, f16x8& nh, f16x8& nl, i32x8& na,
                                              i32x8& nr, int u) {
+#ifdef R2L_ABL_NOEPI  // ablation build: keep the accumulator live, skip the VALU epilogue
+    asm volatile("" ::"v"(acc[2 * PAIR]), "v"(acc[2 * PAIR + 1]));
+    return;
+#endif
     const int idx = 2 * (u & 1) + PAIR;
     float v[2];
     if (!SECOND) {
@@ -495,8 +499,13 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
 #ifdef R2L_ABL_NOEPI
-            body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
-            body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
+            if constexpr (MIX) {
+                body_layer_mix<false>(R, Bh, Ba, Br, Bh, Ba, Br, Bl, act_scale, neg1, q);
+                body_layer_mix<true>(R, Bh, Ba, Br, Bh, Ba, Br, Bl, act_scale, neg1, q);
+            } else {
+                body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
+                body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
+            }
 #else
             if constexpr (MIX) {
                 body_layer_mix<false>(R, Bh, Ba, Br, Nh, Na, Nr, Nl, act_scale, neg1, q);  // Nl unused (SECOND = false)

@@ -113,6 +113,45 @@ def test_packed_stream_decodes_to_weights(pkg, built_lib, mode, np_):
     assert np.abs(value(cpt - 1, 9)).max() == 0
 
 
+def mix_feat(t, q, j):
+    return 16 * (8 * t + (j >> 2)) + 4 * q + (j & 3)
+
+
+def test_fp16_fp8_stream(pkg, built_lib):
+    """Mode 2: head / tail chunks identical to fp16x3; in body chunks piece 2f is the fp16 hi
+    fragment and piece 2f+1 carries e4m3 bytes of (w*S - hi)*2^7 (steps 0..3) and w*S*2^-5 (4..7)
+    in the K=128 element order of r2l_mix_feat.  e4m3 encoding pinned against torch.float8_e4m3fn."""
+    n_block = 1
+    sd = O.make_r2l_state(seed=4, netdepth=2 + 2 * n_block)
+    x3, mix = pack(pkg, sd, n_block, 0), pack(pkg, sd, n_block, 2)
+    CH = FRAGS * 2 * FRAG + AUXB
+    cpt = 32 + 2 * n_block * 8 + 1
+    assert mix.size == x3.size == cpt * CH
+    assert np.array_equal(mix[:32 * CH], x3[:32 * CH]) and np.array_equal(mix[(cpt - 1) * CH:], x3[(cpt - 1) * CH:])
+    assert sorted(mix_feat(t, q, j) for t in range(2) for q in range(4) for j in range(32)) == list(range(256))
+    for li in range(2):
+        Wl = sd[O.r2l_state_names(n_block)[2 + 2 * li]].float()
+        for m in (0, 3, 7):
+            ci = 32 + li * 8 + m
+            base = ci * CH
+            aux = mix[base + 32 * FRAG:base + 32 * FRAG + AUXB].view(np.float32)
+            assert np.array_equal(aux, x3[base + 32 * FRAG:base + 32 * FRAG + AUXB].view(np.float32))
+            Sw = 1.0 / float(aux[32]) / 16.0
+            for f in range(16):
+                # hi pieces unchanged
+                assert np.array_equal(mix[base + 2 * f * FRAG:base + (2 * f + 1) * FRAG], x3[base + 2 * f * FRAG:base + (2 * f + 1) * FRAG])
+                u, s = 2 * m + (f >> 3), f & 7
+                term, t, half = s >> 2, (s >> 1) & 1, s & 1
+                got = torch.from_numpy(mix[base + (2 * f + 1) * FRAG:base + (2 * f + 2) * FRAG].copy()).view(torch.float8_e4m3fn)
+                got = got.float().reshape(64, 16)
+                for lane in (0, 21, 38, 63):
+                    k = [mix_feat(t, lane >> 4, 16 * half + i) for i in range(16)]
+                    w = Wl[16 * u + (lane & 15), k] * Sw
+                    hi = w.half().float()
+                    want = ((w - hi) * 128.0 if term == 0 else w / 32.0).to(torch.float8_e4m3fn).float()
+                    assert torch.equal(got[lane], want), (li, m, f, lane)
+
+
 def test_pack_rejects_bad_input(pkg, built_lib):
     from efficient_nerf_amd import _lib
     sd = O.make_r2l_state(seed=1, netdepth=4)

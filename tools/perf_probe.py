@@ -35,7 +35,10 @@ def time_engine(n_block, prec):
 
 if __name__ == '__main__':
     blocks = [int(x) for x in os.environ.get('PROBE_BLOCKS', '0,11,43').split(',')]
+    modes = os.environ.get('PROBE_MODES', 'fp16x3,fp16_fp8,fp16x1').split(',')
     for prec, name in ((PREC_FP16X3, 'fp16x3'), (2, 'fp16_fp8'), (PREC_FP16X1, 'fp16x1')):
+        if name not in modes:
+            continue
         res = {nb: time_engine(nb, prec) for nb in blocks}
         line = ' '.join(f'nb={nb}:{ms:.3f}ms' for nb, ms in res.items())
         nb0, nb1 = blocks[0], blocks[-1]

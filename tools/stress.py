@@ -5,7 +5,7 @@ import _pkg; _pkg.load()
 from efficient_nerf_amd import R2LEngine, PREC_FP16X1, PREC_FP16X3
 from oracle import r2l_oracle as O
 H = int(os.environ.get('S_H', 800)); nb = int(os.environ.get('S_NB', 43)); reps = int(os.environ.get('S_REPS', 50))
-prec = PREC_FP16X1 if os.environ.get('S_PREC', 'x3') == 'x1' else PREC_FP16X3
+prec = {'x1': PREC_FP16X1, 'x3': PREC_FP16X3, 'mix': 2}[os.environ.get('S_PREC', 'x3')]
 rows = int(os.environ.get('S_ROWS', H))
 sd = O.make_r2l_state(seed=0, netdepth=2 + 2 * nb)
 eng = R2LEngine(H, H, O.focal_from_angle(H), n_block=nb, precision=prec).load_state_dict(sd)
