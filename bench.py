@@ -73,8 +73,8 @@ def main():
     rank, local_rank, world = D.init()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', D.local_device(local_rank))
+    torch.cuda.set_device(dev)
 
     focal = O.focal_from_angle(W)
     sd = O.make_r2l_state(seed=0)  # synthetic weights, reference init (nn.Linear default)
@@ -107,7 +107,7 @@ def main():
     eng.timing(False)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 

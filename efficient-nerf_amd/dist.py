@@ -19,14 +19,22 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:  # R2L_DIST_BACKEND=gloo: rehearsal of an N-rank run on fewer GPUs (see local_device)
+            backend = os.environ.get('R2L_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         kw = {}
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
             kw['device_id'] = torch.device('cuda', local_rank)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def local_device(local_rank):
+    """CUDA device index of a rank: LOCAL_RANK, wrapped when a gloo rehearsal runs more ranks than GPUs."""
+    n = torch.cuda.device_count()
+    return local_rank % n if n else 0
 
 
 def row_shard(H, rank, world):
@@ -51,7 +59,12 @@ def gather_rows(local, H, W, world, group=None):
         pad = torch.zeros((F, mx - local.shape[1], Cc), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 1)
     out = torch.empty((world * F, mx, Cc), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)  # concatenation along dim 0
+    if local.is_cuda and dist.get_backend(group) == 'gloo':  # rehearsal only: gloo gathers through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)  # concatenation along dim 0
     out = out.view(world, F, mx, Cc)
     if all(s == mx for s in sizes):
         return out.permute(1, 0, 2, 3).reshape(F, world * mx, Cc)
