@@ -160,7 +160,7 @@ def main():
             # secondary, outside the timed region: NeRF teacher coarse+fine (BASELINE config 3)
             from efficient_nerf_amd import NeRFEngine
             th = 400
-            tprec = 'fp16x3' if args.precision == 'fp16_fp8' else args.precision  # the teacher kernel has no fp8 mode yet
+            tprec = args.precision
             teng = NeRFEngine(th, th, O.focal_from_angle(th), precision=PRECISIONS[tprec]).load_state_dicts(
                 O.make_teacher_state(1), O.make_teacher_state(2))
             teng.render(poses[0])

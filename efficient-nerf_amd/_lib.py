@@ -4,7 +4,7 @@ import os
 
 PREC_FP16X3 = 0
 PREC_FP16X1 = 1
-PREC_FP16_FP8 = 2  # R2L only: fp16 main pass + fp8 correction terms
+PREC_FP16_FP8 = 2  # fp16 main pass + fp8 correction terms (2 pass-equivalents)
 PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

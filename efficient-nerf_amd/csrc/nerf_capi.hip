@@ -16,8 +16,8 @@
 namespace {
 
 struct PackedNet {
-    char* d_img[2] = {nullptr, nullptr};   // [precision mode]
-    float inv_scale[2][NERF_N_SCALES];
+    char* d_img[3] = {nullptr, nullptr, nullptr};   // [precision mode]
+    float inv_scale[3][NERF_N_SCALES];
     std::vector<std::vector<float>> host_w;  // 24 tensors, state_dict order
     bool loaded = false;
 };
@@ -30,7 +30,8 @@ const size_t kTensorNumel[24] = {
     256 * 319, 256, 256 * 256, 256, 256 * 256, 256,                                    // pts_linears 5..7
     128 * 283, 128, 256 * 256, 256, 256, 1, 3 * 128, 3};
 
-int np_of(int mode) { return mode == R2L_PREC_FP16X3 ? 2 : 1; }
+int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
+bool mode_ok(int mode) { return mode == R2L_PREC_FP16X3 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16_FP8; }
 
 void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
     _Float16 hi, lo;
@@ -42,9 +43,13 @@ void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
 // One layer of the fragment stream: RT row tiles (16 outputs) x KS k-steps (32 inputs).
 // weight(row, col) returns W[row][col] (0 outside), col_of(s, q, j) the input column of element
 // j of lane quarter q of k-step s (or -1), bias(row) the bias.
+// FP16_FP8 (HS > 0): the first HS k-steps (the 256- or 128-wide source activations) keep their fp16 hi
+// fragment in piece 2f and carry in piece 2f+1 the e4m3 bytes of the two correction terms, laid out as
+// in the R2L body (r2l_common.h): with H2 = HS/2 steps per term, step ks holds term ks / H2, fp8
+// K-step (ks % H2) >> 1, byte half ks & 1; feature f of the source is input column wide_col + f.
 void pack_layer(std::vector<char>& img, int np, int F0, int KS, int RT, float Sa,
                 const std::function<float(int, int)>& weight, const std::function<int(int, int, int)>& col_of,
-                const std::function<float(int)>& bias, float Sw, float* inv_scale_out) {
+                const std::function<float(int)>& bias, float Sw, float* inv_scale_out, int HS = 0, int wide_col = 0) {
     const int CH = r2l_chunk_bytes(np);
     const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
     const float S = Sa * Sw;
@@ -58,6 +63,17 @@ void pack_layer(std::vector<char>& img, int np, int F0, int KS, int RT, float Sa
                     const float v = col < 0 ? 0.f : weight(16 * u + (lane & 15), col) * Sw;
                     put_frag(chunk, np, fq % R2L_FRAGS, lane, j, v);
                 }
+            if (ks >= HS) continue;
+            const int H2 = HS / 2, term = ks / H2, t = (ks % H2) >> 1, half = ks & 1;
+            for (int lane = 0; lane < 64; ++lane) {
+                unsigned char* pb = reinterpret_cast<unsigned char*>(chunk + (size_t)(2 * (fq % R2L_FRAGS) + 1) * R2L_FRAG_BYTES + lane * 16);
+                for (int i = 0; i < 16; ++i) {
+                    const int feat = r2l_mix_feat(t, lane >> 4, 16 * half + i);
+                    const float wv = weight(16 * u + (lane & 15), wide_col + feat) * Sw;
+                    const float hi = (float)(_Float16)wv;
+                    pb[i] = r2l_f32_to_e4m3(term == 0 ? ldexpf(wv - hi, R2L_MIX_WL_SHIFT) : ldexpf(wv, -R2L_MIX_W_SHIFT));
+                }
+            }
         }
         const int q0 = F0 + u * KS;
         float* aux = reinterpret_cast<float*>(img.data() + (size_t)(q0 / R2L_FRAGS) * CH + AUX);
@@ -154,8 +170,7 @@ int nerf_create(nerf_ctx** out, int H, int W, double focal, float near_, float f
         return r2l_set_error(R2L_EINVAL, "unsupported sampling N_samples=%d N_importance=%d (need 2..64 coarse, total <= 256)",
                              N_samples, N_importance);
     if (H <= 0 || W <= 0 || !(focal > 0)) return r2l_set_error(R2L_EINVAL, "bad geometry");
-    if (precision_mode != R2L_PREC_FP16X3 && precision_mode != R2L_PREC_FP16X1)
-        return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", precision_mode);
+    if (!mode_ok(precision_mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", precision_mode);
     int n_cu = 0;
     int rc = r2l_require_gfx950(&n_cu);
     if (rc) return rc;
@@ -180,7 +195,7 @@ void nerf_destroy(nerf_ctx* c) {
     if (!c) return;
     free_tmp(c);
     for (auto& n : c->net)
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 3; ++m)
             if (n.d_img[m]) (void)hipFree(n.d_img[m]);
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_zmid) (void)hipFree(c->d_zmid);
@@ -203,6 +218,7 @@ int nerf_set_sampling(nerf_ctx* c, const float* z_coarse_host, int n_z, const fl
 
 static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
     const int np = np_of(mode);
+    const int HSW = mode == R2L_PREC_FP16_FP8 ? 8 : 0;  // fp8 correction pieces on the 256-wide k-steps
     const int CH = r2l_chunk_bytes(np);
     std::vector<char> img((size_t)NERF_CHUNKS * CH, 0);
     const float Sa = c->act_scale;
@@ -225,7 +241,7 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
     for (int li : plain) {
         const int F0 = li <= 4 ? NERF_F0_L1 + 128 * (li - 1) : NERF_F0_L6 + 128 * (li - 6);
         pack_layer(img, np, F0, 8, 16, Sa, mat(2 * li, 256, 256), kap, vec(2 * li + 1, 256),
-                   r2l_pow2_scale(w[2 * li].data(), w[2 * li].size()), &inv[li]);
+                   r2l_pow2_scale(w[2 * li].data(), w[2 * li].size()), &inv[li], HSW, 0);
     }
     // L5: reference input = cat[input_pts(63), h(256)]  (model/nerf_raybased.py:385)
     pack_layer(img, np, NERF_F0_L5, 10, 16, Sa, mat(10, 319, 256),
@@ -233,7 +249,7 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
                    if (ks < 8) return 63 + r2l_kappa(ks, q, j);
                    return nerf_pts_col(ks - 8, q, j);
                },
-               vec(11, 256), r2l_pow2_scale(w[10].data(), w[10].size()), &inv[5]);
+               vec(11, 256), r2l_pow2_scale(w[10].data(), w[10].size()), &inv[5], HSW, 63);
     // FA: rows 0..255 feature_linear, row 256 alpha_linear (row tile 16, row 0)
     {
         const float* fw = w[T_FEAT_W].data();
@@ -243,7 +259,7 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
         const float Sw = max_scale({{fw, w[T_FEAT_W].size()}, {aw, w[T_ALPHA_W].size()}});
         pack_layer(img, np, NERF_F0_FA, 8, 17, Sa,
                    [=](int r, int col) -> float { return r < 256 ? fw[(size_t)r * 256 + col] : (r == 256 ? aw[col] : 0.f); },
-                   kap, [=](int r) -> float { return r < 256 ? fb[r] : (r == 256 ? ab[0] : 0.f); }, Sw, &inv[8]);
+                   kap, [=](int r) -> float { return r < 256 ? fb[r] : (r == 256 ? ab[0] : 0.f); }, Sw, &inv[8], HSW, 0);
     }
     // V: reference input = cat[feature(256), input_views(27)]  (model/nerf_raybased.py:390)
     pack_layer(img, np, NERF_F0_V, 9, 8, Sa, mat(T_VIEWS_W, 283, 128),
@@ -252,10 +268,10 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
                    const int cidx = nerf_view_col(q, j);
                    return cidx < 0 ? -1 : 256 + cidx;
                },
-               vec(T_VIEWS_B, 128), r2l_pow2_scale(w[T_VIEWS_W].data(), w[T_VIEWS_W].size()), &inv[9]);
+               vec(T_VIEWS_B, 128), r2l_pow2_scale(w[T_VIEWS_W].data(), w[T_VIEWS_W].size()), &inv[9], HSW, 0);
     // RGB
     pack_layer(img, np, NERF_F0_RGB, 4, 1, Sa, mat(T_RGB_W, 128, 3), kap, vec(T_RGB_B, 3),
-               r2l_pow2_scale(w[T_RGB_W].data(), w[T_RGB_W].size()), &inv[10]);
+               r2l_pow2_scale(w[T_RGB_W].data(), w[T_RGB_W].size()), &inv[10], HSW / 2, 0);
     if (net.d_img[mode]) {
         (void)hipFree(net.d_img[mode]);
         net.d_img[mode] = nullptr;
@@ -277,7 +293,7 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
         if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
         net.host_w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
     }
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 3; ++m)
         if (net.d_img[m]) {
             (void)hipFree(net.d_img[m]);
             net.d_img[m] = nullptr;
@@ -290,7 +306,7 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
 
 int nerf_set_precision(nerf_ctx* c, int mode) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
-    if (mode != R2L_PREC_FP16X3 && mode != R2L_PREC_FP16X1) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
+    if (!mode_ok(mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
     c->mode = mode;
     for (auto& n : c->net)
         if (n.loaded && !n.d_img[mode]) {
@@ -315,9 +331,10 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     p.n_pts = (long long)n * S;
     p.n_tiles = (int)((p.n_pts + NERF_TILE_PTS - 1) / NERF_TILE_PTS);
     p.act_scale = c->act_scale;
+    p.neg1 = -1.0f;
     memcpy(p.inv_scale, c->net[which].inv_scale[c->mode], sizeof p.inv_scale);
     const int grid = p.n_tiles < c->n_cu ? p.n_tiles : c->n_cu;
-    hipError_t e = nerf_launch_mlp(p, np_of(c->mode), grid, s);
+    hipError_t e = nerf_launch_mlp(p, c->mode, grid, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
     return R2L_OK;
 }

@@ -16,10 +16,11 @@ struct NerfMlpParams {
     long long n_pts;        // n_rays * S
     int n_tiles;            // ceil(n_pts / 128)
     float act_scale;
+    float neg1;             // -1.0f, opaque to the compiler (r2l_device.h pack_lo)
     float inv_scale[NERF_N_SCALES];  // per layer: 1 / (act_scale * weight_scale)
 };
 
-hipError_t nerf_launch_mlp(const NerfMlpParams& p, int np, int grid, hipStream_t stream);
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*
 
 // rays of rows [row_begin,row_end) of one frame (utils/run_nerf_raybased_helpers.py:231-257)
 hipError_t nerf_launch_get_rays(const float* c2w12_host, int W, float half_w, float half_h, float focal,

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/r2l_hip.h"
 #include "nerf_kernels.h"
 #include "r2l_device.h"
 
@@ -35,55 +36,112 @@ struct MlpOut {       // valid in the quarter-0 lanes (q == 0), one value per co
     float rgb[2][3];  // rgb_linear output
 };
 
-// epilogue of accumulator register r of row tile u, column tile c, of a layer with RT row tiles
-template <int NP, int EPI, int RT>
-__device__ __forceinline__ void mlp_epi_reg(const f32x4& acc, float inv, f16x8 (&Dh)[8][2], f16x8 (&Dl)[8][2],
-                                            int u, int c, int r, float act_scale, MlpOut& out) {
+// One activation set (256 features x 32 points per wave) as MFMA B operands: fp16 hi fragments,
+// then either the fp16 lo fragments (FP16X3) or, in FP16_FP8 mode, the e5m2 bytes of the value (a)
+// and of its fp16 residual (r) in the K=128 layout of r2l_common.h.
+struct ActSet {
+    f16x8 h[8][2], l[8][2];
+    i32x8 a[2][2], r[2][2];
+};
+
+// epilogue of accumulator registers 2*pair, 2*pair+1 of row tile u, column tile c, of a layer with RT row tiles
+template <int NP, bool MIX, int EPI, int RT>
+__device__ __forceinline__ void mlp_epi_pair(const f32x4& acc, float inv, ActSet& D, int u, int c, int pair,
+                                             float act_scale, float neg1, MlpOut& out) {
     if (EPI == EPI_RGB) {
-        if (r < 3) out.rgb[c][r] = acc[r] * inv;
+        if (pair == 0) {
+            out.rgb[c][0] = acc[0] * inv;
+            out.rgb[c][1] = acc[1] * inv;
+        } else {
+            out.rgb[c][2] = acc[2] * inv;
+        }
         return;
     }
     if (EPI == EPI_LINEAR_ALPHA && u == RT - 1) {  // row tile 16 of FA: row 0 = alpha_linear
-        if (r == 0) out.alpha[c] = acc[0] * inv;
+        if (pair == 0) out.alpha[c] = acc[0] * inv;
         return;
     }
-    float v = acc[r] * inv;
-    if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
-    split_store<NP>(v * act_scale, Dh[(u >> 1) & 7][c], Dl[(u >> 1) & 7][c], 4 * (u & 1) + r);
+    float v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        v[k] = acc[2 * pair + k] * inv;
+        if (EPI == EPI_RELU) v[k] = fmaxf(v[k], 0.0f);
+        v[k] *= act_scale;
+    }
+    const int idx = 2 * (u & 1) + pair;
+    if (!MIX) {
+        split_store2<NP>(v[0], v[1], D.h[(u >> 1) & 7][c], D.l[(u >> 1) & 7][c], idx, neg1);
+    } else {
+        const f16x2 h = pack_hi(v[0], v[1]);
+        set_dword(D.h[(u >> 1) & 7][c], idx, __builtin_bit_cast(uint32_t, h));
+        const float l0 = fmaf((float)h[0], neg1, v[0]), l1 = fmaf((float)h[1], neg1, v[1]);
+        i32x8& na = D.a[(u >> 3) & 1][c];
+        i32x8& nr = D.r[(u >> 3) & 1][c];
+        if (pair == 0) {
+            na[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], na[u & 7], false);
+            nr[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(l0, l1, nr[u & 7], false);
+        } else {
+            na[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], na[u & 7], true);
+            nr[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(l0, l1, nr[u & 7], true);
+        }
+    }
 }
 
-// One Linear layer = fragment run [F0, F0 + RT*KS).  Input fragments: k-steps 0..7 from
-// (Sh,Sl), k-steps 8.. from (Xh,Xl).  Output row tiles are written as fragments of (Dh,Dl).
-// The epilogue of row tile u-1 is interleaved with the MFMAs of row tile u; the last one's is
-// exposed.
-template <int NP, int KS, int RT, int F0, int EPI>
-__device__ __forceinline__ void mlp_layer(Ring<NP>& R, const f16x8 (&Sh)[8][2], const f16x8 (&Sl)[8][2],
-                                          const f16x8 (&Xh)[2][2], const f16x8 (&Xl)[2][2], f16x8 (&Dh)[8][2],
-                                          f16x8 (&Dl)[8][2], float inv, float act_scale, int q, MlpOut& out) {
+// One Linear layer = fragment run [F0, F0 + RT*KS).  Input fragments: k-steps 0..7 from the set S,
+// k-steps 8.. from (Xh,Xl) (embedding fragments, always hi/lo fp16).  Output row tiles are written
+// as fragments of D.  HS (FP16_FP8 only) = number of leading k-steps that run as fp16 hi pass + fp8
+// correction terms (8 for a 256-wide source, 4 for the 128-wide one, 0: the source is an embedding).
+// The epilogue of row tile u-1 is interleaved with the MFMAs of row tile u; the last one's is exposed.
+template <int NP, bool MIX, int KS, int RT, int F0, int EPI, int HS>
+__device__ __forceinline__ void mlp_layer(Ring<NP>& R, const ActSet& S, const f16x8 (&Xh)[2][2],
+                                          const f16x8 (&Xl)[2][2], ActSet& D, float inv, float act_scale, float neg1,
+                                          int q, MlpOut& out) {
+    constexpr int HM = MIX ? HS : 0;       // k-steps in fp16 + fp8 form
+    constexpr int H2 = HM > 0 ? HM / 2 : 1;  // k-steps per correction term
     f32x4 acc[2], prev[2];
+    i32x4 keep;
 #pragma unroll
     for (int u = 0; u < RT; ++u) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int fq = F0 + u * KS + s;
             const int pos = fq % R2L_FRAGS;
-            ring_step<NP>(R, pos);  // pos == 8: rendezvous; pos >= 8: one refill piece per step
+            ring_step<NP>(R, pos);  // pos == 8: rendezvous + refill
             if (s == 0) {
                 acc[0] = acc_init<NP>(R.use_off, 16 * nerf_aux_slot(fq), q);
                 acc[1] = acc[0];
             }
             AFrag<NP> nxt = (pos + 1 < R2L_FRAGS) ? read_frag<NP>(R.use_off + R.lane * 16, pos + 1)
                                                   : read_frag<NP>(ring_next_off<NP>(R.use_off) + R.lane * 16, 0);
+            if (s < HM) {
+                acc[0] = MFMA(R.pre.h, S.h[s < 8 ? s : 0][0], acc[0]);
+                acc[1] = MFMA(R.pre.h, S.h[s < 8 ? s : 0][1], acc[1]);
+                const i32x4 piece = __builtin_bit_cast(i32x4, R.pre.l);
+                if ((s & 1) == 0) {
+                    keep = piece;
+                } else {
+                    const i32x8 a8 = {keep[0], keep[1], keep[2], keep[3], piece[0], piece[1], piece[2], piece[3]};
+                    const int t = ((s % H2) >> 1) & 1;
+                    if (s / H2 == 0) {
+                        acc[0] = MFMA8(a8, S.a[t][0], acc[0], R2L_MIX_SCALE_WL);
+                        acc[1] = MFMA8(a8, S.a[t][1], acc[1], R2L_MIX_SCALE_WL);
+                    } else {
+                        acc[0] = MFMA8(a8, S.r[t][0], acc[0], R2L_MIX_SCALE_W);
+                        acc[1] = MFMA8(a8, S.r[t][1], acc[1], R2L_MIX_SCALE_W);
+                    }
+                }
+            } else {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (s < 8) acc[c] = mfma_step<NP>(R.pre, Sh[s < 8 ? s : 0][c], Sl[s < 8 ? s : 0][c], acc[c]);
-                else acc[c] = mfma_step<NP>(R.pre, Xh[s >= 8 ? s - 8 : 0][c], Xl[s >= 8 ? s - 8 : 0][c], acc[c]);
+                for (int c = 0; c < 2; ++c) {
+                    if (s < 8) acc[c] = mfma_step<NP>(R.pre, S.h[s < 8 ? s : 0][c], S.l[s < 8 ? s : 0][c], acc[c]);
+                    else acc[c] = mfma_step<NP>(R.pre, Xh[s >= 8 ? s - 8 : 0][c], Xl[s >= 8 ? s - 8 : 0][c], acc[c]);
+                }
             }
             R.pre = nxt;
             if (u > 0) {
 #pragma unroll
-                for (int i = (8 * s + KS - 1) / KS; i < (8 * (s + 1) + KS - 1) / KS && i < 8; ++i)
-                    mlp_epi_reg<NP, EPI, RT>(prev[i >> 2], inv, Dh, Dl, u - 1, i >> 2, i & 3, act_scale, out);
+                for (int i = (4 * s + KS - 1) / KS; i < (4 * (s + 1) + KS - 1) / KS && i < 4; ++i)
+                    mlp_epi_pair<NP, MIX, EPI, RT>(prev[i >> 1], inv, D, u - 1, i >> 1, i & 1, act_scale, neg1, out);
             }
             if (pos == R2L_FRAGS - 1) ring_next<NP>(R);
         }
@@ -91,11 +149,12 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const f16x8 (&Sh)[8][2], 
         prev[1] = acc[1];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mlp_epi_reg<NP, EPI, RT>(prev[i >> 2], inv, Dh, Dl, RT - 1, i >> 2, i & 3, act_scale, out);
+    for (int i = 0; i < 4; ++i) mlp_epi_pair<NP, MIX, EPI, RT>(prev[i >> 1], inv, D, RT - 1, i >> 1, i & 1, act_scale, neg1, out);
 }
 
-template <int NP>
+template <int NP, bool MIX>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
+    static_assert(!MIX || NP == 2, "FP16_FP8 uses the two-part chunk");
     typedef KCfg<NP> C;
     Ring<NP> R;
     R.wimg = p.wimg;
@@ -108,6 +167,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
     const int lane = R.lane;
     const int q = lane >> 4;
     const float act_scale = p.act_scale;
+    const float neg1 = p.neg1;
 
 #pragma unroll
     for (int i = 0; i < C::D; ++i) ring_issue<NP>(R);
@@ -115,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
     __builtin_amdgcn_s_barrier();
     R.pre = read_frag<NP>(lane * 16, 0);
 
-    f16x8 A1h[8][2], A1l[8][2], A2h[8][2], A2l[8][2];
+    ActSet A1, A2;
     f16x8 Eh[2][2], El[2][2], Vh[2][2], Vl[2][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {  // unused second slot of the "extra" operand of the V layer
@@ -191,41 +251,49 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
             out.alpha[c] = 0.f;
             out.rgb[c][0] = out.rgb[c][1] = out.rgb[c][2] = 0.f;
         }
-        // L0: E -> A2   (KS = 2: the source operand is E parked in A1[0..1])
+        // L0: E -> A2   (KS = 2: the source operand is E parked in A1[0..1], always hi/lo fp16)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                A1h[e][c] = Eh[e][c];
-                A1l[e][c] = El[e][c];
+                A1.h[e][c] = Eh[e][c];
+                A1.l[e][c] = El[e][c];
             }
-        mlp_layer<NP, 2, 16, NERF_F0_L0, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, p.inv_scale[0], act_scale, q, out);
+        mlp_layer<NP, MIX, 2, 16, NERF_F0_L0, EPI_RELU, 0>(R, A1, Eh, El, A2, p.inv_scale[0], act_scale, neg1, q, out);
         for (int it = 0; it < 3; ++it) {
             if (it == 2) {
                 // L5: [h(256) | E] -> A1, then move to A2 so the two-layer body is reused
-                mlp_layer<NP, 10, 16, NERF_F0_L5, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[5], act_scale,
-                                                            q, out);
+                mlp_layer<NP, MIX, 10, 16, NERF_F0_L5, EPI_RELU, 8>(R, A2, Eh, El, A1, p.inv_scale[5], act_scale, neg1,
+                                                                    q, out);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        A2h[i][c] = A1h[i][c];
-                        A2l[i][c] = A1l[i][c];
+                    for (int i = 0; i < 8; ++i) {
+                        A2.h[i][c] = A1.h[i][c];
+                        if (!MIX) A2.l[i][c] = A1.l[i][c];
                     }
+                    if (MIX) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            A2.a[t][c] = A1.a[t][c];
+                            A2.r[t][c] = A1.r[t][c];
+                        }
+                    }
+                }
             }
             // (L1,L2) (L3,L4) (L6,L7): the fragment run of the pair is contiguous per iteration
             const float inva = p.inv_scale[it == 0 ? 1 : (it == 1 ? 3 : 6)];
             const float invb = p.inv_scale[it == 0 ? 2 : (it == 1 ? 4 : 7)];
-            mlp_layer<NP, 8, 16, NERF_F0_L1, EPI_RELU>(R, A2h, A2l, Eh, El, A1h, A1l, inva, act_scale, q, out);
-            mlp_layer<NP, 8, 16, NERF_F0_L1 + 128, EPI_RELU>(R, A1h, A1l, Eh, El, A2h, A2l, invb, act_scale, q, out);
+            mlp_layer<NP, MIX, 8, 16, NERF_F0_L1, EPI_RELU, 8>(R, A2, Eh, El, A1, inva, act_scale, neg1, q, out);
+            mlp_layer<NP, MIX, 8, 16, NERF_F0_L1 + 128, EPI_RELU, 8>(R, A1, Eh, El, A2, invb, act_scale, neg1, q, out);
         }
         // FA: feature_linear | alpha_linear (no activation) -> A1, sigma
-        mlp_layer<NP, 8, 17, NERF_F0_FA, EPI_LINEAR_ALPHA>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[8], act_scale,
-                                                           q, out);
+        mlp_layer<NP, MIX, 8, 17, NERF_F0_FA, EPI_LINEAR_ALPHA, 8>(R, A2, Eh, El, A1, p.inv_scale[8], act_scale, neg1,
+                                                                   q, out);
         // V: [feature | view embedding] -> 128, relu -> A2[0..3]
-        mlp_layer<NP, 9, 8, NERF_F0_V, EPI_RELU>(R, A1h, A1l, Vh, Vl, A2h, A2l, p.inv_scale[9], act_scale, q, out);
+        mlp_layer<NP, MIX, 9, 8, NERF_F0_V, EPI_RELU, 8>(R, A1, Vh, Vl, A2, p.inv_scale[9], act_scale, neg1, q, out);
         // RGB: 128 -> 3 (4 k-steps), then leave the half-used last chunk
-        mlp_layer<NP, 4, 1, NERF_F0_RGB, EPI_RGB>(R, A2h, A2l, Eh, El, A1h, A1l, p.inv_scale[10], act_scale, q, out);
+        mlp_layer<NP, MIX, 4, 1, NERF_F0_RGB, EPI_RGB, 4>(R, A2, Eh, El, A1, p.inv_scale[10], act_scale, neg1, q, out);
         ring_mid<NP>(R);
         R.pre = read_frag<NP>(ring_next_off<NP>(R.use_off) + lane * 16, 0);
         ring_next<NP>(R);
@@ -481,21 +549,22 @@ __global__ __launch_bounds__(256) void nerf_merge_kernel(const float* __restrict
 // ====================================================================================
 // launchers
 // ====================================================================================
-template <int NP>
+template <int NP, bool MIX>
 static hipError_t launch_mlp(const NerfMlpParams& p, int grid, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp_kernel<NP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp_kernel<NP, MIX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(nerf_mlp_kernel<NP>, dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    hipLaunchKernelGGL((nerf_mlp_kernel<NP, MIX>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
     return hipGetLastError();
 }
 
-hipError_t nerf_launch_mlp(const NerfMlpParams& p, int np, int grid, hipStream_t stream) {
-    return np == 2 ? launch_mlp<2>(p, grid, stream) : launch_mlp<1>(p, grid, stream);
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream) {
+    if (mode == R2L_PREC_FP16_FP8) return launch_mlp<2, true>(p, grid, stream);
+    return mode == R2L_PREC_FP16X3 ? launch_mlp<2, false>(p, grid, stream) : launch_mlp<1, false>(p, grid, stream);
 }
 
 hipError_t nerf_launch_get_rays(const float* c, int W, float half_w, float half_h, float focal, int pix_begin,

@@ -37,7 +37,7 @@ extern "C" {
  *   R2L_PREC_FP16X3  hi/lo split of both operands, 3 MFMA passes per k-step
  *                    (ah*wh + ah*wl + al*wh): L_inf vs the fp32 reference ~1e-6;
  *   R2L_PREC_FP16X1  single pass on fp16-rounded operands: L_inf ~4e-4, 3x fewer MFMAs.
- *   R2L_PREC_FP16_FP8  (R2L only) fp16 main pass + the two correction terms of FP16X3 on the
+ *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the
  *                    block-scaled fp8 MFMA (weights e4m3, activations e5m2) at twice the fp16
  *                    rate: 2 pass-equivalents per k-step, L_inf ~2.5e-5 (< 1e-4). */
 #define R2L_PREC_FP16X3 0

@@ -145,6 +145,23 @@ def test_render_frame_rows_vs_oracle(engine, g):
     assert rgb.shape == (2, 400, 3) and disp.shape == (2, 400) and torch.equal(rgb.view(-1, 3), out['rgb_map'])
 
 
+def test_teacher_fp16_fp8_mode(pkg, g):
+    """fp16 main pass + fp8 correction terms: raw network outputs and the composited maps stay
+    inside the tolerances of the fp16x3 tests (1e-4 on rgb)."""
+    from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8
+    eng = NeRFEngine(400, 400, float(g['focal']), precision=PREC_FP16_FP8, z_coarse=T(g['z_vals0'][0]),
+                     u=torch.linspace(0., 1., 128))
+    eng.load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    ro, rd = T(g['rays_o']).cuda(), T(g['rays_d']).cuda()
+    e0 = close(eng.run_network(0, ro, rd, T(g['z_vals0'][0]).cuda()).cpu().numpy(), g['raw0'], 2e-4)
+    e1 = close(eng.run_network(1, ro, rd, T(g['z_all']).cuda()).cpu().numpy(), g['raw'], 2e-4)
+    out = eng.render_rays(ro, rd, extras=True)
+    errs = {name: close(out[key].cpu().numpy(), g[f'{name}_w'], 1e-4)
+            for key, name in (('rgb_map', 'rgb'), ('acc_map', 'acc'), ('rgb0', 'rgb0'))}
+    print(f'teacher fp16_fp8 L_inf: raw coarse {e0:.2e}, fine {e1:.2e};', {k: f'{v:.2e}' for k, v in errs.items()})
+    eng.close()
+
+
 def test_teacher_fp16x1_mode_and_errors(pkg, g):
     from efficient_nerf_amd import NeRFEngine, PREC_FP16X1, R2LError
     eng = NeRFEngine(400, 400, float(g['focal']), precision=PREC_FP16X1, z_coarse=T(g['z_vals0'][0]),
