@@ -115,7 +115,7 @@ def main(argv=None):
     --n_pose_kd N --datadir_kd old:new` (README.md:79 of the reference)."""
     import argparse
     from . import frontend as fe
-    from . import NeRFEngine, PREC_FP16X1, PREC_FP16X3
+    from . import NeRFEngine, PRECISIONS
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument('--create_data', type=str, default='spiral_evenly_spaced')
     ap.add_argument('--teacher_ckpt', type=str, default='')
@@ -135,7 +135,7 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     ckpt = fe.load_checkpoint(own.teacher_ckpt)
     _, (H, W, focal) = fe.load_test_poses(args)
-    prec = PREC_FP16X3 if args.precision == 'fp16x3' else PREC_FP16X1
+    prec = PRECISIONS[args.precision]
     eng = NeRFEngine(H, W, focal, 2., 6., N_samples=args.N_samples, N_importance=args.N_importance,
                      white_bkgd=args.white_bkgd, precision=prec)
     eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
