@@ -239,6 +239,23 @@ def load_test_poses(args):
     return poses, (H, W, focal)
 
 
+def load_test_set(args):
+    """--render_test with a mounted Blender scene (main.py:922-937, 1004-1012): the test split's
+    poses, intrinsics and ground-truth RGB (composited on white with --white_bkgd).  Returns
+    (poses, (H, W, focal), gt [N,H,W,3] or None); falls back to `load_test_poses` (no GT) when the
+    scene's images are not there."""
+    from . import blender
+    tf = os.path.join(args.datadir, 'transforms_test.json')
+    if args.synthetic_poses > 0 or args.dataset_type != 'blender' or not os.path.exists(tf):
+        return load_test_poses(args) + (None,)
+    with open(tf) as fp:
+        first = json.load(fp)['frames'][0]['file_path']
+    if not os.path.exists(os.path.join(args.datadir, first + '.png')):
+        return load_test_poses(args) + (None,)
+    imgs, poses, hwf, _ = blender.load_blender_data(args.datadir, args.half_res, args.testskip, splits=('test',))
+    return poses, tuple(hwf), blender.composite(imgs, args.white_bkgd)
+
+
 # ----------------------------------------------------------------------------------------
 # output helpers
 # ----------------------------------------------------------------------------------------
@@ -247,8 +264,9 @@ def to8b(x):
 
 
 def write_png(path, rgb8):
-    """Minimal RGB8 PNG writer (imageio is not a dependency here)."""
-    h, w, _ = rgb8.shape
+    """Minimal 8-bit RGB / RGBA PNG writer (imageio is not a dependency here)."""
+    h, w, ch = rgb8.shape
+    assert ch in (3, 4) and rgb8.dtype == np.uint8
     raw = b''.join(b'\x00' + rgb8[y].tobytes() for y in range(h))
 
     def chunk(tag, data):
@@ -256,7 +274,7 @@ def write_png(path, rgb8):
         return c + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
 
     with open(path, 'wb') as f:
-        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2, 0, 0, 0)) +
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2 if ch == 3 else 6, 0, 0, 0)) +
                 chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
 
 
@@ -311,7 +329,8 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     world = tdist.get_world_size() if tdist.is_initialized() else 1
     rank = tdist.get_rank() if tdist.is_initialized() else 0
     r0, r1 = D.row_shard(H, rank, world)
-    rgbs, psnrs = [], []
+    from .metrics import ssim_hwc
+    rgbs, psnrs, ssims = [], [], []
     for i, c2w in enumerate(render_poses):
         torch.cuda.synchronize()
         t0 = time.time()
@@ -325,14 +344,19 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
             log(f'[#{i}] frame, rendering done, time for this frame: {time.time() - t0:.4f}s')
         rgbs.append(rgb)
         if gt_imgs is not None:
-            psnrs.append(mse2psnr(torch.mean((rgb - gt_imgs[i].to(rgb.device)) ** 2)))
+            gt = gt_imgs[i].to(rgb.device)
+            psnrs.append(mse2psnr(torch.mean((rgb - gt) ** 2)))
+            ssims.append(float(ssim_hwc(rgb, gt)))  # main.py:334-335
         if savedir is not None and rank == 0:
             write_png(os.path.join(savedir, f'{i:03d}.png'), to8b(rgb.cpu().numpy()))
+            if gt_imgs is not None:  # main.py:340-341
+                write_png(os.path.join(savedir, f'{i:03d}_gt.png'), to8b(gt_imgs[i].cpu().numpy()))
     rgbs = torch.stack(rgbs, 0)
     misc = {}
     if gt_imgs is not None:
         misc['test_psnr'] = mse2psnr(torch.mean((rgbs - gt_imgs.to(rgbs.device)) ** 2))
         misc['test_psnr_v2'] = float(np.mean(psnrs))
+        misc['test_ssim'] = float(np.mean(ssims))
     return rgbs, misc
 
 
@@ -348,7 +372,11 @@ def main(argv=None):
     log = print if rank == 0 else (lambda *a, **k: None)
     ckpt = load_checkpoint(args.pretrained_ckpt)
     log(f'Load pretrained ckpt successfully: "{args.pretrained_ckpt}".')
-    poses, hwf = load_test_poses(args)
+    gt = None
+    if args.render_test:
+        poses, hwf, gt = load_test_set(args)
+    else:
+        poses, hwf = load_test_poses(args)
     kind, eng = build_engine(args, hwf, ckpt)
     outdir = args.outdir or os.path.join(args.basedir, args.expname or 'render', 'gen_img')
     if rank == 0:
@@ -356,7 +384,7 @@ def main(argv=None):
     log('RENDER ONLY')
     t_ = time.time()
     with torch.no_grad():
-        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=None, savedir=outdir, log=log)
+        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log)
     dt = time.time() - t_
     if rank == 0:
         np.save(os.path.join(outdir, 'rgbs.npy'), rgbs.cpu().numpy())
@@ -364,6 +392,7 @@ def main(argv=None):
         log(f'Rendered {len(poses)} view(s) {H}x{W} on {world} GPU(s) in {dt:.2f}s '
             f'({len(poses) * H * W / dt:.3e} rays/s incl. host I/O)')
         if 'test_psnr' in misc:
-            log(f"[TEST] TestPSNR {misc['test_psnr']:.4f} TestPSNRv2 {misc['test_psnr_v2']:.4f}")
+            log(f"[TEST] TestPSNR {misc['test_psnr']:.4f} TestPSNRv2 {misc['test_psnr_v2']:.4f} "
+                f"TestSSIM {misc['test_ssim']:.4f}")
         log(f'Save renders: "{outdir}"')
     return 0

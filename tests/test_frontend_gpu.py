@@ -41,6 +41,42 @@ def test_r2l_render_only_cli(pkg, tmp_path):
         assert np.abs(rgbs[i] - ref).max() <= 1e-4
 
 
+def test_r2l_render_test_against_mounted_scene(pkg, tmp_path):
+    """--render_test with a Blender-layout scene on disk (transforms_test.json + RGBA PNGs): the
+    test split's own poses are rendered and PSNR / SSIM against the frames are reported
+    (main.py:331-335, 1080).  The frames are the CPU oracle's renders quantised to 8 bit, so the
+    report must come out at the quantisation floor of to8b (truncation: MSE = (1/255)^2/3 -> 52.9 dB)."""
+    import json
+    import re
+    from efficient_nerf_amd import frontend as fe
+    H = 32
+    sd = O.make_r2l_state(seed=6, netdepth=4)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    scene = tmp_path / 'scene'
+    os.makedirs(scene / 'test')
+    focal = O.focal_from_angle(H)
+    poses = O.novel_poses(6)
+    frames = []
+    for i, c2w in enumerate(poses):
+        rgb = O.r2l_render(sd, H, H, focal, c2w).view(H, H, 3).numpy()
+        rgba = np.concatenate([fe.to8b(rgb), np.full((H, H, 1), 255, np.uint8)], -1)
+        fe.write_png(str(scene / 'test' / f'r_{i}.png'), rgba)
+        frames.append({'file_path': f'./test/r_{i}', 'transform_matrix': c2w.tolist()})
+    with open(scene / 'transforms_test.json', 'w') as fp:
+        json.dump({'camera_angle_x': O.LEGO_CAMERA_ANGLE_X, 'frames': frames}, fp)
+    out = str(tmp_path / 'out')
+    log = run_main(['--model_name', 'R2L', '--config', 'configs/lego_noview_800x800.txt', '--datadir', str(scene),
+                    '--n_sample_per_ray', '16', '--netwidth', '256', '--netdepth', '4', '--use_residual', '--trial.ON',
+                    '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck, '--render_only', '--render_test',
+                    '--testskip', '2', '--outdir', out])
+    m = re.search(r'TestPSNR ([0-9.]+) TestPSNRv2 ([0-9.]+) TestSSIM ([0-9.]+)', log)
+    assert m, log[-1500:]
+    assert abs(float(m.group(1)) - 52.9) < 0.3 and abs(float(m.group(2)) - 52.9) < 0.3 and float(m.group(3)) > 0.995, m.group(0)
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    assert rgbs.shape == (3, H, H, 3) and os.path.exists(os.path.join(out, '002_gt.png'))  # frames[::2]
+
+
 def test_teacher_render_only_cli(pkg, tmp_path):
     from efficient_nerf_amd import frontend as fe
     t0, t1 = O.make_teacher_state(1), O.make_teacher_state(2)
