@@ -45,6 +45,8 @@ SIGNATURES = {
     'nerf_set_precision': (C.c_int, [_vp, C.c_int]),
     'nerf_set_sampling': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
     'nerf_get_rays': (C.c_int, [C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'nerf_set_ndc': (C.c_int, [_vp, C.c_int, C.c_float]),
+    'nerf_ndc_rays': (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_float, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     'nerf_run_network': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'nerf_sample_pdf_u': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     'nerf_render': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),

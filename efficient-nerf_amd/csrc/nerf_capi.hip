@@ -96,6 +96,8 @@ float max_scale(std::initializer_list<std::pair<const float*, size_t>> ts) {
 
 struct nerf_ctx {
     int H, W, N_samples, N_importance, white_bkgd, mode, n_cu;
+    int ndc = 0;            // render() projects the rays to NDC first (main.py:160-162)
+    float ndc_near = 1.0f;
     double focal;
     float near_, far_, act_scale;
     std::vector<float> z_coarse, u;  // host copies
@@ -104,12 +106,13 @@ struct nerf_ctx {
     // per-call temporaries, grown on demand (sized for `cap` rays)
     int cap = 0;
     float *d_rays_o = nullptr, *d_rays_d = nullptr, *d_raw0 = nullptr, *d_w0 = nullptr, *d_zs = nullptr,
-          *d_zall = nullptr, *d_raw = nullptr, *d_rgb0 = nullptr, *d_disp0 = nullptr, *d_acc0 = nullptr;
+          *d_zall = nullptr, *d_raw = nullptr, *d_rgb0 = nullptr, *d_disp0 = nullptr, *d_acc0 = nullptr,
+          *d_ndc_o = nullptr, *d_ndc_d = nullptr, *d_vdir = nullptr;
 };
 
 static void free_tmp(nerf_ctx* c) {
     float** ps[] = {&c->d_rays_o, &c->d_rays_d, &c->d_raw0, &c->d_w0, &c->d_zs, &c->d_zall, &c->d_raw,
-                    &c->d_rgb0, &c->d_disp0, &c->d_acc0};
+                    &c->d_rgb0, &c->d_disp0, &c->d_acc0, &c->d_ndc_o, &c->d_ndc_d, &c->d_vdir};
     for (auto p : ps)
         if (*p) {
             (void)hipFree(*p);
@@ -125,7 +128,8 @@ static int ensure_tmp(nerf_ctx* c, int n) {
     struct { float** p; size_t numel; } req[] = {
         {&c->d_rays_o, (size_t)n * 3}, {&c->d_rays_d, (size_t)n * 3}, {&c->d_raw0, (size_t)n * S0 * 4},
         {&c->d_w0, (size_t)n * S0},    {&c->d_zs, (size_t)n * c->N_importance}, {&c->d_zall, (size_t)n * S1},
-        {&c->d_raw, (size_t)n * S1 * 4}, {&c->d_rgb0, (size_t)n * 3}, {&c->d_disp0, (size_t)n}, {&c->d_acc0, (size_t)n}};
+        {&c->d_raw, (size_t)n * S1 * 4}, {&c->d_rgb0, (size_t)n * 3}, {&c->d_disp0, (size_t)n}, {&c->d_acc0, (size_t)n},
+        {&c->d_ndc_o, (size_t)n * 3}, {&c->d_ndc_d, (size_t)n * 3}, {&c->d_vdir, (size_t)n * 3}};
     for (auto& r : req) {
         hipError_t e = hipMalloc((void**)r.p, r.numel * sizeof(float));
         if (e != hipSuccess) {
@@ -317,9 +321,10 @@ int nerf_set_precision(nerf_ctx* c, int mode) {
 }
 
 static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* rays_d, const float* z, int z_stride,
-                   int S, int n, float* raw, hipStream_t s) {
+                   int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr) {
     NerfMlpParams p;
     memset(&p, 0, sizeof p);
+    p.viewdirs = viewdirs;
     p.wimg = c->net[which].d_img[c->mode];
     p.raw = raw;
     p.rays_o = rays_o;
@@ -349,7 +354,15 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
 static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d, int n, float* rgb, float* disp,
                            float* acc, float* depth, hipStream_t s) {
     const int S0 = c->N_samples, NI = c->N_importance, S1 = S0 + NI;
-    int rc = run_mlp(c, 0, rays_o, rays_d, c->d_zc, 0, S0, n, c->d_raw0, s);  // coarse network_fn
+    const float* vd = nullptr;
+    if (c->ndc) {  // viewdirs from the world rays, then everything downstream sees the NDC rays (main.py:148-162)
+        HIPCHK(nerf_launch_ndc_rays(rays_o, rays_d, n, c->H, c->W, c->focal, c->ndc_near, c->d_ndc_o, c->d_ndc_d,
+                                    c->d_vdir, s), "ndc_rays");
+        rays_o = c->d_ndc_o;
+        rays_d = c->d_ndc_d;
+        vd = c->d_vdir;
+    }
+    int rc = run_mlp(c, 0, rays_o, rays_d, c->d_zc, 0, S0, n, c->d_raw0, s, vd);  // coarse network_fn
     if (rc) return rc;
     HIPCHK(nerf_launch_raw2outputs(c->d_raw0, c->d_zc, 0, rays_d, n, S0, c->white_bkgd, c->d_rgb0, c->d_disp0,
                                    c->d_acc0, c->d_w0, nullptr, s), "raw2outputs(coarse)");
@@ -357,7 +370,7 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
     HIPCHK(nerf_launch_sample_pdf(c->d_zmid, 0, c->d_w0, S0, 1, n, S0 - 1, c->d_u, NI, c->d_zs, s), "sample_pdf");
     // z_vals = sort(cat(z_vals, z_samples))                                 (main.py:730-732)
     HIPCHK(nerf_launch_merge(c->d_zc, 0, S0, c->d_zs, NI, n, c->d_zall, s), "merge");
-    rc = run_mlp(c, 1, rays_o, rays_d, c->d_zall, S1, S1, n, c->d_raw, s);   // network_fine
+    rc = run_mlp(c, 1, rays_o, rays_d, c->d_zall, S1, S1, n, c->d_raw, s, vd);   // network_fine
     if (rc) return rc;
     HIPCHK(nerf_launch_raw2outputs(c->d_raw, c->d_zall, S1, rays_d, n, S1, c->white_bkgd, rgb, disp, acc, nullptr,
                                    depth, s), "raw2outputs(fine)");
@@ -390,6 +403,26 @@ int nerf_render(nerf_ctx* c, const float* c2w_host, int row_begin, int row_end, 
     HIPCHK(nerf_launch_get_rays(c2w_host, c->W, (float)(c->W * .5), (float)(c->H * .5), (float)c->focal,
                                 row_begin * c->W, n, c->d_rays_o, c->d_rays_d, s), "get_rays");
     return render_rays_dev(c, c->d_rays_o, c->d_rays_d, n, rgb_dev, disp_dev, acc_dev, depth_dev, s);
+}
+
+int nerf_set_ndc(nerf_ctx* c, int on, float ndc_near) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (on && !(ndc_near > 0)) return r2l_set_error(R2L_EINVAL, "ndc_near=%g", ndc_near);
+    c->ndc = on ? 1 : 0;
+    c->ndc_near = ndc_near;
+    return R2L_OK;
+}
+
+int nerf_ndc_rays(int H, int W, double focal, float near_, const float* rays_o_dev, const float* rays_d_dev, int n,
+                  float* out_o_dev, float* out_d_dev, void* stream) {
+    if (!rays_o_dev || !rays_d_dev || !out_o_dev || !out_d_dev || n < 0 || H <= 0 || W <= 0 || !(focal > 0))
+        return r2l_set_error(R2L_EINVAL, "bad argument to nerf_ndc_rays");
+    int rc = r2l_require_gfx950(nullptr);
+    if (rc) return rc;
+    if (n == 0) return R2L_OK;
+    HIPCHK(nerf_launch_ndc_rays(rays_o_dev, rays_d_dev, n, H, W, focal, near_, out_o_dev, out_d_dev, nullptr,
+                                (hipStream_t)stream), "ndc_rays");
+    return R2L_OK;
 }
 
 int nerf_last_extras(nerf_ctx* c, const float** rgb0, const float** z_samples, const float** z_vals,

@@ -9,6 +9,7 @@ struct NerfMlpParams {
     float* raw;             // [n_pts, 4] out: rgb(3), sigma(1)   (NeRF.forward output order)
     const float* rays_o;    // [n_rays, 3]
     const float* rays_d;    // [n_rays, 3]
+    const float* viewdirs;  // [n_rays, 3] unit view directions, or NULL: rays_d / ||rays_d||
     const float* z;         // [n_rays, S] or, when z_stride == 0, one shared row [S]
     int z_stride;
     int S;                  // samples per ray
@@ -25,6 +26,11 @@ hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream
 // rays of rows [row_begin,row_end) of one frame (utils/run_nerf_raybased_helpers.py:231-257)
 hipError_t nerf_launch_get_rays(const float* c2w12_host, int W, float half_w, float half_h, float focal,
                                 int pix_begin, int n, float* rays_o, float* rays_d, hipStream_t stream);
+
+// ndc_rays (utils/run_nerf_raybased_helpers.py:260-279) of n rays; viewdirs (optional) receives
+// rays_d / ||rays_d|| of the input rays; out_o / out_d may be NULL when only viewdirs is wanted
+hipError_t nerf_launch_ndc_rays(const float* rays_o, const float* rays_d, int n, int H, int W, double focal, float near_,
+                                float* out_o, float* out_d, float* viewdirs, hipStream_t stream);
 
 // raw [n,S,4], z [n,S] (z_stride 0 = shared row), rays_d [n,3]; any output may be null
 hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_stride, const float* rays_d, int n,

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 xs[k] = __fadd_rn(o[k], __fmul_rn(d[k], z));  // rays_o + rays_d * z  (main.py:701)
-                vs[k] = __fdiv_rn(d[k], nrm);
+                // NDC renders carry the view directions of the world-space rays (main.py:148-162)
+                vs[k] = p.viewdirs ? p.viewdirs[(size_t)ray * 3 + k] : __fdiv_rn(d[k], nrm);
             }
             // ---- embedding fragments (nerf_common.h: nerf_pts_col / nerf_view_col) ---------
             {   // E step 0: coordinate q>>1, frequencies 0..7, sin|cos by q&1
@@ -331,6 +332,39 @@ __global__ void nerf_get_rays_kernel(float c00, float c01, float c02, float c03,
         rays_d[(size_t)i * 3 + k] = __fadd_rn(s, __fmul_rn(-1.0f, c[4 * k + 2]));
         rays_o[(size_t)i * 3 + k] = c[4 * k + 3];
     }
+}
+
+// ====================================================================================
+// ndc_rays (utils/run_nerf_raybased_helpers.py:260-279) + the view directions render() takes from
+// the world-space rays before the projection (main.py:148-157): one thread per ray, the
+// reference's operation order, one rounding per operation.
+//   c0 = fl32(-1/(W/(2 focal))), c1 = fl32(-1/(H/(2 focal))), two_near = fl32(2 near), mtwo_near = fl32(-2 near)
+// ====================================================================================
+__global__ void nerf_ndc_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, int n, float c0,
+                                     float c1, float near_, float two_near, float mtwo_near, float* __restrict__ out_o,
+                                     float* __restrict__ out_d, float* __restrict__ viewdirs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ox = rays_o[(size_t)i * 3], oy = rays_o[(size_t)i * 3 + 1], oz = rays_o[(size_t)i * 3 + 2];
+    const float dx = rays_d[(size_t)i * 3], dy = rays_d[(size_t)i * 3 + 1], dz = rays_d[(size_t)i * 3 + 2];
+    if (viewdirs) {  // rays_d / ||rays_d|| of the WORLD rays (same arithmetic as nerf_mlp_kernel)
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(dx * dx, dy * dy), dz * dz));
+        viewdirs[(size_t)i * 3] = __fdiv_rn(dx, nrm);
+        viewdirs[(size_t)i * 3 + 1] = __fdiv_rn(dy, nrm);
+        viewdirs[(size_t)i * 3 + 2] = __fdiv_rn(dz, nrm);
+    }
+    if (!out_o) return;
+    const float t = __fdiv_rn(-__fadd_rn(near_, oz), dz);       // -(near + o_z) / d_z
+    const float px = __fadd_rn(ox, __fmul_rn(t, dx));            // origin moved to the near plane
+    const float py = __fadd_rn(oy, __fmul_rn(t, dy));
+    const float pz = __fadd_rn(oz, __fmul_rn(t, dz));
+    const float rx = __fdiv_rn(px, pz), ry = __fdiv_rn(py, pz);  // used by the d0 / d1 terms
+    out_o[(size_t)i * 3] = __fdiv_rn(__fmul_rn(c0, px), pz);     // (c0 * o_x) / o_z
+    out_o[(size_t)i * 3 + 1] = __fdiv_rn(__fmul_rn(c1, py), pz);
+    out_o[(size_t)i * 3 + 2] = __fadd_rn(1.0f, __fdiv_rn(two_near, pz));
+    out_d[(size_t)i * 3] = __fmul_rn(c0, __fadd_rn(__fdiv_rn(dx, dz), -rx));
+    out_d[(size_t)i * 3 + 1] = __fmul_rn(c1, __fadd_rn(__fdiv_rn(dy, dz), -ry));
+    out_d[(size_t)i * 3 + 2] = __fdiv_rn(mtwo_near, pz);
 }
 
 // ====================================================================================
@@ -565,6 +599,14 @@ static hipError_t launch_mlp(const NerfMlpParams& p, int grid, hipStream_t strea
 hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream) {
     if (mode == R2L_PREC_FP16_FP8) return launch_mlp<2, true>(p, grid, stream);
     return mode == R2L_PREC_FP16X3 ? launch_mlp<2, false>(p, grid, stream) : launch_mlp<1, false>(p, grid, stream);
+}
+
+hipError_t nerf_launch_ndc_rays(const float* rays_o, const float* rays_d, int n, int H, int W, double focal, float near_,
+                                float* out_o, float* out_d, float* viewdirs, hipStream_t stream) {
+    const float c0 = (float)(-1. / (W / (2. * focal))), c1 = (float)(-1. / (H / (2. * focal)));
+    hipLaunchKernelGGL(nerf_ndc_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rays_o, rays_d, n, c0, c1, near_,
+                       (float)(2. * near_), (float)(-2. * near_), out_o, out_d, viewdirs);
+    return hipGetLastError();
 }
 
 hipError_t nerf_launch_get_rays(const float* c, int W, float half_w, float half_h, float focal, int pix_begin,

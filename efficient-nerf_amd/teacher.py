@@ -93,6 +93,17 @@ def merge_sorted(z_vals, z_samples):
     return out
 
 
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """utils/run_nerf_raybased_helpers.py:260-279 on the GPU: [..., 3] rays -> projected rays."""
+    o = rays_o.reshape(-1, 3).to(rays_o.device if rays_o.is_cuda else _dev(None), torch.float32).contiguous()
+    d = rays_d.reshape(-1, 3).to(o.device, torch.float32).contiguous()
+    oo, dd = torch.empty_like(o), torch.empty_like(d)
+    with torch.cuda.device(o.device):
+        check(lib().nerf_ndc_rays(int(H), int(W), float(focal), float(near), dptr(o), dptr(d), o.shape[0], dptr(oo),
+                                  dptr(dd), current_stream()))
+    return oo.view(rays_o.shape), dd.view(rays_d.shape)
+
+
 class NeRFEngine:
     """One nerf_ctx: coarse + fine NeRF(D=8, W=256, use_viewdirs) and the render_rays
     pipeline (include/r2l_hip.h)."""
@@ -102,7 +113,9 @@ class NeRFEngine:
         'alpha_linear.weight', 'alpha_linear.bias', 'rgb_linear.weight', 'rgb_linear.bias']
 
     def __init__(self, H, W, focal, near=2., far=6., N_samples=64, N_importance=128, multires=10, multires_views=4,
-                 white_bkgd=True, precision=PREC_FP16X3, device=None, z_coarse=None, u=None):
+                 white_bkgd=True, precision=PREC_FP16X3, device=None, z_coarse=None, u=None, ndc=False, lindisp=False):
+        """ndc: render(..., ndc=True) of the reference (forward-facing scenes; pass near=0, far=1 as
+        main.py:917-918 does); lindisp: coarse depths linear in inverse depth (main.py:679-680)."""
         self.device = _dev(device)
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.N_samples, self.N_importance = int(N_samples), int(N_importance)
@@ -114,10 +127,17 @@ class NeRFEngine:
         # main.py:676-678 / helpers:293 evaluated with the host's torch, as the reference does
         if z_coarse is None:
             t_vals = torch.linspace(0., 1., steps=self.N_samples)
-            z_coarse = float(near) * (1. - t_vals) + float(far) * (t_vals)
+            if not lindisp:
+                z_coarse = float(near) * (1. - t_vals) + float(far) * (t_vals)
+            else:
+                z_coarse = 1. / (1. / float(near) * (1. - t_vals) + 1. / float(far) * (t_vals))
         if u is None:
             u = torch.linspace(0., 1., steps=self.N_importance)
         self.set_sampling(z_coarse, u)
+        self.ndc = bool(ndc)
+        if ndc:
+            with torch.cuda.device(self.device):
+                check(lib().nerf_set_ndc(self._ctx, 1, 1.0))  # ndc_rays(H, W, focal, 1., ...)  (main.py:162)
 
     def set_sampling(self, z_coarse, u):
         z = torch.as_tensor(z_coarse).detach().to('cpu', torch.float32).contiguous()
@@ -226,8 +246,9 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=False, near=2.
     """main.py:107-186 call shape: returns [rgb_map, disp_map, acc_map, extras_dict] reshaped
     to the ray batch.  `engine` is the NeRFEngine holding network_fn / network_fine (the
     reference passes them through **kwargs).  `chunk` does not affect results (main.py:124)."""
-    if ndc:
-        raise NotImplementedError('NDC rays (LLFF) are a next-row item, not built yet')
+    if ndc != bool(getattr(engine, 'ndc', False)):
+        raise R2LError(f'render(ndc={ndc}) on an engine built with ndc={getattr(engine, "ndc", False)}: '
+                       'construct NeRFEngine(..., ndc=True, near=0., far=1.) for forward-facing scenes')
     if not use_viewdirs:
         raise R2LError('the teacher path is built for use_viewdirs=True networks')
     if engine is None:

@@ -162,6 +162,15 @@ int nerf_last_extras(nerf_ctx* ctx, const float** rgb0, const float** z_samples,
 int nerf_copy_extras(nerf_ctx* ctx, int n, float* rgb0_dev, float* z_samples_dev, float* z_vals_dev,
                      float* raw_dev, void* stream);
 
+/* Forward-facing scenes (render(..., ndc=True), main.py:148-162): when on, nerf_render and
+ * nerf_render_rays take the view directions from the given (world-space) rays, project the rays
+ * with ndc_rays(H, W, focal, ndc_near, ...) and sample / composite along the projected rays; the
+ * context's near / far are then NDC depths (0 and 1 in the reference, main.py:917-918). */
+int nerf_set_ndc(nerf_ctx* ctx, int on, float ndc_near);
+/* ndc_rays (utils/run_nerf_raybased_helpers.py:260-279): n rays [n,3] -> projected [n,3] pairs. */
+int nerf_ndc_rays(int H, int W, double focal, float near_, const float* rays_o_dev,
+                  const float* rays_d_dev, int n, float* out_o_dev, float* out_d_dev, void* stream);
+
 /* get_rays (utils/run_nerf_raybased_helpers.py:231-257) for rows [row_begin,row_end):
  * rays_o_dev, rays_d_dev [rows*W, 3]; c2w [3,4] on the host. */
 int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_begin, int row_end,

@@ -333,15 +333,32 @@ def merge_z(z_vals, z_samples):
     return torch.sort(torch.cat([z_vals, z_samples], -1), -1)[0]
 
 
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """utils/run_nerf_raybased_helpers.py:260-279: origins moved to the near plane, then the
+    perspective projection of origin and direction (Python-float constants times f32 tensors)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    p = rays_o + t[..., None] * rays_d
+    sx, sy = -1. / (W / (2. * focal)), -1. / (H / (2. * focal))
+    o = torch.stack([sx * p[..., 0] / p[..., 2], sy * p[..., 1] / p[..., 2], 1. + 2. * near / p[..., 2]], -1)
+    d = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - p[..., 0] / p[..., 2]),
+                     sy * (rays_d[..., 1] / rays_d[..., 2] - p[..., 1] / p[..., 2]),
+                     -2. * near / p[..., 2]], -1)
+    return o, d
+
+
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=64,
-                N_importance=128, white_bkgd=True, dtype=torch.float32):
+                N_importance=128, white_bkgd=True, dtype=torch.float32, viewdirs=None, lindisp=False):
     """main.py:624-756 (render_rays) + main.py:148-157 (viewdirs), perturb=0, no noise."""
-    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    if viewdirs is None:
+        viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     n = rays_o.shape[0]
     near_t = near * torch.ones_like(rays_d[..., :1])
     far_t = far * torch.ones_like(rays_d[..., :1])
     t_vals = torch.linspace(0., 1., steps=N_samples)
-    z_vals = near_t * (1. - t_vals) + far_t * (t_vals)  # [n, N_samples] (main.py:673-682)
+    if not lindisp:
+        z_vals = near_t * (1. - t_vals) + far_t * (t_vals)  # [n, N_samples] (main.py:673-682)
+    else:
+        z_vals = 1. / (1. / near_t * (1. - t_vals) + 1. / far_t * (t_vals))
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
     raw0 = run_network(sd_coarse, pts, viewdirs, dtype=dtype)
     rgb0, disp0, acc0, weights0, depth0 = raw2outputs(raw0, z_vals, rays_d, white_bkgd)
@@ -356,16 +373,22 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=6
                 raw0=raw0, raw=raw, z_std=torch.std(z_samples, dim=-1, unbiased=False))
 
 
-def teacher_render(sd_coarse, sd_fine, H, W, focal, c2w, rows=None, chunk=4096, **kw):
-    """main.py:107-186 (render, c2w given, ndc=False, use_viewdirs=True) over a row range."""
+def teacher_render(sd_coarse, sd_fine, H, W, focal, c2w, rows=None, chunk=4096, ndc=False, **kw):
+    """main.py:107-186 (render, c2w given, use_viewdirs=True) over a row range; ndc=True projects the
+    rays with ndc_rays(H, W, focal, 1., ...) after the view directions were taken (main.py:148-162)."""
     rays_o, rays_d = get_rays(H, W, focal, c2w[:3, :4])
     if rows is not None:
         rays_o, rays_d = rays_o[rows[0]:rows[1]], rays_d[rows[0]:rows[1]]
     rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    vd = None
+    if ndc:
+        vd = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+        rays_o, rays_d = ndc_rays(H, W, focal, 1., rays_o, rays_d)
     outs = []
     with torch.no_grad():
         for s in range(0, rays_o.shape[0], chunk):
-            outs.append(render_rays(sd_coarse, sd_fine, rays_o[s:s + chunk], rays_d[s:s + chunk], **kw))
+            outs.append(render_rays(sd_coarse, sd_fine, rays_o[s:s + chunk], rays_d[s:s + chunk],
+                                    viewdirs=None if vd is None else vd[s:s + chunk], **kw))
     return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
 

@@ -45,6 +45,16 @@ if __name__ == '__main__':
         mse = RH.img2mse(a, b)
         out[f'mse_{i}'] = mse.numpy()
         out[f'psnr_{i}'] = RH.mse2psnr(mse).numpy() if float(mse) > 0 else np.array([np.inf], dtype=np.float32)
+    # ndc_rays (helpers:260-279) on forward-facing and awkward rays
+    ro = torch.randn(64, 3, generator=g) * 0.3
+    rd = torch.randn(64, 3, generator=g)
+    rd[:, 2] = -rd[:, 2].abs() - 0.2   # looking down -z like LLFF cameras
+    rd[0] = torch.tensor([0., 0., -1.])
+    ro[1] = torch.tensor([0., 0., 0.])
+    for (H_, W_, f_) in ((378, 504, 407.5657), (400, 400, 555.5555155968841)):
+        o2, d2 = RH.ndc_rays(H_, W_, f_, 1., ro, rd)
+        out[f'ndc_o_{H_}'], out[f'ndc_d_{H_}'] = o2.numpy(), d2.numpy()
+    out['ndc_in_o'], out['ndc_in_d'] = ro.numpy(), rd.numpy()
     np.savez_compressed(os.path.join(HERE, 'metrics.npz'), **out)
     print('metrics.npz', len(out), 'arrays', os.path.getsize(os.path.join(HERE, 'metrics.npz')) // 1024, 'KiB')
     print({k: float(np.ravel(v)[0]) for k, v in out.items() if k.startswith(('ssim', 'psnr'))})

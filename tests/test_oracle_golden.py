@@ -152,3 +152,12 @@ def test_sample_pdf_adversarial(g_scan):
     merged = O.merge_z(O.coarse_z_vals(2., 6., 64, zs.shape[0]), zs)
     np.testing.assert_array_equal(merged.numpy(), g_scan['pdf_merged'])
     assert (merged[:, 1:] >= merged[:, :-1]).all()
+
+
+def test_oracle_ndc_rays_matches_reference(golden_dir):
+    """ndc_rays (helpers:260-279) restated in the oracle == the reference's outputs, bit for bit."""
+    g = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    ro, rd = torch.from_numpy(g['ndc_in_o']), torch.from_numpy(g['ndc_in_d'])
+    for H, W, f in ((378, 504, 407.5657), (400, 400, 555.5555155968841)):
+        o, d = O.ndc_rays(H, W, f, 1., ro, rd)
+        assert np.array_equal(o.numpy(), g[f'ndc_o_{H}']) and np.array_equal(d.numpy(), g[f'ndc_d_{H}'])

@@ -145,6 +145,50 @@ def test_render_frame_rows_vs_oracle(engine, g):
     assert rgb.shape == (2, 400, 3) and disp.shape == (2, 400) and torch.equal(rgb.view(-1, 3), out['rgb_map'])
 
 
+def test_ndc_rays_bit_exact(pkg, golden_dir):
+    """nerf_ndc_rays vs the reference's ndc_rays outputs (tests/golden/metrics.npz): non-square
+    LLFF-like intrinsics and the square Blender ones, bit for bit."""
+    from efficient_nerf_amd import ndc_rays
+    m = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    ro, rd = T(m['ndc_in_o']).cuda(), T(m['ndc_in_d']).cuda()
+    for H, W, f in ((378, 504, 407.5657), (400, 400, 555.5555155968841)):
+        o, d = ndc_rays(H, W, f, 1., ro, rd)
+        assert np.array_equal(o.cpu().numpy(), m[f'ndc_o_{H}']) and np.array_equal(d.cpu().numpy(), m[f'ndc_d_{H}'])
+    o2, d2 = ndc_rays(378, 504, 407.5657, 1., ro.view(8, 8, 3), rd.view(8, 8, 3))  # any leading shape
+    assert o2.shape == (8, 8, 3) and np.array_equal(o2.cpu().numpy().reshape(-1, 3), m['ndc_o_378'])
+
+
+def test_forward_facing_render_ndc_and_lindisp(pkg):
+    """render(..., ndc=True) (main.py:148-162): view directions from the world rays, sampling and
+    compositing along the projected rays, near/far = 0/1; non-square frame; and lindisp sampling
+    (main.py:679-680) on a bounded scene -- both against the CPU oracle."""
+    from efficient_nerf_amd import NeRFEngine, R2LError, render
+    t0, t1 = O.make_teacher_state(3), O.make_teacher_state(4)
+    H, W, focal = 12, 20, 18.0
+    c2w = torch.eye(4)[:3, :4].clone()
+    c2w[:, 3] = torch.tensor([0.1, -0.05, 0.3])
+    eng = NeRFEngine(H, W, focal, near=0., far=1., ndc=True).load_state_dicts(t0, t1)
+    out = eng.render(c2w)
+    ref = O.teacher_render(t0, t1, H, W, focal, c2w, near=0., far=1., ndc=True, white_bkgd=True)
+    for k in ('rgb_map', 'acc_map'):
+        err = close(out[k].cpu().numpy(), ref[k].numpy(), 1e-4)
+    dg, dw = out['disp_map'].cpu().numpy(), ref['disp_map'].numpy()
+    assert (np.abs(dg - dw) <= 1e-4 * np.abs(dw) + 1e-5).all()
+    print(f'ndc render rgb L_inf {err:.2e}')
+    rgb, disp, acc, _ = render(H, W, focal, c2w=c2w, ndc=True, engine=eng)
+    assert rgb.shape == (H, W, 3) and torch.equal(rgb.view(-1, 3), out['rgb_map'])
+    with pytest.raises(R2LError):
+        render(H, W, focal, c2w=c2w, ndc=False, engine=eng)  # engine was built for NDC
+    eng.close()
+    eng2 = NeRFEngine(16, 16, 20.0, near=2., far=6., lindisp=True).load_state_dicts(t0, t1)
+    c2 = O.pose_spherical(20., -30., 4.)
+    out2 = eng2.render(c2, rows=(6, 9))
+    ref2 = O.teacher_render(t0, t1, 16, 16, 20.0, c2, rows=(6, 9), lindisp=True, white_bkgd=True)
+    close(out2['rgb_map'].cpu().numpy(), ref2['rgb_map'].numpy(), 1e-4)
+    close(out2['z_vals'].cpu().numpy() if 'z_vals' in out2 else ref2['z_vals'].numpy(), ref2['z_vals'].numpy(), 2e-4)
+    eng2.close()
+
+
 def test_teacher_fp16_fp8_mode(pkg, g):
     """fp16 main pass + fp8 correction terms: raw network outputs and the composited maps stay
     inside the tolerances of the fp16x3 tests (1e-4 on rgb)."""
