@@ -195,12 +195,26 @@ def test_linearity_free_properties_full_size(engines, g):
     """Size-independent checks at the BASELINE 800x800 size: outputs in (0,1), finite,
     deterministic across launches, and PSNR vs the fp64-evaluated oracle on a strided
     subset within 0.01 dB of the fp32 reference's own PSNR."""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3
     eng = engines[800]
     c2w = T(g['poses'][3])
     a = eng.render(c2w)
     b = eng.render(c2w)
     assert torch.equal(a, b)
     assert torch.isfinite(a).all() and (a > 0).all() and (a < 1).all()
+    # the bench's default mode at the bench's size: deterministic, finite, and within the contract of
+    # the fp16x3 frame everywhere (640,000 rays), row ranges and pose batches agree bit for bit
+    eng.set_precision(PREC_FP16_FP8)
+    try:
+        m = eng.render(c2w)
+        assert torch.equal(m, eng.render(c2w)) and torch.isfinite(m).all()
+        assert (m - a).abs().max().item() <= 1e-4
+        part = eng.render(c2w, rows=(311, 517))
+        assert torch.equal(part, m.view(800, 800, 3)[311:517].reshape(-1, 3))
+        two = eng.render_batch(torch.stack([c2w, T(g['poses'][1])])[:, :3, :4].contiguous().cuda(), rows=(100, 200))
+        assert torch.equal(two[0], m.view(800, 800, 3)[100:200].reshape(-1, 3))
+    finally:
+        eng.set_precision(PREC_FP16X3)
 
 
 def test_mirror_model_call_chain(pkg, g, sd88):
