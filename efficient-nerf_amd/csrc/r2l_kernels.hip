@@ -1,11 +1,13 @@
 // R2L (neural light field) hot path for MI355X / gfx950, hand-written HIP.
 //
-//   r2l_resmlp_kernel<NP>  K1+K2+K3 fused: get_rays + 16-point sampling + sinusoidal
+//   r2l_resmlp_kernel<NP, MIX>
+//                          K1+K2+K3 fused: get_rays + 16-point sampling + sinusoidal
 //                          embedding + 88-layer width-256 residual MLP + sigmoid, one
 //                          persistent workgroup per CU, activations resident in registers,
 //                          weights streamed global -> LDS ring (LDS-DMA) -> MFMA A operand.
-//                          NP = 2: fp16 hi/lo split, 3 MFMA per k-step (fp32-grade result)
-//                          NP = 1: single fp16 pass.
+//                          <2, false>: fp16 hi/lo split, 3 MFMA per k-step (fp32-grade result)
+//                          <2, true> : fp16 hi pass + the two correction terms on the fp8 MFMA (body)
+//                          <1, false>: single fp16 pass.
 //   r2l_sample_embed_kernel / r2l_embed_kernel
 //                          stand-alone K1+K2 (PointSampler.sample_test,
 //                          PositionalEmbedder.__call__) for parity tests and the API mirror.
@@ -146,7 +148,7 @@ __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1,
 // One row tile (16 output features) of a body layer: 8 k-steps x 2 column tiles.  A
 // fragments are read one step ahead (the chunk's last step prefetches fragment 0 of the next
 // chunk, certified by this chunk's ring_mid).  The 8 accumulator values of the previous row
-// tile get their VALU epilogue interleaved, one per k-step.
+// tile get their VALU epilogue interleaved, one register pair every second k-step.
 template <int NP, bool SECOND, bool HAVE_PREV>
 __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
@@ -159,7 +161,7 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
 #pragma unroll
     for (int s = 0; s < R2L_KSTEPS; ++s) {
         const int f = upos * R2L_KSTEPS + s;
-        ring_step<NP>(R, f);  // f == 8: rendezvous; f >= 8: one refill piece per step
+        ring_step<NP>(R, f);  // f == 8: rendezvous + refill burst
         AFrag<NP> nxt = (f + 1 < R2L_FRAGS) ? read_frag<NP>(lane_base, f + 1) : read_frag<NP>(next_base, 0);
         acc[0] = mfma_step<NP>(R.pre, Bh[s][0], Bl[s][0], acc[0]);
         acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
