@@ -170,8 +170,9 @@ int nerf_create(nerf_ctx** out, int H, int W, double focal, float near_, float f
     if (multires != 10 || multires_views != 4)
         return r2l_set_error(R2L_EINVAL, "unsupported embedder multires=%d multires_views=%d (built for 10 / 4)",
                              multires, multires_views);
-    if (N_samples < 2 || N_samples > 64 || N_importance < 1 || N_samples + N_importance > 256)
-        return r2l_set_error(R2L_EINVAL, "unsupported sampling N_samples=%d N_importance=%d (need 2..64 coarse, total <= 256)",
+    // N_samples = 2 leaves sample_pdf a single bin and an empty cdf: the reference raises there too
+    if (N_samples < 3 || N_samples > 64 || N_importance < 1 || N_samples + N_importance > 256)
+        return r2l_set_error(R2L_EINVAL, "unsupported sampling N_samples=%d N_importance=%d (need 3..64 coarse, total <= 256)",
                              N_samples, N_importance);
     if (H <= 0 || W <= 0 || !(focal > 0)) return r2l_set_error(R2L_EINVAL, "bad geometry");
     if (!mode_ok(precision_mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", precision_mode);

@@ -638,7 +638,7 @@ hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_strid
 
 hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, int w_off,
                                   int n, int n_bins, const float* u, int N, float* samples, hipStream_t stream) {
-    if (n_bins < 2 || n_bins > 64) return hipErrorInvalidValue;
+    if (n_bins < 2 || n_bins > 64) return hipErrorInvalidValue;  // the reference's sample_pdf itself fails on a single bin
     hipLaunchKernelGGL(nerf_sample_pdf_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, bins, bins_stride, weights,
                        w_stride, w_off, n, n_bins, u, N, samples);
     return hipGetLastError();

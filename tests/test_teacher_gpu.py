@@ -189,6 +189,29 @@ def test_forward_facing_render_ndc_and_lindisp(pkg):
     eng2.close()
 
 
+@pytest.mark.parametrize('S0,NI', [(32, 40), (3, 1), (64, 192), (17, 50)])
+def test_other_sampling_sizes_vs_oracle(pkg, S0, NI):
+    """N_samples / N_importance other than the 64 / 128 of the configs (ragged lanes in the scan
+    kernels, the S = 256 maximum, the smallest 3 + 1; N_samples = 2 fails in the reference's own
+    sample_pdf and is rejected) against the CPU oracle."""
+    from efficient_nerf_amd import NeRFEngine, R2LError
+    with pytest.raises(R2LError):
+        NeRFEngine(8, 8, 10., N_samples=2, N_importance=4)
+    t0, t1 = O.make_teacher_state(5), O.make_teacher_state(6)
+    H = W = 12
+    focal = 14.0
+    eng = NeRFEngine(H, W, focal, N_samples=S0, N_importance=NI).load_state_dicts(t0, t1)
+    c2w = O.pose_spherical(-60., -20., 4.)
+    out = eng.render(c2w, rows=(3, 9), extras=True)
+    ref = O.teacher_render(t0, t1, H, W, focal, c2w, rows=(3, 9), N_samples=S0, N_importance=NI, white_bkgd=True)
+    e = close(out['rgb_map'].cpu().numpy(), ref['rgb_map'].numpy(), 1e-4)
+    close(out['acc_map'].cpu().numpy(), ref['acc_map'].numpy(), 1e-4)
+    assert out['z_vals'].shape == (6 * W, S0 + NI)
+    close(out['z_vals'].cpu().numpy(), ref['z_vals'].numpy(), 2e-4)
+    print(f'S0={S0} NI={NI}: rgb L_inf {e:.2e}')
+    eng.close()
+
+
 def test_teacher_fp16_fp8_mode(pkg, g):
     """fp16 main pass + fp8 correction terms: raw network outputs and the composited maps stay
     inside the tolerances of the fp16x3 tests (1e-4 on rgb)."""
