@@ -585,12 +585,16 @@ __global__ __launch_bounds__(256) void nerf_merge_kernel(const float* __restrict
 // ====================================================================================
 template <int NP, bool MIX>
 static hipError_t launch_mlp(const NerfMlpParams& p, int grid, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp_kernel<NP, MIX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
+    // the > 64 KiB dynamic-LDS opt-in is per device: a process may drive several GPUs
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp_kernel<NP, MIX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((nerf_mlp_kernel<NP, MIX>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
     return hipGetLastError();
