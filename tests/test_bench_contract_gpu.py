@@ -1,0 +1,34 @@
+"""GPU: bench.py prints exactly one JSON line carrying the driver's contract fields, the roofline
+and (at N = 1) the CPU baseline + parity objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_schema():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                        '--cpu-rays', '8000', '--no-teacher'], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'rays/s' and d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 640000 * 1e3 / d['ms_per_step']) <= 1e-6 * d['value']
+    rf = d['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12 and 0.05 < rf['frac'] < 1.0
+    assert abs(rf['achieved'] - 11789824 * 640000 / (rf['avg_kernel_ms'] * 1e-3) / 1e12) <= 1e-6 * rf['achieved']
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['unit'] == 'rays/s' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
+    assert d['parity']['within_tolerance'] and d['parity']['linf_vs_cpu_oracle'] <= 1e-4
