@@ -156,6 +156,21 @@ def main():
                                              % (n_cpu_rows * W, n_cpu_rows, t_cpu)}
             out['parity'] = {'linf_vs_cpu_oracle': err, 'psnr_vs_cpu_oracle_db': O.psnr(gpu, ref),
                              'rays_checked': n_cpu_rows * W, 'tolerance': 1e-4, 'within_tolerance': bool(err <= 1e-4)}
+        if world == 1 and args.precision != 'fp16x3':
+            # secondary, outside the timed region: the same frames in the hi/lo-split fp16 mode (fp32-grade result)
+            eng.set_precision(PRECISIONS['fp16x3'])
+            eng.render_batch(pose_dev[0], rows=(r0, r1), out=local)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s_ in range(5):
+                eng.render_batch(pose_dev[s_ % total_steps], rows=(r0, r1), out=local)
+            torch.cuda.synchronize()
+            dt3 = (time.perf_counter() - t1) / 5
+            alt = {'precision': 'fp16x3', 'value': H * W / dt3, 'unit': 'rays/s', 'ms_per_step': dt3 * 1e3}
+            if 'parity' in out:
+                alt['linf_vs_cpu_oracle'] = (eng.render(poses[0]).cpu()[:n_cpu_rows * W] - ref).abs().max().item()
+            out['alt_precision'] = alt
+            eng.set_precision(prec)
         if not args.no_teacher and world == 1:
             # secondary, outside the timed region: NeRF teacher coarse+fine (BASELINE config 3)
             from efficient_nerf_amd import NeRFEngine
