@@ -148,6 +148,39 @@ def test_render_fp16_fp8_mode(g, engines, pkg):
         e2.close()
 
 
+@pytest.mark.parametrize('kind', ['laplace', 'sparse', 'outlier'])
+def test_precision_modes_on_other_weight_distributions(pkg, kind):
+    """The contract-meeting modes on weights that do not look like nn.Linear's uniform init (heavy
+    Laplace tails; half the weights zero; 0.05 % of them 12x larger), full depth: the error budget
+    of fp16_fp8 (e4m3 weight residuals, e5m2 activations) must not depend on the distribution."""
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H = 32
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=21, netdepth=88)
+    gen = torch.Generator().manual_seed(5)
+    for k, w in list(sd.items()):
+        if not k.endswith('weight'):
+            continue
+        if kind == 'laplace':
+            u = torch.rand(w.shape, generator=gen) - 0.5
+            sd[k] = (-torch.sign(u) * torch.log1p(-2 * u.abs()) * w.std() / np.sqrt(2)).float()
+        elif kind == 'sparse':
+            sd[k] = w * (torch.rand(w.shape, generator=gen) < 0.5).float() * float(np.sqrt(2))
+        else:
+            w2 = w.clone()
+            w2.view(-1)[torch.randint(0, w.numel(), (max(1, w.numel() // 2000),), generator=gen)] *= 12.0
+            sd[k] = w2
+    c2w = O.pose_spherical(30., -30., 4.)
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    eng = R2LEngine(H, H, focal, n_block=43).load_state_dict(sd)
+    e3 = (eng.render(c2w).cpu() - ref).abs().max().item()
+    eng.set_precision(PREC_FP16_FP8)
+    e8 = (eng.render(c2w).cpu() - ref).abs().max().item()
+    eng.close()
+    print(f'{kind}: fp16x3 {e3:.2e}, fp16_fp8 {e8:.2e}')
+    assert e3 <= 5e-6 and e8 <= TOL_X3
+
+
 def test_row_ranges_batches_and_given_rays_agree(g, engines):
     """Row sharding (the multi-GPU split), device-resident pose batches and the given-rays
     entry point all reproduce the whole-frame render bit-for-bit."""
