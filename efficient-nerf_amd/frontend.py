@@ -319,10 +319,12 @@ def build_engine(args, hwf, ckpt):
     raise R2LError(f'model_name={args.model_name} is not a render path of this build')
 
 
-def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=print):
+def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=print, given_rays=None):
     """main.py:189-398 for the R2L and nerf branches: per-pose render, per-frame timing lines,
-    PSNR when GT is given.  Rows of each frame are sharded over the ranks of torch.distributed
-    (if initialised) and assembled with one all-gather."""
+    PSNR / SSIM when GT is given.  Rows of each frame are sharded over the ranks of
+    torch.distributed (if initialised) and assembled with one all-gather.  `given_rays` =
+    (all_rays_o, all_rays_d) [N, H*W, 3] replaces the camera rays (--given_render_path_rays,
+    main.py:207-230: the DONERF test path through PointSampler.sample_train)."""
     from . import dist as D
     import torch.distributed as tdist
     H, W, focal = hwf
@@ -331,13 +333,19 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     r0, r1 = D.row_shard(H, rank, world)
     from .metrics import ssim_hwc
     rgbs, psnrs, ssims = [], [], []
-    for i, c2w in enumerate(render_poses):
+    n_frames = len(given_rays[0]) if given_rays is not None else len(render_poses)
+    for i in range(n_frames):
         torch.cuda.synchronize()
         t0 = time.time()
-        if kind == 'R2L':
-            local = eng.render(c2w[:3, :4], rows=(r0, r1))
+        if given_rays is not None:
+            ro = given_rays[0][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+            rd = given_rays[1][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+            local = eng.render_rays(ro, rd)
+            local = local if kind == 'R2L' else local['rgb_map']
+        elif kind == 'R2L':
+            local = eng.render(render_poses[i][:3, :4], rows=(r0, r1))
         else:
-            local = eng.render(c2w[:3, :4], rows=(r0, r1))['rgb_map']
+            local = eng.render(render_poses[i][:3, :4], rows=(r0, r1))['rgb_map']
         rgb = D.gather_rows(local[None], H, W, world)[0].view(H, W, 3)
         torch.cuda.synchronize()
         if rank == 0:
@@ -377,6 +385,18 @@ def main(argv=None):
         poses, hwf, gt = load_test_set(args)
     else:
         poses, hwf = load_test_poses(args)
+    given = None
+    if args.given_render_path_rays:  # main.py:207-213
+        loaded = torch.load(args.given_render_path_rays, map_location='cpu')
+        given = (loaded['all_rays_o'].float(), loaded['all_rays_d'].float())
+        if 'gt_imgs' in loaded:
+            gt = loaded['gt_imgs'].float()
+        log(f'Use given render_path rays: "{args.given_render_path_rays}"')
+    if args.render_factor != 0:  # main.py:197-201: render downsampled, compare with the top-left crop
+        H_, W_, f_ = hwf
+        hwf = (int(H_ / args.render_factor), int(W_ / args.render_factor), f_ / args.render_factor)
+        if gt is not None:
+            gt = gt[:, :hwf[0], :hwf[1]]
     kind, eng = build_engine(args, hwf, ckpt)
     outdir = args.outdir or os.path.join(args.basedir, args.expname or 'render', 'gen_img')
     if rank == 0:
@@ -384,13 +404,13 @@ def main(argv=None):
     log('RENDER ONLY')
     t_ = time.time()
     with torch.no_grad():
-        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log)
+        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log, given_rays=given)
     dt = time.time() - t_
     if rank == 0:
         np.save(os.path.join(outdir, 'rgbs.npy'), rgbs.cpu().numpy())
         H, W, _ = hwf
-        log(f'Rendered {len(poses)} view(s) {H}x{W} on {world} GPU(s) in {dt:.2f}s '
-            f'({len(poses) * H * W / dt:.3e} rays/s incl. host I/O)')
+        log(f'Rendered {len(rgbs)} view(s) {H}x{W} on {world} GPU(s) in {dt:.2f}s '
+            f'({len(rgbs) * H * W / dt:.3e} rays/s incl. host I/O)')
         if 'test_psnr' in misc:
             log(f"[TEST] TestPSNR {misc['test_psnr']:.4f} TestPSNRv2 {misc['test_psnr_v2']:.4f} "
                 f"TestSSIM {misc['test_ssim']:.4f}")

@@ -77,6 +77,34 @@ def test_r2l_render_test_against_mounted_scene(pkg, tmp_path):
     assert rgbs.shape == (3, H, H, 3) and os.path.exists(os.path.join(out, '002_gt.png'))  # frames[::2]
 
 
+def test_given_render_path_rays_and_render_factor(pkg, tmp_path):
+    """--given_render_path_rays (main.py:207-230: rays from a .pt file through the sample_train
+    path) fed with the camera rays of two poses must reproduce the pose render; --render_factor 2
+    halves H, W and focal (main.py:197-201)."""
+    from efficient_nerf_amd import frontend as fe
+    sd = O.make_r2l_state(seed=9, netdepth=4)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    H = 32  # --H 64 with the config's half_res
+    focal = O.focal_from_angle(64) / 2.
+    poses = O.novel_poses(2)
+    ro, rd = zip(*[O.rays_from_dirs(O.camera_dirs(H, H, focal), c[:3, :4]) for c in poses])
+    rays = str(tmp_path / 'rays.pt')
+    torch.save({'all_rays_o': torch.stack([r.reshape(-1, 3) for r in ro]), 'all_rays_d': torch.stack([r.reshape(-1, 3) for r in rd])}, rays)
+    base = ['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256',
+            '--netdepth', '4', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck,
+            '--render_only', '--synthetic_poses', '2', '--H', '64']
+    run_main(base + ['--outdir', str(tmp_path / 'a')])
+    run_main(base + ['--outdir', str(tmp_path / 'b'), '--given_render_path_rays', rays])
+    a, b = np.load(tmp_path / 'a' / 'rgbs.npy'), np.load(tmp_path / 'b' / 'rgbs.npy')
+    assert a.shape == b.shape == (2, H, H, 3) and np.abs(a - b).max() <= 2e-6
+    run_main(base + ['--outdir', str(tmp_path / 'c'), '--render_factor', '2'])
+    c = np.load(tmp_path / 'c' / 'rgbs.npy')
+    assert c.shape == (2, H // 2, H // 2, 3)
+    ref = O.r2l_render(sd, H // 2, H // 2, focal / 2., poses[0]).view(H // 2, H // 2, 3).numpy()
+    assert np.abs(c[0] - ref).max() <= 1e-4
+
+
 def test_teacher_render_only_cli(pkg, tmp_path):
     from efficient_nerf_amd import frontend as fe
     t0, t1 = O.make_teacher_state(1), O.make_teacher_state(2)
