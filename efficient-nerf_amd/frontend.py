@@ -401,6 +401,21 @@ def main(argv=None):
     outdir = args.outdir or os.path.join(args.basedir, args.expname or 'render', 'gen_img')
     if rank == 0:
         os.makedirs(outdir, exist_ok=True)
+    if args.benchmark:  # main.py:1124-1133: timeit(100) of render_func(model, pose) on the first pose
+        if kind != 'R2L':
+            raise SystemExit('--benchmark times render_func, the R2L path (main.py:401-404)')
+        H, W, _ = hwf
+        pose = poses[0][:3, :4]
+        for _ in range(3):
+            eng.render(pose)
+        torch.cuda.synchronize()
+        t_ = time.time()
+        for _ in range(100):
+            eng.render(pose)
+        torch.cuda.synchronize()
+        dt = (time.time() - t_) / 100
+        log(f'render_func(model, pose): {dt * 1e3:.3f} ms per {H}x{W} frame over 100 runs ({H * W / dt:.3e} rays/s)')
+        return 0
     log('RENDER ONLY')
     t_ = time.time()
     with torch.no_grad():

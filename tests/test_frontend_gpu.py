@@ -98,6 +98,8 @@ def test_given_render_path_rays_and_render_factor(pkg, tmp_path):
     run_main(base + ['--outdir', str(tmp_path / 'b'), '--given_render_path_rays', rays])
     a, b = np.load(tmp_path / 'a' / 'rgbs.npy'), np.load(tmp_path / 'b' / 'rgbs.npy')
     assert a.shape == b.shape == (2, H, H, 3) and np.abs(a - b).max() <= 2e-6
+    log = run_main(base + ['--benchmark'])  # main.py:1124-1133
+    assert 'render_func(model, pose)' in log and 'rays/s' in log
     run_main(base + ['--outdir', str(tmp_path / 'c'), '--render_factor', '2'])
     c = np.load(tmp_path / 'c' / 'rgbs.npy')
     assert c.shape == (2, H // 2, H // 2, 3)
