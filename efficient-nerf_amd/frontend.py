@@ -220,9 +220,12 @@ def load_test_poses(args):
     if args.synthetic_poses <= 0 and os.path.exists(tf):
         with open(tf) as fp:
             meta = json.load(fp)
-        skip = 1 if args.testskip == 0 else args.testskip
-        frames = meta['frames'][::skip]
-        poses = torch.tensor(np.array([f['transform_matrix'] for f in frames]).astype(np.float32))
+        if args.render_test:
+            skip = 1 if args.testskip == 0 else args.testskip
+            frames = meta['frames'][::skip]
+            poses = torch.tensor(np.array([f['transform_matrix'] for f in frames]).astype(np.float32))
+        else:  # the video path: n_pose = 40 views on the -30 degree circle (load_blender.py:35, 91-93)
+            poses = torch.stack([pose_spherical(t, -30., 4.) for t in np.linspace(-180, 180, 40 + 1)[:-1]], 0)
         H = W = args.H or 800
         angle = float(meta['camera_angle_x'])
     else:
