@@ -130,9 +130,13 @@ def test_poses_and_intrinsics(fe, tmp_path):
     frames = [{'file_path': f'./test/r_{i}', 'transform_matrix': O.pose_spherical(10. * i, -30., 4.).tolist()} for i in range(10)]
     import json
     (d / 'transforms_test.json').write_text(json.dumps({'camera_angle_x': 0.6911112070083618, 'frames': frames}))
-    b = fe.parse_args(['--datadir', str(d), '--testskip', '4', '--dataset_type', 'blender'])
+    b = fe.parse_args(['--datadir', str(d), '--testskip', '4', '--dataset_type', 'blender', '--render_test'])
     poses, (H, W, focal) = fe.load_test_poses(b)
     assert poses.shape == (3, 4, 4) and (H, W) == (800, 800) and abs(focal - 1111.1110311937682) < 1e-6
+    # without --render_test: the video path, 40 views on the -30 degree circle (load_blender.py:35, 91-93)
+    v = fe.parse_args(['--datadir', str(d), '--dataset_type', 'blender'])
+    vposes, hwf = fe.load_test_poses(v)
+    assert vposes.shape == (40, 4, 4) and hwf[:2] == (800, 800) and torch.equal(vposes, O.novel_poses(40))
 
 
 def test_png_writer(fe, tmp_path):
