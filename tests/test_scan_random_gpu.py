@@ -1,0 +1,66 @@
+"""GPU: randomised shapes and values for the scan kernels (raw2outputs, sample_pdf, merge)
+against the CPU oracle -- every S from the ragged 1-per-lane to the 256 maximum, ray counts that
+do not fill a workgroup, repeated / extreme values.  Seeds are fixed; the cases are drawn with
+numpy so the file needs nothing beyond the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def cases(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 40)), int(rng.integers(2, 257)), int(rng.integers(0, 2 ** 31))) for _ in range(n_cases)]
+
+
+@pytest.mark.parametrize('n,S,seed', cases(14, 1) + [(1, 2, 5), (5, 256, 6), (4, 64, 7), (3, 65, 8), (7, 128, 9), (2, 129, 10)])
+def test_raw2outputs_random(pkg, n, S, seed):
+    from efficient_nerf_amd import raw2outputs
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.randn(n, S, 4, generator=g) * float(torch.rand(1, generator=g) * 6 + 0.2)
+    if seed % 3 == 0:
+        raw[..., 3] = raw[..., 3].abs() * 50.  # dense: transmittance underflows quickly
+    z = torch.sort(2. + 4. * torch.rand(n, S, generator=g), -1)[0]
+    if seed % 4 == 1 and S > 3:
+        z[:, S // 2] = z[:, S // 2 - 1]  # a zero-length interval
+    rd = torch.randn(n, 3, generator=g)
+    for white in (False, True):
+        got = raw2outputs(raw.cuda(), z.cuda(), rd.cuda(), 0, white)
+        want = O.raw2outputs(raw, z, rd, white)
+        for name, a, b in zip(['rgb', 'disp', 'acc', 'weights', 'depth'], got, want):
+            a, b = a.cpu().numpy(), b.numpy()
+            assert a.shape == b.shape and (np.isnan(a) == np.isnan(b)).all(), name
+            m = ~np.isnan(b)
+            if name == 'disp':
+                assert (np.abs(a[m] - b[m]) <= 2e-5 * np.abs(b[m]) + 1e-6).all(), (name, n, S)
+            else:
+                assert np.abs(a[m] - b[m]).max(initial=0.) <= 4e-6 * max(1.0, np.abs(b[m]).max(initial=0.)), (name, n, S)
+
+
+@pytest.mark.parametrize('n,nb,N,seed', [(3, 63, 128, 1), (1, 2, 1, 2), (9, 17, 50, 3), (5, 64, 192, 4), (2, 33, 7, 5),
+                                         (6, 5, 64, 6), (4, 40, 255, 7)])
+def test_sample_pdf_and_merge_random(pkg, n, nb, N, seed):
+    from efficient_nerf_amd import merge_sorted, sample_pdf
+    g = torch.Generator().manual_seed(seed)
+    bins = torch.sort(2. + 4. * torch.rand(n, nb, generator=g), -1)[0]
+    w = torch.rand(n, nb - 1, generator=g) ** (seed % 4 + 1)
+    if seed % 2 == 0 and nb > 4:
+        w[:, 1:3] = 0.
+    zs = sample_pdf(bins.cuda(), w.cuda(), N, det=True)
+    want = O.sample_pdf(bins, w, N)
+    got = zs.cpu()
+    assert got.shape == want.shape == (n, N)
+    err = (got - want).abs()
+    binw = float((bins[:, 1:] - bins[:, :-1]).max()) if nb > 1 else 0.
+    # continuous except across the reference's `denom < 1e-5 -> 1` rule (see test_teacher_gpu)
+    assert float((err <= 2e-5).float().mean()) >= 0.98 and float(err.max()) <= binw * 1.001 + 1e-6
+    assert bool((got[:, 1:] - got[:, :-1] >= -1e-6).all())
+    # merge of two ascending rows == sort of the concatenation, bit for bit, for any lengths <= 256
+    na = min(256 - N, nb) if N < 256 else 0
+    if na > 0:
+        a = bins[:, :na].contiguous()
+        m = merge_sorted(a.cuda(), want.cuda())
+        assert torch.equal(m.cpu(), torch.sort(torch.cat([a, want], -1), -1)[0])
