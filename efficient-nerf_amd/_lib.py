@@ -4,8 +4,10 @@ import os
 
 PREC_FP16X3 = 0
 PREC_FP16X1 = 1
-PREC_FP16_FP8 = 2  # fp16 main pass + fp8 correction terms (2 pass-equivalents)
-PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8}
+PREC_FP16_FP8 = 2  # fp16 main pass + fp8 correction terms (2 pass-equivalents); hand-scheduled body kernel
+PREC_FP16_FP8_FUSED = 3  # the same arithmetic in the single compiler-scheduled kernel (A/B measurements)
+PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8,
+              'fp16_fp8_fused': PREC_FP16_FP8_FUSED}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('R2L_LIB_PATH', os.path.join(_HERE, 'libr2l_hip.so'))  # override: ablation builds (tools/)
@@ -33,7 +35,11 @@ SIGNATURES = {
     'r2l_sample_embed': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     'r2l_embed': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'r2l_debug_pack_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_longlong]),
+    'r2l_debug_pack_body_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, _vp, C.c_longlong,
+                                                C.POINTER(C.c_longlong)]),
+    'r2l_debug_body': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     'r2l_flops_per_ray': (C.c_longlong, [_vp]),
+    'r2l_kernel_flops_per_ray': (C.c_longlong, [_vp]),
     'r2l_weight_image_bytes': (C.c_longlong, [_vp]),
     'r2l_rays_per_tile': (C.c_int, [_vp]),
     'r2l_timing_enable': (C.c_int, [_vp, C.c_int]),

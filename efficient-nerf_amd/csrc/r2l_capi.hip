@@ -130,8 +130,13 @@ struct r2l_ctx {
     int n_cu;
     bool loaded;
     std::vector<std::vector<float>> host_w;  // state_dict order
-    char* d_img[3];                           // [mode] packed image
-    size_t img_bytes[3];
+    char* d_img[4];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
+    size_t img_bytes[4];
+    char* d_body;                             // FP16_FP8: body stream v3 (r2l_body.hip) | aux blocks | tail
+    size_t body_bytes, aux_off, tail_off;
+    float* d_xa;                              // FP16_FP8: head output / body output of one launch slice
+    float* d_xb;
+    int x_tiles;                              // capacity of d_xa / d_xb in ray tiles
     float* d_scratch;
     float* d_z;  // device copy of z
     bool timing;
@@ -140,7 +145,9 @@ struct r2l_ctx {
 };
 
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
-static bool mode_ok(int mode) { return mode == R2L_PREC_FP16X3 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16_FP8; }
+static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_FP8_FUSED; }
+#define R2L_N_MODES 4
+#define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head/body/tail launch triple (1 KiB of x per ray, twice)
 
 int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far_, int n_sample, int L,
                int width, int n_block, int use_residual, int precision_mode) {
@@ -169,8 +176,14 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
     c->act_scale = 16.0f;
     c->n_cu = n_cu;
     c->loaded = false;
-    c->d_img[0] = c->d_img[1] = c->d_img[2] = nullptr;
-    c->img_bytes[0] = c->img_bytes[1] = c->img_bytes[2] = 0;
+    for (int m = 0; m < R2L_N_MODES; ++m) {
+        c->d_img[m] = nullptr;
+        c->img_bytes[m] = 0;
+    }
+    c->d_body = nullptr;
+    c->body_bytes = c->aux_off = c->tail_off = 0;
+    c->d_xa = c->d_xb = nullptr;
+    c->x_tiles = 0;
     c->d_scratch = nullptr;
     c->d_z = nullptr;
     c->timing = false;
@@ -194,8 +207,11 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
 
 void r2l_destroy(r2l_ctx* c) {
     if (!c) return;
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < R2L_N_MODES; ++m)
         if (c->d_img[m]) (void)hipFree(c->d_img[m]);
+    if (c->d_body) (void)hipFree(c->d_body);
+    if (c->d_xa) (void)hipFree(c->d_xa);
+    if (c->d_xb) (void)hipFree(c->d_xb);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_z) (void)hipFree(c->d_z);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -215,10 +231,30 @@ static void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
 }
 
 static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img);
+static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
 
 static int build_image(r2l_ctx* c, int mode) {
     std::vector<char> img;
-    pack_image_host(c, mode, img);
+    if (mode == R2L_PREC_FP16_FP8) {
+        // head launch: the 32 head chunks of the hi|lo image; body + tail: the v3 stream
+        std::vector<char> full;
+        pack_image_host(c, R2L_PREC_FP16X3, full);
+        img.assign(full.begin(), full.begin() + (size_t)R2L_HEAD_CHUNKS * r2l_chunk_bytes(2));
+        std::vector<char> body;
+        int rc = pack_body_v3(c, body, &c->aux_off, &c->tail_off);
+        if (rc) return rc;
+        if (c->d_body) {
+            (void)hipFree(c->d_body);
+            c->d_body = nullptr;
+        }
+        hipError_t eb = hipMalloc((void**)&c->d_body, body.size());
+        if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc body stream: %s", hipGetErrorString(eb));
+        eb = hipMemcpy(c->d_body, body.data(), body.size(), hipMemcpyHostToDevice);
+        if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy body stream: %s", hipGetErrorString(eb));
+        c->body_bytes = body.size();
+    } else {
+        pack_image_host(c, mode, img);
+    }
     if (c->d_img[mode]) {
         (void)hipFree(c->d_img[mode]);
         c->d_img[mode] = nullptr;
@@ -232,7 +268,8 @@ static int build_image(r2l_ctx* c, int mode) {
 }
 
 // host-only: the packed chunk stream of r2l_common.h (no GPU needed; also behind r2l_debug_pack_host)
-static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) {
+static void pack_image_host(const r2l_ctx* c, int mode_in, std::vector<char>& img) {
+    const int mode = mode_in == R2L_PREC_FP16_FP8_FUSED ? R2L_PREC_FP16_FP8 : mode_in;  // the fused kernel's image
     const int np = np_of(mode);
     const int CH = r2l_chunk_bytes(np);
     const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
@@ -313,6 +350,100 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
     }
 }
 
+// ---- FP16_FP8 body stream v3 (gen/body_gen.py pack_body_image is the Python restatement) ---------------
+// Per ResMLP block: 16 chunks of 32 KiB (layer 1: 8, layer 2: 8); chunk m = row tiles 2m, 2m+1; 32 pieces of
+// 1 KiB (64 lanes x 16 B): piece upos*8 + s = fp16 hi fragment of k-step s (UNSCALED weights);
+// piece 16 + upos*8 + 2j + half = 16 B/lane of the e4m3 operand j of the row tile, j = (term, t) in the order
+// (0,0) (1,0) (0,1) (1,1): term 0 = (w - hi(w)) * 2^(20-e), term 1 = w * 2^(8-e), e = exponent of the layer's
+// max|w|.  The E8M0 scales that undo the shifts travel in the aux block: 4 KiB per block = 256 f32 bias of
+// layer 1 (act_scale domain, with the layer-2 biases of all earlier blocks folded in: x~_i = x_i - sum_{j<i} b2_j)
+// | per lane quarter (swl1, sw1, swl2, sw2) | pad.  Tail: [3,256] W_t / act_scale, then b_t + W_t sum_j b2_j.
+static int layer_exponent(const float* w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        const float a = fabsf(w[i]);
+        if (a > m && isfinite(a)) m = a;
+    }
+    if (m == 0.f) return -4;
+    int e;
+    frexpf(m, &e);
+    return e;
+}
+
+static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_off, size_t* tail_off) {
+    const int nb = c->n_block;
+    const size_t CH = 32768, AUXB = 4096;
+    const size_t stream = (size_t)nb * 16 * CH;
+    *aux_off = stream;
+    *tail_off = stream + (size_t)nb * AUXB;
+    out.assign(*tail_off + (3 * 256 + 4) * sizeof(float), 0);
+    std::vector<double> Bsum(256, 0.0);
+    const float Sa = c->act_scale;
+    for (int b = 0; b < nb; ++b) {
+        const float* W[2] = {c->host_w[2 + 4 * b].data(), c->host_w[4 + 4 * b].data()};
+        const float* b1 = c->host_w[3 + 4 * b].data();
+        const float* b2 = c->host_w[5 + 4 * b].data();
+        uint32_t* aux = reinterpret_cast<uint32_t*>(out.data() + *aux_off + (size_t)b * AUXB);
+        for (int n = 0; n < 256; ++n) {
+            double acc = b1[n];
+            for (int k = 0; k < 256; ++k) acc += (double)W[0][(size_t)n * 256 + k] * Bsum[k];
+            const float v = (float)(acc * Sa);
+            memcpy(&aux[n], &v, 4);
+        }
+        for (int layer = 0; layer < 2; ++layer) {
+            const float* Wl = W[layer];
+            const int e = layer_exponent(Wl, 65536);
+            if (e < -12 || e > 6)
+                return r2l_set_error(R2L_EINVAL, "body block %d layer %d: max|w| = 2^%d is outside the range the fp16 + e4m3 "
+                                     "weight split covers (2^-12 .. 2^6); use R2L_PREC_FP16X3", b, layer, e);
+            const uint32_t bwl = 0x01010101u * (uint32_t)(127 - (20 - e)), bw = 0x01010101u * (uint32_t)(127 - (8 - e));
+            for (int q = 0; q < 4; ++q) {
+                aux[256 + 4 * q + 2 * layer] = bwl;
+                aux[256 + 4 * q + 2 * layer + 1] = bw;
+            }
+            for (int m = 0; m < 8; ++m) {
+                char* chunk = out.data() + ((size_t)(b * 2 + layer) * 8 + m) * CH;
+                for (int upos = 0; upos < 2; ++upos) {
+                    const int u = 2 * m + upos;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int q = lane >> 4;
+                        const float* row = Wl + (size_t)(16 * u + (lane & 15)) * 256;
+                        for (int s = 0; s < 8; ++s) {
+                            _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(upos * 8 + s) * 1024 + lane * 16);
+                            for (int j = 0; j < 8; ++j) ph[j] = (_Float16)row[r2l_kappa(s, q, j)];
+                        }
+                        for (int j = 0; j < 4; ++j) {
+                            const int term = j & 1, t = j >> 1;
+                            for (int el = 0; el < 32; ++el) {
+                                const float w = row[r2l_mix_feat(t, q, el)];
+                                const float hi = (float)(_Float16)w;
+                                const float v = term == 0 ? ldexpf(w - hi, 20 - e) : ldexpf(w, 8 - e);
+                                unsigned char* pb = reinterpret_cast<unsigned char*>(
+                                    chunk + (size_t)(16 + upos * 8 + 2 * j + (el >> 4)) * 1024 + lane * 16);
+                                pb[el & 15] = r2l_f32_to_e4m3(v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        for (int k = 0; k < 256; ++k) Bsum[k] += b2[k];
+    }
+    const int ti = 2 + 4 * nb;
+    const float* Wt = c->host_w[ti].data();
+    const float* bt = c->host_w[ti + 1].data();
+    float* tw = reinterpret_cast<float*>(out.data() + *tail_off);
+    for (int r = 0; r < 3; ++r) {
+        double acc = bt[r];
+        for (int k = 0; k < 256; ++k) {
+            tw[r * 256 + k] = Wt[(size_t)r * 256 + k] / Sa;
+            acc += (double)Wt[(size_t)r * 256 + k] * Bsum[k];
+        }
+        tw[768 + r] = (float)acc;
+    }
+    return R2L_OK;
+}
+
 int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
     if (!c || !tensors) return r2l_set_error(R2L_EINVAL, "NULL argument");
     const int expect = 4 + 4 * c->n_block;
@@ -330,7 +461,7 @@ int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
         if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
         c->host_w.emplace_back(tensors[i], tensors[i] + n);
     }
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < R2L_N_MODES; ++m)
         if (c->d_img[m]) {
             (void)hipFree(c->d_img[m]);
             c->d_img[m] = nullptr;
@@ -363,6 +494,53 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
     pack_image_host(&c, precision_mode, img);
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
+}
+
+// Host-only: the FP16_FP8 body stream (chunks | aux blocks | tail) of pack_body_v3, for the CPU tests that run
+// gen/body_gen.py's emulator on exactly the bytes the GPU streams.  offs[0] = aux offset, offs[1] = tail offset.
+long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, int n_block, char* out, long long cap,
+                                   long long* offs) {
+    if (!tensors || n_tensors != 4 + 4 * n_block || n_block < 0) return r2l_set_error(R2L_EINVAL, "bad tensor list");
+    r2l_ctx c;
+    c.n_block = n_block;
+    c.act_scale = 16.0f;
+    for (int i = 0; i < n_tensors; ++i) {
+        size_t n;
+        if (i == 0) n = (size_t)R2L_WIDTH * R2L_IN;
+        else if (i == 1) n = R2L_WIDTH;
+        else if (i == n_tensors - 2) n = 3 * R2L_WIDTH;
+        else if (i == n_tensors - 1) n = 3;
+        else n = ((i - 2) % 2 == 0) ? (size_t)R2L_WIDTH * R2L_WIDTH : R2L_WIDTH;
+        c.host_w.emplace_back(tensors[i], tensors[i] + n);
+    }
+    std::vector<char> img;
+    size_t aux_off = 0, tail_off = 0;
+    int rc = pack_body_v3(&c, img, &aux_off, &tail_off);
+    if (rc) return rc;
+    if (offs) {
+        offs[0] = (long long)aux_off;
+        offs[1] = (long long)tail_off;
+    }
+    if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
+    return (long long)img.size();
+}
+
+// The hand-scheduled body alone: x_out = body(x_in) on n_tiles ray tiles in the register-image layout
+// [tile][wave 4][u*2+c 32][lane 64][4] f32 (act_scale domain, layer-2 biases folded: see pack_body_v3).
+int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_tiles, void* stream) {
+    if (!c || !x_in_dev || !x_out_dev || n_tiles < 1) return r2l_set_error(R2L_EINVAL, "bad argument to r2l_debug_body");
+    if (!c->loaded || c->mode != R2L_PREC_FP16_FP8 || c->n_block < 1)
+        return r2l_set_error(R2L_ESTATE, "r2l_debug_body needs loaded weights, R2L_PREC_FP16_FP8 and n_block >= 1");
+    R2LBodyParams pb;
+    pb.wimg = c->d_body;
+    pb.aux = c->d_body + c->aux_off;
+    pb.xin = x_in_dev;
+    pb.xout = x_out_dev;
+    pb.n_tiles = n_tiles;
+    pb.n_block = c->n_block;
+    hipError_t e = r2l_launch_body(pb, n_tiles < c->n_cu ? n_tiles : c->n_cu, (hipStream_t)stream);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
+    return R2L_OK;
 }
 
 int r2l_set_precision(r2l_ctx* c, int mode) {
@@ -398,21 +576,94 @@ static void fill_common(const r2l_ctx* c, R2LParams& p) {
     p.scratch = c->d_scratch;
 }
 
+static int timing_events(r2l_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+    if (c->ev_used + 2 > (int)c->ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            hipError_t er = hipEventCreate(&e);
+            if (er != hipSuccess) return r2l_set_error(R2L_EHIP, "hipEventCreate: %s", hipGetErrorString(er));
+            c->ev.push_back(e);
+        }
+    }
+    *e0 = c->ev[c->ev_used];
+    *e1 = c->ev[c->ev_used + 1];
+    c->ev_used += 2;
+    return R2L_OK;
+}
+
+// FP16_FP8: head launch -> hand-scheduled body launch -> tail launch per slice of <= R2L_SLICE_TILES ray tiles;
+// the slices reuse two library-owned x buffers (1 KiB per ray each), stream-ordered.  The timing events bracket
+// the body launch (the dominant kernel).
+static int ensure_x(r2l_ctx* c, int tiles) {
+    if (tiles <= c->x_tiles) return R2L_OK;
+    if (c->d_xa) (void)hipFree(c->d_xa);
+    if (c->d_xb) (void)hipFree(c->d_xb);
+    c->d_xa = c->d_xb = nullptr;
+    c->x_tiles = 0;
+    const size_t bytes = (size_t)tiles * R2L_TILE_RAYS * R2L_WIDTH * sizeof(float);
+    hipError_t e = hipMalloc((void**)&c->d_xa, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_xb, bytes);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc x buffers (%zu B each): %s", bytes, hipGetErrorString(e));
+    c->x_tiles = tiles;
+    return R2L_OK;
+}
+
+static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
+    const int slice = p.n_tiles < R2L_SLICE_TILES ? p.n_tiles : R2L_SLICE_TILES;
+    int rc = ensure_x(c, slice);
+    if (rc) return rc;
+    for (int t0 = 0; t0 < p.n_tiles; t0 += R2L_SLICE_TILES) {
+        const int nt = p.n_tiles - t0 < R2L_SLICE_TILES ? p.n_tiles - t0 : R2L_SLICE_TILES;
+        const int grid = nt < c->n_cu ? nt : c->n_cu;
+        R2LParams ph = p;
+        ph.wimg = c->d_img[R2L_PREC_FP16_FP8];
+        ph.chunks_per_tile = R2L_HEAD_CHUNKS;
+        ph.xbuf = c->d_xa;
+        ph.tile_begin = t0;
+        ph.n_tiles = nt;
+        hipError_t e = r2l_launch_head(ph, grid, s);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
+        const float* body_out = c->d_xa;
+        if (c->n_block > 0) {
+            R2LBodyParams pb;
+            pb.wimg = c->d_body;
+            pb.aux = c->d_body + c->aux_off;
+            pb.xin = c->d_xa;
+            pb.xout = c->d_xb;
+            pb.n_tiles = nt;
+            pb.n_block = c->n_block;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->timing) {
+                rc = timing_events(c, &e0, &e1);
+                if (rc) return rc;
+                (void)hipEventRecord(e0, s);
+            }
+            e = r2l_launch_body(pb, grid, s);
+            if (c->timing) (void)hipEventRecord(e1, s);
+            if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
+            body_out = c->d_xb;
+        }
+        R2LTailParams pt;
+        pt.xa = c->use_residual ? c->d_xa : nullptr;
+        pt.xb = body_out;
+        pt.wt = reinterpret_cast<const float*>(c->d_body + c->tail_off);
+        pt.rgb = p.rgb;
+        pt.n_tiles = nt;
+        pt.tile_begin = t0;
+        pt.n_rays = p.n_rays;
+        e = r2l_launch_tail(pt, s);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l tail launch: %s", hipGetErrorString(e));
+    }
+    return R2L_OK;
+}
+
 static int timed_launch(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
+    if (c->mode == R2L_PREC_FP16_FP8) return launch_split(c, p, s);
     const int grid = p.n_tiles < c->n_cu ? p.n_tiles : c->n_cu;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
-        if (c->ev_used + 2 > (int)c->ev.size()) {
-            for (int i = 0; i < 2; ++i) {
-                hipEvent_t e;
-                hipError_t er = hipEventCreate(&e);
-                if (er != hipSuccess) return r2l_set_error(R2L_EHIP, "hipEventCreate: %s", hipGetErrorString(er));
-                c->ev.push_back(e);
-            }
-        }
-        e0 = c->ev[c->ev_used];
-        e1 = c->ev[c->ev_used + 1];
-        c->ev_used += 2;
+        int rc = timing_events(c, &e0, &e1);
+        if (rc) return rc;
         (void)hipEventRecord(e0, s);
     }
     hipError_t e = r2l_launch_resmlp(p, c->mode, grid, s);
@@ -494,7 +745,15 @@ long long r2l_flops_per_ray(const r2l_ctx* c) {
     if (!c) return 0;
     return 2LL * ((long long)R2L_IN * R2L_WIDTH + 2LL * c->n_block * R2L_WIDTH * R2L_WIDTH + R2L_WIDTH * 3);
 }
-long long r2l_weight_image_bytes(const r2l_ctx* c) { return c ? (long long)c->img_bytes[c->mode] : 0; }
+long long r2l_kernel_flops_per_ray(const r2l_ctx* c) {
+    if (!c) return 0;
+    if (c->mode == R2L_PREC_FP16_FP8) return 2LL * 2LL * c->n_block * R2L_WIDTH * R2L_WIDTH;  // r2l_body_kernel
+    return r2l_flops_per_ray(c);
+}
+long long r2l_weight_image_bytes(const r2l_ctx* c) {
+    if (!c) return 0;
+    return (long long)c->img_bytes[c->mode] + (c->mode == R2L_PREC_FP16_FP8 ? (long long)c->body_bytes : 0);
+}
 int r2l_rays_per_tile(const r2l_ctx*) { return R2L_TILE_RAYS; }
 
 int r2l_timing_enable(r2l_ctx* c, int on) {

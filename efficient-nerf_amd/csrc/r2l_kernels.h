@@ -9,6 +9,8 @@ struct R2LParams {
     const float* rays_o;   // device [n_rays, 3] or nullptr (then camera rays)
     const float* rays_d;
     float* scratch;        // [grid, 4 waves, 32, 64 lanes, 4] f32: head output kept for the global skip
+    float* xbuf;           // head-only launch: [n_tiles, 4 waves, 32, 64 lanes, 4] f32 head output
+    int tile_begin;        // first ray tile of this launch within the call (ray index = (tile_begin + tile) * 128 + ...)
     float c2w_host[12];
     const float* z;        // device [16]: PointSampler.z_vals (model/nerf_raybased.py:88-90); a pointer, not an
                            // array: dynamic indexing into a by-value kernarg array spills the struct to scratch
@@ -18,6 +20,26 @@ struct R2LParams {
 };
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*
+hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream);              // head layer -> p.xbuf
+
+// hand-scheduled body (r2l_body.hip): x <- ResMLP blocks(x) on the register image written by the head launch
+struct R2LBodyParams {
+    const char* wimg;   // body stream v3: n_block * 16 chunks of 32 KiB
+    const char* aux;    // n_block aux blocks of 4 KiB (bias of layer 1 | E8M0 scales)
+    const float* xin;   // [n_tiles, 4, 32, 64, 4] f32
+    float* xout;
+    int n_tiles, n_block;
+};
+struct R2LTailParams {
+    const float* xa;    // head output (global skip), may be nullptr
+    const float* xb;    // body output (or head output when n_block == 0)
+    const float* wt;    // [3, 256] tail weight / act_scale, then 3 folded biases
+    float* rgb;         // [n_rays, 3]
+    int n_tiles, tile_begin, n_rays;
+};
+hipError_t r2l_launch_body(const R2LBodyParams& p, int grid, hipStream_t stream);
+hipError_t r2l_launch_tail(const R2LTailParams& p, hipStream_t stream);
+int r2l_body_lds_bytes();
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,
                                    hipStream_t stream);
 hipError_t r2l_launch_embed(const float* x, long long total, int L, float* emb_out,

@@ -324,9 +324,12 @@ __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d)
     return (q & 2) ? ((q & 1) ? d : c) : ((q & 1) ? b : a);
 }
 
-template <int NP, bool MIX>
+// HEAD_ONLY: stop after the head layer and leave relu(head) (act_scale domain, register image
+// [tile][wave][u*2+c][lane][4] f32) in p.xbuf for r2l_body_kernel / r2l_tail_kernel (r2l_body.hip).
+template <int NP, bool MIX, bool HEAD_ONLY = false>
 __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     static_assert(!MIX || NP == 2, "FP16_FP8 uses the two-part chunk");
+    static_assert(!HEAD_ONLY || !MIX, "the head runs in the fp16 hi/lo layout");
     typedef KCfg<NP> C;
     Ring<NP> R;
     R.wimg = p.wimg;
@@ -355,13 +358,13 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     i32x8 Ba[2][2], Br[2][2], Na[2][2], Nr[2][2];   // MIX: e5m2 activations / activation residuals, K-step x column tile
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        // a lane serves ray (lane & 15) of both column tiles
+        // a lane serves ray (lane & 15) of both column tiles (p.tile_begin: this launch is a slice of the call)
         Ray6 rr[2];
         int ray[2];
         bool valid[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int ray_raw = tile * R2L_TILE_RAYS + R.wave * R2L_RAYS_PER_WAVE + c * 16 + (lane & 15);
+            const int ray_raw = (p.tile_begin + tile) * R2L_TILE_RAYS + R.wave * R2L_RAYS_PER_WAVE + c * 16 + (lane & 15);
             valid[c] = ray_raw < p.n_rays;
             ray[c] = valid[c] ? ray_raw : p.n_rays - 1;
             rr[c] = make_ray(p, ray[c]);
@@ -476,7 +479,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
         }
 
         // head epilogue: h0 = relu(acc/scale) (scaled domain); keep a copy for the global skip
-        float* scr = p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
+        float* scr = HEAD_ONLY ? p.xbuf + ((size_t)(tile * R2L_WAVES + R.wave) * 32) * 256 + lane * 4
+                               : p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
 #pragma unroll
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(x[u][c][r] * inv_head, 0.0f);
                     x[u][c][r] = v;
-                    if (!MIX) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
+                    if (!MIX && !HEAD_ONLY) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
                 if (MIX) {  // x[u][c] already holds relu(.) in the scaled domain: split it (inv = 1, no relu needed)
                     set_dword(Bh[u >> 1][c], 2 * (u & 1), 0u);
@@ -494,9 +498,10 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                     set_dword(Bl[u >> 1][c], 2 * (u & 1) + 1, 0u);
                     epi_tile_mix<true>(x[u][c], 1.0f, neg1, Bh[u >> 1][c], Bl[u >> 1][c], Ba[u >> 3][c], Br[u >> 3][c], u);
                 }
-                if (p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
+                if (HEAD_ONLY || p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
             }
         }
+        if constexpr (HEAD_ONLY) continue;
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
@@ -592,8 +597,23 @@ static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream
     return hipGetLastError();
 }
 
+hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<2, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<2>::LDS);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((r2l_resmlp_kernel<2, false, true>), dim3(grid), dim3(256), KCfg<2>::LDS, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream) {
-    if (mode == R2L_PREC_FP16_FP8) return launch_resmlp<2, true>(p, grid, stream);
+    if (mode == R2L_PREC_FP16_FP8_FUSED) return launch_resmlp<2, true>(p, grid, stream);
     return mode == R2L_PREC_FP16X3 ? launch_resmlp<2, false>(p, grid, stream) : launch_resmlp<1, false>(p, grid, stream);
 }
 

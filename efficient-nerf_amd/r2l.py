@@ -155,10 +155,25 @@ class R2LEngine:
                                          current_stream()))
         return pts, emb
 
+    def debug_body(self, x_in):
+        """The hand-scheduled body kernel alone (PREC_FP16_FP8): x_in [n_tiles, 4, 32, 64, 4] f32 device
+        tensor in the register-image layout -> body(x_in), same layout (parity tests)."""
+        if x_in.dim() != 5 or tuple(x_in.shape[1:]) != (4, 32, 64, 4):
+            raise R2LError(f'x_in must be [n_tiles,4,32,64,4]; got {tuple(x_in.shape)}')
+        out = torch.empty_like(x_in)
+        with torch.cuda.device(self.device):
+            check(lib().r2l_debug_body(self._ctx, dptr(x_in), dptr(out), x_in.shape[0], current_stream()))
+        return out
+
     # -- introspection --------------------------------------------------------------
     @property
     def flops_per_ray(self):
         return int(lib().r2l_flops_per_ray(self._ctx))
+
+    @property
+    def kernel_flops_per_ray(self):
+        """algorithmic flops per ray of the kernel the timing events bracket"""
+        return int(lib().r2l_kernel_flops_per_ray(self._ctx))
 
     @property
     def weight_image_bytes(self):

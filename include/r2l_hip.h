@@ -43,6 +43,8 @@ extern "C" {
 #define R2L_PREC_FP16X3 0
 #define R2L_PREC_FP16X1 1
 #define R2L_PREC_FP16_FP8 2
+/* the round-1 single-kernel form of FP16_FP8 (compiler-scheduled body); kept for A/B measurements */
+#define R2L_PREC_FP16_FP8_FUSED 3
 
 typedef struct r2l_ctx r2l_ctx;
 typedef struct nerf_ctx nerf_ctx;
@@ -112,8 +114,19 @@ int r2l_embed(const float* x_dev, int n, int dim, int L, float* emb_out_dev, voi
 long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_block,
                               int precision_mode, char* out, long long cap);
 
+/* Host-only: the R2L_PREC_FP16_FP8 body stream (32 KiB chunks | 4 KiB aux blocks | tail weights) that
+ * r2l_load_weights uploads for r2l_body_kernel; offs[0] / offs[1] receive the aux / tail byte offsets. */
+long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, int n_block,
+                                   char* out, long long cap, long long* offs);
+/* The hand-scheduled body kernel alone (R2L_PREC_FP16_FP8): x_out = ResMLP blocks(x_in) on n_tiles ray
+ * tiles in the register-image layout [tile][4][32][64][4] f32 (csrc/r2l_body.hip); parity tests only. */
+int r2l_debug_body(r2l_ctx* ctx, const float* x_in_dev, float* x_out_dev, int n_tiles, void* stream);
+
 /* introspection for bench.py / DESIGN.md */
 long long r2l_flops_per_ray(const r2l_ctx* ctx);      /* algorithmic: 2*MACs of the network */
+/* algorithmic flops per ray of the kernel the timing events bracket: the whole network for the single-kernel
+ * modes, the 2*n_block body layers (r2l_body_kernel) for R2L_PREC_FP16_FP8 */
+long long r2l_kernel_flops_per_ray(const r2l_ctx* ctx);
 long long r2l_weight_image_bytes(const r2l_ctx* ctx); /* packed fp16 image streamed per ray tile */
 int r2l_rays_per_tile(const r2l_ctx* ctx);
 /* HIP-event timing of the dominant kernel on the stream it is launched on: when enabled,

@@ -1,0 +1,135 @@
+"""The generated gfx950 body loop (csrc/gen/body_gen.py), checked on the CPU: the generator's lane-accurate
+emulator runs the exact instruction stream that is assembled into r2l_body_kernel on the bytes the C++
+packer (pack_body_v3) produces, and the result is compared with a float64 evaluation of the ResMLP blocks
+(model/nerf_raybased.py:443-465).  The emulator also enforces the stream's own contracts: no register is
+read before the counted lgkmcnt covers its ds_read, no LDS byte is read before its LDS-DMA was certified
+by vmcnt + barrier, MFMA results are not touched too early."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', 'gen'))
+import body_gen as G  # noqa: E402
+
+import _pkg  # noqa: E402
+_pkg.load()
+from efficient_nerf_amd import _lib  # noqa: E402
+
+
+def make_weights(nb, seed=0, gain=1.0):
+    rng = np.random.default_rng(seed)
+    k = 1 / 16
+    W1s = [(gain * rng.uniform(-k, k, (256, 256))).astype(np.float32) for _ in range(nb)]
+    W2s = [rng.uniform(-k, k, (256, 256)).astype(np.float32) for _ in range(nb)]
+    b1s = [rng.uniform(-k, k, 256).astype(np.float32) for _ in range(nb)]
+    b2s = [rng.uniform(-k, k, 256).astype(np.float32) for _ in range(nb)]
+    return W1s, b1s, W2s, b2s
+
+
+def ref_blocks(x, W1s, b1s, W2s, b2s):
+    x = x.astype(np.float64)
+    for W1, b1, W2, b2 in zip(W1s, b1s, W2s, b2s):
+        h = np.maximum(x @ W1.astype(np.float64).T + b1, 0)
+        x = x + h @ W2.astype(np.float64).T + b2
+    return x
+
+
+def fp16x1_error(x, W1s, b1s, W2s, b2s):
+    """L_inf of the same blocks with fp16-rounded operands and exact accumulation (what the correction terms
+    are there to remove)"""
+    def f16(a):
+        return a.astype(np.float16).astype(np.float64)
+    xx = x.astype(np.float64)
+    for W1, b1, W2, b2 in zip(W1s, b1s, W2s, b2s):
+        h = np.maximum(f16(xx) @ f16(W1).T + b1, 0)
+        xx = xx + f16(h) @ f16(W2).T + b2
+    return np.abs(xx - ref_blocks(x, W1s, b1s, W2s, b2s)).max()
+
+
+def to_regs(xs):
+    """[32 rays, 256] -> the wave's register image [128, 64]"""
+    regs = np.zeros((128, 64), dtype=np.float32)
+    lanes = np.arange(64)
+    for u in range(16):
+        for c in range(2):
+            for i in range(4):
+                regs[(u * 2 + c) * 4 + i] = xs[c * 16 + (lanes & 15), 16 * u + 4 * (lanes >> 4) + i]
+    return regs
+
+
+def from_regs(regs):
+    xs = np.zeros((32, 256))
+    lanes = np.arange(64)
+    for u in range(16):
+        for c in range(2):
+            for i in range(4):
+                xs[c * 16 + (lanes & 15), 16 * u + 4 * (lanes >> 4) + i] = regs[(u * 2 + c) * 4 + i]
+    return xs
+
+
+def cxx_pack(W1s, b1s, W2s, b2s):
+    nb = len(W1s)
+    tensors = [np.zeros((256, 1008), np.float32), np.zeros(256, np.float32)]
+    for b in range(nb):
+        tensors += [W1s[b], b1s[b], W2s[b], b2s[b]]
+    rng = np.random.default_rng(5)
+    tensors += [rng.uniform(-1 / 16, 1 / 16, (3, 256)).astype(np.float32), rng.uniform(-1 / 16, 1 / 16, 3).astype(np.float32)]
+    keep, arr = _lib.host_ptrs([torch.from_numpy(np.ascontiguousarray(t)) for t in tensors])
+    offs = (C.c_longlong * 2)()
+    n = _lib.lib().r2l_debug_pack_body_host(arr, len(keep), nb, None, 0, offs)
+    assert n > 0, _lib.lib().r2l_last_error()
+    buf = np.zeros(n, dtype=np.uint8)
+    assert _lib.lib().r2l_debug_pack_body_host(arr, len(keep), nb, C.c_void_p(buf.ctypes.data), n, offs) == n
+    return buf, int(offs[0]), int(offs[1]), tensors
+
+
+def test_cxx_packer_matches_python_restatement():
+    W = make_weights(2, seed=3)
+    buf, aux_off, tail_off, tensors = cxx_pack(*W)
+    img, aux, Bsum = G.pack_body_image(*W)
+    assert aux_off == img.size and tail_off == aux_off + 2 * G.AUX_BYTES
+    assert np.array_equal(buf[:aux_off], img)
+    assert np.array_equal(buf[aux_off:tail_off].view(np.uint32).reshape(2, -1), aux)
+    tw = buf[tail_off:].view(np.float32)
+    Wt, bt = tensors[-2], tensors[-1]
+    assert np.allclose(tw[:768].reshape(3, 256) * 16.0, Wt, rtol=0, atol=0)
+    assert np.allclose(tw[768:771], bt + Wt.astype(np.float64) @ Bsum, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('nb,wave,burst', [(1, 0, False), (3, 2, False), (2, 3, True)])
+def test_emulated_stream_matches_float64(nb, wave, burst):
+    W = make_weights(nb, seed=nb)
+    buf, aux_off, tail_off, _ = cxx_pack(*W)
+    img = buf[:aux_off]
+    aux = buf[aux_off:tail_off].view(np.uint32).reshape(nb, -1)
+    _, _, Bsum = G.pack_body_image(*W) if nb == 1 else (None, None, np.sum([b.astype(np.float64) for b in W[3][:nb]], axis=0))
+    rng = np.random.default_rng(7)
+    x = np.maximum(rng.normal(0, 1, (32, 256)), 0).astype(np.float32)
+    S = 16.0
+    out, errs = G.emulate_tile(G.Opts(dma_burst=burst), img, aux, to_regs(x * S), nb, wave=wave)
+    assert not errs, errs[:10]
+    got = from_regs(out) / S + Bsum
+    ref = ref_blocks(x, *W)
+    err = np.abs(got - ref).max()
+    # fp16 main pass + e4m3 x e5m2 correction terms: ~1e-5 per block at |x| ~ 4 (plain fp16: 3e-4)
+    assert err < 2.5e-5 * nb and err < fp16x1_error(x, *W) / 8, err
+
+
+def test_layer_scales_follow_the_weight_exponent():
+    # a layer 8x larger needs other E8M0 scales; the stream must stay as accurate
+    W = make_weights(1, seed=11, gain=8.0)
+    buf, aux_off, tail_off, _ = cxx_pack(*W)
+    aux = buf[aux_off:tail_off].view(np.uint32).reshape(1, -1)
+    assert (aux[0, 256] & 0xff) == 127 - (20 - G.layer_exponent(W[0][0]))
+    assert (aux[0, 258] & 0xff) == 127 - (20 - G.layer_exponent(W[2][0]))
+    x = np.maximum(np.random.default_rng(1).normal(0, 1, (32, 256)), 0).astype(np.float32)
+    out, errs = G.emulate_tile(G.Opts(), buf[:aux_off], aux, to_regs(x * 16.0), 1)
+    assert not errs, errs[:10]
+    ref = ref_blocks(x, *W)
+    got = from_regs(out) / 16.0 + W[3][0].astype(np.float64)
+    assert np.abs(got - ref).max() < fp16x1_error(x, *W) / 8
