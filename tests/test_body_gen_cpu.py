@@ -116,7 +116,7 @@ def test_emulated_stream_matches_float64(nb, wave, burst):
     got = from_regs(out) / S + Bsum
     ref = ref_blocks(x, *W)
     err = np.abs(got - ref).max()
-    # fp16 main pass + e4m3 x e5m2 correction terms: ~1e-5 per block at |x| ~ 4 (plain fp16: 3e-4)
+    # fp16 main pass + bf6 x bf6 correction terms: ~1e-5 per block at |x| ~ 4 (plain fp16: 3e-4)
     assert err < 2.5e-5 * nb and err < fp16x1_error(x, *W) / 8, err
 
 
@@ -125,8 +125,8 @@ def test_layer_scales_follow_the_weight_exponent():
     W = make_weights(1, seed=11, gain=8.0)
     buf, aux_off, tail_off, _ = cxx_pack(*W)
     aux = buf[aux_off:tail_off].view(np.uint32).reshape(1, -1)
-    assert (aux[0, 256] & 0xff) == 127 - (20 - G.layer_exponent(W[0][0]))
-    assert (aux[0, 258] & 0xff) == 127 - (20 - G.layer_exponent(W[2][0]))
+    assert (aux[0, 256] & 0xff) == 127 + G.weight_exps(G.layer_exponent(W[0][0]))[0]
+    assert (aux[0, 258] & 0xff) == 127 + G.weight_exps(G.layer_exponent(W[2][0]))[0]
     x = np.maximum(np.random.default_rng(1).normal(0, 1, (32, 256)), 0).astype(np.float32)
     out, errs = G.emulate_tile(G.Opts(), buf[:aux_off], aux, to_regs(x * 16.0), 1)
     assert not errs, errs[:10]
