@@ -71,6 +71,21 @@ def gather_rows(local, H, W, world, group=None):
     return torch.cat([out[r, :, :sizes[r]] for r in range(world)], 1)
 
 
+def all_gather_cat(t, group=None):
+    """[world * n, ...] = every rank's `t` [n, ...] concatenated along dim 0, on every rank: ONE all-gather
+    (RCCL over xGMI; a gloo rehearsal with device tensors goes through the host)."""
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, t.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
 def barrier_sync():
     if torch.cuda.is_available():
         torch.cuda.synchronize()

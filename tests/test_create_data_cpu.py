@@ -1,0 +1,103 @@
+"""CPU / gloo: the multi-rank logic of `create_data rand` (efficient-nerf_amd/create_data.py) -- pose ownership by
+index inside a save group, one all-gather per group, shards written by rank k % world -- must produce a directory
+that is byte-identical for every world size, also when i_save % world != 0 and over several groups (the round-1
+code corrupted that case).  The teacher is replaced by a deterministic stand-in (the kernels have their own GPU
+test, tests/test_create_data_gpu.py); `get_rays` is the CPU oracle's.  Also: the BlenderDataset_v2 reader."""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class FakeTeacher:
+    device = torch.device('cpu')
+
+    def render_rays(self, rays_o, rays_d):
+        m = torch.tensor([[.3, -.2, .5], [.1, .7, -.4], [-.6, .2, .3]])
+        return {'rgb_map': torch.sigmoid(rays_d @ m + rays_o @ m.T * .1)}
+
+
+def _run(rank, world, port, out_dir, n_pose, i_save, H, W):
+    sys.path.insert(0, ROOT)
+    import _pkg
+    _pkg.load()
+    from efficient_nerf_amd import dist as D
+    from efficient_nerf_amd.create_data import RandStream, create_rand
+    from oracle import r2l_oracle as O
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world))
+        D.init(backend='gloo')
+
+    def get_rays_fn(H, W, focal, c2w, device=None):
+        return O.get_rays(H, W, focal, c2w)
+    n = create_rand(FakeTeacher(), H, W, O.focal_from_angle(W), n_pose, out_dir, i_save=i_save, split_size=64,
+                    stream=RandStream(), log=lambda *a, **k: None, get_rays_fn=get_rays_fn)
+    assert n == (n_pose // i_save) * (i_save * H * W // 64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def _digest(d):
+    out = {}
+    for name in sorted(os.listdir(d)):
+        if name.endswith('.npy'):
+            out[name] = hashlib.sha256(open(os.path.join(d, name), 'rb').read()).hexdigest()
+    return out
+
+
+@pytest.mark.parametrize('world,i_save,n_pose', [(2, 5, 11), (3, 5, 11), (3, 4, 9)])
+def test_multi_rank_directory_is_identical_to_single_rank(tmp_path, world, i_save, n_pose):
+    H, W = 6, 8
+    d1, dn = str(tmp_path / 'w1'), str(tmp_path / f'w{world}')
+    _run(0, 1, 0, d1, n_pose, i_save, H, W)
+    mp.spawn(_run, args=(world, _free_port(), dn, n_pose, i_save, H, W), nprocs=world, join=True)
+    a, b = _digest(d1), _digest(dn)
+    assert len(a) == (n_pose // i_save) * (i_save * H * W // 64) and len(a) >= 2 * (i_save * H * W // 64)
+    assert a == b
+    # no all-zero rows (a slot read back without having been written shows up as zeros)
+    for name in a:
+        arr = np.load(os.path.join(dn, name))
+        assert arr.shape == (64, 9) and arr.dtype == np.float32
+        assert (np.abs(arr).sum(1) > 0).all()
+
+
+def test_shard_reader_round_trip(tmp_path):
+    sys.path.insert(0, ROOT)
+    import _pkg
+    _pkg.load()
+    from efficient_nerf_amd.create_data import BlenderDataset_v2
+    d = str(tmp_path / 'shards')
+    _run(0, 1, 0, d, 4, 2, 6, 8)
+    ds = BlenderDataset_v2(d, pseudo_ratio=-1)
+    files = sorted(x for x in os.listdir(d) if x.endswith('.npy'))
+    assert len(ds) == len(files) == 2 * (2 * 48 // 64)
+    seen = []
+    for k in range(len(ds)):
+        ro, rd, rgb = ds[k]
+        raw = np.load(ds.all_splits[k])
+        assert ro.shape == rd.shape == rgb.shape == (64, 3)
+        assert np.array_equal(torch.cat([ro, rd, rgb], -1).numpy(), raw)
+        seen.append(os.path.basename(ds.all_splits[k]))
+    assert sorted(seen) == files
+    # original (train_*) + pseudo mixing as in the reference: num_pseudo = int(n_orig / (1 - ratio)) - n_orig
+    np.save(os.path.join(d, 'train_0.npy'), np.zeros((64, 9), np.float32))
+    np.random.seed(0)
+    ds2 = BlenderDataset_v2(d, pseudo_ratio=0.5)
+    assert len(ds2) == 2 and sum(os.path.basename(p).startswith('train_') for p in ds2.all_splits) == 1
