@@ -61,6 +61,10 @@ SIGNATURES = {
     'nerf_copy_extras': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'nerf_raw2outputs': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nerf_sample_pdf': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'nerf_sample_pdf_ex': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    'nerf_raw2outputs_noise': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'nerf_copy_extras0': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    'nerf_render_rays_ex': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nerf_merge_sorted': (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
 }
 

@@ -102,6 +102,7 @@ struct nerf_ctx {
     float near_, far_, act_scale;
     std::vector<float> z_coarse, u;  // host copies
     float *d_zc = nullptr, *d_zmid = nullptr, *d_u = nullptr;
+    float* d_zsort = nullptr;  // z_samples sorted (random uniforms only)
     PackedNet net[2];
     // per-call temporaries, grown on demand (sized for `cap` rays)
     int cap = 0;
@@ -112,7 +113,7 @@ struct nerf_ctx {
 
 static void free_tmp(nerf_ctx* c) {
     float** ps[] = {&c->d_rays_o, &c->d_rays_d, &c->d_raw0, &c->d_w0, &c->d_zs, &c->d_zall, &c->d_raw,
-                    &c->d_rgb0, &c->d_disp0, &c->d_acc0, &c->d_ndc_o, &c->d_ndc_d, &c->d_vdir};
+                    &c->d_rgb0, &c->d_disp0, &c->d_acc0, &c->d_ndc_o, &c->d_ndc_d, &c->d_vdir, &c->d_zsort};
     for (auto p : ps)
         if (*p) {
             (void)hipFree(*p);
@@ -129,7 +130,8 @@ static int ensure_tmp(nerf_ctx* c, int n) {
         {&c->d_rays_o, (size_t)n * 3}, {&c->d_rays_d, (size_t)n * 3}, {&c->d_raw0, (size_t)n * S0 * 4},
         {&c->d_w0, (size_t)n * S0},    {&c->d_zs, (size_t)n * c->N_importance}, {&c->d_zall, (size_t)n * S1},
         {&c->d_raw, (size_t)n * S1 * 4}, {&c->d_rgb0, (size_t)n * 3}, {&c->d_disp0, (size_t)n}, {&c->d_acc0, (size_t)n},
-        {&c->d_ndc_o, (size_t)n * 3}, {&c->d_ndc_d, (size_t)n * 3}, {&c->d_vdir, (size_t)n * 3}};
+        {&c->d_ndc_o, (size_t)n * 3}, {&c->d_ndc_d, (size_t)n * 3}, {&c->d_vdir, (size_t)n * 3},
+        {&c->d_zsort, (size_t)n * c->N_importance}};
     for (auto& r : req) {
         hipError_t e = hipMalloc((void**)r.p, r.numel * sizeof(float));
         if (e != hipSuccess) {
@@ -351,9 +353,21 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
         if (e_ != hipSuccess) return r2l_set_error(R2L_EHIP, what ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// Randomness of render_rays (training-time options of the reference; all null on the test path).  The caller draws
+// the numbers exactly as the reference does (torch.rand / the pytest numpy streams) and hands them over:
+//   z_coarse [n, N_samples]  jittered coarse depths, main.py:684-699 (perturb > 0)
+//   u        [n, N_importance] sample_pdf's uniforms, helpers:298-307 (det = False)
+//   noise0   [n, N_samples], noise1 [n, N_samples + N_importance]: randn * raw_noise_std, main.py:592-600
+struct RenderOpts {
+    const float* z_coarse = nullptr;
+    const float* u = nullptr;
+    const float* noise0 = nullptr;
+    const float* noise1 = nullptr;
+};
+
 // render_rays (main.py:624-756) for n rays already in device memory
 static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d, int n, float* rgb, float* disp,
-                           float* acc, float* depth, hipStream_t s) {
+                           float* acc, float* depth, hipStream_t s, const RenderOpts& o = RenderOpts()) {
     const int S0 = c->N_samples, NI = c->N_importance, S1 = S0 + NI;
     const float* vd = nullptr;
     if (c->ndc) {  // viewdirs from the world rays, then everything downstream sees the NDC rays (main.py:148-162)
@@ -363,19 +377,50 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
         rays_d = c->d_ndc_d;
         vd = c->d_vdir;
     }
-    int rc = run_mlp(c, 0, rays_o, rays_d, c->d_zc, 0, S0, n, c->d_raw0, s, vd);  // coarse network_fn
+    const float* zc = o.z_coarse ? o.z_coarse : c->d_zc;
+    const int zc_stride = o.z_coarse ? S0 : 0;
+    int rc = run_mlp(c, 0, rays_o, rays_d, zc, zc_stride, S0, n, c->d_raw0, s, vd);  // coarse network_fn
     if (rc) return rc;
-    HIPCHK(nerf_launch_raw2outputs(c->d_raw0, c->d_zc, 0, rays_d, n, S0, c->white_bkgd, c->d_rgb0, c->d_disp0,
-                                   c->d_acc0, c->d_w0, nullptr, s), "raw2outputs(coarse)");
-    // sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=True)   (main.py:722-728)
-    HIPCHK(nerf_launch_sample_pdf(c->d_zmid, 0, c->d_w0, S0, 1, n, S0 - 1, c->d_u, NI, c->d_zs, s), "sample_pdf");
-    // z_vals = sort(cat(z_vals, z_samples))                                 (main.py:730-732)
-    HIPCHK(nerf_launch_merge(c->d_zc, 0, S0, c->d_zs, NI, n, c->d_zall, s), "merge");
+    HIPCHK(nerf_launch_raw2outputs(c->d_raw0, zc, zc_stride, rays_d, n, S0, c->white_bkgd, c->d_rgb0, c->d_disp0,
+                                   c->d_acc0, c->d_w0, nullptr, s, o.noise0), "raw2outputs(coarse)");
+    // sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0))   (main.py:722-728)
+    if (o.z_coarse)
+        HIPCHK(nerf_launch_sample_pdf(o.z_coarse, S0, 1, c->d_w0, S0, 1, n, S0 - 1, o.u ? o.u : c->d_u, o.u ? NI : 0, NI,
+                                      c->d_zs, nullptr, nullptr, s), "sample_pdf");
+    else
+        HIPCHK(nerf_launch_sample_pdf(c->d_zmid, 0, 0, c->d_w0, S0, 1, n, S0 - 1, o.u ? o.u : c->d_u, o.u ? NI : 0, NI,
+                                      c->d_zs, nullptr, nullptr, s), "sample_pdf");
+    // z_vals = sort(cat(z_vals, z_samples))                                 (main.py:730-732): both rows ascending ->
+    // rank merge; with random uniforms the samples are sorted first
+    const float* zs_sorted = c->d_zs;
+    if (o.u) {
+        HIPCHK(nerf_launch_sort_rows(c->d_zs, n, NI, c->d_zsort, s), "sort z_samples");
+        zs_sorted = c->d_zsort;
+    }
+    HIPCHK(nerf_launch_merge(zc, zc_stride, S0, zs_sorted, NI, n, c->d_zall, s), "merge");
     rc = run_mlp(c, 1, rays_o, rays_d, c->d_zall, S1, S1, n, c->d_raw, s, vd);   // network_fine
     if (rc) return rc;
     HIPCHK(nerf_launch_raw2outputs(c->d_raw, c->d_zall, S1, rays_d, n, S1, c->white_bkgd, rgb, disp, acc, nullptr,
-                                   depth, s), "raw2outputs(fine)");
+                                   depth, s, o.noise1), "raw2outputs(fine)");
     return R2L_OK;
+}
+
+int nerf_render_rays_ex(nerf_ctx* c, const float* rays_o_dev, const float* rays_d_dev, int n, const float* z_coarse_dev,
+                        const float* u_dev, const float* noise0_dev, const float* noise1_dev, float* rgb_dev,
+                        float* disp_dev, float* acc_dev, float* depth_dev, void* stream) {
+    if (!c || !rays_o_dev || !rays_d_dev || !rgb_dev) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (!c->net[0].loaded || !c->net[1].loaded)
+        return r2l_set_error(R2L_ESTATE, "nerf_render before nerf_load_weights of both networks");
+    if (n < 0) return r2l_set_error(R2L_EINVAL, "n=%d", n);
+    if (n == 0) return R2L_OK;
+    int rc = ensure_tmp(c, n);
+    if (rc) return rc;
+    RenderOpts o;
+    o.z_coarse = z_coarse_dev;
+    o.u = u_dev;
+    o.noise0 = noise0_dev;
+    o.noise1 = noise1_dev;
+    return render_rays_dev(c, rays_o_dev, rays_d_dev, n, rgb_dev, disp_dev, acc_dev, depth_dev, (hipStream_t)stream, o);
 }
 
 int nerf_render_rays(nerf_ctx* c, const float* rays_o_dev, const float* rays_d_dev, int n, float* rgb_dev,
@@ -450,6 +495,18 @@ int nerf_copy_extras(nerf_ctx* c, int n, float* rgb0_dev, float* z_samples_dev, 
     return R2L_OK;
 }
 
+// the rest of render_rays' return set (main.py:743-750): disp0, acc0 of the coarse pass and
+// z_std = torch.std(z_samples, dim=-1, unbiased=False); any pointer may be null
+int nerf_copy_extras0(nerf_ctx* c, int n, float* disp0_dev, float* acc0_dev, float* z_std_dev, void* stream) {
+    if (!c || c->cap == 0) return r2l_set_error(R2L_ESTATE, "no render has run on this context");
+    if (n < 0 || n > c->cap) return r2l_set_error(R2L_EINVAL, "n=%d exceeds the last render (%d rays)", n, c->cap);
+    hipStream_t s = (hipStream_t)stream;
+    if (disp0_dev) HIPCHK(hipMemcpyAsync(disp0_dev, c->d_disp0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s), "copy disp0");
+    if (acc0_dev) HIPCHK(hipMemcpyAsync(acc0_dev, c->d_acc0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s), "copy acc0");
+    if (z_std_dev && n > 0) HIPCHK(nerf_launch_row_std(c->d_zs, n, c->N_importance, z_std_dev, s), "z_std");
+    return R2L_OK;
+}
+
 int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_begin, int row_end, float* rays_o_dev,
                   float* rays_d_dev, void* stream) {
     if (!c2w_host || !rays_o_dev || !rays_d_dev || row_begin < 0 || row_end > H || row_begin >= row_end)
@@ -472,49 +529,45 @@ int nerf_run_network(nerf_ctx* c, int which, const float* rays_o_dev, const floa
     return run_mlp(c, which, rays_o_dev, rays_d_dev, z_dev, z_stride, S, n, raw_dev, (hipStream_t)stream);
 }
 
-int nerf_raw2outputs(const float* raw, const float* z, const float* rays_d, int n, int S, int white_bkgd, float* rgb,
-                     float* disp, float* acc, float* weights, float* depth, void* stream) {
+int nerf_raw2outputs_noise(const float* raw, const float* z, const float* rays_d, const float* noise, int n, int S,
+                           int white_bkgd, float* rgb, float* disp, float* acc, float* weights, float* depth, void* stream) {
     if (!raw || !z || !rays_d || n < 0 || S < 1 || S > 256)
         return r2l_set_error(R2L_EINVAL, "bad argument to nerf_raw2outputs (S must be 1..256)");
     int rc = r2l_require_gfx950(nullptr);
     if (rc) return rc;
     if (n == 0) return R2L_OK;
     HIPCHK(nerf_launch_raw2outputs(raw, z, S, rays_d, n, S, white_bkgd, rgb, disp, acc, weights, depth,
-                                   (hipStream_t)stream), "raw2outputs");
+                                   (hipStream_t)stream, noise), "raw2outputs");
     return R2L_OK;
 }
 
-int nerf_sample_pdf(const float* bins, const float* weights, int n, int n_bins, int N, float* samples, void* stream) {
+int nerf_raw2outputs(const float* raw, const float* z, const float* rays_d, int n, int S, int white_bkgd, float* rgb,
+                     float* disp, float* acc, float* weights, float* depth, void* stream) {
+    return nerf_raw2outputs_noise(raw, z, rays_d, nullptr, n, S, white_bkgd, rgb, disp, acc, weights, depth, stream);
+}
+
+int nerf_sample_pdf_ex(const float* bins, const float* weights, int n, int n_bins, const float* u_dev, int u_per_ray, int N,
+                       float* samples, float* cdf_out_dev, int* inds_out_dev, void* stream) {
     if (!bins || !weights || !samples || n < 0 || n_bins < 2 || n_bins > 64 || N < 1)
         return r2l_set_error(R2L_EINVAL, "bad argument to nerf_sample_pdf (n_bins must be 2..64)");
+    if (u_per_ray && !u_dev) return r2l_set_error(R2L_EINVAL, "u_per_ray without u");
     int rc = r2l_require_gfx950(nullptr);
     if (rc) return rc;
     if (n == 0) return R2L_OK;
-    // u = torch.linspace(0, 1, N): scalar formula here; contexts carry the caller's tensor
-    std::vector<float> u(N);
-    r2l_linspace01(N, u.data());
-    float* d_u = nullptr;
-    HIPCHK(hipMalloc((void**)&d_u, N * sizeof(float)), "hipMalloc u");
-    hipError_t e = hipMemcpyAsync(d_u, u.data(), N * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);  // u lives on the host stack
-    if (e == hipSuccess)
-        e = nerf_launch_sample_pdf(bins, n_bins, weights, n_bins - 1, 0, n, n_bins, d_u, N, samples, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(d_u);
-    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "sample_pdf: %s", hipGetErrorString(e));
+    HIPCHK(nerf_launch_sample_pdf(bins, n_bins, 0, weights, n_bins - 1, 0, n, n_bins, u_dev, u_per_ray ? N : 0, N, samples,
+                                  cdf_out_dev, inds_out_dev, (hipStream_t)stream), "sample_pdf");
     return R2L_OK;
+}
+
+// u = torch.linspace(0, 1, N) by the scalar formula, evaluated in the kernel (stream-ordered, nothing allocated)
+int nerf_sample_pdf(const float* bins, const float* weights, int n, int n_bins, int N, float* samples, void* stream) {
+    return nerf_sample_pdf_ex(bins, weights, n, n_bins, nullptr, 0, N, samples, nullptr, nullptr, stream);
 }
 
 int nerf_sample_pdf_u(const float* bins, const float* weights, int n, int n_bins, const float* u_dev, int N,
                       float* samples, void* stream) {
-    if (!bins || !weights || !samples || !u_dev || n < 0 || n_bins < 2 || n_bins > 64 || N < 1)
-        return r2l_set_error(R2L_EINVAL, "bad argument to nerf_sample_pdf_u (n_bins must be 2..64)");
-    int rc = r2l_require_gfx950(nullptr);
-    if (rc) return rc;
-    if (n == 0) return R2L_OK;
-    HIPCHK(nerf_launch_sample_pdf(bins, n_bins, weights, n_bins - 1, 0, n, n_bins, u_dev, N, samples,
-                                  (hipStream_t)stream), "sample_pdf");
-    return R2L_OK;
+    if (!u_dev) return r2l_set_error(R2L_EINVAL, "bad argument to nerf_sample_pdf_u (u is NULL)");
+    return nerf_sample_pdf_ex(bins, weights, n, n_bins, u_dev, 0, N, samples, nullptr, nullptr, stream);
 }
 
 int nerf_merge_sorted(const float* a, int na, const float* b, int nb, int n, float* out, void* stream) {

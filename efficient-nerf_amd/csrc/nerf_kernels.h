@@ -32,13 +32,21 @@ hipError_t nerf_launch_get_rays(const float* c2w12_host, int W, float half_w, fl
 hipError_t nerf_launch_ndc_rays(const float* rays_o, const float* rays_d, int n, int H, int W, double focal, float near_,
                                 float* out_o, float* out_d, float* viewdirs, hipStream_t stream);
 
-// raw [n,S,4], z [n,S] (z_stride 0 = shared row), rays_d [n,3]; any output may be null
+// raw [n,S,4], z [n,S] (z_stride 0 = shared row), rays_d [n,3]; any output may be null; noise [n,S] or null is
+// added to the density before the relu (raw_noise_std > 0, main.py:592-600)
 hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_stride, const float* rays_d, int n,
                                    int S, int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
-                                   float* depth, hipStream_t stream);
-// bins [n,n_bins] (stride 0 = shared), weights [n, w_stride] using columns [w_off, w_off + n_bins - 1)
-hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, int w_off,
-                                  int n, int n_bins, const float* u, int N, float* samples, hipStream_t stream);
+                                   float* depth, hipStream_t stream, const float* noise = nullptr);
+// bins [n,n_bins] (stride 0 = shared; bins_are_z: rows of n_bins + 1 depths, bins = their midpoints), weights
+// [n, w_stride] using columns [w_off, w_off + n_bins - 1); u null (= linspace(0,1,N)), [N] (u_stride 0) or [n,N];
+// cdf_out [n,n_bins] / inds_out [n,N] optional taps
+hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, int bins_are_z, const float* weights, int w_stride,
+                                  int w_off, int n, int n_bins, const float* u, int u_stride, int N, float* samples,
+                                  float* cdf_out, int* inds_out, hipStream_t stream);
+// out[i, :] = sort(x[i, :N]) ascending, N <= 256
+hipError_t nerf_launch_sort_rows(const float* x, int n, int N, float* out, hipStream_t stream);
+// out[i] = std(x[i, :N], unbiased=False)
+hipError_t nerf_launch_row_std(const float* x, int n, int N, float* out, hipStream_t stream);
 // a [n,na] (stride 0 = shared) and b [n,nb] ascending -> out [n, na+nb] ascending
 hipError_t nerf_launch_merge(const float* a, int a_stride, int na, const float* b, int nb, int n, float* out,
                              hipStream_t stream);

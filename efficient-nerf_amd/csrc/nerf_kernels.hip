@@ -422,7 +422,8 @@ __global__ __launch_bounds__(256) void nerf_raw2outputs_kernel(const float* __re
                                                                float* __restrict__ disp_map,
                                                                float* __restrict__ acc_map,
                                                                float* __restrict__ weights_out,
-                                                               float* __restrict__ depth_map) {
+                                                               float* __restrict__ depth_map,
+                                                               const float* __restrict__ noise) {
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (ray >= n) return;
@@ -442,7 +443,8 @@ __global__ __launch_bounds__(256) void nerf_raw2outputs_kernel(const float* __re
         float dist = (ii < S - 1) ? (zn - zc) : 1e10f;  // dists = cat(z[1:]-z[:-1], 1e10)
         dist = dist * norm;
         const f32x4 r4 = *reinterpret_cast<const f32x4*>(raw + ((size_t)ray * S + ii) * 4);
-        const float sig = fmaxf(r4[3], 0.0f);                 // F.relu
+        // raw2alpha(raw[..., 3] + noise, dists), noise = randn * raw_noise_std drawn by the caller (main.py:592-600)
+        const float sig = fmaxf(noise ? r4[3] + noise[(size_t)ray * S + ii] : r4[3], 0.0f);  // F.relu
         float a = 1.0f - expf(-sig * dist);                   // 1 - exp(-relu(raw) * dists)
         if (!ok) a = 0.0f;
         alpha[c] = a;
@@ -501,15 +503,49 @@ __global__ __launch_bounds__(256) void nerf_raw2outputs_kernel(const float* __re
 }
 
 // ====================================================================================
-// sample_pdf (det=True): one wave per ray, n_bins <= 64
+// sample_pdf: one wave per ray, n_bins <= 64  (utils/run_nerf_raybased_helpers.py:283-330; the reference runs it
+// on the CPU, main.py:723-728, so the float accumulation orders below are ATen's CPU orders)
 // ====================================================================================
-__global__ __launch_bounds__(256) void nerf_sample_pdf_kernel(const float* __restrict__ bins, int bins_stride,
+// torch.sum(x, -1) of a contiguous float row on the CPU (ATen SumKernel, vectorized_inner_sum): 8-lane vectors,
+// 4 interleaved vector accumulators over groups of 4 vectors, the remaining whole vectors into accumulator 0,
+// ((a0 + a1) + a2) + a3 per lane, then a scalar chain: the row's tail elements first, then the 8 lane sums.
+// Verified bit for bit against torch.sum on rows of 30 .. 190 floats (tools/torch_sum_order.py).
+__device__ __forceinline__ float torch_cpu_row_sum(const float* row /* LDS, zero padded to 64 */, float* cols /* LDS [8] */,
+                                                   int nw, int lane) {
+    const int nv = nw >> 3, full = (nv >> 2) << 2;
+    if (lane < 8) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int v = 0; v < full; v += 4) {
+            a0 = __fadd_rn(a0, row[(v + 0) * 8 + lane]);
+            a1 = __fadd_rn(a1, row[(v + 1) * 8 + lane]);
+            a2 = __fadd_rn(a2, row[(v + 2) * 8 + lane]);
+            a3 = __fadd_rn(a3, row[(v + 3) * 8 + lane]);
+        }
+        for (int v = full; v < nv; ++v) a0 = __fadd_rn(a0, row[v * 8 + lane]);
+        cols[lane] = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float fin = 0.f;
+    for (int k = nv * 8; k < nw; ++k) fin = __fadd_rn(fin, row[k]);
+    for (int k = 0; k < 8; ++k) fin = __fadd_rn(fin, cols[k]);
+    return fin;
+}
+
+// bins: [n, n_bins] (stride 0 = one shared row); with bins_are_z the row holds n_bins + 1 depths and
+// bins = .5 * (z[1:] + z[:-1]) (main.py:722).  u: nullptr = torch.linspace(0, 1, N) (det, evaluated here by the
+// scalar formula), else [N] (u_stride 0) or one row per ray (u_stride = N: the perturb > 0 path draws u per ray).
+// cdf_out [n, n_bins], inds_out [n, N] (searchsorted(cdf, u, right=True)): optional parity taps.
+__global__ __launch_bounds__(256) void nerf_sample_pdf_kernel(const float* __restrict__ bins, int bins_stride, int bins_are_z,
                                                               const float* __restrict__ weights, int w_stride,
                                                               int w_off, int n, int n_bins,
-                                                              const float* __restrict__ u_arr, int N,
-                                                              float* __restrict__ samples) {
+                                                              const float* __restrict__ u_arr, int u_stride, int N,
+                                                              float* __restrict__ samples, float* __restrict__ cdf_out,
+                                                              int* __restrict__ inds_out) {
     __shared__ float s_cdf[4][64];
     __shared__ float s_bins[4][64];
+    __shared__ float s_w[4][64];
+    __shared__ float s_col[4][8];
     const int wv = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wv;
     const int lane = threadIdx.x & 63;
@@ -517,21 +553,32 @@ __global__ __launch_bounds__(256) void nerf_sample_pdf_kernel(const float* __res
     const int nw = n_bins - 1;
     float w = 0.0f;
     if (lane < nw) w = weights[(size_t)ray * w_stride + w_off + lane] + 1e-5f;  // weights + 1e-5
-    const float total = (float)wave_sum_f64((double)w);                          // torch.sum(weights, -1)
+    s_w[wv][lane] = w;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float total = torch_cpu_row_sum(s_w[wv], s_col[wv], nw, lane);          // torch.sum(weights, -1)
     const float pdf = (lane < nw) ? w / total : 0.0f;
     const double cs = wave_scan_add((double)pdf, lane);                          // cumsum (double accumulate)
     if (lane < nw) s_cdf[wv][lane + 1] = (float)cs;
     if (lane == 63) s_cdf[wv][0] = 0.0f;                                          // cat(zeros, cdf)
-    if (lane < n_bins) s_bins[wv][lane] = bins[(size_t)ray * bins_stride + lane];
+    if (lane < n_bins) {
+        const float* br = bins + (size_t)ray * bins_stride;
+        s_bins[wv][lane] = bins_are_z ? 0.5f * __fadd_rn(br[lane + 1], br[lane]) : br[lane];
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (cdf_out && lane < n_bins) cdf_out[(size_t)ray * n_bins + lane] = s_cdf[wv][lane];
+    const float step = N > 1 ? 1.0f / (float)(N - 1) : 0.0f;
     for (int k = lane; k < N; k += 64) {
-        const float u = u_arr[k];
+        float u;
+        if (u_arr) u = u_arr[(size_t)ray * u_stride + k];
+        else u = (k < N / 2 || N == 1) ? __fmul_rn(step, (float)k) : __fsub_rn(1.0f, __fmul_rn(step, (float)(N - k - 1)));
         int lo = 0, hi = n_bins;  // searchsorted(cdf, u, right=True): first index with cdf > u
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (s_cdf[wv][mid] <= u) lo = mid + 1; else hi = mid;
         }
+        if (inds_out) inds_out[(size_t)ray * N + k] = lo;
         const int below = lo - 1 > 0 ? lo - 1 : 0;
         const int above = lo < n_bins - 1 ? lo : n_bins - 1;
         const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
@@ -541,6 +588,53 @@ __global__ __launch_bounds__(256) void nerf_sample_pdf_kernel(const float* __res
         const float t = (u - c0) / denom;
         samples[(size_t)ray * N + k] = b0 + t * (b1 - b0);
     }
+}
+
+// rows of N <= 256 floats sorted ascending (bitonic network in LDS, one wave per row): with random uniforms
+// (perturb > 0) sample_pdf's output is not monotone and the reference's sort (main.py:730-732) is a real sort
+__global__ __launch_bounds__(256) void nerf_sort_rows_kernel(const float* __restrict__ x, int n, int N, float* __restrict__ out) {
+    __shared__ float s[4][256];
+    const int wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    const int lane = threadIdx.x & 63;
+    if (ray >= n) return;
+    for (int i = lane; i < 256; i += 64) s[wv][i] = i < N ? x[(size_t)ray * N + i] : __builtin_huge_valf();
+    for (int k = 2; k <= 256; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int i = lane; i < 256; i += 64) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float a = s[wv][i], b = s[wv][p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s[wv][i] = b;
+                        s[wv][p] = a;
+                    }
+                }
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int i = lane; i < N; i += 64) out[(size_t)ray * N + i] = s[wv][i];
+}
+
+// torch.std(z_samples, dim=-1, unbiased=False) of [n, N] rows (main.py:749): one wave per ray
+__global__ __launch_bounds__(256) void nerf_row_std_kernel(const float* __restrict__ x, int n, int N, float* __restrict__ out) {
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (ray >= n) return;
+    double s = 0.0;
+    for (int k = lane; k < N; k += 64) s += (double)x[(size_t)ray * N + k];
+    const double mean = wave_sum_f64(s) / N;
+    double q = 0.0;
+    for (int k = lane; k < N; k += 64) {
+        const double d = (double)x[(size_t)ray * N + k] - mean;
+        q += d * d;
+    }
+    const double var = wave_sum_f64(q) / N;
+    if (lane == 0) out[ray] = (float)sqrt(var);
 }
 
 // ====================================================================================
@@ -623,12 +717,12 @@ hipError_t nerf_launch_get_rays(const float* c, int W, float half_w, float half_
 
 hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_stride, const float* rays_d, int n,
                                    int S, int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
-                                   float* depth, hipStream_t stream) {
+                                   float* depth, hipStream_t stream, const float* noise) {
     const dim3 grid((n + 3) / 4), block(256);
     const int C = (S + 63) / 64;
 #define R2O(c)                                                                                              \
     hipLaunchKernelGGL(nerf_raw2outputs_kernel<c>, grid, block, 0, stream, raw, z, z_stride, rays_d, n, S, \
-                       white_bkgd, rgb, disp, acc, weights, depth)
+                       white_bkgd, rgb, disp, acc, weights, depth, noise)
     switch (C) {
         case 1: R2O(1); break;
         case 2: R2O(2); break;
@@ -640,11 +734,23 @@ hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_strid
     return hipGetLastError();
 }
 
-hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, const float* weights, int w_stride, int w_off,
-                                  int n, int n_bins, const float* u, int N, float* samples, hipStream_t stream) {
-    if (n_bins < 2 || n_bins > 64) return hipErrorInvalidValue;  // the reference's sample_pdf itself fails on a single bin
-    hipLaunchKernelGGL(nerf_sample_pdf_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, bins, bins_stride, weights,
-                       w_stride, w_off, n, n_bins, u, N, samples);
+hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, int bins_are_z, const float* weights, int w_stride,
+                                  int w_off, int n, int n_bins, const float* u, int u_stride, int N, float* samples,
+                                  float* cdf_out, int* inds_out, hipStream_t stream) {
+    if (n_bins < 2 || n_bins > 64 || N < 1) return hipErrorInvalidValue;  // the reference's sample_pdf itself fails on a single bin
+    hipLaunchKernelGGL(nerf_sample_pdf_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, bins, bins_stride, bins_are_z,
+                       weights, w_stride, w_off, n, n_bins, u, u_stride, N, samples, cdf_out, inds_out);
+    return hipGetLastError();
+}
+
+hipError_t nerf_launch_sort_rows(const float* x, int n, int N, float* out, hipStream_t stream) {
+    if (N < 1 || N > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nerf_sort_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, N, out);
+    return hipGetLastError();
+}
+
+hipError_t nerf_launch_row_std(const float* x, int n, int N, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(nerf_row_std_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, N, out);
     return hipGetLastError();
 }
 

@@ -289,21 +289,38 @@ def mse2psnr(mse):
 # render_path
 # ----------------------------------------------------------------------------------------
 def build_engine(args, hwf, ckpt):
+    """Engine for the flags of the reference command line.  Every flag that changes what the reference network
+    computes is either honoured or refused: a checkpoint trained with another activation / res_scale / depth must
+    not render silently wrong images (ResMLP honours them: model/nerf_raybased.py:443-465)."""
     from . import NeRFEngine, PRECISIONS, R2LEngine, R2LError
     H, W, focal = hwf
     prec = PRECISIONS[args.precision]
-    near, far = 2., 6.  # main.py:930-931 (blender)
+    llff_ndc = args.dataset_type == 'llff' and not args.no_ndc
+    if args.dataset_type == 'blender':
+        near, far = 2., 6.  # main.py:930-931
+    elif llff_ndc:
+        near, far = 0., 1.  # main.py:917-918
+    elif args.trial.near > 0 and args.trial.far > 0:
+        near = far = None   # taken from --trial.near / --trial.far below
+    else:
+        raise R2LError(f'dataset_type={args.dataset_type} with --no_ndc takes near / far from the scene bounds '
+                       f'(main.py:913-916), which need the dataset: pass --trial.near and --trial.far')
     if args.trial.near > 0:
         near = args.trial.near
     if args.trial.far > 0:
         far = args.trial.far
-    if args.dataset_type != 'blender':
-        raise R2LError(f'dataset_type={args.dataset_type}: only the blender (non-NDC) path is built')
     if args.model_name in ('R2L', 'nerf_v3.2'):
+        if llff_ndc:
+            raise R2LError('the R2L path is built for world-space rays (blender / --no_ndc)')
         if args.plucker or args.learn_depth or args.linear_tail or args.layerwise_netwidths:
             raise R2LError('plucker / learn_depth / linear_tail / layerwise_netwidths variants are not built')
         if not args.trial.ON or args.trial.body_arch != 'resmlp':
             raise R2LError('R2L rendering needs --trial.ON --trial.body_arch resmlp (README.md:51)')
+        if args.act.lower() != 'relu' or args.trial.inact.lower() != 'relu' or args.trial.outact.lower() != 'none' \
+                or float(args.trial.res_scale) != 1. or int(args.trial.n_learnable) != 2:
+            raise R2LError(f'act={args.act} trial.inact={args.trial.inact} trial.outact={args.trial.outact} '
+                           f'trial.res_scale={args.trial.res_scale} trial.n_learnable={args.trial.n_learnable}: the ResMLP '
+                           f'kernels are built for relu / relu / none / 1 / 2 (model/nerf_raybased.py:443-465)')
         n_block = args.trial.n_block if args.trial.n_block > 0 else (args.netdepth - 2) // 2
         eng = R2LEngine(H, W, focal, near, far, n_sample=args.n_sample_per_ray, L=args.multires,
                         width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec)
@@ -312,11 +329,15 @@ def build_engine(args, hwf, ckpt):
     if args.model_name == 'nerf':
         if not args.use_viewdirs or args.N_importance <= 0:
             raise R2LError('the teacher path is built for use_viewdirs=True, N_importance>0 (configs/lego.txt)')
+        if (args.netdepth, args.netwidth, args.netdepth_fine, args.netwidth_fine) != (8, 256, 8, 256) or args.i_embed != 0:
+            raise R2LError(f'netdepth/netwidth(_fine) = {args.netdepth}/{args.netwidth}/{args.netdepth_fine}/'
+                           f'{args.netwidth_fine}, i_embed={args.i_embed}: the teacher kernels are built for the 8 x 256 NeRF '
+                           f'with positional encoding (model/nerf_raybased.py:339-401)')
         if 'network_fine_state_dict' not in ckpt:
             raise KeyError("checkpoint lacks 'network_fine_state_dict'")
         eng = NeRFEngine(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance,
                          multires=args.multires, multires_views=args.multires_views, white_bkgd=args.white_bkgd,
-                         precision=prec)
+                         precision=prec, ndc=llff_ndc, lindisp=args.lindisp)  # main.py:160-162, 525-528, 679-680
         eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
         return 'nerf', eng
     raise R2LError(f'model_name={args.model_name} is not a render path of this build')
@@ -379,7 +400,7 @@ def main(argv=None):
     if not args.pretrained_ckpt:
         raise SystemExit('--pretrained_ckpt is required with --render_only')
     rank, local_rank, world = D.init()
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(D.local_device(local_rank))
     log = print if rank == 0 else (lambda *a, **k: None)
     ckpt = load_checkpoint(args.pretrained_ckpt)
     log(f'Load pretrained ckpt successfully: "{args.pretrained_ckpt}".')

@@ -12,6 +12,7 @@ R2LError.  No CPU fallback.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -40,43 +41,66 @@ def get_rays(H, W, focal, c2w, trans_origin='', focal_scale=1, rows=None, device
     return ro.view(r1 - r0, W, 3), rd.view(r1 - r0, W, 3)
 
 
+def _raw_noise(shape, raw_noise_std, pytest, dev):
+    """main.py:592-598: torch.randn * std; with pytest the numpy stream the reference switches to"""
+    if pytest:
+        np.random.seed(0)
+        return torch.Tensor(np.random.rand(*list(shape)) * raw_noise_std).to(dev)
+    return torch.randn(shape, device=dev) * raw_noise_std
+
+
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, verbose=False):
     """main.py:556-621.  raw [n,S,4], z_vals [n,S], rays_d [n,3] ->
     rgb_map [n,3], disp_map [n], acc_map [n], weights [n,S], depth_map [n]."""
-    if raw_noise_std > 0.:
-        raise NotImplementedError('raw_noise_std > 0 is a training-only path (out of scope)')
     dev = raw.device
     raw, rays_d = _f32(raw, dev), _f32(rays_d, dev)
     n, S = raw.shape[0], raw.shape[1]
+    noise = _f32(_raw_noise((n, S), raw_noise_std, pytest, dev), dev) if raw_noise_std > 0. else None
     z_vals = _f32(z_vals.expand(n, S) if z_vals.dim() == 2 else z_vals, dev)
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     disp, acc, depth = (torch.empty((n,), dtype=torch.float32, device=dev) for _ in range(3))
     weights = torch.empty((n, S), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        check(lib().nerf_raw2outputs(dptr(raw), dptr(z_vals), dptr(rays_d), n, S, int(bool(white_bkgd)), dptr(rgb),
-                                     dptr(disp), dptr(acc), dptr(weights), dptr(depth), current_stream()))
+        check(lib().nerf_raw2outputs_noise(dptr(raw), dptr(z_vals), dptr(rays_d), dptr(noise), n, S, int(bool(white_bkgd)),
+                                           dptr(rgb), dptr(disp), dptr(acc), dptr(weights), dptr(depth), current_stream()))
     return rgb, disp, acc, weights, depth
 
 
-def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
-    """helpers:283-330 with det=True (the perturb==0 test path).  bins [n,B], weights
-    [n,B-1] -> samples [n,N_samples].  `u` defaults to torch.linspace(0,1,N_samples)
-    evaluated on the host exactly as the reference does."""
-    if not det:
-        raise NotImplementedError('det=False draws torch.rand samples: training-only path (out of scope)')
+def _sample_pdf_u(n, N_samples, det, pytest, dev):
+    """helpers:293-307: the uniforms sample_pdf inverts the cdf at, drawn the way the reference draws them.
+    Returns (u, per_ray)."""
+    if pytest:
+        np.random.seed(0)
+        if det:
+            return torch.Tensor(np.linspace(0., 1., N_samples)).to(dev), False   # np.linspace in float64, then float32
+        return torch.Tensor(np.random.rand(n, N_samples)).to(dev), True
+    if det:
+        return torch.linspace(0., 1., steps=N_samples).to(dev), False            # evaluated on the host as the reference does
+    return torch.rand((n, N_samples), device=dev), True
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None, taps=False):
+    """helpers:283-330.  bins [n,B], weights [n,B-1] -> samples [n,N_samples].  `u` (optional, [N] or
+    [n,N]) replaces the draw; taps=True also returns (cdf [n,B], inds [n,N] int32 = searchsorted(cdf, u, right))."""
     dev = bins.device
     bins, weights = _f32(bins, dev), _f32(weights, dev)
     n, B = bins.shape
     if weights.shape != (n, B - 1):
         raise R2LError(f'weights must be [n, {B - 1}]; got {tuple(weights.shape)}')
     if u is None:
-        u = torch.linspace(0., 1., steps=N_samples)
+        u, per_ray = _sample_pdf_u(n, N_samples, det, pytest, dev)
+    else:
+        per_ray = u.dim() == 2
     u = _f32(u, dev)
+    if u.shape[-1] != N_samples or (per_ray and u.shape[0] != n):
+        raise R2LError(f'u must be [{N_samples}] or [{n}, {N_samples}]; got {tuple(u.shape)}')
     out = torch.empty((n, N_samples), dtype=torch.float32, device=dev)
+    cdf = torch.empty((n, B), dtype=torch.float32, device=dev) if taps else None
+    inds = torch.empty((n, N_samples), dtype=torch.int32, device=dev) if taps else None
     with torch.cuda.device(dev):
-        check(lib().nerf_sample_pdf_u(dptr(bins), dptr(weights), n, B, dptr(u), N_samples, dptr(out),
-                                      current_stream()))
-    return out
+        check(lib().nerf_sample_pdf_ex(dptr(bins), dptr(weights), n, B, dptr(u), int(per_ray), N_samples, dptr(out),
+                                       dptr(cdf), None if inds is None else C.c_void_p(inds.data_ptr()), current_stream()))
+    return (out, cdf, inds) if taps else out
 
 
 def merge_sorted(z_vals, z_samples):
@@ -130,7 +154,8 @@ class NeRFEngine:
             if not lindisp:
                 z_coarse = float(near) * (1. - t_vals) + float(far) * (t_vals)
             else:
-                z_coarse = 1. / (1. / float(near) * (1. - t_vals) + 1. / float(far) * (t_vals))
+                nt, ft = torch.tensor(float(near)), torch.tensor(float(far))  # tensor arithmetic as in main.py:679-680
+                z_coarse = 1. / (1. / nt * (1. - t_vals) + 1. / ft * (t_vals))      # (near = 0 gives inf / nan there too)
         if u is None:
             u = torch.linspace(0., 1., steps=self.N_importance)
         self.set_sampling(z_coarse, u)
@@ -196,7 +221,10 @@ class NeRFEngine:
         zv = torch.empty((n, S1), dtype=torch.float32, device=dev)
         raw = torch.empty((n, S1, 4), dtype=torch.float32, device=dev)
         check(lib().nerf_copy_extras(self._ctx, n, dptr(rgb0), dptr(zs), dptr(zv), dptr(raw), current_stream()))
-        return {'rgb0': rgb0, 'z_samples': zs, 'z_vals': zv, 'raw': raw}
+        disp0, acc0, z_std = (torch.empty((n,), dtype=torch.float32, device=dev) for _ in range(3))
+        check(lib().nerf_copy_extras0(self._ctx, n, dptr(disp0), dptr(acc0), dptr(z_std), current_stream()))
+        # main.py:743-750: rgb0, disp0, acc0, z_std (+ raw with retraw); z_samples / z_vals for the parity tests
+        return {'rgb0': rgb0, 'disp0': disp0, 'acc0': acc0, 'z_std': z_std, 'z_samples': zs, 'z_vals': zv, 'raw': raw}
 
     def render(self, c2w, rows=None, extras=False):
         """render(H, W, focal, c2w=c2w[:3,:4]) of main.py:107-186 for rows [r0,r1):
@@ -213,14 +241,39 @@ class NeRFEngine:
                 ret.update(self._extras(n))
         return ret
 
-    def render_rays(self, rays_o, rays_d, extras=False):
-        """render(..., rays=(rays_o, rays_d)) / render_rays of main.py:624-756."""
+    def render_rays(self, rays_o, rays_d, extras=False, perturb=0., raw_noise_std=0., pytest=False):
+        """render(..., rays=(rays_o, rays_d)) / render_rays of main.py:624-756.  perturb > 0: stratified jitter of
+        the coarse depths (main.py:684-699) and random sample_pdf uniforms (det=False); raw_noise_std > 0: noise on
+        the densities (main.py:592-600); pytest=True: the reference's fixed numpy streams.  The numbers are drawn
+        here, in the reference's order, and handed to the library."""
         rays_o, rays_d = _f32(rays_o, self.device).view(-1, 3), _f32(rays_d, self.device).view(-1, 3)
         n = rays_o.shape[0]
         rgb, disp, acc, depth = self._outs(n)
+        zc = u = n0 = n1 = None
+        dev = self.device
+        if perturb > 0.:
+            # evaluated on the host (n x N_samples floats): device elementwise kernels contract a + b*c into an fma
+            z = self.z_coarse.expand(n, self.N_samples)
+            mids = .5 * (z[..., 1:] + z[..., :-1])
+            upper = torch.cat([mids, z[..., -1:]], -1)
+            lower = torch.cat([z[..., :1], mids], -1)
+            if pytest:
+                np.random.seed(0)
+                t_rand = torch.Tensor(np.random.rand(n, self.N_samples))
+            else:
+                t_rand = torch.rand((n, self.N_samples))
+            zc = _f32(lower + (upper - lower) * t_rand, dev)
+        if raw_noise_std > 0.:
+            n0 = _f32(_raw_noise((n, self.N_samples), raw_noise_std, pytest, dev), dev)
+        if perturb > 0.:
+            u = _f32(_sample_pdf_u(n, self.N_importance, False, pytest, dev)[0], dev)
+        elif pytest:  # det with the pytest stream: u = float32(np.linspace) on every ray
+            u = _f32(_sample_pdf_u(n, self.N_importance, True, True, dev)[0].expand(n, self.N_importance), dev)
+        if raw_noise_std > 0.:
+            n1 = _f32(_raw_noise((n, self.N_samples + self.N_importance), raw_noise_std, pytest, dev), dev)
         with torch.cuda.device(self.device):
-            check(lib().nerf_render_rays(self._ctx, dptr(rays_o), dptr(rays_d), n, dptr(rgb), dptr(disp), dptr(acc),
-                                         dptr(depth), current_stream()))
+            check(lib().nerf_render_rays_ex(self._ctx, dptr(rays_o), dptr(rays_d), n, dptr(zc), dptr(u), dptr(n0), dptr(n1),
+                                            dptr(rgb), dptr(disp), dptr(acc), dptr(depth), current_stream()))
             ret = {'rgb_map': rgb, 'disp_map': disp, 'acc_map': acc, 'depth_map': depth}
             if extras:
                 ret.update(self._extras(n))

@@ -174,6 +174,17 @@ int nerf_last_extras(nerf_ctx* ctx, const float** rgb0, const float** z_samples,
  * z_vals [n,S0+S1], raw_fine [n,S0+S1,4] */
 int nerf_copy_extras(nerf_ctx* ctx, int n, float* rgb0_dev, float* z_samples_dev, float* z_vals_dev,
                      float* raw_dev, void* stream);
+/* disp0 [n], acc0 [n] of the coarse pass and z_std [n] = std(z_samples, unbiased=False): the rest of
+ * render_rays' return set (main.py:743-750); any pointer may be NULL */
+int nerf_copy_extras0(nerf_ctx* ctx, int n, float* disp0_dev, float* acc0_dev, float* z_std_dev, void* stream);
+/* render_rays with the training-time randomness of the reference supplied by the caller (each pointer may be
+ * NULL = the deterministic test path): z_coarse_dev [n,N_samples] jittered coarse depths (perturb > 0,
+ * main.py:684-699), u_dev [n,N_importance] (sample_pdf det=False, helpers:298-307), noise0_dev [n,N_samples] /
+ * noise1_dev [n,N_samples+N_importance] = randn * raw_noise_std (main.py:592-600) */
+int nerf_render_rays_ex(nerf_ctx* ctx, const float* rays_o_dev, const float* rays_d_dev, int n,
+                        const float* z_coarse_dev, const float* u_dev, const float* noise0_dev,
+                        const float* noise1_dev, float* rgb_dev, float* disp_dev, float* acc_dev,
+                        float* depth_dev, void* stream);
 
 /* Forward-facing scenes (render(..., ndc=True), main.py:148-162): when on, nerf_render and
  * nerf_render_rays take the view directions from the given (world-space) rays, project the rays
@@ -199,12 +210,26 @@ int nerf_run_network(nerf_ctx* ctx, int which, const float* rays_o_dev, const fl
 int nerf_raw2outputs(const float* raw, const float* z, const float* rays_d, int n, int S,
                      int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
                      float* depth, void* stream);
-/* bins [n,n_bins], weights [n,n_bins-1] -> samples [n,N] (det=True: u = linspace(0,1,N)) */
+/* the same with noise_dev [n,S] (or NULL) added to the density before the relu: raw_noise_std > 0,
+ * main.py:592-600; the caller draws randn * raw_noise_std (or the pytest numpy stream) as the reference does */
+int nerf_raw2outputs_noise(const float* raw, const float* z, const float* rays_d, const float* noise_dev,
+                           int n, int S, int white_bkgd, float* rgb, float* disp, float* acc,
+                           float* weights, float* depth, void* stream);
+/* bins [n,n_bins], weights [n,n_bins-1] -> samples [n,N] (det=True: u = linspace(0,1,N), evaluated
+ * in the kernel by the scalar formula).  The float sums follow ATen's CPU orders (the reference runs
+ * sample_pdf on the CPU, main.py:723-728): torch.sum = 8-lane x 4-accumulator cascade, cumsum = double
+ * accumulation rounded per element.  All three entry points are stream-ordered and allocate nothing. */
 int nerf_sample_pdf(const float* bins, const float* weights, int n, int n_bins, int N,
                     float* samples, void* stream);
-/* same with caller-provided u_dev [N] (device), fully stream-ordered */
+/* same with caller-provided u_dev [N] (device) */
 int nerf_sample_pdf_u(const float* bins, const float* weights, int n, int n_bins,
                       const float* u_dev, int N, float* samples, void* stream);
+/* general form: u_dev NULL (linspace), [N] (u_per_ray = 0) or [n,N] (u_per_ray = 1: det = False, the
+ * caller draws u as helpers:298-307 does); optional parity taps cdf_out_dev [n,n_bins] (= cat(0, cumsum(pdf)))
+ * and inds_out_dev [n,N] int32 (= searchsorted(cdf, u, right=True)) */
+int nerf_sample_pdf_ex(const float* bins, const float* weights, int n, int n_bins, const float* u_dev,
+                       int u_per_ray, int N, float* samples, float* cdf_out_dev, int* inds_out_dev,
+                       void* stream);
 /* a [n,na] and b [n,nb], each row ascending -> out [n,na+nb] ascending */
 int nerf_merge_sorted(const float* a, int na, const float* b, int nb, int n, float* out,
                       void* stream);

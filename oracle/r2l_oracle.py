@@ -280,13 +280,23 @@ def run_network(sd, pts, viewdirs, multires=10, multires_views=4, netchunk=1024 
     return torch.cat(outs, 0).reshape(list(pts.shape[:-1]) + [4]).float()
 
 
-def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
-    """main.py:556-621 (raw_noise_std=0): alpha-compositing along the ray."""
+def raw_noise(shape, raw_noise_std, pytest=False):
+    """main.py:592-598: randn * std, or with pytest the numpy stream np.random.seed(0); rand(*shape) * std"""
+    if pytest:
+        np.random.seed(0)
+        return torch.Tensor(np.random.rand(*list(shape)) * raw_noise_std)
+    return torch.randn(shape) * raw_noise_std
+
+
+def raw2outputs(raw, z_vals, rays_d, white_bkgd=False, raw_noise_std=0., pytest=False, noise=None):
+    """main.py:556-621: alpha-compositing along the ray (`noise`: explicit [n,S] tensor instead of a draw)."""
     dists = z_vals[..., 1:] - z_vals[..., :-1]
     dists = torch.cat([dists, torch.Tensor([1e10]).expand(dists[..., :1].shape)], -1)
     dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
     rgb = torch.sigmoid(raw[..., :3])
-    alpha = 1. - torch.exp(-F.relu(raw[..., 3]) * dists)
+    if noise is None:
+        noise = raw_noise(raw[..., 3].shape, raw_noise_std, pytest) if raw_noise_std > 0. else 0.
+    alpha = 1. - torch.exp(-F.relu(raw[..., 3] + noise) * dists)
     weights = alpha * torch.cumprod(
         torch.cat([torch.ones((alpha.shape[0], 1)), 1. - alpha + 1e-10], -1), -1)[:, :-1]
     rgb_map = torch.sum(weights[..., None] * rgb, -2)
@@ -299,14 +309,27 @@ def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
     return rgb_map, disp_map, acc_map, weights, depth_map
 
 
-def sample_pdf(bins, weights, N_samples, det=True):
-    """utils/run_nerf_raybased_helpers.py:283-330 (det=True, pytest=False)."""
-    assert det, 'only the deterministic (perturb==0) test path is on the hot path'
+def sample_pdf_u(shape, N_samples, det=True, pytest=False):
+    """the uniforms of helpers:293-307: linspace (det) / torch.rand, or with pytest the numpy stream"""
+    new_shape = list(shape) + [N_samples]
+    if pytest:
+        np.random.seed(0)
+        u = np.broadcast_to(np.linspace(0., 1., N_samples), new_shape) if det else np.random.rand(*new_shape)
+        return torch.Tensor(u)
+    if det:
+        return torch.linspace(0., 1., steps=N_samples).expand(new_shape)
+    return torch.rand(new_shape)
+
+
+def sample_pdf(bins, weights, N_samples, det=True, pytest=False, u=None, taps=False):
+    """utils/run_nerf_raybased_helpers.py:283-330.  `u`: explicit [n, N_samples] uniforms instead of a draw;
+    taps=True also returns (cdf, inds)."""
     weights = weights + 1e-5
     pdf = weights / torch.sum(weights, -1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    u = torch.linspace(0., 1., steps=N_samples)
+    if u is None:
+        u = sample_pdf_u(cdf.shape[:-1], N_samples, det, pytest)
     u = u.expand(list(cdf.shape[:-1]) + [N_samples]).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.max(torch.zeros_like(inds - 1), inds - 1)
@@ -318,7 +341,21 @@ def sample_pdf(bins, weights, N_samples, det=True):
     denom = (cdf_g[..., 1] - cdf_g[..., 0])
     denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
     t = (u - cdf_g[..., 0]) / denom
-    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+    samples = bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
+    return (samples, cdf, inds) if taps else samples
+
+
+def perturb_z_vals(z_vals, pytest=False, t_rand=None):
+    """main.py:684-699: stratified jitter of the coarse depths"""
+    mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    upper = torch.cat([mids, z_vals[..., -1:]], -1)
+    lower = torch.cat([z_vals[..., :1], mids], -1)
+    if t_rand is None:
+        t_rand = torch.rand(z_vals.shape)
+        if pytest:
+            np.random.seed(0)
+            t_rand = torch.Tensor(np.random.rand(*list(z_vals.shape)))
+    return lower + (upper - lower) * t_rand
 
 
 def coarse_z_vals(near, far, N_samples, n_rays):
@@ -347,8 +384,9 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
 
 
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=64,
-                N_importance=128, white_bkgd=True, dtype=torch.float32, viewdirs=None, lindisp=False):
-    """main.py:624-756 (render_rays) + main.py:148-157 (viewdirs), perturb=0, no noise."""
+                N_importance=128, white_bkgd=True, dtype=torch.float32, viewdirs=None, lindisp=False,
+                perturb=0., raw_noise_std=0., pytest=False):
+    """main.py:624-756 (render_rays) + main.py:148-157 (viewdirs)."""
     if viewdirs is None:
         viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     n = rays_o.shape[0]
@@ -359,15 +397,17 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=6
         z_vals = near_t * (1. - t_vals) + far_t * (t_vals)  # [n, N_samples] (main.py:673-682)
     else:
         z_vals = 1. / (1. / near_t * (1. - t_vals) + 1. / far_t * (t_vals))
+    if perturb > 0.:
+        z_vals = perturb_z_vals(z_vals, pytest)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
     raw0 = run_network(sd_coarse, pts, viewdirs, dtype=dtype)
-    rgb0, disp0, acc0, weights0, depth0 = raw2outputs(raw0, z_vals, rays_d, white_bkgd)
+    rgb0, disp0, acc0, weights0, depth0 = raw2outputs(raw0, z_vals, rays_d, white_bkgd, raw_noise_std, pytest)
     z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-    z_samples = sample_pdf(z_mid, weights0[..., 1:-1], N_importance, det=True)
+    z_samples = sample_pdf(z_mid, weights0[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
     z_all = merge_z(z_vals, z_samples)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
     raw = run_network(sd_fine, pts, viewdirs, dtype=dtype)
-    rgb, disp, acc, weights, depth = raw2outputs(raw, z_all, rays_d, white_bkgd)
+    rgb, disp, acc, weights, depth = raw2outputs(raw, z_all, rays_d, white_bkgd, raw_noise_std, pytest)
     return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, rgb0=rgb0,
                 disp0=disp0, acc0=acc0, weights0=weights0, z_samples=z_samples, z_vals=z_all,
                 raw0=raw0, raw=raw, z_std=torch.std(z_samples, dim=-1, unbiased=False))

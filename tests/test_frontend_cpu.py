@@ -151,3 +151,22 @@ def test_png_writer(fe, tmp_path):
     raw = zlib.decompress(data[i + 4:i + 4 + n])
     rows = [raw[y * (1 + 7 * 3) + 1:(y + 1) * (1 + 7 * 3)] for y in range(5)]
     assert b''.join(rows) == img.tobytes()
+
+
+def test_build_engine_refuses_flags_the_kernels_do_not_honour(fe):
+    """A checkpoint trained with another activation / res_scale / depth must raise, not render silently wrong
+    images (the reference's ResMLP honours these flags: model/nerf_raybased.py:443-465)."""
+    import _pkg
+    _pkg.load()
+    from efficient_nerf_amd import R2LError
+    base = ['--model_name', 'R2L', '--dataset_type', 'blender', '--netdepth', '88', '--n_sample_per_ray', '16', '--trial.ON',
+            '--trial.body_arch', 'resmlp', '--use_residual']
+    for extra in (['--act', 'gelu'], ['--trial.inact', 'lrelu'], ['--trial.outact', 'relu'], ['--trial.res_scale', '0.5'],
+                  ['--trial.n_learnable', '3'], ['--linear_tail'], ['--dataset_type', 'llff']):
+        with pytest.raises(R2LError):
+            fe.build_engine(fe.parse_args(base + extra), (8, 8, 10.), {})
+    nerf = ['--model_name', 'nerf', '--dataset_type', 'blender', '--use_viewdirs', '--N_importance', '128']
+    for extra in (['--netdepth', '6'], ['--netwidth_fine', '128'], ['--i_embed', '-1'],
+                  ['--dataset_type', 'llff', '--no_ndc']):   # no_ndc needs the scene bounds or --trial.near/far
+        with pytest.raises(R2LError):
+            fe.build_engine(fe.parse_args(nerf + extra), (8, 8, 10.), {})

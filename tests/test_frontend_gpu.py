@@ -122,6 +122,30 @@ def test_teacher_render_only_cli(pkg, tmp_path):
     assert np.abs(rgbs[0].reshape(-1, 3) - ref['rgb_map'].numpy()).max() <= 1e-4
 
 
+def test_teacher_llff_ndc_cli(pkg, tmp_path):
+    """--dataset_type llff without --no_ndc: render(..., ndc=True) with near, far = 0, 1 (main.py:160-162, 525-528,
+    917-918), here also with --lindisp (main.py:679-680); poses / intrinsics synthetic (the LLFF loader is not built)."""
+    from efficient_nerf_amd import frontend as fe
+    t0, t1 = O.make_teacher_state(1), O.make_teacher_state(2)
+    ck = str(tmp_path / 'nerf.tar')
+    fe.save_checkpoint(ck, t0, t1)
+    focal = .5 * 14 / np.tan(.5 * 0.6911112070083618)
+    common = ['--model_name', 'nerf', '--use_viewdirs', '--N_importance', '128', '--pretrained_ckpt', ck, '--render_only',
+              '--render_test', '--synthetic_poses', '1', '--H', '10', '--W', '14']
+    out = str(tmp_path / 'ndc')
+    run_main(common + ['--dataset_type', 'llff', '--outdir', out])
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    assert rgbs.shape == (1, 10, 14, 3)
+    ref = O.teacher_render(t0, t1, 10, 14, focal, O.novel_poses(1)[0], ndc=True, near=0., far=1., white_bkgd=False)
+    assert np.abs(rgbs[0].reshape(-1, 3) - ref['rgb_map'].numpy()).max() <= 1e-4
+    # --lindisp reaches the engine (with the blender bounds: near = 0 of the NDC path makes 1/near infinite in the reference too)
+    out = str(tmp_path / 'lindisp')
+    run_main(common + ['--dataset_type', 'blender', '--lindisp', '--outdir', out])
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    ref = O.teacher_render(t0, t1, 10, 14, focal, O.novel_poses(1)[0], white_bkgd=False, lindisp=True)
+    assert np.abs(rgbs[0].reshape(-1, 3) - ref['rgb_map'].numpy()).max() <= 1e-4
+
+
 def test_cli_rejects_unsupported(pkg, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--model_name', 'R2L'], cwd=ROOT,
                        capture_output=True, text=True)

@@ -161,3 +161,21 @@ def test_oracle_ndc_rays_matches_reference(golden_dir):
     for H, W, f in ((378, 504, 407.5657), (400, 400, 555.5555155968841)):
         o, d = O.ndc_rays(H, W, f, 1., ro, rd)
         assert np.array_equal(o.numpy(), g[f'ndc_o_{H}']) and np.array_equal(d.numpy(), g[f'ndc_d_{H}'])
+
+
+def test_oracle_randomness_matches_reference_streams(golden_dir):
+    """perturb / raw_noise_std / pytest streams of the oracle against vectors from the imported reference
+    (tests/golden/make_golden_rand.py)"""
+    gr = np.load(os.path.join(golden_dir, 'rand_cases.npz'))
+    sc = np.load(os.path.join(golden_dir, 'scan_cases.npz'))
+    bins, w = torch.from_numpy(sc['pdf_bins']), torch.from_numpy(sc['pdf_weights'])
+    s, cdf, inds = O.sample_pdf(bins, w, 128, det=True, taps=True)
+    assert np.array_equal(cdf.numpy(), gr['pdf_cdf']) and np.array_equal(inds.numpy(), gr['pdf_inds'])
+    for det in (False, True):
+        assert np.array_equal(O.sample_pdf(bins, w, 128, det=det, pytest=True).numpy(), gr[f'pdf_samples_pytest_det{int(det)}'])
+    for S in (64, 192):
+        raw, z, rd = (torch.from_numpy(sc[f'{k}_{S}']) for k in ('raw', 'z', 'rays_d'))
+        r = O.raw2outputs(raw, z, rd, True, raw_noise_std=0.7, pytest=True)
+        assert np.array_equal(r[3].numpy(), gr[f'noise_weights_{S}_1'], equal_nan=True)
+    zc = O.perturb_z_vals(O.coarse_z_vals(2., 6., 64, gr['rr_z_coarse'].shape[0]), pytest=True)
+    assert np.array_equal(zc.numpy(), gr['rr_z_coarse'])

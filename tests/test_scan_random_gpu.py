@@ -11,6 +11,26 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def torch_sum_is_8lane():
+    """does torch.sum(float row) on this host follow ATen's 8-lane x 4-accumulator order (as in the build container)?"""
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(256, 62, generator=g) * torch.rand(256, 1, generator=g)
+    f = np.float32
+    a = x.numpy()
+    acc = [np.zeros((256, 8), f) for _ in range(4)]
+    for k in range(4):
+        acc[k] = acc[k] + a[:, 8 * k:8 * k + 8]
+    for v in (4, 5, 6):
+        acc[0] = (acc[0] + a[:, 8 * v:8 * v + 8]).astype(f)
+    col = (((acc[0] + acc[1]).astype(f) + acc[2]).astype(f) + acc[3]).astype(f)
+    fin = np.zeros(256, f)
+    for k in range(56, 62):
+        fin = (fin + a[:, k]).astype(f)
+    for k in range(8):
+        fin = (fin + col[:, k]).astype(f)
+    return bool((fin == torch.sum(x, -1).numpy()).all())
+
+
 def cases(n_cases, seed):
     rng = np.random.default_rng(seed)
     return [(int(rng.integers(1, 40)), int(rng.integers(2, 257)), int(rng.integers(0, 2 ** 31))) for _ in range(n_cases)]
@@ -53,10 +73,15 @@ def test_sample_pdf_and_merge_random(pkg, n, nb, N, seed):
     want = O.sample_pdf(bins, w, N)
     got = zs.cpu()
     assert got.shape == want.shape == (n, N)
-    err = (got - want).abs()
-    binw = float((bins[:, 1:] - bins[:, :-1]).max()) if nb > 1 else 0.
-    # continuous except across the reference's `denom < 1e-5 -> 1` rule (see test_teacher_gpu)
-    assert float((err <= 2e-5).float().mean()) >= 0.98 and float(err.max()) <= binw * 1.001 + 1e-6
+    # bit for bit against torch on this host, provided its torch.sum uses the accumulation order the kernel restates
+    # (8-lane vectors; checked by torch_sum_is_8lane): otherwise a last-ulp difference of `total` may move a sample
+    # across the reference's `denom < 1e-5 -> 1` rule by up to one bin
+    if torch_sum_is_8lane():
+        assert torch.equal(got, want), int((got != want).sum())
+    else:
+        err = (got - want).abs()
+        binw = float((bins[:, 1:] - bins[:, :-1]).max()) if nb > 1 else 0.
+        assert float((err <= 2e-5).float().mean()) >= 0.98 and float(err.max()) <= binw * 1.001 + 1e-6
     assert bool((got[:, 1:] - got[:, :-1] >= -1e-6).all())
     # merge of two ascending rows == sort of the concatenation, bit for bit, for any lengths <= 256
     na = min(256 - N, nb) if N < 256 else 0

@@ -69,13 +69,10 @@ def test_sample_pdf_and_merge_adversarial(pkg, gs):
     bins, w = T(gs['pdf_bins']).cuda(), T(gs['pdf_weights']).cuda()
     zs = sample_pdf(bins, w, 128, det=True)
     got, want = zs.cpu().numpy(), gs['pdf_samples']
-    # the inverse CDF is continuous except where the reference's `denom < 1e-5 -> 1` rule
-    # flattens a bin: there a last-ulp difference in cdf can move a sample by one bin width
-    err = np.abs(got - want)
-    binw = float(np.diff(gs['pdf_bins'][0]).max())
-    assert (err <= 1e-5).mean() >= 0.995, (err > 1e-5).sum()
-    assert err.max() <= binw * 1.001
-    assert (np.diff(got, axis=1) >= -1e-6).all()  # non-decreasing
+    # bit for bit: the kernel restates ATen's CPU accumulation orders (torch.sum: 8-lane x 4-accumulator cascade,
+    # cumsum: double accumulation) because the reference runs sample_pdf on the CPU (main.py:723-728); the
+    # integer work (searchsorted) is pinned separately in tests/test_teacher_rand_gpu.py
+    np.testing.assert_array_equal(got, want)
     # merge: exact multiset, exact order
     z64 = O.coarse_z_vals(2., 6., 64, zs.shape[0]).cuda()
     merged = merge_sorted(z64, T(want).cuda())
