@@ -24,6 +24,10 @@ _vp = C.c_void_p
 SIGNATURES = {
     'r2l_last_error': (C.c_char_p, []),
     'r2l_device_count': (C.c_int, []),
+    'r2l_comm_unique_id': (C.c_int, [_vp]),
+    'r2l_comm_create': (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    'r2l_comm_destroy': (None, [_vp]),
+    'r2l_gather_image': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     'r2l_create': (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_double, C.c_float, C.c_float,
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'r2l_destroy': (None, [_vp]),

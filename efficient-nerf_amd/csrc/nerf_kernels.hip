@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/r2l_hip.h"
 #include "nerf_kernels.h"
 #include "r2l_device.h"
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(256) void nerf_merge_kernel(const float* __restrict
 template <int NP, bool MIX>
 static hipError_t launch_mlp(const NerfMlpParams& p, int grid, hipStream_t stream) {
     // the > 64 KiB dynamic-LDS opt-in is per device: a process may drive several GPUs
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -91,11 +91,7 @@ struct Ring {
 template <int NP>
 __device__ __forceinline__ void ring_issue_piece(Ring<NP>& R, int piece) {
     typedef KCfg<NP> C;
-#ifdef R2L_ABL_DMASMALL  // timing-only: always fetch chunk 0 (L1-resident): LDS writes stay, L2 traffic goes
-    const char* src = R.wimg + R.wave * (4 * NP * R2L_FRAG_BYTES) + (uint32_t)R.lane * 16u;
-#else
     const char* src = R.wimg + (size_t)R.issue_pos * C::CH + R.wave * (4 * NP * R2L_FRAG_BYTES) + (uint32_t)R.lane * 16u;
-#endif
     const uint32_t dst = R.issue_off + R.wave * (4 * NP * R2L_FRAG_BYTES);
     const int last = (NP == 2) ? 7 : 4;
     switch (piece) {
@@ -120,69 +116,8 @@ __device__ __forceinline__ void ring_issue_piece(Ring<NP>& R, int piece) {
 
 template <int NP>
 __device__ __forceinline__ void ring_issue(Ring<NP>& R) {  // all pieces at once (prologue, chunk tails)
-#ifdef R2L_ASM_DMA
-    // Same instructions the builtin path emits (VGPR-pair address, immediate offsets shared by the
-    // global and the LDS address), but from ONE inline-asm statement so that hipcc does not see an
-    // LDS-DMA permanently in flight (it would turn every LDS wait into lgkmcnt(0)).  M0 is saved
-    // and restored; every M0 write is followed by a wait state before the DMA that reads it.
-    typedef KCfg<NP> C;
-    const char* src = R.wimg + (size_t)R.issue_pos * C::CH + R.wave * (4 * NP * R2L_FRAG_BYTES) + (uint32_t)R.lane * 16u;
-    const char* asrc = R.wimg + (size_t)R.issue_pos * C::CH + C::AUX + R.wave * 256 + (uint32_t)R.lane * 4u;
-    const uint32_t adst = R.issue_off + C::AUX + R.wave * 256;
-    uint32_t keep;
-    if (NP == 2) {
-        // one base in the middle of the wave's 8 KiB: signed 13-bit offsets -4096..3072 reach all 8 pieces
-        const char* mid = src + 4096;
-        const uint32_t dmid = R.issue_off + R.wave * (4 * NP * R2L_FRAG_BYTES) + 4096;
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[dst]\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:-4096\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:-3072\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:-2048\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:-1024\n\t"
-            "global_load_lds_dwordx4 %[a0], off\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:1024\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:2048\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:3072\n\t"
-            "s_mov_b32 m0, %[adst]\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dword %[aa], off\n\t"
-            "s_nop 7\n\t"   // keep M0 and the address VGPRs untouched for a few cycles after the last issue
-            "s_nop 7\n\t"
-            "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep)
-            : [dst] "s"(dmid), [adst] "s"(adst), [a0] "v"(mid), [aa] "v"(asrc)
-            : "memory");
-    } else {
-        const uint32_t dst = R.issue_off + R.wave * (4 * NP * R2L_FRAG_BYTES);
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %[keep], m0\n\t"
-            "s_mov_b32 m0, %[dst]\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %[a0], off\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:1024\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:2048\n\t"
-            "global_load_lds_dwordx4 %[a0], off offset:3072\n\t"
-            "s_mov_b32 m0, %[adst]\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dword %[aa], off\n\t"
-            "s_nop 7\n\t"   // keep M0 and the address VGPRs untouched for a few cycles after the last issue
-            "s_nop 7\n\t"
-            "s_mov_b32 m0, %[keep]"
-            : [keep] "=&s"(keep)
-            : [dst] "s"(dst), [adst] "s"(adst), [a0] "v"(src), [aa] "v"(asrc)
-            : "memory");
-    }
-    R.issue_pos = (R.issue_pos + 1 == R.cpt) ? 0 : R.issue_pos + 1;
-    R.issue_off = (R.issue_off + C::CH == (uint32_t)C::LDS) ? 0u : R.issue_off + C::CH;
-#else
 #pragma unroll
     for (int piece = 0; piece < 8; ++piece) ring_issue_piece<NP>(R, piece);
-#endif
 }
 
 #define R2L_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -192,15 +127,8 @@ __device__ __forceinline__ void ring_issue(Ring<NP>& R) {  // all pieces at once
 // refilled with chunk c+D: by ring_issue_piece over the following k-steps, or at once (ring_mid).
 template <int NP>
 __device__ __forceinline__ void ring_sync(Ring<NP>& R) {
-#ifdef R2L_ABL_NODMA  // ablation build: no rendezvous, no refill (LDS keeps the prologue's chunks)
-    return;
-#endif
-#ifndef R2L_ABL_NOWAIT
     R2L_WAIT_VMCNT(KCfg<NP>::WAIT_MID);
-#endif
-#ifndef R2L_ABL_NOBARRIER
     __builtin_amdgcn_s_barrier();
-#endif
 }
 
 // fragment position f (0..15) inside a chunk: rendezvous + refill at 8.  (Spreading the
@@ -211,18 +139,14 @@ template <int NP>
 __device__ __forceinline__ void ring_step(Ring<NP>& R, int f) {
     if (f == R2L_FRAGS / 2) {
         ring_sync<NP>(R);
-#if !defined(R2L_ABL_NOISSUE) && !defined(R2L_ABL_NODMA)
         ring_issue<NP>(R);
-#endif
     }
 }
 
 template <int NP>
 __device__ __forceinline__ void ring_mid(Ring<NP>& R) {
     ring_sync<NP>(R);
-#if !defined(R2L_ABL_NOISSUE) && !defined(R2L_ABL_NODMA)
     ring_issue<NP>(R);
-#endif
 }
 
 template <int NP>

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/r2l_hip.h"
 #include "r2l_common.h"
 #include "r2l_kernels.h"
@@ -127,10 +129,6 @@ __global__ void r2l_embed_kernel(const float* __restrict__ x_in, long long total
 template <int NP, bool SECOND>
 __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1, f32x4& xu, f16x8& nh, f16x8& nl, int u,
                                         int r) {
-#ifdef R2L_ABL_NOEPI  // ablation build: keep the accumulator live, skip the VALU epilogue
-    asm volatile("" ::"v"(acc[2 * r]), "v"(acc[2 * r + 1]));
-    return;
-#endif
     // r = pair index (0, 1): registers 2r, 2r+1 -> dword 2(u&1) + r of the fragments
     float v[2];
 #pragma unroll
@@ -204,10 +202,6 @@ __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2],
 template <bool SECOND, int PAIR>
 __device__ __forceinline__ void epi_pair_mix(const f32x4& acc, float inv, float neg1, f16x8& nh, f16x8& nl, i32x8& na,
                                              i32x8& nr, int u) {
-#ifdef R2L_ABL_NOEPI  // ablation build: keep the accumulator live, skip the VALU epilogue
-    asm volatile("" ::"v"(acc[2 * PAIR]), "v"(acc[2 * PAIR + 1]));
-    return;
-#endif
     const int idx = 2 * (u & 1) + PAIR;
     float v[2];
     if (!SECOND) {
@@ -505,15 +499,6 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
-#ifdef R2L_ABL_NOEPI
-            if constexpr (MIX) {
-                body_layer_mix<false>(R, Bh, Ba, Br, Bh, Ba, Br, Bl, act_scale, neg1, q);
-                body_layer_mix<true>(R, Bh, Ba, Br, Bh, Ba, Br, Bl, act_scale, neg1, q);
-            } else {
-                body_layer<NP, false>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
-                body_layer<NP, true>(R, Bh, Bl, Bh, Bl, x, act_scale, neg1, q);
-            }
-#else
             if constexpr (MIX) {
                 body_layer_mix<false>(R, Bh, Ba, Br, Nh, Na, Nr, Nl, act_scale, neg1, q);  // Nl unused (SECOND = false)
                 body_layer_mix<true>(R, Nh, Na, Nr, Bh, Ba, Br, Bl, act_scale, neg1, q);   // x += ..., in place
@@ -521,7 +506,6 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                 body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q);
                 body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q);
             }
-#endif
         }
 
         // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------
@@ -583,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 template <int NP, bool MIX>
 static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream) {
     // the > 64 KiB dynamic-LDS opt-in is per device: a process may drive several GPUs
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -599,7 +583,7 @@ static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream
 
 template <int NP>
 static hipError_t launch_head(const R2LParams& p, int grid, hipStream_t stream) {
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

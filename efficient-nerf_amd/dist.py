@@ -44,12 +44,84 @@ def row_shard(H, rank, world):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
-def gather_rows(local, H, W, world, group=None):
+class RowGather:
+    """Assembles row-sharded frames on every rank with the library's one collective (include/r2l_hip.h:
+    r2l_gather_image = one grouped RCCL launch over xGMI).  The frames arrive in [frame][row] order in a
+    pre-allocated buffer: no copy follows the collective.  One instance per (process, device); the 128-byte RCCL id
+    travels from rank 0 over the torch.distributed process group (host side, once)."""
+
+    def __init__(self, rank, world, device):
+        import ctypes as C
+        from . import _lib
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        idbuf = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(_lib.lib().r2l_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+        if world > 1:
+            obj = [bytes(idbuf)]
+            dist.broadcast_object_list(obj, src=0)
+            idbuf = (C.c_char * 128).from_buffer_copy(obj[0])
+        self._comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().r2l_comm_create(C.byref(self._comm), rank, world, C.cast(idbuf, C.c_void_p)))
+        self._out = None
+
+    def gather(self, local, H, W):
+        """local [F, rows_local*W, C] f32 on the device -> [F, H*W, C] (a view of the instance's buffer: consume it
+        before the next call)."""
+        from . import _lib
+        F, _, Cc = local.shape
+        r0, r1 = row_shard(H, self.rank, self.world)
+        assert local.shape[1] == (r1 - r0) * W and local.dtype == torch.float32 and local.is_cuda, local.shape
+        if self._out is None or self._out.shape != (F, H * W, Cc):
+            self._out = torch.empty((F, H * W, Cc), dtype=torch.float32, device=local.device)
+        with torch.cuda.device(local.device):
+            _lib.check(_lib.lib().r2l_gather_image(self._comm, _lib.dptr(local.contiguous()), _lib.dptr(self._out), F, H, W * Cc,
+                                                   _lib.current_stream()))
+        return self._out
+
+    def close(self):
+        try:
+            from . import _lib
+        except ImportError:  # interpreter shutdown
+            return
+        if getattr(self, '_comm', None) is not None and self._comm.value and _lib._lib is not None:
+            _lib.lib().r2l_comm_destroy(self._comm)
+            self._comm = None
+
+    __del__ = close
+
+
+_row_gather = {}
+
+
+def gather_backend(device_index, world):
+    """which implementation assembled the frames of this process: for bench.py's JSON line"""
+    g = _row_gather.get((device_index, world), 'none')
+    return 'none' if g == 'none' else ('r2l_gather_image (RCCL, C-ABI)' if g is not None else 'torch.distributed all_gather (RCCL)')
+
+
+def gather_rows(local, H, W, world, group=None, force_collective=False):
     """local: [F, rows_local*W, C] slab of F frames rendered by this rank (its row shard).
-    Returns [F, H*W, C] on every rank.  Equal shards: one all_gather_into_tensor; ragged
-    shards (H % world != 0): pad to the largest shard, gather once, strip."""
-    if world == 1:
+    Returns [F, H*W, C] on every rank.  Device tensors under the nccl backend (or world 1 with force_collective:
+    the GPU test of the collective) go through RowGather (RCCL, frame-major output, no copy); the gloo path (CPU
+    tests, rehearsals) gathers once with torch.distributed and reorders on the host side."""
+    if world == 1 and not force_collective:
         return local
+    use_rccl = local.is_cuda and (world == 1 or dist.get_backend(group) == 'nccl')
+    if use_rccl:
+        key = (local.device.index, world)
+        if key not in _row_gather:
+            try:
+                _row_gather[key] = RowGather(dist.get_rank(group) if world > 1 else 0, world, local.device)
+            except Exception as e:  # e.g. RCCL cannot be bound by the library: the same collective through torch.distributed
+                if world == 1:
+                    raise
+                import sys
+                print(f'[dist] r2l_gather_image unavailable ({e}); assembling with torch.distributed (RCCL) instead', file=sys.stderr)
+                _row_gather[key] = None
+        if _row_gather[key] is not None:
+            return _row_gather[key].gather(local, H, W)
     F, _, Cc = local.shape
     rank = dist.get_rank(group)
     sizes = [(row_shard(H, r, world)[1] - row_shard(H, r, world)[0]) * W for r in range(world)]
@@ -58,14 +130,7 @@ def gather_rows(local, H, W, world, group=None):
     if local.shape[1] != mx:
         pad = torch.zeros((F, mx - local.shape[1], Cc), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 1)
-    out = torch.empty((world * F, mx, Cc), dtype=local.dtype, device=local.device)
-    if local.is_cuda and dist.get_backend(group) == 'gloo':  # rehearsal only: gloo gathers through the host
-        host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
-        out.copy_(host)
-    else:
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)  # concatenation along dim 0
-    out = out.view(world, F, mx, Cc)
+    out = all_gather_cat(local, group).view(world, F, mx, Cc)
     if all(s == mx for s in sizes):
         return out.permute(1, 0, 2, 3).reshape(F, world * mx, Cc)
     return torch.cat([out[r, :, :sizes[r]] for r in range(world)], 1)

@@ -54,6 +54,25 @@ const char* r2l_last_error(void);
 int r2l_device_count(void);
 
 /* ---------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, the rows of a frame split contiguously over the ranks (rank r renders rows
+ * [r*H/G + min(r, H%G), ...), the first H % G ranks one row more: r2l_render(..., row_begin, row_end, ...)),
+ * ONE RCCL collective over xGMI assembles the frames on every rank.  The reference has no counterpart (it
+ * renders on one GPU, main.py:473): SURVEY.md 8(b) seam 3 is the contract.  RCCL is bound at run time; a
+ * process that never calls these needs no librccl.
+ *   r2l_comm_unique_id   rank 0 obtains the 128-byte id and hands it to the other ranks by any host channel
+ *   r2l_comm_create      every rank, after hipSetDevice(its GPU): ncclCommInitRank
+ *   r2l_gather_image     local_rows_dev [n_frames, rows_of_this_rank * row_floats] -> full_image_dev
+ *                        [n_frames, H * row_floats] on every rank (row_floats = W * 3 for RGB), stream-ordered;
+ *                        one grouped launch: ncclAllGather per frame (equal shards) or ncclBroadcast per shard
+ * --------------------------------------------------------------------------------- */
+typedef struct r2l_comm r2l_comm;
+int r2l_comm_unique_id(char* id_out128);
+int r2l_comm_create(r2l_comm** out, int rank, int world, const char* id128);
+void r2l_comm_destroy(r2l_comm* comm);
+int r2l_gather_image(r2l_comm* comm, const float* local_rows_dev, float* full_image_dev, int n_frames, int H,
+                     int row_floats, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * R2L student (neural light field).  Replaces, under torch.no_grad():
  *   PointSampler.__init__            model/nerf_raybased.py:78-92   -> r2l_create
  *   NeRF_v3_2.__init__ + load        model/nerf_raybased.py:483-537,

@@ -146,6 +146,47 @@ def test_teacher_llff_ndc_cli(pkg, tmp_path):
     assert np.abs(rgbs[0].reshape(-1, 3) - ref['rgb_map'].numpy()).max() <= 1e-4
 
 
+def test_checkpoint_saved_from_cuda_dataparallel(pkg, tmp_path):
+    """What the reference's training run writes (main.py:482-509, 1516-1542; helpers:408-425): the state_dict of an
+    nn.DataParallel-wrapped model living on cuda:0 -- `module.` prefixes, CUDA-device tensors -- saved by a real
+    torch.save.  A fresh process (the CLI) loads it through load_checkpoint and renders; compared with the CPU oracle."""
+    import torch.nn as nn
+    n_block = 3
+
+    class Res(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = nn.Sequential(nn.Linear(256, 256), nn.ReLU(True), nn.Linear(256, 256))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = nn.Sequential(nn.Linear(1008, 256), nn.ReLU(True))
+            self.body = nn.Sequential(*[Res() for _ in range(n_block)])
+            self.tail = nn.Sequential(nn.Linear(256, 3), nn.Sigmoid())
+
+    sd = O.make_r2l_state(seed=4, netdepth=2 + 2 * n_block)
+    net = Net()
+    net.load_state_dict(sd)
+    dp = nn.DataParallel(net.cuda())
+    saved = dp.state_dict()
+    assert all(k.startswith('module.') and v.is_cuda for k, v in saved.items())
+    ck = str(tmp_path / 'dp_cuda.tar')
+    torch.save({'global_step': 123, 'best_psnr': 30.1, 'best_psnr_step': 100, 'network_fn_state_dict': saved,
+                'optimizer_state_dict': {'state': {}, 'param_groups': []}}, ck)
+    out = str(tmp_path / 'out')
+    run_main(['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256',
+              '--netdepth', str(2 + 2 * n_block), '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp',
+              '--pretrained_ckpt', ck, '--render_only', '--render_test', '--synthetic_poses', '2', '--H', '32', '--outdir', out])
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    H = 16  # half_res in the config
+    assert rgbs.shape == (2, H, H, 3)
+    poses = O.novel_poses(2)
+    for i in range(2):
+        ref = O.r2l_render(sd, H, H, O.focal_from_angle(32) / 2., poses[i]).view(H, H, 3).numpy()
+        assert np.abs(rgbs[i] - ref).max() <= 1e-4
+
+
 def test_cli_rejects_unsupported(pkg, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--model_name', 'R2L'], cwd=ROOT,
                        capture_output=True, text=True)

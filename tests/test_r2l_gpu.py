@@ -85,18 +85,49 @@ def test_mirror_objects_materialize(pkg, g):
 
 
 @pytest.mark.parametrize('H', [8, 400, 800])
-def test_render_matches_reference_golden(g, engines, H):
-    """Full frame through the fused kernel vs rgb computed by the reference's modules."""
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8', 'fp16_fp8_fused'])
+def test_render_matches_reference_golden(g, engines, H, prec):
+    """Full frame vs rgb computed by the reference's modules (model/nerf_raybased.py:76-126, 191-208, 539-544), at
+    the reference's own CPU case (8), config 2 (400) and the bench's size (800), in every precision mode that
+    claims the 1e-4 contract -- fp16_fp8 is the bench's mode (head launch + hand-scheduled body + tail)."""
+    from efficient_nerf_amd import PRECISIONS, PREC_FP16X3
     eng = engines[H]
     idx = T(g[f'idx_{H}']).cuda()
-    worst = 0.
-    for p in range(4):
-        rgb = eng.render(T(g['poses'][p]))
-        assert rgb.shape == (H * H, 3)
-        err = np.abs(rgb[idx].cpu().numpy() - g[f'rgb_{H}_{p}']).max()
-        worst = max(worst, err)
-    print(f'H={H} fp16x3 L_inf vs reference golden: {worst:.3e}')
-    assert worst <= TOL_X3
+    eng.set_precision(PRECISIONS[prec])
+    try:
+        worst = 0.
+        for p in range(4):
+            rgb = eng.render(T(g['poses'][p]))
+            assert rgb.shape == (H * H, 3)
+            worst = max(worst, np.abs(rgb[idx].cpu().numpy() - g[f'rgb_{H}_{p}']).max())
+        print(f'H={H} {prec} L_inf vs reference golden: {worst:.3e}')
+        assert worst <= (TOL_X3 if prec == 'fp16x3' else 6e-5)
+    finally:
+        eng.set_precision(PREC_FP16X3)
+
+
+@pytest.mark.parametrize('blk', [0, 21, 42])
+def test_body_kernel_against_reference_layer_activations(g, sd88, pkg, blk):
+    """The committed per-layer activations of the reference network (hooks on its modules, 4 rays) against the
+    hand-scheduled body kernel alone: block `blk` as a one-block network, input = the reference's activation in
+    front of it, output vs the reference's activation behind it."""
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    acts = torch.from_numpy(g['layer_acts'])          # [44, 4, 256]: head output, then the 43 block outputs
+    sd = {k: sd88[k] for k in ('head.0.weight', 'head.0.bias', 'tail.0.weight', 'tail.0.bias')}
+    for j in (0, 2):
+        for kind in ('weight', 'bias'):
+            sd[f'body.0.body.{j}.{kind}'] = sd88[f'body.{blk}.body.{j}.{kind}']
+    eng = R2LEngine(8, 8, O.focal_from_angle(8), n_block=1, precision=PREC_FP16_FP8).load_state_dict(sd)
+    S = 16.0
+    rays = torch.zeros(128, 256)
+    rays[:4] = acts[blk]
+    x = (rays * S).reshape(1, 4, 2, 16, 16, 4, 4).permute(0, 1, 4, 2, 5, 3, 6).reshape(1, 4, 32, 64, 4).contiguous().cuda()
+    out = eng.debug_body(x).cpu().reshape(1, 4, 16, 2, 4, 16, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(128, 256) / S
+    got = out[:4] + sd88[f'body.{blk}.body.2.bias']     # the layer-2 bias is folded out of the kernel's x
+    err = (got - acts[blk + 1]).abs().max().item()
+    print(f'block {blk}: L_inf vs the reference activations {err:.2e} (|x| up to {acts[blk + 1].abs().max():.1f})')
+    assert err <= 5e-5 * max(1., float(acts[blk + 1].abs().max()))
+    eng.close()
 
 
 def test_render_fp16x1_mode(g, engines, pkg):
