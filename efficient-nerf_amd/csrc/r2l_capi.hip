@@ -131,8 +131,8 @@ struct r2l_ctx {
     int n_cu;
     bool loaded;
     std::vector<std::vector<float>> host_w;  // state_dict order
-    char* d_img[4];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
-    size_t img_bytes[4];
+    char* d_img[3];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
+    size_t img_bytes[3];
     char* d_body;                             // FP16_FP8: body stream v3 (r2l_body.hip) | aux blocks | tail
     size_t body_bytes, aux_off, tail_off;
     float* d_xa;                              // FP16_FP8: head output / body output of one launch slice
@@ -147,8 +147,8 @@ struct r2l_ctx {
 };
 
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
-static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_FP8_FUSED; }
-#define R2L_N_MODES 4
+static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_FP8; }
+#define R2L_N_MODES 3
 #define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head/body/tail launch triple (1 KiB of x per ray, twice)
 
 int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far_, int n_sample, int L,
@@ -272,8 +272,7 @@ static int build_image(r2l_ctx* c, int mode) {
 }
 
 // host-only: the packed chunk stream of r2l_common.h (no GPU needed; also behind r2l_debug_pack_host)
-static void pack_image_host(const r2l_ctx* c, int mode_in, std::vector<char>& img) {
-    const int mode = mode_in == R2L_PREC_FP16_FP8_FUSED ? R2L_PREC_FP16_FP8 : mode_in;  // the fused kernel's image
+static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) {
     const int np = np_of(mode);
     const int CH = r2l_chunk_bytes(np);
     const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
@@ -316,18 +315,6 @@ static void pack_image_host(const r2l_ctx* c, int mode_in, std::vector<char>& im
                         int k = r2l_kappa(ks, lane >> 4, j);
                         put_frag(chunk, np, f, lane, j, Wl[(size_t)(16 * u + (lane & 15)) * R2L_WIDTH + k] * Sw);
                     }
-                if (mode != R2L_PREC_FP16_FP8) continue;
-                // piece 2f+1: e4m3 operand bytes of the two correction terms (r2l_common.h)
-                const int term = ks >> 2, t = (ks >> 1) & 1, half = ks & 1;
-                for (int lane = 0; lane < 64; ++lane) {
-                    unsigned char* pb = reinterpret_cast<unsigned char*>(chunk + (size_t)(2 * f + 1) * R2L_FRAG_BYTES + lane * 16);
-                    for (int i = 0; i < 16; ++i) {
-                        const int k = r2l_mix_feat(t, lane >> 4, 16 * half + i);
-                        const float w = Wl[(size_t)(16 * u + (lane & 15)) * R2L_WIDTH + k] * Sw;
-                        const float hi = (float)(_Float16)w;
-                        pb[i] = r2l_f32_to_e4m3(term == 0 ? ldexpf(w - hi, R2L_MIX_WL_SHIFT) : ldexpf(w, -R2L_MIX_W_SHIFT));
-                    }
-                }
             }
             for (int i = 0; i < 32; ++i) aux(ci)[i] = bl[32 * m + i] * S;
             aux(ci)[32] = 1.0f / S;

@@ -24,7 +24,7 @@ hipError_t r2l_launch_head(const R2LParams& p, int np, int grid, hipStream_t str
 
 // hand-scheduled body (r2l_body.hip): x <- ResMLP blocks(x) on the register image written by the head launch
 struct R2LBodyParams {
-    const char* wimg;   // body stream v3: n_block * 16 chunks of 32 KiB
+    const char* wimg;   // body stream: n_block * 16 chunks of 28 KiB (r2l_capi.hip pack_body_v3)
     const char* aux;    // n_block aux blocks of 4 KiB (bias of layer 1 | E8M0 scales)
     const float* xin;   // [n_tiles, 4, 32, 64, 4] f32
     float* xout;

@@ -1,13 +1,14 @@
 // R2L (neural light field) hot path for MI355X / gfx950, hand-written HIP.
 //
-//   r2l_resmlp_kernel<NP, MIX>
+//   r2l_resmlp_kernel<NP, HEAD_ONLY>
 //                          K1+K2+K3 fused: get_rays + 16-point sampling + sinusoidal
 //                          embedding + 88-layer width-256 residual MLP + sigmoid, one
 //                          persistent workgroup per CU, activations resident in registers,
 //                          weights streamed global -> LDS ring (LDS-DMA) -> MFMA A operand.
-//                          <2, false>: fp16 hi/lo split, 3 MFMA per k-step (fp32-grade result)
-//                          <2, true> : fp16 hi pass + the two correction terms on the fp8 MFMA (body)
-//                          <1, false>: single fp16 pass.
+//                          <2>: fp16 hi/lo split, 3 MFMA per k-step (fp32-grade result, R2L_PREC_FP16X3)
+//                          <1>: single fp16 pass (R2L_PREC_FP16X1)
+//                          <2, true>: the head layer only, its output left in HBM for the hand-scheduled
+//                          body kernel of R2L_PREC_FP16_FP8 (r2l_body.hip) and the tail kernel.
 //   r2l_sample_embed_kernel / r2l_embed_kernel
 //                          stand-alone K1+K2 (PointSampler.sample_test,
 //                          PositionalEmbedder.__call__) for parity tests and the API mirror.
@@ -191,110 +192,6 @@ __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2],
                             Nl[(R2L_RTILES - 1) >> 1][i >> 1], R2L_RTILES - 1, i & 1);
 }
 
-// ---- FP16_FP8 body: fp16 main pass + two fp8 correction terms ---------------------------------
-// In this mode the residual stream x has no fp32 copy: it lives as the fp16 pair (hi, lo) of the
-// block-input fragments (|x - hi - lo| <= 2^-22 |x|), which frees 64 registers per lane.
-// Two consecutive accumulator values (registers 2*PAIR, 2*PAIR+1 of row tile u, one column tile):
-//   SECOND = false: v = relu(acc/scale)
-//   SECOND = true : v = (hi + lo) + acc/scale, the fragments updated in place (+ the fp16 lo)
-// written as fp16 hi, e5m2 of the value and e5m2 of its fp16 residual (byte pair PAIR of register
-// u&7 of the next layer's fp8 K-step u>>3).
-template <bool SECOND, int PAIR>
-__device__ __forceinline__ void epi_pair_mix(const f32x4& acc, float inv, float neg1, f16x8& nh, f16x8& nl, i32x8& na,
-                                             i32x8& nr, int u) {
-    const int idx = 2 * (u & 1) + PAIR;
-    float v[2];
-    if (!SECOND) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) v[k] = fmaxf(acc[2 * PAIR + k] * inv, 0.0f);
-    } else {
-        const f16x2 ho = get_pair(nh, idx), lo = get_pair(nl, idx);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) v[k] = fmaf(acc[2 * PAIR + k], inv, (float)ho[k]) + (float)lo[k];
-    }
-    const f16x2 h = pack_hi(v[0], v[1]);
-    set_dword(nh, idx, __builtin_bit_cast(uint32_t, h));
-    const float l0 = fmaf((float)h[0], neg1, v[0]), l1 = fmaf((float)h[1], neg1, v[1]);
-    if (SECOND) set_dword(nl, idx, __builtin_bit_cast(uint32_t, pack_hi(l0, l1)));
-    na[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], na[u & 7], PAIR != 0);
-    nr[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(l0, l1, nr[u & 7], PAIR != 0);
-}
-
-template <bool SECOND>
-__device__ __forceinline__ void epi_tile_mix(const f32x4& acc, float inv, float neg1, f16x8& nh, f16x8& nl, i32x8& na,
-                                             i32x8& nr, int u) {
-    epi_pair_mix<SECOND, 0>(acc, inv, neg1, nh, nl, na, nr, u);
-    epi_pair_mix<SECOND, 1>(acc, inv, neg1, nh, nl, na, nr, u);
-}
-
-// One row tile of a body layer in FP16_FP8 mode: per k-step s one fp16 MFMA per column tile; the
-// chunk's odd pieces are the 16-byte halves of the e4m3 operands, so every second step one fp8
-// K=128 MFMA per column tile follows (steps 1, 3: w_lo x activations; 5, 7: w x activation residuals).
-template <bool SECOND, bool HAVE_PREV>
-__device__ __forceinline__ void body_rtile_mix(Ring<2>& R, int upos, const f16x8 (&Bh)[8][2], const i32x8 (&Ba)[2][2],
-                                               const i32x8 (&Br)[2][2], f16x8 (&Nh)[8][2], i32x8 (&Na)[2][2],
-                                               i32x8 (&Nr)[2][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
-                                               const f32x4 (&prev)[2], float inv, float neg1, int uprev, int q) {
-    const uint32_t slot = R.use_off;
-    const uint32_t lane_base = slot + R.lane * 16;
-    const uint32_t next_base = ring_next_off<2>(slot) + R.lane * 16;
-    acc[0] = acc_init<2>(slot, 16 * upos, q);
-    acc[1] = acc[0];
-    i32x8 a8;
-#pragma unroll
-    for (int s = 0; s < R2L_KSTEPS; ++s) {
-        const int f = upos * R2L_KSTEPS + s;
-        ring_step<2>(R, f);
-        // fp16 fragment one step ahead (R.pre.h); the two 16-byte halves of an e4m3 operand at even s
-        const f16x8 nxt = (f + 1 < R2L_FRAGS)
-                              ? *reinterpret_cast<const f16x8*>(smem + lane_base + (2 * (f + 1)) * R2L_FRAG_BYTES)
-                              : *reinterpret_cast<const f16x8*>(smem + next_base);
-        if ((s & 1) == 0) {
-            const i32x4 lo = *reinterpret_cast<const i32x4*>(smem + lane_base + (2 * f + 1) * R2L_FRAG_BYTES);
-            const i32x4 hi = *reinterpret_cast<const i32x4*>(smem + lane_base + (2 * f + 3) * R2L_FRAG_BYTES);
-            a8 = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-        acc[0] = MFMA(R.pre.h, Bh[s][0], acc[0]);
-        acc[1] = MFMA(R.pre.h, Bh[s][1], acc[1]);
-        if (s & 1) {
-            const int t = (s >> 1) & 1;
-            if (s < 4) {
-                acc[0] = MFMA8(a8, Ba[t][0], acc[0], R2L_MIX_SCALE_WL);
-                acc[1] = MFMA8(a8, Ba[t][1], acc[1], R2L_MIX_SCALE_WL);
-            } else {
-                acc[0] = MFMA8(a8, Br[t][0], acc[0], R2L_MIX_SCALE_W);
-                acc[1] = MFMA8(a8, Br[t][1], acc[1], R2L_MIX_SCALE_W);
-            }
-            if (HAVE_PREV) {
-                const int c = s >> 2;
-                if (((s >> 1) & 1) == 0)
-                    epi_pair_mix<SECOND, 0>(prev[c], inv, neg1, Nh[uprev >> 1][c], Nl[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
-                else
-                    epi_pair_mix<SECOND, 1>(prev[c], inv, neg1, Nh[uprev >> 1][c], Nl[uprev >> 1][c], Na[uprev >> 3][c], Nr[uprev >> 3][c], uprev);
-            }
-        }
-        R.pre.h = nxt;
-    }
-    if (upos == 1) ring_next<2>(R);
-}
-
-template <bool SECOND>
-__device__ __forceinline__ void body_layer_mix(Ring<2>& R, const f16x8 (&Bh)[8][2], const i32x8 (&Ba)[2][2],
-                                               const i32x8 (&Br)[2][2], f16x8 (&Nh)[8][2], i32x8 (&Na)[2][2],
-                                               i32x8 (&Nr)[2][2], f16x8 (&Nl)[8][2], float act_scale, float neg1, int q) {
-    const float inv = aux_inv_scale<2>(R.use_off) * act_scale;
-    f32x4 accA[2], accB[2];  // alternate between row tiles: the idle one is being drained by the epilogue
-    body_rtile_mix<SECOND, false>(R, 0, Bh, Ba, Br, Nh, Na, Nr, Nl, accA, accB, inv, neg1, 0, q);
-#pragma unroll
-    for (int u = 1; u < R2L_RTILES; ++u) {
-        if (u & 1) body_rtile_mix<SECOND, true>(R, 1, Bh, Ba, Br, Nh, Na, Nr, Nl, accB, accA, inv, neg1, u - 1, q);
-        else body_rtile_mix<SECOND, true>(R, 0, Bh, Ba, Br, Nh, Na, Nr, Nl, accA, accB, inv, neg1, u - 1, q);
-    }
-    const int ul = R2L_RTILES - 1;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) epi_tile_mix<SECOND>(accB[c], inv, neg1, Nh[ul >> 1][c], Nl[ul >> 1][c], Na[ul >> 3][c], Nr[ul >> 3][c], ul);
-}
-
 // one head k-step (one chunk): 16 row tiles against the generated B fragments of both column
 // tiles.  GEN is a statement using `i` (0..15), expanded between the MFMA groups: it produces
 // element (i>>3, i&7) of the NEXT k-step's fragments, so the embedding VALU work runs under this
@@ -320,10 +217,8 @@ __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d)
 
 // HEAD_ONLY: stop after the head layer and leave relu(head) (act_scale domain, register image
 // [tile][wave][u*2+c][lane][4] f32) in p.xbuf for r2l_body_kernel / r2l_tail_kernel (r2l_body.hip).
-template <int NP, bool MIX, bool HEAD_ONLY = false>
+template <int NP, bool HEAD_ONLY = false>
 __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
-    static_assert(!MIX || NP == 2, "FP16_FP8 uses the two-part chunk");
-    static_assert(!HEAD_ONLY || !MIX, "the head runs in the fp16 hi/lo layout");
     typedef KCfg<NP> C;
     Ring<NP> R;
     R.wimg = p.wimg;
@@ -348,8 +243,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     R.pre = read_frag<NP>(lane * 16, 0);
 
     f32x4 x[16][2];
-    f16x8 Bh[8][2], Bl[8][2], Nh[8][2], Nl[8][2];   // fp16 fragments (Bl / Nl: lo parts; in MIX only for the tail)
-    i32x8 Ba[2][2], Br[2][2], Na[2][2], Nr[2][2];   // MIX: e5m2 activations / activation residuals, K-step x column tile
+    f16x8 Bh[8][2], Bl[8][2], Nh[8][2], Nl[8][2];   // fp16 fragments (Bl / Nl: lo parts)
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // a lane serves ray (lane & 15) of both column tiles (p.tile_begin: this launch is a slice of the call)
@@ -483,14 +377,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(x[u][c][r] * inv_head, 0.0f);
                     x[u][c][r] = v;
-                    if (!MIX && !HEAD_ONLY) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
-                }
-                if (MIX) {  // x[u][c] already holds relu(.) in the scaled domain: split it (inv = 1, no relu needed)
-                    set_dword(Bh[u >> 1][c], 2 * (u & 1), 0u);
-                    set_dword(Bh[u >> 1][c], 2 * (u & 1) + 1, 0u);
-                    set_dword(Bl[u >> 1][c], 2 * (u & 1), 0u);
-                    set_dword(Bl[u >> 1][c], 2 * (u & 1) + 1, 0u);
-                    epi_tile_mix<true>(x[u][c], 1.0f, neg1, Bh[u >> 1][c], Bl[u >> 1][c], Ba[u >> 3][c], Br[u >> 3][c], u);
+                    if (!HEAD_ONLY) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
                 if (HEAD_ONLY || p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
             }
@@ -499,13 +386,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
-            if constexpr (MIX) {
-                body_layer_mix<false>(R, Bh, Ba, Br, Nh, Na, Nr, Nl, act_scale, neg1, q);  // Nl unused (SECOND = false)
-                body_layer_mix<true>(R, Nh, Na, Nr, Bh, Ba, Br, Bl, act_scale, neg1, q);   // x += ..., in place
-            } else {
-                body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q);
-                body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q);
-            }
+            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q);
+            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q);
         }
 
         // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------
@@ -513,11 +395,6 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
         for (int u = 0; u < 16; ++u) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                if (MIX) {  // the residual stream lives in the fragments (hi + lo)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        x[u][c][r] = (float)Bh[u >> 1][c][4 * (u & 1) + r] + (float)Bl[u >> 1][c][4 * (u & 1) + r];
-                }
                 if (p.use_residual) {
                     const f32x4 h0 = *reinterpret_cast<const f32x4*>(scr + (u * 2 + c) * 256);
                     x[u][c] = x[u][c] + h0;
@@ -531,7 +408,6 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             const uint32_t slot = R.use_off;
             const uint32_t lane_base = slot + lane * 16;
             const float inv = aux_inv_scale<NP>(slot);
-            if (MIX) R.pre = read_frag<NP>(lane_base, 0);  // the body's prefetch carried only the hi part
             f32x4 acc[2];
             acc[0] = acc_init<NP>(slot, 0, q);
             acc[1] = acc[0];
@@ -564,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
-template <int NP, bool MIX>
+template <int NP>
 static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream) {
     // the > 64 KiB dynamic-LDS opt-in is per device: a process may drive several GPUs
     static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
@@ -572,12 +448,12 @@ static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP, MIX>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((r2l_resmlp_kernel<NP, MIX>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    hipLaunchKernelGGL((r2l_resmlp_kernel<NP>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -588,12 +464,12 @@ static hipError_t launch_head(const R2LParams& p, int grid, hipStream_t stream) 
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP, false, true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((r2l_resmlp_kernel<NP, false, true>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    hipLaunchKernelGGL((r2l_resmlp_kernel<NP, true>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -602,8 +478,7 @@ hipError_t r2l_launch_head(const R2LParams& p, int np, int grid, hipStream_t str
 }
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream) {
-    if (mode == R2L_PREC_FP16_FP8_FUSED) return launch_resmlp<2, true>(p, grid, stream);
-    return mode == R2L_PREC_FP16X3 ? launch_resmlp<2, false>(p, grid, stream) : launch_resmlp<1, false>(p, grid, stream);
+    return mode == R2L_PREC_FP16X3 ? launch_resmlp<2>(p, grid, stream) : launch_resmlp<1>(p, grid, stream);
 }
 
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,

@@ -38,13 +38,13 @@ extern "C" {
  *                    (ah*wh + ah*wl + al*wh): L_inf vs the fp32 reference ~1e-6;
  *   R2L_PREC_FP16X1  single pass on fp16-rounded operands: L_inf ~4e-4, 3x fewer MFMAs.
  *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the
- *                    block-scaled fp8 MFMA (weights e4m3, activations e5m2) at twice the fp16
- *                    rate: 2 pass-equivalents per k-step, L_inf ~2.5e-5 (< 1e-4). */
+ *                    block-scaled low-precision MFMA (v_mfma_scale_f32_16x16x128_f8f6f4), L_inf ~3e-5 (< 1e-4):
+ *                    R2L: both operands in OCP bf6 (e3m2) at 4x the fp16 rate (1.5 pass-equivalents per
+ *                    k-step; head launch -> hand-scheduled body kernel -> tail launch);
+ *                    teacher: weights e4m3, activations e5m2 at twice the fp16 rate (2 pass-equivalents). */
 #define R2L_PREC_FP16X3 0
 #define R2L_PREC_FP16X1 1
 #define R2L_PREC_FP16_FP8 2
-/* the round-1 single-kernel form of FP16_FP8 (compiler-scheduled body); kept for A/B measurements */
-#define R2L_PREC_FP16_FP8_FUSED 3
 
 typedef struct r2l_ctx r2l_ctx;
 typedef struct nerf_ctx nerf_ctx;
@@ -133,7 +133,7 @@ int r2l_embed(const float* x_dev, int n, int dim, int L, float* emb_out_dev, voi
 long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_block,
                               int precision_mode, char* out, long long cap);
 
-/* Host-only: the R2L_PREC_FP16_FP8 body stream (32 KiB chunks | 4 KiB aux blocks | tail weights) that
+/* Host-only: the R2L_PREC_FP16_FP8 body stream (28 KiB chunks | 4 KiB aux blocks | tail weights) that
  * r2l_load_weights uploads for r2l_body_kernel; offs[0] / offs[1] receive the aux / tail byte offsets. */
 long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, int n_block,
                                    char* out, long long cap, long long* offs);

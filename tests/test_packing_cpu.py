@@ -113,43 +113,45 @@ def test_packed_stream_decodes_to_weights(pkg, built_lib, mode, np_):
     assert np.abs(value(cpt - 1, 9)).max() == 0
 
 
-def mix_feat(t, q, j):
-    return 16 * (8 * t + (j >> 2)) + 4 * q + (j & 3)
-
-
-def test_fp16_fp8_stream(pkg, built_lib):
-    """Mode 2: head / tail chunks identical to fp16x3; in body chunks piece 2f is the fp16 hi
-    fragment and piece 2f+1 carries e4m3 bytes of (w*S - hi)*2^7 (steps 0..3) and w*S*2^-5 (4..7)
-    in the K=128 element order of r2l_mix_feat.  e4m3 encoding pinned against torch.float8_e4m3fn."""
+def test_fp16_fp8_head_image_and_body_stream(pkg, built_lib):
+    """R2L_PREC_FP16_FP8 streams two images: the head launch reads the 32 head chunks of the hi|lo layout
+    (r2l_debug_pack_host), the body kernel the 28 KiB-chunk stream of r2l_debug_pack_body_host, whose bytes are pinned
+    against the generator's Python restatement in tests/test_body_gen_cpu.py.  Here: the head chunks are those of the
+    fp16x3 image, and the bf6 codes decode to the weights they stand for."""
+    import ctypes as C
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'efficient-nerf_amd', 'csrc', 'gen'))
+    import body_gen as G
+    from efficient_nerf_amd import _lib
     n_block = 1
     sd = O.make_r2l_state(seed=4, netdepth=2 + 2 * n_block)
     x3, mix = pack(pkg, sd, n_block, 0), pack(pkg, sd, n_block, 2)
     CH = FRAGS * 2 * FRAG + AUXB
-    cpt = 32 + 2 * n_block * 8 + 1
-    assert mix.size == x3.size == cpt * CH
-    assert np.array_equal(mix[:32 * CH], x3[:32 * CH]) and np.array_equal(mix[(cpt - 1) * CH:], x3[(cpt - 1) * CH:])
-    assert sorted(mix_feat(t, q, j) for t in range(2) for q in range(4) for j in range(32)) == list(range(256))
-    for li in range(2):
-        Wl = sd[O.r2l_state_names(n_block)[2 + 2 * li]].float()
-        for m in (0, 3, 7):
-            ci = 32 + li * 8 + m
-            base = ci * CH
-            aux = mix[base + 32 * FRAG:base + 32 * FRAG + AUXB].view(np.float32)
-            assert np.array_equal(aux, x3[base + 32 * FRAG:base + 32 * FRAG + AUXB].view(np.float32))
-            Sw = 1.0 / float(aux[32]) / 16.0
-            for f in range(16):
-                # hi pieces unchanged
-                assert np.array_equal(mix[base + 2 * f * FRAG:base + (2 * f + 1) * FRAG], x3[base + 2 * f * FRAG:base + (2 * f + 1) * FRAG])
-                u, s = 2 * m + (f >> 3), f & 7
-                term, t, half = s >> 2, (s >> 1) & 1, s & 1
-                got = torch.from_numpy(mix[base + (2 * f + 1) * FRAG:base + (2 * f + 2) * FRAG].copy()).view(torch.float8_e4m3fn)
-                got = got.float().reshape(64, 16)
-                for lane in (0, 21, 38, 63):
-                    k = [mix_feat(t, lane >> 4, 16 * half + i) for i in range(16)]
-                    w = Wl[16 * u + (lane & 15), k] * Sw
-                    hi = w.half().float()
-                    want = ((w - hi) * 128.0 if term == 0 else w / 32.0).to(torch.float8_e4m3fn).float()
-                    assert torch.equal(got[lane], want), (li, m, f, lane)
+    assert np.array_equal(mix[:32 * CH], x3[:32 * CH])     # mode 2 of r2l_debug_pack_host = the head launch's image
+    keep, arr = _lib.host_ptrs([sd[n] for n in O.r2l_state_names(n_block)])
+    offs = (C.c_longlong * 2)()
+    n = _lib.lib().r2l_debug_pack_body_host(arr, len(keep), n_block, None, 0, offs)
+    buf = np.zeros(n, dtype=np.uint8)
+    assert _lib.lib().r2l_debug_pack_body_host(arr, len(keep), n_block, C.c_void_p(buf.ctypes.data), n, offs) == n
+    assert offs[0] == n_block * 16 * G.CHUNK and offs[1] == offs[0] + n_block * G.AUX_BYTES
+    W1 = sd['body.0.body.0.weight'].float().numpy()
+    ex = G.layer_exponent(W1)
+    el, ew = G.weight_exps(ex)
+    aux = buf[offs[0]:offs[0] + G.AUX_BYTES].view(np.uint32)
+    assert (aux[256] & 0xff) == 127 + el and (aux[257] & 0xff) == 127 + ew
+    # chunk 3 (row tiles 6, 7) of layer 1, row tile 7, operand j = 1 (w itself, K-step 0): decode lane 37
+    m, upos, j, lane = 3, 1, 1, 37
+    base = m * G.CHUNK
+    lo = buf[base + G.piece_a6(upos, j) * 1024 + lane * 16:][:16]
+    pc, off = G.piece_a6b(upos, j)
+    hi = buf[base + pc * 1024 + off + lane * 8:][:8]
+    codes = G.unpack6(np.concatenate([lo, hi]).view(np.uint32)[None])[0]
+    vals = G.BF6[codes] * 2.0 ** ew
+    want = np.array([W1[16 * (2 * m + upos) + (lane & 15), G.mix_feat(0, lane >> 4, e)] for e in range(32)])
+    assert np.abs(vals - want).max() <= 0.13 * np.abs(want).max()  # e3m2: 2 mantissa bits
+    assert np.abs(vals - want).max() > 0
 
 
 def test_pack_rejects_bad_input(pkg, built_lib):

@@ -85,7 +85,7 @@ def test_mirror_objects_materialize(pkg, g):
 
 
 @pytest.mark.parametrize('H', [8, 400, 800])
-@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8', 'fp16_fp8_fused'])
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8'])
 def test_render_matches_reference_golden(g, engines, H, prec):
     """Full frame vs rgb computed by the reference's modules (model/nerf_raybased.py:76-126, 191-208, 539-544), at
     the reference's own CPU case (8), config 2 (400) and the bench's size (800), in every precision mode that

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import _pkg
 _pkg.load()
-from efficient_nerf_amd import R2LEngine, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_FP8_FUSED
+from efficient_nerf_amd import R2LEngine, PREC_FP16X3, PREC_FP16_FP8
 from oracle import r2l_oracle as O
 
 
@@ -67,7 +67,7 @@ def main():
             sd = O.make_r2l_state(seed=0, netdepth=2 + 2 * nb)
             c2w = O.pose_spherical(30., -30., 4.)
             ref = O.r2l_render(sd, H, H, focal, c2w)
-            for name, prec in (('fp16x3', PREC_FP16X3), ('fp16_fp8', PREC_FP16_FP8), ('fused', PREC_FP16_FP8_FUSED)):
+            for name, prec in (('fp16x3', PREC_FP16X3), ('fp16_fp8', PREC_FP16_FP8)):
                 eng = R2LEngine(H, H, focal, n_block=nb, precision=prec).load_state_dict(sd)
                 rgb = eng.render(c2w).cpu()
                 print(f'full H={H} nb={nb} {name}: L_inf vs oracle {(rgb - ref).abs().max().item():.3e}', flush=True)
@@ -77,7 +77,7 @@ def main():
         sd = O.make_r2l_state(seed=0, netdepth=2 + 2 * nb)
         poses = O.novel_poses(8)[:, :3, :4].contiguous().cuda()
         outs = {}
-        for name, prec in (('fused', PREC_FP16_FP8_FUSED), ('fp16_fp8', PREC_FP16_FP8)):
+        for name, prec in (('fp16x3', PREC_FP16X3), ('fp16_fp8', PREC_FP16_FP8)):
             eng = R2LEngine(H, H, focal, n_block=nb, precision=prec).load_state_dict(sd)
             for _ in range(3):
                 eng.render_batch(poses[0:1])
@@ -93,7 +93,7 @@ def main():
             outs[name] = eng.render_batch(poses[0:1]).cpu()
             print(f'time {name}: {dt * 1e3:.3f} ms/frame = {H * H / dt:.3e} rays/s; timed kernel {kt / max(kn, 1):.3f} ms '
                   f'({eng.kernel_flops_per_ray * H * H / (kt / max(kn, 1) * 1e-3) / 2.5e15:.3f} of 2.5 PF)', flush=True)
-        print('fused vs split L_inf', (outs['fused'] - outs['fp16_fp8']).abs().max().item())
+        print('fp16x3 vs fp16_fp8 L_inf', (outs['fp16x3'] - outs['fp16_fp8']).abs().max().item())
 
 
 if __name__ == '__main__':
