@@ -1,0 +1,856 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled gfx950 layer chain of the NeRF teacher MLP (model/nerf_raybased.py:377-401,
+NeRF.forward with use_viewdirs, 8 x 256 + view branch): the second instance of the machine of body_gen.py.
+
+One straight-line asm block computes all eleven Linear layers for the 128 points of a workgroup tile (a wave owns 32
+points = two column tiles of 16), from the embedding fragments the HIP prologue leaves in AGPRs to raw = (rgb, sigma) in
+8 VGPRs:
+
+  layer  source (B operands)                     MFMAs per row tile and column tile      row tiles  epilogue     destination
+  L0     pts embedding E (AGPR, fp16 hi | lo)    2 k-steps x 3 passes                    16         relu         Q
+  L1     Q                                       8 fp16 + 4 bf6 (K = 128)                16         relu         P   (L2: P -> Q, L3, L4)
+  L5     E, then Q                               2 x 3, 8 + 4                            16         relu         P
+  L6, L7 P -> Q -> P
+  FA     P -> feature (no activation) | alpha    8 + 4                                   17         - | sigma    Q | out
+  V      view embedding (AGPR), then Q           1 x 3, 8 + 4                            8          relu         P (k-steps 0..3)
+  RGB    P (128 wide)                            4 + 2                                   1          rgb          out
+
+Arithmetic of a 256- (128-) wide source as in body_gen.py: fp16 main pass + bf6(W - hi(W)) x bf6(a) + bf6(W) x bf6(a - hi(a))
+at 4x the fp16 rate.  The embedding k-steps (sines and cosines: not reducible to 3 bits) run as three fp16 passes on hi / lo
+fragments of both operands and come FIRST in a row tile, so a layer's first MFMAs do not wait for the previous layer's last
+epilogue.  Weights are unscaled; every layer carries its two E8M0 scale bytes next to its bias.
+
+LDS: 4 ring slots of 32 KiB + 16 KiB resident bias / scale table (loaded once per workgroup by the HIP prologue).  The
+weight stream of one tile is 80 chunks, each a whole number of row tiles (L0 2 x 8 row tiles, standard layers 8 x 2, L5
+16 x 1, FA 9 x 2, V 4 x 2, RGB 1); 80 = 0 mod 4 and every tile starts at stream offset 0, so every LDS and stream address
+is an immediate.  Ring protocol as in the R2L body (3 chunks ahead, one counted vmcnt wait + barrier per chunk, LDS-DMA).
+A tile block starts with `s_waitcnt vmcnt(0)` + barrier (chunks 0..2 were issued by the previous block's tail, or by the
+kernel prologue) and ends with the next tile's chunks 0..2 in flight.
+
+`python nerf_gen.py --emit DIR` writes nerf_mlp_asm.inc (the tile block; placeholders %[eh00] ... for the 12 AGPR inputs,
+%[o0] ... %[o7] for the outputs, %[wimg] %[wave]) and nerf_mlp_pro_asm.inc (the ring prologue).  tests/test_nerf_gen_cpu.py
+runs the lane-accurate emulator against a float64 evaluation of the network and the static hazard check of body_gen.py.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+import body_gen as B
+from body_gen import (Ins, vr, ar, vreg, areg, sreg, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accw, v_cvt_pk_f16,
+                      v_cvt_pk32_bf6, s_nop, salu, ds_read_b128, ds_read_b64, f_to_bf6, pack6, layer_exponent,
+                      weight_exps, f32_bits, Filler, check_hazards_stream, kappa, mix_feat)
+
+# ---------------------------------------------------------------------------------------------
+# register map
+# ---------------------------------------------------------------------------------------------
+V_SET = {'P': 0, 'Q': 64}     # fp16 hi B operands of the two activation sets: + c*32 + s*4
+V_ACC, V_BIAS, V_HI, V_A6, V_LO, V_TMP = 128, 144, 152, 168, 180, 212
+V_L0, V_L1, V_L8A, V_L8B, V_AUX, V_LANE = 232, 233, 234, 235, 236, 237
+V_SBA, V_SBL, V_CVA, V_CVL = 238, 239, 240, 241
+V_SC = 242                    # 242,243 | 244,245: E8M0 weight scales of even | odd layers
+V_LOFF = 246                  # lane*16 + 4096 (second LDS-DMA group)
+N_VGPR_CLOBBER = 248          # v248.. belong to the compiler (the 8 outputs)
+A_SET = {'P': 0, 'Q': 48}     # bf6 B operands: + term*24 + (t*2+c)*6
+A_E = 96                      # emulator numbering of the inputs: Eh 96 + (e*2+c)*4, El 112 + ..., Vh 128 + c*4, Vl 136 + c*4
+N_AGPR_CLOBBER = 96
+
+S_W = 40                      # 40,41 stream base
+S_WAVE = 42
+S_NEG1, S_M0SAVE = 43, 44
+S_G = 46                      # 46,47 LDS-DMA source
+S_WPW = 48                    # 48..55: wave * PW * 1024 for PW = 1..8
+N_SGPR_LO, N_SGPR_HI = 40, 56
+
+SLOT = 32768
+NSLOT = 4
+LDS_AUX = NSLOT * SLOT
+AUX_LAYER = 1280              # per layer: 272 f32 bias | at byte 1152: 4 lane quarters x (swl, sw, 0, 0)
+AUX_SCALES = 1152
+AUX_BYTES = 16384
+LDS_BYTES = LDS_AUX + AUX_BYTES
+ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
+
+
+class Layer:
+    def __init__(self, name, src, dst, ks, extra, rt, epi, rt_per_chunk, fan_out):
+        self.name, self.src, self.dst, self.ks, self.extra, self.rt, self.epi = name, src, dst, ks, extra, rt, epi
+        self.rt_per_chunk = rt_per_chunk
+        self.fan_out = fan_out           # real output rows
+        self.nj = ks // 2                # K=128 MFMAs per row tile and column tile (2 terms x ks/4)
+        self.nx = len(extra)
+
+    def j_order(self):
+        """(term, t) of the K=128 MFMAs in issue order: term 0 = (w - hi) x bf6(a), 1 = w x bf6(a - hi)"""
+        return [(0, 0), (1, 0), (0, 1), (1, 1)] if self.ks == 8 else [(0, 0), (1, 0)]
+
+    def chunk_pieces(self):
+        r = self.rt_per_chunk
+        return r * self.ks + r * self.nj + (r * self.nj + 1) // 2 + r * self.nx * 2
+
+
+def chain():
+    E2 = [('E', 0), ('E', 1)]
+    L = [Layer('L0', None, 'Q', 0, E2, 16, 'relu', 8, 256)]
+    sets = ['Q', 'P']
+    for i in range(1, 5):
+        L.append(Layer('L%d' % i, sets[(i - 1) % 2], sets[i % 2], 8, [], 16, 'relu', 2, 256))
+    L.append(Layer('L5', 'Q', 'P', 8, E2, 16, 'relu', 1, 256))
+    L.append(Layer('L6', 'P', 'Q', 8, [], 16, 'relu', 2, 256))
+    L.append(Layer('L7', 'Q', 'P', 8, [], 16, 'relu', 2, 256))
+    L.append(Layer('FA', 'P', 'Q', 8, [], 17, 'feat', 2, 257))
+    L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', 2, 128))
+    L.append(Layer('RGB', 'P', None, 4, [], 1, 'rgb', 1, 3))
+    return L
+
+
+CHAIN = chain()
+
+
+class Tile:
+    def __init__(self, idx, li, u):
+        self.idx, self.li, self.u, self.layer = idx, li, u, CHAIN[li]
+
+
+def _tiles_and_chunks():
+    tiles, chunks = [], []
+    for li, L in enumerate(CHAIN):
+        u = 0
+        while u < L.rt:
+            n = min(L.rt_per_chunk, L.rt - u)
+            ids = []
+            for k in range(n):
+                ids.append(len(tiles))
+                tiles.append(Tile(len(tiles), li, u + k))
+            pieces = L.chunk_pieces()
+            chunks.append(dict(tiles=ids, pieces=pieces, pw=(pieces + 3) // 4, li=li))
+            u += n
+    return tiles, chunks
+
+
+TILES, CHUNKS = _tiles_and_chunks()
+NT = len(TILES)
+NCH = len(CHUNKS)
+assert NCH % NSLOT == 0, NCH
+assert max(c['pw'] for c in CHUNKS) * 4096 <= SLOT
+CHUNK_OFF = [0]
+for _c in CHUNKS:
+    CHUNK_OFF.append(CHUNK_OFF[-1] + _c['pw'] * 4096)
+STREAM_BYTES = CHUNK_OFF[-1]
+TILE_CHUNK = {}
+for _ci, _c in enumerate(CHUNKS):
+    for _k, _t in enumerate(_c['tiles']):
+        TILE_CHUNK[_t] = (_ci, _k)
+TILE_OF = {(t.li, t.u): t.idx for t in TILES}
+
+
+def piece_of(L, k, what, idx):
+    """(1 KiB piece, byte offset inside it) within its chunk of an operand of the k-th row tile of the chunk.  what: 'hi'
+    (fp16 fragment of main k-step idx), 'b6' / 'b6b' (first 16 / last 8 bytes per lane of bf6 operand idx), 'xh' / 'xl'
+    (hi / lo fragment of embedding k-step idx)"""
+    r = L.rt_per_chunk
+    if what == 'hi':
+        return k * L.ks + idx, 0
+    base = r * L.ks
+    if what == 'b6':
+        return base + k * L.nj + idx, 0
+    base += r * L.nj
+    if what == 'b6b':
+        o = (k * L.nj + idx) * 512
+        return base + o // 1024, o % 1024
+    base += (r * L.nj + 1) // 2
+    if what == 'xh':
+        return base + (k * L.nx + idx) * 2, 0
+    if what == 'xl':
+        return base + (k * L.nx + idx) * 2 + 1, 0
+    raise ValueError(what)
+
+
+# ---------------------------------------------------------------------------------------------
+# embedding layouts (nerf_common.h restated) and the host packer restated
+# ---------------------------------------------------------------------------------------------
+def pts_col(e, q, j):
+    if e == 0:
+        return 3 + j * 6 + (3 if (q & 1) else 0) + (q >> 1)
+    if q < 2:
+        return 3 + j * 6 + (3 if (q & 1) else 0) + 2
+    if j < 6:
+        return 3 + (8 + (j & 1)) * 6 + (3 if q == 3 else 0) + (j >> 1)
+    if q == 2:
+        return j - 6
+    return 2 if j == 6 else -1
+
+
+def view_col(q, j):
+    if q < 3:
+        return 3 + (j & 3) * 6 + (3 if (j >> 2) else 0) + q
+    return j if j < 3 else -1
+
+
+def layer_matrices(t):
+    """per CHAIN layer (W_main [rows, K] or None, W_emb [rows, 63 | 27] or None, bias) from the 24 state_dict tensors
+    (model/nerf_raybased.py:357-375 order), float32 numpy"""
+    t = [np.asarray(x, dtype=np.float32) for x in t]
+    W = lambda i, r, c: t[i].reshape(r, c)
+    out = [(None, W(0, 256, 63), t[1])]
+    for i in range(1, 5):
+        out.append((W(2 * i, 256, 256), None, t[2 * i + 1]))
+    w5 = W(10, 256, 319)                                                   # cat([input_pts, h]) (:385)
+    out.append((np.ascontiguousarray(w5[:, 63:]), np.ascontiguousarray(w5[:, :63]), t[11]))
+    for i in (6, 7):
+        out.append((W(2 * i, 256, 256), None, t[2 * i + 1]))
+    out.append((np.concatenate([W(18, 256, 256), W(20, 1, 256)], 0), None, np.concatenate([t[19].reshape(-1), t[21].reshape(-1)])))
+    wv = W(16, 128, 283)                                                   # cat([feature, input_views]) (:390)
+    out.append((np.ascontiguousarray(wv[:, :256]), np.ascontiguousarray(wv[:, 256:]), t[17]))
+    out.append((W(22, 3, 128), None, t[23]))
+    return out
+
+
+def pack_teacher(tensors, act_scale=16.0):
+    """(stream bytes of one tile [STREAM_BYTES], aux bytes [AUX_BYTES]): Python restatement of nerf_capi.hip
+    pack_teacher_bf6"""
+    mats = layer_matrices(tensors)
+    img = np.zeros(STREAM_BYTES, dtype=np.uint8)
+    aux = np.zeros(AUX_BYTES // 4, dtype=np.uint32)
+    lanes = np.arange(64)
+    q, r = lanes >> 4, lanes & 15
+    for li, L in enumerate(CHAIN):
+        Wm, We, bias = mats[li]
+        a0 = li * AUX_LAYER // 4
+        aux[a0:a0 + len(bias)] = (bias.astype(np.float64) * act_scale).astype(np.float32).view(np.uint32)
+        el = ew = 0
+        if Wm is not None:
+            el, ew = weight_exps(layer_exponent(Wm))
+            for qq in range(4):
+                aux[a0 + AUX_SCALES // 4 + 4 * qq] = 0x01010101 * (127 + el)
+                aux[a0 + AUX_SCALES // 4 + 4 * qq + 1] = 0x01010101 * (127 + ew)
+            hi = Wm.astype(np.float16)
+        for u in range(L.rt):
+            ci, k = TILE_CHUNK[TILE_OF[(li, u)]]
+            base = CHUNK_OFF[ci]
+            rows = 16 * u + r
+            ok = rows < L.fan_out
+            rws = np.where(ok, rows, 0)
+
+            def put(what, idx, data, nbytes=1024):
+                p, o = piece_of(L, k, what, idx)
+                a = base + p * 1024 + o
+                img[a:a + nbytes] = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+
+            for s in range(L.ks):
+                frag = np.zeros((64, 8), dtype=np.float16)
+                for j in range(8):
+                    frag[:, j] = np.where(ok, hi[rws, kappa(s, q, j)], 0)
+                put('hi', s, frag)
+            for j, (term, tt) in enumerate(L.j_order() if L.ks else []):
+                codes = np.zeros((64, 32), dtype=np.uint8)
+                for e in range(32):
+                    kk = mix_feat(tt, q, e)
+                    w = np.where(ok, Wm[rws, kk], 0).astype(np.float64)
+                    h = np.where(ok, hi[rws, kk], 0).astype(np.float64)
+                    codes[:, e] = f_to_bf6(np.ldexp(w - h, -el) if term == 0 else np.ldexp(w, -ew))
+                words = pack6(codes)
+                put('b6', j, words[:, :4])
+                put('b6b', j, words[:, 4:], 512)
+            for xi, (kind, e) in enumerate(L.extra):
+                fh = np.zeros((64, 8), dtype=np.float16)
+                fl = np.zeros((64, 8), dtype=np.float16)
+                for j in range(8):
+                    for qq in range(4):
+                        col = pts_col(e, qq, j) if kind == 'E' else view_col(qq, j)
+                        if col < 0:
+                            continue
+                        m = (q == qq) & ok
+                        w = We[rws, col].astype(np.float32)
+                        h = w.astype(np.float16)
+                        fh[m, j] = h[m]
+                        fl[m, j] = (w - h.astype(np.float32)).astype(np.float16)[m]
+                put('xh', xi, fh)
+                put('xl', xi, fl)
+    return img, aux.view(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# builders beyond body_gen's
+# ---------------------------------------------------------------------------------------------
+def E_reg(kind, e, c, lo):
+    if kind == 'E':
+        return A_E + (16 if lo else 0) + (e * 2 + c) * 4
+    return A_E + 32 + (8 if lo else 0) + c * 4
+
+
+def E_name(kind, e, c, lo):
+    if kind == 'E':
+        return '%%[e%s%d%d]' % ('l' if lo else 'h', e, c)
+    return '%%[v%s%d]' % ('l' if lo else 'h', c)
+
+
+INPUT_NAMES = ([('e%s%d%d' % (hl, e, c), E_reg('E', e, c, hl == 'l')) for hl in 'hl' for e in range(2) for c in range(2)] +
+               [('v%s%d' % (hl, c), E_reg('V', 0, c, hl == 'l')) for hl in 'hl' for c in range(2)])
+
+
+def mfma16(d, a, bfile, b, c, tag='', btext=None):
+    """v[d:d+3] = A(v[a:a+3]) x B([bfile] b:b+3) + v[c:c+3]; btext: asm operand placeholder of an AGPR input"""
+    rf = {'v': vreg, 'a': areg}
+    text = 'v_mfma_f32_16x16x32_f16 %s, %s, %s, %s' % (vreg(d, 4), vreg(a, 4), btext or rf[bfile](b, 4), vreg(c, 4))
+
+    def emu(st):
+        lanes = np.arange(64)
+        Ah = B._halves(st.V[a:a + 4])
+        Bh = B._halves(st.regs(bfile)[b:b + 4])
+        Am = np.zeros((16, 32))
+        Bm = np.zeros((32, 16))
+        for j in range(8):
+            Am[lanes & 15, 8 * (lanes >> 4) + j] = Ah[:, j]
+            Bm[8 * (lanes >> 4) + j, lanes & 15] = Bh[:, j]
+        D = Am @ Bm
+        C = st.V[c:c + 4].view(np.float32).astype(np.float64)
+        out = np.zeros((4, 64), dtype=np.float32)
+        for i in range(4):
+            out[i] = (C[i] + D[4 * (lanes >> 4) + i, lanes & 15]).astype(np.float32)
+        st.V[d:d + 4] = out.view(np.uint32)
+
+    rb = vr(b, 4) if bfile == 'v' else ar(b, 4)
+    return Ins(text, 'mfma16', rd=vr(a, 4) + rb + vr(c, 4), wr=vr(d, 4), emu=emu, tag=tag)
+
+
+def v_resid16(dst, dst_high, hpk, half, t):
+    """half `dst_high` of dst = fp16(t - (float)half(hpk)):  v_fma_mixlo/hi_f16 dst, hpk.f16[half], -1.0 (SGPR), t"""
+    op = 'v_fma_mixhi_f16' if dst_high else 'v_fma_mixlo_f16'
+    sel = ' op_sel:[1,0,0]' if half else ''
+    text = '%s %s, %s, %s, %s%s op_sel_hi:[1,0,0]' % (op, vreg(dst), vreg(hpk), sreg(S_NEG1), vreg(t), sel)
+
+    def emu(st):
+        h = ((st.V[hpk] >> (16 * half)) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
+        r = (st.f32('v', t) - h).astype(np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+        if dst_high:
+            st.V[dst] = (st.V[dst] & 0x0000ffff) | (r << 16)
+        else:
+            st.V[dst] = (st.V[dst] & 0xffff0000) | r
+    return valu(text, vr(hpk) + vr(t), vr(dst), emu, partial=True)
+
+
+def mfma6(d, a, b_agpr, scale_a, scale_b, tag=''):
+    return B.mfma6('v', d, a, b_agpr, scale_a, scale_b, tag)
+
+
+def v_mov_out(k, src):
+    """output operand k <- v[src] (the emulator keeps outputs in st.out)"""
+    def emu(st):
+        st.out[k] = st.V[src].copy()
+    return valu('v_mov_b32 %%[o%d], %s' % (k, vreg(src)), vr(src), [], emu)
+
+
+def dma_piece(i, pw, tag=''):
+    """piece i of this wave's pw KiB of a chunk: global_load_lds_dwordx4 v_off, s[S_G:S_G+1] offset:imm with LDS
+    destination M0 + imm + lane*16; pieces 4.. use the +4096 offset register and M0 + 4096"""
+    voffr = V_L0 if i < 4 else V_LOFF
+    imm = 1024 * (i & 3)
+    text = 'global_load_lds_dwordx4 %s, %s offset:%d' % (vreg(voffr), sreg(S_G, 2), imm)
+
+    def emu(st):
+        copies = []
+        g = st.S[S_G]
+        for w in range(4):
+            dw = (w - st.wave) * pw * 1024
+            for l in range(64):
+                src = g + int(st.V[voffr][l]) + dw + imm
+                dst = st.m0 + dw + imm + l * 16
+                assert 0 <= dst and dst + 16 <= LDS_AUX, dst
+                assert 0 <= src and src + 16 <= len(st.img), (src, len(st.img))
+                copies.append((dst, st.img[src:src + 16].copy()))
+                st.lds_pending[dst:dst + 16] = True
+        st.pend_dma.append(copies)
+    return Ins(text, 'dma', rd=vr(voffr), emu=emu, cost=8, tag=tag)
+
+
+class NState(B.State):
+    def __init__(self, wave, img, aux):
+        B.State.__init__(self, wave, img, np.zeros((1, 1024), dtype=np.uint32), 0)
+        self.lds = np.zeros(LDS_BYTES, dtype=np.uint8)
+        self.lds_pending = np.zeros(LDS_BYTES, dtype=bool)
+        self.lds[LDS_AUX:LDS_AUX + len(aux)] = aux
+        self.out = {}
+
+
+# ---------------------------------------------------------------------------------------------
+# anchors: the MFMAs in program order
+# ---------------------------------------------------------------------------------------------
+def tile_anchors(L):
+    """MFMAs of one row tile as (kind, k, c, p): ('x', xi, c, pass) of the embedding k-steps first (pass 0 Wh x Eh,
+    1 Wh x El, 2 Wl x Eh), then ('m16', s, c, 0) and, behind the last nj main k-steps, ('m6', j, c, 0)"""
+    out = []
+    for xi in range(L.nx):
+        for p in range(3):
+            for c in range(2):
+                out.append(('x', xi, c, p))
+    for s in range(L.ks):
+        out.append(('m16', s, 0, 0))
+        out.append(('m16', s, 1, 0))
+        j = s - (L.ks - L.nj)
+        if j >= 0:
+            out.append(('m6', j, 0, 0))
+            out.append(('m6', j, 1, 0))
+    return out
+
+
+ANCH = [tile_anchors(t.layer) for t in TILES]
+ABASE = [0]
+for _a in ANCH:
+    ABASE.append(ABASE[-1] + len(_a))
+N_ANCH = ABASE[-1]
+
+
+def aidx(T, kind, k, c, p=0):
+    return ABASE[T] + ANCH[T].index((kind, k, c, p))
+
+
+def afirst(T):
+    return ABASE[T] if T < NT else N_ANCH
+
+
+def operand_key(T, kind, k, p):
+    if kind == 'x':
+        return ('xl' if p == 2 else 'xh', T, k)
+    return ('hi' if kind == 'm16' else 'a6', T, k)
+
+
+def hset(name, s, c):
+    return V_SET[name] + c * 32 + s * 4
+
+
+def b6(name, term, t, c):
+    return A_SET[name] + term * 24 + (t * 2 + c) * 6
+
+
+def ACC(p, c):
+    return V_ACC + p * 8 + c * 4
+
+
+def LO(c):
+    return V_LO + c * 16
+
+
+def TMP(c):
+    return V_TMP + c * 10
+
+
+def epilogue_ops(T, c):
+    """epilogue of tile T for column tile c: [(Ins, consumer)], consumer None | ('hi', s) | ('b6', term, t)"""
+    t = TILES[T]
+    L, u = t.layer, t.u
+    acc = ACC(T & 1, c)
+    tb = TMP(c)
+    cv = tb + 4
+    ops = []
+    if L.epi == 'rgb':
+        return [(v_mov_out(c * 4 + k, acc + k), None) for k in range(3)]
+    if L.epi == 'feat' and u == 16:
+        return [(v_mov_out(c * 4 + 3, acc), None)]
+    if L.epi == 'relu':
+        tv = [tb + i for i in range(4)]
+        for i in range(4):
+            ops.append((v_max0(tv[i], acc + i), None))
+    else:
+        tv = [acc + i for i in range(4)]
+    lo = LO(c) + 2 * (u & 7)
+    h01 = hset(L.dst, u >> 1, c) + 2 * (u & 1)
+    h23 = h01 + 1
+    ops.append((v_cvt_pk_f16(h01, tv[0], tv[1]), ('hi', u >> 1)))
+    ops.append((v_cvt_pk_f16(h23, tv[2], tv[3]), ('hi', u >> 1)))
+    # half-register writes: low halves first, then the high halves (never two writers of one register back to back)
+    ops.append((v_resid16(lo, 0, h01, 0, tv[0]), None))
+    ops.append((v_resid16(lo + 1, 0, h23, 0, tv[2]), None))
+    ops.append((v_resid16(lo, 1, h01, 1, tv[1]), None))
+    ops.append((v_resid16(lo + 1, 1, h23, 1, tv[3]), None))
+    if (u & 7) == 7:
+        tt = u >> 3
+        ops.append((v_cvt_pk32_bf6(cv, hset(L.dst, 4 * tt, c), V_CVA), None))
+        for i in range(6):
+            ops.append((v_accw(b6(L.dst, 0, tt, c) + i, cv + i), ('b6', 0, tt)))
+        ops.append((v_cvt_pk32_bf6(cv, LO(c), V_CVL), None))
+        for i in range(6):
+            ops.append((v_accw(b6(L.dst, 1, tt, c) + i, cv + i), ('b6', 1, tt)))
+    return ops
+
+
+class Opts:
+    def __init__(self, **kw):
+        self.lead = 8          # anchors a fragment read is issued ahead of its first MFMA
+        self.lead6 = 5
+        self.cap = 3           # issue slots for fillers behind each MFMA
+        self.dma_gap = 3       # anchors between two LDS-DMA pieces
+        self.__dict__.update(kw)
+
+
+def lds_addr(slot, byte_off, width):
+    off = slot * SLOT + byte_off
+    lo, hi = (V_L0, V_L1) if width == 16 else (V_L8A, V_L8B)
+    return (lo, off) if off < 65536 else (hi, off - 65536)
+
+
+def rdv_anchor(ci):
+    """anchor in front of which chunk ci's rendezvous (vmcnt wait + barrier + refill) sits: the middle of the chunk"""
+    ts = CHUNKS[ci]['tiles']
+    if len(ts) >= 2:
+        return afirst(ts[len(ts) // 2])
+    return afirst(ts[0]) + len(ANCH[ts[0]]) // 2
+
+
+def chunk_issue_seq(cn, slot):
+    """SALU + LDS-DMA instructions that fetch chunk cn (index into the tile's stream, wrapped) into ring slot `slot`"""
+    ch = CHUNKS[cn % NCH]
+    pw = ch['pw']
+    off = CHUNK_OFF[cn % NCH]
+    wp = S_WPW + pw - 1
+    seq = [salu('s_add_u32 %s, %s, %s' % (sreg(S_G), sreg(S_W), sreg(wp)), lambda st: st.S.__setitem__(S_G, st.S[S_W] + st.S[wp])),
+           salu('s_addc_u32 %s, %s, 0' % (sreg(S_G + 1), sreg(S_W + 1)))]
+    if off:
+        seq += [salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_G), sreg(S_G), off), lambda st: st.S.__setitem__(S_G, st.S[S_G] + off)),
+                salu('s_addc_u32 %s, %s, 0' % (sreg(S_G + 1), sreg(S_G + 1)))]
+    seq.append(salu('s_add_u32 m0, %s, 0x%x' % (sreg(wp), slot * SLOT), lambda st: setattr(st, 'm0', st.S[wp] + slot * SLOT)))
+    seq.append(s_nop(0))
+    for i in range(pw):
+        if i == 4:
+            seq.append(salu('s_add_u32 m0, m0, 0x1000', lambda st: setattr(st, 'm0', st.m0 + 4096)))
+            seq.append(s_nop(0))
+        seq.append(dma_piece(i, pw, tag=('dma', cn, i)))
+    return seq, pw
+
+
+def build_fillers(opts):
+    F = []
+    bufmap = {}
+    # ---- operands in consumption order -------------------------------------------------------------
+    first, last, order = {}, {}, []
+    for T in range(NT):
+        for i, (kind, k, c, p) in enumerate(ANCH[T]):
+            key = operand_key(T, kind, k, p)
+            a = ABASE[T] + i
+            if key not in first:
+                first[key] = a
+                order.append(key)
+            last[key] = a
+    hi_keys = [k for k in order if k[0] != 'a6']
+    a6_keys = [k for k in order if k[0] == 'a6']
+
+    def certified(T):
+        """anchor behind which the chunk of tile T may be read"""
+        ci, _ = TILE_CHUNK[T]
+        return -1 if ci < 3 else rdv_anchor(ci - 1) + 1
+
+    for n, key in enumerate(hi_keys):
+        what, T, k = key
+        L = TILES[T].layer
+        ci, kc = TILE_CHUNK[T]
+        pc, po = piece_of(L, kc, what, k)
+        bv, off = lds_addr(ci % NSLOT, pc * 1024 + po, 16)
+        buf = V_HI + (n % 4) * 4
+        bufmap[key] = buf
+        hard = last[hi_keys[n - 4]] if n >= 4 else -1
+        F.append(Filler(ds_read_b128(buf, bv, off, tag=key), max(hard, first[key] - opts.lead, certified(T)), first[key], ('rd',)))
+    for n, key in enumerate(a6_keys):
+        what, T, k = key
+        L = TILES[T].layer
+        ci, kc = TILE_CHUNK[T]
+        buf = V_A6 + (n % 2) * 6
+        bufmap[key] = buf
+        hard = last[a6_keys[n - 2]] if n >= 2 else -1
+        e = max(hard, first[key] - opts.lead6, certified(T))
+        pc, po = piece_of(L, kc, 'b6', k)
+        bv, off = lds_addr(ci % NSLOT, pc * 1024 + po, 16)
+        F.append(Filler(ds_read_b128(buf, bv, off, tag=key + (0,)), e, first[key], ('rd6',)))
+        pc, po = piece_of(L, kc, 'b6b', k)
+        bv, off = lds_addr(ci % NSLOT, pc * 1024 + po, 8)
+        F.append(Filler(ds_read_b64(buf + 4, bv, off, tag=key + (1,)), e, first[key], ('rd6',)))
+    # ---- bias and scales (resident table) ------------------------------------------------------------
+    for T, t in enumerate(TILES):
+        F.append(Filler(ds_read_b128(V_BIAS + (T & 1) * 4, V_AUX, t.li * AUX_LAYER + 64 * t.u, tag=('bias', T)),
+                        afirst(T - 1) + 1 if T >= 1 else -1, afirst(T), ('aux',)))
+        if t.u == 0 and t.layer.ks:
+            prev0 = TILE_OF[(t.li - 1, 0)]      # layer li-2 (same scale registers) is over once layer li-1 runs
+            F.append(Filler(ds_read_b64(V_SC + 2 * (t.li & 1), V_AUX, t.li * AUX_LAYER + AUX_SCALES, tag=('scale', t.li)),
+                            afirst(prev0) + 1, aidx(T, 'm6', 0, 0), ('aux',)))
+    # ---- epilogue of tile T-1 under tile T -------------------------------------------------------------
+    for T in range(1, NT):
+        tp = TILES[T - 1]
+        for c in range(2):
+            e0 = afirst(T) + 2 + c          # two further MFMAs behind the last writer of its accumulator
+            for ins, cons in epilogue_ops(T - 1, c):
+                dl = afirst(T + 1)          # the accumulator buffer is reused by tile T+1
+                if cons is not None:
+                    Ln = CHAIN[tp.li + 1]
+                    T0n = TILE_OF[(tp.li + 1, 0)]
+                    if cons[0] == 'hi':
+                        if cons[1] < Ln.ks:
+                            dl = min(dl, aidx(T0n, 'm16', cons[1], 0) - 2)
+                    elif (cons[1], cons[2]) in Ln.j_order():
+                        dl = min(dl, aidx(T0n, 'm6', Ln.j_order().index((cons[1], cons[2])), 0) - 2)
+                F.append(Filler(ins, e0, dl, ('epi', c)))
+    # ---- rendezvous + refill -----------------------------------------------------------------------------
+    group = {}                          # chunk number -> LDS-DMA instructions per wave
+    for ci in range(NCH):
+        ar = rdv_anchor(ci)
+        nxt = rdv_anchor(ci + 1) if ci + 1 < NCH else N_ANCH
+        ch = ('dma',)
+        F.append(Filler(waitcnt_vm(group.get(ci + 2, 0)), ar - 1, ar + 1, ch))
+        F.append(Filler(barrier(), ar - 1, ar + 1, ch))
+        seq, pw = chunk_issue_seq(ci + 3, (ci + 3) % NSLOT)
+        group[ci + 3] = pw
+        k = 0
+        for ins in seq:
+            if ins.kind != 'dma' and k == 0:
+                F.append(Filler(ins, ar - 1, min(ar + 4, nxt - 1), ch))
+            else:
+                F.append(Filler(ins, min(ar + 1 + opts.dma_gap * k, nxt - 2), nxt - 1, ch))
+                if ins.kind == 'dma':
+                    k += 1
+    return F, bufmap
+
+
+class Sched:
+    def __init__(self):
+        self.out = []
+        self.ds_issued = 0
+        self.ds_done = 0
+        self.ds_index = {}
+
+    def emit(self, ins):
+        self.out.append(ins)
+        if ins.kind == 'ds':
+            self.ds_index[ins.tag] = self.ds_issued
+            self.ds_issued += 1
+
+    def need(self, key):
+        idx = self.ds_index[key]
+        if idx < self.ds_done:
+            return
+        self.emit(waitcnt_lgkm(self.ds_issued - idx - 1))
+        self.ds_done = idx + 1
+
+
+def schedule(opts):
+    """the tile block between its entry (vmcnt(0) + barrier) and its exposed last epilogue: [Ins]"""
+    sch = Sched()
+    fillers, bufmap = build_fillers(opts)
+    for i, f in enumerate(fillers):
+        f.seq = i
+    chains = {}
+    for f in fillers:
+        chains.setdefault(f.chain, []).append(f)
+    for ch in chains.values():
+        for i in range(len(ch) - 2, -1, -1):   # a filler must not hold up a successor with an earlier deadline
+            ch[i].deadline = min(ch[i].deadline, ch[i + 1].deadline)
+    heads = {ch: 0 for ch in chains}
+
+    def ready(pos):
+        r = []
+        for ch, lst in chains.items():
+            i = heads[ch]
+            if i < len(lst) and lst[i].earliest <= pos:
+                r.append(lst[i])
+        r.sort(key=lambda f: (f.deadline, f.seq))
+        return r
+
+    def issue(f):
+        sch.emit(f.ins)
+        heads[f.chain] += 1
+
+    while True:
+        r = ready(-1)
+        if not r:
+            break
+        issue(r[0])
+    T = 0
+    for a in range(N_ANCH):
+        while True:
+            r = [f for f in ready(a - 1) if f.deadline <= a]
+            if not r:
+                break
+            issue(r[0])
+        while a >= ABASE[T + 1]:
+            T += 1
+        t = TILES[T]
+        L = t.layer
+        kind, k, c, p = ANCH[T][a - ABASE[T]]
+        d = ACC(T & 1, c)
+        is_first = (a - ABASE[T]) == c           # the first MFMA of column tile c starts from the bias
+        csrc = V_BIAS + (T & 1) * 4 if is_first else d
+        if is_first:
+            sch.need(('bias', T))
+        key = operand_key(T, kind, k, p)
+        if kind == 'x':
+            sch.need(key)
+            ek, e = L.extra[k]
+            ins = mfma16(d, bufmap[key], 'a', E_reg(ek, e, c, p == 1), csrc, tag=('x', T, k, c, p), btext=E_name(ek, e, c, p == 1))
+        elif kind == 'm16':
+            sch.need(key)
+            ins = mfma16(d, bufmap[key], 'v', hset(L.src, k, c), csrc, tag=('m16', T, k, c))
+        else:
+            sch.need(key + (1,))
+            term, tt = L.j_order()[k]
+            if t.u == 0 and k == 0 and c == 0:
+                sch.need(('scale', t.li))
+            ins = mfma6(d, bufmap[key], b6(L.src, term, tt, c), V_SC + 2 * (t.li & 1) + term, V_SBA if term == 0 else V_SBL,
+                        tag=('m6', T, k, c))
+        sch.emit(ins)
+        budget = opts.cap
+        while budget > 0:
+            r = ready(a)
+            if not r:
+                break
+            issue(r[0])
+            budget -= r[0].ins.cost
+    while True:          # what is left of the refill of the next tile's first chunks
+        r = ready(N_ANCH + 10 ** 6)
+        if not r:
+            break
+        issue(r[0])
+    return sch.out
+
+
+def setup_ops():
+    """(text lines, emulator function) of the per-block constant setup"""
+    L = []
+    a = L.append
+    a('s_mov_b32 %s, m0' % sreg(S_M0SAVE))
+    a('s_mov_b64 %s, %%[wimg]' % sreg(S_W, 2))
+    a('s_mov_b32 %s, %%[wave]' % sreg(S_WAVE))
+    a('s_mov_b32 %s, 0xbf800000' % sreg(S_NEG1))
+    a('s_lshl_b32 %s, %s, 10' % (sreg(S_WPW), sreg(S_WAVE)))
+    for k in range(1, 8):
+        a('s_add_u32 %s, %s, %s' % (sreg(S_WPW + k), sreg(S_WPW + k - 1), sreg(S_WPW)))
+    a('v_mbcnt_lo_u32_b32 %s, -1, 0' % vreg(V_LANE))
+    a('v_mbcnt_hi_u32_b32 %s, -1, %s' % (vreg(V_LANE), vreg(V_LANE)))
+    a('v_lshlrev_b32 %s, 4, %s' % (vreg(V_L0), vreg(V_LANE)))
+    a('v_add_u32 %s, 0x10000, %s' % (vreg(V_L1), vreg(V_L0)))
+    a('v_add_u32 %s, 0x1000, %s' % (vreg(V_LOFF), vreg(V_L0)))
+    a('v_lshlrev_b32 %s, 3, %s' % (vreg(V_L8A), vreg(V_LANE)))
+    a('v_add_u32 %s, 0x10000, %s' % (vreg(V_L8B), vreg(V_L8A)))
+    a('v_lshrrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_LANE)))
+    a('v_lshlrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_AUX)))
+    a('v_add_u32 %s, 0x%x, %s' % (vreg(V_AUX), LDS_AUX, vreg(V_AUX)))
+    a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBA), 0x01010101 * (127 + ACT_EXP)))
+    a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBL), 0x01010101 * (127 + RES_EXP)))
+    a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVA), f32_bits(2.0 ** ACT_EXP)))
+    a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVL), f32_bits(2.0 ** RES_EXP)))
+
+    def emu(st):
+        lanes = np.arange(64, dtype=np.uint32)
+        st.V[V_LANE] = lanes
+        st.V[V_L0] = lanes * 16
+        st.V[V_L1] = lanes * 16 + 65536
+        st.V[V_LOFF] = lanes * 16 + 4096
+        st.V[V_L8A] = lanes * 8
+        st.V[V_L8B] = lanes * 8 + 65536
+        st.V[V_AUX] = LDS_AUX + (lanes >> 4) * 16
+        st.V[V_SBA] = 0x01010101 * (127 + ACT_EXP)
+        st.V[V_SBL] = 0x01010101 * (127 + RES_EXP)
+        st.V[V_CVA] = f32_bits(2.0 ** ACT_EXP)
+        st.V[V_CVL] = f32_bits(2.0 ** RES_EXP)
+        st.S[S_W] = 0
+        for k in range(8):
+            st.S[S_WPW + k] = st.wave * (k + 1) * 1024
+    return L, emu
+
+
+def prologue_ops():
+    """ring prologue: chunks 0, 1, 2 -> slots 0, 1, 2"""
+    seq = []
+    for k in range(3):
+        seq += chunk_issue_seq(k, k)[0]
+    return seq
+
+
+def tail_ops():
+    """exposed epilogue of the last row tile (RGB)"""
+    ops = [s_nop(15), s_nop(15)]
+    for c in range(2):
+        ops += [ins for ins, _ in epilogue_ops(NT - 1, c)]
+    return ops
+
+
+def block_stream(opts):
+    return [waitcnt_vm(0), barrier()] + schedule(opts) + tail_ops()
+
+
+def emit(dirname, opts):
+    setup, _ = setup_ops()
+    body = block_stream(opts)
+    n = {}
+    for ins in body:
+        n[ins.kind] = n.get(ins.kind, 0) + 1
+    with open(os.path.join(dirname, 'nerf_mlp_asm.inc'), 'w') as f:
+        f.write('// GENERATED by gen/nerf_gen.py -- do not edit.  One 128-point tile of the teacher MLP: %s\n' %
+                ', '.join('%s %d' % kv for kv in sorted(n.items())))
+        for line in setup + [i.text for i in body] + ['s_mov_b32 m0, %s' % sreg(S_M0SAVE)]:
+            f.write('"%s\\n\\t"\n' % line)
+    with open(os.path.join(dirname, 'nerf_mlp_pro_asm.inc'), 'w') as f:
+        f.write('// GENERATED by gen/nerf_gen.py -- do not edit.  Ring prologue: chunks 0..2 of the stream\n')
+        for line in setup + [i.text for i in prologue_ops()] + ['s_mov_b32 m0, %s' % sreg(S_M0SAVE)]:
+            f.write('"%s\\n\\t"\n' % line)
+    def clob(nv0, nv1, na):
+        regs = ['v%d' % i for i in range(nv0, nv1)] + ['a%d' % i for i in range(na)]
+        regs += ['s%d' % i for i in range(N_SGPR_LO, N_SGPR_HI)] + ['vcc', 'scc', 'memory']
+        return ', '.join('"%s"' % r for r in regs) + '\n'
+
+    with open(os.path.join(dirname, 'nerf_mlp_clobbers.inc'), 'w') as f:
+        f.write('// GENERATED by gen/nerf_gen.py: registers the tile block owns\n' + clob(0, N_VGPR_CLOBBER, N_AGPR_CLOBBER))
+    with open(os.path.join(dirname, 'nerf_mlp_pro_clobbers.inc'), 'w') as f:
+        f.write('// GENERATED by gen/nerf_gen.py: registers the ring prologue owns\n' + clob(V_L0, N_VGPR_CLOBBER, 0))
+    return n, body
+
+
+# ---------------------------------------------------------------------------------------------
+# emulation of one wave over one tile (tests)
+# ---------------------------------------------------------------------------------------------
+def emulate_tile(opts, img, aux, frags, wave=0, n_tiles=1, check_hazards=True, body=None):
+    """frags: {input name: uint32 [4, 64]} (INPUT_NAMES).  Returns (outputs float32 [8, 64], errors)."""
+    body = body or block_stream(opts)
+    st = NState(wave, img, aux)
+    _, setup = setup_ops()
+    setup(st)
+    for name, reg in INPUT_NAMES:
+        st.A[reg:reg + 4] = frags[name]
+    st.run(prologue_ops())
+    for _ in range(n_tiles):
+        st.out = {}
+        st.run(body)
+    errs = list(st.errors)
+    if st.pend_ds:
+        errs.append('%d LDS reads never waited for' % len(st.pend_ds))
+    if check_hazards:
+        errs += check_hazards_stream(body)
+    out = np.stack([st.out[k] for k in range(8)]).view(np.float32)
+    return out, errs
+
+
+def model_cycles(body):
+    return B.model_cycles(body)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--emit', help='directory for nerf_mlp_asm.inc / nerf_mlp_pro_asm.inc')
+    ap.add_argument('--dump', help='write the tile block as plain text')
+    ap.add_argument('--lead', type=int, default=8)
+    ap.add_argument('--lead6', type=int, default=5)
+    ap.add_argument('--cap', type=int, default=3)
+    ap.add_argument('--dma-gap', type=int, default=3)
+    a = ap.parse_args()
+    opts = Opts(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap)
+    print('tiles', NT, 'chunks', NCH, 'MFMAs', N_ANCH, 'stream bytes', STREAM_BYTES)
+    if a.emit:
+        n, body = emit(a.emit, opts)
+        print('wrote', a.emit, n, 'model cycles per tile', model_cycles(body))
+    if a.dump:
+        body = block_stream(opts)
+        with open(a.dump, 'w') as f:
+            for ins in body:
+                f.write(ins.text + '\n')
+        print('model cycles per tile', model_cycles(body))
+
+
+if __name__ == '__main__':
+    sys.exit(main())

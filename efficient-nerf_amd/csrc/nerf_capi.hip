@@ -43,13 +43,9 @@ void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
 // One layer of the fragment stream: RT row tiles (16 outputs) x KS k-steps (32 inputs).
 // weight(row, col) returns W[row][col] (0 outside), col_of(s, q, j) the input column of element
 // j of lane quarter q of k-step s (or -1), bias(row) the bias.
-// FP16_FP8 (HS > 0): the first HS k-steps (the 256- or 128-wide source activations) keep their fp16 hi
-// fragment in piece 2f and carry in piece 2f+1 the e4m3 bytes of the two correction terms, laid out as
-// in the R2L body (r2l_common.h): with H2 = HS/2 steps per term, step ks holds term ks / H2, fp8
-// K-step (ks % H2) >> 1, byte half ks & 1; feature f of the source is input column wide_col + f.
 void pack_layer(std::vector<char>& img, int np, int F0, int KS, int RT, float Sa,
                 const std::function<float(int, int)>& weight, const std::function<int(int, int, int)>& col_of,
-                const std::function<float(int)>& bias, float Sw, float* inv_scale_out, int HS = 0, int wide_col = 0) {
+                const std::function<float(int)>& bias, float Sw, float* inv_scale_out) {
     const int CH = r2l_chunk_bytes(np);
     const int AUX = R2L_FRAGS * np * R2L_FRAG_BYTES;
     const float S = Sa * Sw;
@@ -63,17 +59,6 @@ void pack_layer(std::vector<char>& img, int np, int F0, int KS, int RT, float Sa
                     const float v = col < 0 ? 0.f : weight(16 * u + (lane & 15), col) * Sw;
                     put_frag(chunk, np, fq % R2L_FRAGS, lane, j, v);
                 }
-            if (ks >= HS) continue;
-            const int H2 = HS / 2, term = ks / H2, t = (ks % H2) >> 1, half = ks & 1;
-            for (int lane = 0; lane < 64; ++lane) {
-                unsigned char* pb = reinterpret_cast<unsigned char*>(chunk + (size_t)(2 * (fq % R2L_FRAGS) + 1) * R2L_FRAG_BYTES + lane * 16);
-                for (int i = 0; i < 16; ++i) {
-                    const int feat = r2l_mix_feat(t, lane >> 4, 16 * half + i);
-                    const float wv = weight(16 * u + (lane & 15), wide_col + feat) * Sw;
-                    const float hi = (float)(_Float16)wv;
-                    pb[i] = r2l_f32_to_e4m3(term == 0 ? ldexpf(wv - hi, R2L_MIX_WL_SHIFT) : ldexpf(wv, -R2L_MIX_W_SHIFT));
-                }
-            }
         }
         const int q0 = F0 + u * KS;
         float* aux = reinterpret_cast<float*>(img.data() + (size_t)(q0 / R2L_FRAGS) * CH + AUX);
@@ -90,6 +75,122 @@ float max_scale(std::initializer_list<std::pair<const float*, size_t>> ts) {
             if (a > m && isfinite(a)) m = a;
         }
     return r2l_pow2_scale(&m, 1);
+}
+
+
+// FP16_FP8: the stream of the hand-scheduled layer chain (gen/nerf_gen.py; restated there as pack_teacher and compared
+// byte for byte by tests/test_nerf_gen_cpu.py).  Eleven layers in execution order; a layer = RT row tiles of 16 outputs,
+// cut into chunks of RPC row tiles; a chunk = 1 KiB pieces (64 lanes x 16 B), PW = ceil(pieces / 4) KiB per wave:
+//   [k*KS + s]            fp16 hi fragment of main k-step s of the chunk's k-th row tile (UNSCALED weights)
+//   [RPC*KS + k*NJ + j]   first 16 B/lane of bf6 operand j (NJ = KS/2: (term, t) = (0,0) (1,0) [(0,1) (1,1)])
+//   then ceil(RPC*NJ/2) pieces holding the last 8 B/lane of operand k*NJ + j at byte (k*NJ + j) * 512
+//   then per row tile and embedding k-step: the fp16 hi fragment, the fp16 lo fragment
+// bf6 operands as in the R2L body (r2l_capi.hip): term 0 = (w - hi(w)) / 2^(e-16), term 1 = w / 2^(e-4), e = exponent
+// of the layer's max|w|, element i of a lane = input feature r2l_mix_feat(t, lane>>4, i).  Behind the stream: the
+// resident table, per layer NERF_CHAIN_AUX_LAYER bytes = bias x act_scale | the two E8M0 scale bytes per lane quarter.
+struct ChainLayer { int ks, nx, rt, rpc, fan_out; };
+const ChainLayer kChain[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
+                               {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
+                               {8, 0, 17, 2, 257}, {8, 1, 8, 2, 128},  {4, 0, 1, 1, 3}};
+
+struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding column), bias(row); rows < fan_out
+    std::function<float(int, int)> main, emb;
+    std::function<float(int)> bias;
+    bool is_pts;    // embedding k-steps: pts (nerf_pts_col) or view (nerf_view_col)
+};
+
+int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img) {
+    img.assign((size_t)NERF_CHAIN_STREAM_BYTES + NERF_CHAIN_AUX_BYTES, 0);
+    auto mat = [&](int ti, int ncol, int col0) {
+        const float* p = w[ti].data();
+        return [p, ncol, col0](int r, int col) -> float { return p[(size_t)r * ncol + col0 + col]; };
+    };
+    auto vec = [&](int ti) {
+        const float* p = w[ti].data();
+        return [p](int r) -> float { return p[r]; };
+    };
+    ChainSrc src[11];
+    src[0] = {nullptr, mat(0, 63, 0), vec(1), true};
+    const int plain[6] = {1, 2, 3, 4, 6, 7};
+    for (int li : plain) src[li] = {mat(2 * li, 256, 0), nullptr, vec(2 * li + 1), true};
+    src[5] = {mat(10, 319, 63), mat(10, 319, 0), vec(11), true};     // cat([input_pts, h])  (model/nerf_raybased.py:385)
+    {
+        const float *fw = w[T_FEAT_W].data(), *aw = w[T_ALPHA_W].data(), *fb = w[T_FEAT_B].data(), *ab = w[T_ALPHA_B].data();
+        src[8] = {[=](int r, int k) -> float { return r < 256 ? fw[(size_t)r * 256 + k] : aw[k]; }, nullptr,
+                  [=](int r) -> float { return r < 256 ? fb[r] : ab[0]; }, true};
+    }
+    src[9] = {mat(T_VIEWS_W, 283, 0), mat(T_VIEWS_W, 283, 256), vec(T_VIEWS_B), false};  // cat([feature, views]) (:390)
+    src[10] = {mat(T_RGB_W, 128, 0), nullptr, vec(T_RGB_B), true};
+    size_t chunk_off = 0;
+    uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + NERF_CHAIN_STREAM_BYTES);
+    for (int li = 0; li < 11; ++li) {
+        const ChainLayer& L = kChain[li];
+        const ChainSrc& S = src[li];
+        const int nj = L.ks / 2, K = L.ks * 32;
+        const int pieces = L.rpc * L.ks + L.rpc * nj + (L.rpc * nj + 1) / 2 + L.rpc * L.nx * 2;
+        const size_t chunk_bytes = (size_t)((pieces + 3) / 4) * 4096;
+        uint32_t* al = aux + (size_t)li * NERF_CHAIN_AUX_LAYER / 4;
+        for (int r = 0; r < L.fan_out; ++r) {
+            const float v = (float)((double)S.bias(r) * Sa);
+            memcpy(&al[r], &v, 4);
+        }
+        int el = 0, ew = 0;
+        if (L.ks) {
+            std::vector<float> all((size_t)L.fan_out * K);
+            for (int r = 0; r < L.fan_out; ++r)
+                for (int k = 0; k < K; ++k) all[(size_t)r * K + k] = S.main(r, k);
+            const int e = r2l_layer_exponent(all.data(), all.size());
+            if (e < -12 || e > 6)
+                return r2l_set_error(R2L_EINVAL, "teacher layer %d: max|w| = 2^%d is outside the range the fp16 + bf6 weight "
+                                     "split covers (2^-12 .. 2^6); use R2L_PREC_FP16X3", li, e);
+            el = e - 16;
+            ew = e - 4;
+            for (int q = 0; q < 4; ++q) {
+                al[NERF_CHAIN_AUX_SCALES / 4 + 4 * q] = 0x01010101u * (uint32_t)(127 + el);
+                al[NERF_CHAIN_AUX_SCALES / 4 + 4 * q + 1] = 0x01010101u * (uint32_t)(127 + ew);
+            }
+        }
+        for (int u = 0; u < L.rt; ++u) {
+            char* chunk = img.data() + chunk_off + (size_t)(u / L.rpc) * chunk_bytes;
+            const int k = u % L.rpc;
+            const int p_b6 = L.rpc * L.ks, p_b6b = p_b6 + L.rpc * nj, p_x = p_b6b + (L.rpc * nj + 1) / 2;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = lane >> 4, row = 16 * u + (lane & 15);
+                if (row >= L.fan_out) continue;
+                for (int s = 0; s < L.ks; ++s) {
+                    _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(k * L.ks + s) * 1024 + lane * 16);
+                    for (int j = 0; j < 8; ++j) ph[j] = (_Float16)S.main(row, r2l_kappa(s, q, j));
+                }
+                for (int j = 0; j < nj; ++j) {
+                    const int term = j & 1, t = j >> 1;
+                    uint64_t bits[3] = {0, 0, 0};
+                    for (int i = 0; i < 32; ++i) {
+                        const float wv = S.main(row, r2l_mix_feat(t, q, i));
+                        const float hi = (float)(_Float16)wv;
+                        const double v = term == 0 ? ldexp((double)wv - (double)hi, -el) : ldexp((double)wv, -ew);
+                        const uint64_t code = r2l_f_to_bf6(v);
+                        const int bit = 6 * i, wd = bit >> 6, sh = bit & 63;
+                        bits[wd] |= code << sh;
+                        if (sh > 58) bits[wd + 1] |= code >> (64 - sh);
+                    }
+                    memcpy(chunk + (size_t)(p_b6 + k * nj + j) * 1024 + lane * 16, bits, 16);
+                    memcpy(chunk + (size_t)p_b6b * 1024 + (size_t)(k * nj + j) * 512 + lane * 8, &bits[2], 8);
+                }
+                for (int x = 0; x < L.nx; ++x) {
+                    _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(p_x + (k * L.nx + x) * 2) * 1024 + lane * 16);
+                    _Float16* pl = ph + 512;
+                    for (int j = 0; j < 8; ++j) {
+                        const int col = S.is_pts ? nerf_pts_col(x, q, j) : nerf_view_col(q, j);
+                        if (col < 0) continue;
+                        r2l_split_f16(S.emb(row, col), &ph[j], &pl[j]);
+                    }
+                }
+            }
+        }
+        chunk_off += (size_t)((L.rt + L.rpc - 1) / L.rpc) * chunk_bytes;
+    }
+    if (chunk_off != NERF_CHAIN_STREAM_BYTES) return r2l_set_error(R2L_EINVAL, "internal: chain stream is %zu bytes", chunk_off);
+    return R2L_OK;
 }
 
 }  // namespace
@@ -223,9 +324,25 @@ int nerf_set_sampling(nerf_ctx* c, const float* z_coarse_host, int n_z, const fl
     return upload_sampling(c);
 }
 
+static int upload_img(PackedNet& net, int mode, const std::vector<char>& img) {
+    if (net.d_img[mode]) {
+        (void)hipFree(net.d_img[mode]);
+        net.d_img[mode] = nullptr;
+    }
+    hipError_t e = hipMalloc((void**)&net.d_img[mode], img.size());
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc image: %s", hipGetErrorString(e));
+    e = hipMemcpy(net.d_img[mode], img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy image: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
 static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
+    if (mode == R2L_PREC_FP16_FP8) {  // the layer chain's own stream (nerf_chain_kernel)
+        std::vector<char> img;
+        int rc = pack_chain(net.host_w, c->act_scale, img);
+        return rc ? rc : upload_img(net, mode, img);
+    }
     const int np = np_of(mode);
-    const int HSW = mode == R2L_PREC_FP16_FP8 ? 8 : 0;  // fp8 correction pieces on the 256-wide k-steps
     const int CH = r2l_chunk_bytes(np);
     std::vector<char> img((size_t)NERF_CHUNKS * CH, 0);
     const float Sa = c->act_scale;
@@ -248,7 +365,7 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
     for (int li : plain) {
         const int F0 = li <= 4 ? NERF_F0_L1 + 128 * (li - 1) : NERF_F0_L6 + 128 * (li - 6);
         pack_layer(img, np, F0, 8, 16, Sa, mat(2 * li, 256, 256), kap, vec(2 * li + 1, 256),
-                   r2l_pow2_scale(w[2 * li].data(), w[2 * li].size()), &inv[li], HSW, 0);
+                   r2l_pow2_scale(w[2 * li].data(), w[2 * li].size()), &inv[li]);
     }
     // L5: reference input = cat[input_pts(63), h(256)]  (model/nerf_raybased.py:385)
     pack_layer(img, np, NERF_F0_L5, 10, 16, Sa, mat(10, 319, 256),
@@ -256,7 +373,7 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
                    if (ks < 8) return 63 + r2l_kappa(ks, q, j);
                    return nerf_pts_col(ks - 8, q, j);
                },
-               vec(11, 256), r2l_pow2_scale(w[10].data(), w[10].size()), &inv[5], HSW, 63);
+               vec(11, 256), r2l_pow2_scale(w[10].data(), w[10].size()), &inv[5]);
     // FA: rows 0..255 feature_linear, row 256 alpha_linear (row tile 16, row 0)
     {
         const float* fw = w[T_FEAT_W].data();
@@ -266,7 +383,7 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
         const float Sw = max_scale({{fw, w[T_FEAT_W].size()}, {aw, w[T_ALPHA_W].size()}});
         pack_layer(img, np, NERF_F0_FA, 8, 17, Sa,
                    [=](int r, int col) -> float { return r < 256 ? fw[(size_t)r * 256 + col] : (r == 256 ? aw[col] : 0.f); },
-                   kap, [=](int r) -> float { return r < 256 ? fb[r] : (r == 256 ? ab[0] : 0.f); }, Sw, &inv[8], HSW, 0);
+                   kap, [=](int r) -> float { return r < 256 ? fb[r] : (r == 256 ? ab[0] : 0.f); }, Sw, &inv[8]);
     }
     // V: reference input = cat[feature(256), input_views(27)]  (model/nerf_raybased.py:390)
     pack_layer(img, np, NERF_F0_V, 9, 8, Sa, mat(T_VIEWS_W, 283, 128),
@@ -275,19 +392,11 @@ static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
                    const int cidx = nerf_view_col(q, j);
                    return cidx < 0 ? -1 : 256 + cidx;
                },
-               vec(T_VIEWS_B, 128), r2l_pow2_scale(w[T_VIEWS_W].data(), w[T_VIEWS_W].size()), &inv[9], HSW, 0);
+               vec(T_VIEWS_B, 128), r2l_pow2_scale(w[T_VIEWS_W].data(), w[T_VIEWS_W].size()), &inv[9]);
     // RGB
     pack_layer(img, np, NERF_F0_RGB, 4, 1, Sa, mat(T_RGB_W, 128, 3), kap, vec(T_RGB_B, 3),
-               r2l_pow2_scale(w[T_RGB_W].data(), w[T_RGB_W].size()), &inv[10], HSW / 2, 0);
-    if (net.d_img[mode]) {
-        (void)hipFree(net.d_img[mode]);
-        net.d_img[mode] = nullptr;
-    }
-    hipError_t e = hipMalloc((void**)&net.d_img[mode], img.size());
-    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc image: %s", hipGetErrorString(e));
-    e = hipMemcpy(net.d_img[mode], img.data(), img.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy image: %s", hipGetErrorString(e));
-    return R2L_OK;
+               r2l_pow2_scale(w[T_RGB_W].data(), w[T_RGB_W].size()), &inv[10]);
+    return upload_img(net, mode, img);
 }
 
 int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n_tensors) {
@@ -519,6 +628,21 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 }
 
 // run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
+long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, char* out, long long cap, long long* offs) {
+    if (!tensors || n_tensors != 24) return r2l_set_error(R2L_EINVAL, "expected 24 tensors");
+    std::vector<std::vector<float>> w;
+    for (int i = 0; i < 24; ++i) {
+        if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
+        w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
+    }
+    std::vector<char> img;
+    int rc = pack_chain(w, 16.0f, img);
+    if (rc) return rc;
+    if (offs) offs[0] = NERF_CHAIN_STREAM_BYTES;
+    if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
+    return (long long)img.size();
+}
+
 int nerf_run_network(nerf_ctx* c, int which, const float* rays_o_dev, const float* rays_d_dev, const float* z_dev,
                      int z_stride, int S, int n, float* raw_dev, void* stream) {
     if (!c || !rays_o_dev || !rays_d_dev || !z_dev || !raw_dev) return r2l_set_error(R2L_EINVAL, "NULL argument");

@@ -29,6 +29,13 @@
 #define NERF_F0_FA 960
 #define NERF_F0_V 1096
 #define NERF_F0_RGB 1168
+// FP16_FP8: stream of gen/nerf_gen.py (80 chunks of whole row tiles, 1 KiB pieces) followed by the resident table
+#define NERF_CHAIN_STREAM_BYTES 2166784
+#define NERF_CHAIN_AUX_BYTES 16384
+#define NERF_CHAIN_AUX_LAYER 1280   // per layer: 272 f32 bias | at byte 1152: 4 lane quarters x (swl, sw, 0, 0)
+#define NERF_CHAIN_AUX_SCALES 1152
+#define NERF_CHAIN_RING_BYTES (4 * 32768)
+#define NERF_CHAIN_LDS (NERF_CHAIN_RING_BYTES + NERF_CHAIN_AUX_BYTES)
 #define NERF_N_SCALES 12  // L0..L7, FA, V, RGB (+1 spare)
 #define NERF_PTS_PER_WAVE 32
 #define NERF_TILE_PTS 128

@@ -38,16 +38,13 @@ struct MlpOut {       // valid in the quarter-0 lanes (q == 0), one value per co
     float rgb[2][3];  // rgb_linear output
 };
 
-// One activation set (256 features x 32 points per wave) as MFMA B operands: fp16 hi fragments,
-// then either the fp16 lo fragments (FP16X3) or, in FP16_FP8 mode, the e5m2 bytes of the value (a)
-// and of its fp16 residual (r) in the K=128 layout of r2l_common.h.
+// One activation set (256 features x 32 points per wave) as MFMA B operands: fp16 hi and lo fragments
 struct ActSet {
     f16x8 h[8][2], l[8][2];
-    i32x8 a[2][2], r[2][2];
 };
 
 // epilogue of accumulator registers 2*pair, 2*pair+1 of row tile u, column tile c, of a layer with RT row tiles
-template <int NP, bool MIX, int EPI, int RT>
+template <int NP, int EPI, int RT>
 __device__ __forceinline__ void mlp_epi_pair(const f32x4& acc, float inv, ActSet& D, int u, int c, int pair,
                                              float act_scale, float neg1, MlpOut& out) {
     if (EPI == EPI_RGB) {
@@ -71,37 +68,17 @@ __device__ __forceinline__ void mlp_epi_pair(const f32x4& acc, float inv, ActSet
         v[k] *= act_scale;
     }
     const int idx = 2 * (u & 1) + pair;
-    if (!MIX) {
-        split_store2<NP>(v[0], v[1], D.h[(u >> 1) & 7][c], D.l[(u >> 1) & 7][c], idx, neg1);
-    } else {
-        const f16x2 h = pack_hi(v[0], v[1]);
-        set_dword(D.h[(u >> 1) & 7][c], idx, __builtin_bit_cast(uint32_t, h));
-        const float l0 = fmaf((float)h[0], neg1, v[0]), l1 = fmaf((float)h[1], neg1, v[1]);
-        i32x8& na = D.a[(u >> 3) & 1][c];
-        i32x8& nr = D.r[(u >> 3) & 1][c];
-        if (pair == 0) {
-            na[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], na[u & 7], false);
-            nr[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(l0, l1, nr[u & 7], false);
-        } else {
-            na[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], na[u & 7], true);
-            nr[u & 7] = __builtin_amdgcn_cvt_pk_bf8_f32(l0, l1, nr[u & 7], true);
-        }
-    }
+    split_store2<NP>(v[0], v[1], D.h[(u >> 1) & 7][c], D.l[(u >> 1) & 7][c], idx, neg1);
 }
 
 // One Linear layer = fragment run [F0, F0 + RT*KS).  Input fragments: k-steps 0..7 from the set S,
-// k-steps 8.. from (Xh,Xl) (embedding fragments, always hi/lo fp16).  Output row tiles are written
-// as fragments of D.  HS (FP16_FP8 only) = number of leading k-steps that run as fp16 hi pass + fp8
-// correction terms (8 for a 256-wide source, 4 for the 128-wide one, 0: the source is an embedding).
+// k-steps 8.. from (Xh,Xl) (embedding fragments).  Output row tiles are written as fragments of D.
 // The epilogue of row tile u-1 is interleaved with the MFMAs of row tile u; the last one's is exposed.
-template <int NP, bool MIX, int KS, int RT, int F0, int EPI, int HS>
+template <int NP, int KS, int RT, int F0, int EPI>
 __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const ActSet& S, const f16x8 (&Xh)[2][2],
                                           const f16x8 (&Xl)[2][2], ActSet& D, float inv, float act_scale, float neg1,
                                           int q, MlpOut& out) {
-    constexpr int HM = MIX ? HS : 0;       // k-steps in fp16 + fp8 form
-    constexpr int H2 = HM > 0 ? HM / 2 : 1;  // k-steps per correction term
     f32x4 acc[2], prev[2];
-    i32x4 keep;
 #pragma unroll
     for (int u = 0; u < RT; ++u) {
 #pragma unroll
@@ -115,35 +92,16 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const ActSet& S, const f1
             }
             AFrag<NP> nxt = (pos + 1 < R2L_FRAGS) ? read_frag<NP>(R.use_off + R.lane * 16, pos + 1)
                                                   : read_frag<NP>(ring_next_off<NP>(R.use_off) + R.lane * 16, 0);
-            if (s < HM) {
-                acc[0] = MFMA(R.pre.h, S.h[s < 8 ? s : 0][0], acc[0]);
-                acc[1] = MFMA(R.pre.h, S.h[s < 8 ? s : 0][1], acc[1]);
-                const i32x4 piece = __builtin_bit_cast(i32x4, R.pre.l);
-                if ((s & 1) == 0) {
-                    keep = piece;
-                } else {
-                    const i32x8 a8 = {keep[0], keep[1], keep[2], keep[3], piece[0], piece[1], piece[2], piece[3]};
-                    const int t = ((s % H2) >> 1) & 1;
-                    if (s / H2 == 0) {
-                        acc[0] = MFMA8(a8, S.a[t][0], acc[0], R2L_MIX_SCALE_WL);
-                        acc[1] = MFMA8(a8, S.a[t][1], acc[1], R2L_MIX_SCALE_WL);
-                    } else {
-                        acc[0] = MFMA8(a8, S.r[t][0], acc[0], R2L_MIX_SCALE_W);
-                        acc[1] = MFMA8(a8, S.r[t][1], acc[1], R2L_MIX_SCALE_W);
-                    }
-                }
-            } else {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (s < 8) acc[c] = mfma_step<NP>(R.pre, S.h[s < 8 ? s : 0][c], S.l[s < 8 ? s : 0][c], acc[c]);
-                    else acc[c] = mfma_step<NP>(R.pre, Xh[s >= 8 ? s - 8 : 0][c], Xl[s >= 8 ? s - 8 : 0][c], acc[c]);
-                }
+            for (int c = 0; c < 2; ++c) {
+                if (s < 8) acc[c] = mfma_step<NP>(R.pre, S.h[s < 8 ? s : 0][c], S.l[s < 8 ? s : 0][c], acc[c]);
+                else acc[c] = mfma_step<NP>(R.pre, Xh[s >= 8 ? s - 8 : 0][c], Xl[s >= 8 ? s - 8 : 0][c], acc[c]);
             }
             R.pre = nxt;
             if (u > 0) {
 #pragma unroll
                 for (int i = (4 * s + KS - 1) / KS; i < (4 * (s + 1) + KS - 1) / KS && i < 4; ++i)
-                    mlp_epi_pair<NP, MIX, EPI, RT>(prev[i >> 1], inv, D, u - 1, i >> 1, i & 1, act_scale, neg1, out);
+                    mlp_epi_pair<NP, EPI, RT>(prev[i >> 1], inv, D, u - 1, i >> 1, i & 1, act_scale, neg1, out);
             }
             if (pos == R2L_FRAGS - 1) ring_next<NP>(R);
         }
@@ -151,12 +109,81 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const ActSet& S, const f1
         prev[1] = acc[1];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) mlp_epi_pair<NP, MIX, EPI, RT>(prev[i >> 1], inv, D, RT - 1, i >> 1, i & 1, act_scale, neg1, out);
+    for (int i = 0; i < 4; ++i) mlp_epi_pair<NP, EPI, RT>(prev[i >> 1], inv, D, RT - 1, i >> 1, i & 1, act_scale, neg1, out);
 }
 
-template <int NP, bool MIX>
+// Inputs of one 128-point tile for this lane (a lane serves point (lane & 15) of both column tiles of its wave):
+// pts = rays_o + rays_d * z (main.py:701), view directions (main.py:148-162) and the fragments of both embeddings
+// (nerf_common.h: nerf_pts_col / nerf_view_col), act_scale folded in, as fp16 hi | lo B operands.
+template <int NP>
+__device__ __forceinline__ void nerf_tile_inputs(const NerfMlpParams& p, int tile, int wave, int lane, f16x8 (&Eh)[2][2],
+                                                 f16x8 (&El)[2][2], f16x8 (&Vh)[2][2], f16x8 (&Vl)[2][2],
+                                                 long long (&pt)[2], bool (&valid)[2]) {
+    const int q = lane >> 4;
+    const float act_scale = p.act_scale;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {  // a lane serves point (lane & 15) of both column tiles
+        const long long pt_raw = (long long)tile * NERF_TILE_PTS + wave * NERF_PTS_PER_WAVE + c * 16 + (lane & 15);
+        valid[c] = pt_raw < p.n_pts;
+        pt[c] = valid[c] ? pt_raw : p.n_pts - 1;
+        const int ray = (int)(pt[c] / p.S);
+        const int smp = (int)(pt[c] - (long long)ray * p.S);
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = p.rays_o[(size_t)ray * 3 + k];
+            d[k] = p.rays_d[(size_t)ray * 3 + k];
+        }
+        const float z = p.z[(size_t)ray * p.z_stride + smp];
+        // viewdirs = rays_d / ||rays_d||  (main.py:154-156)
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(d[0] * d[0], d[1] * d[1]), d[2] * d[2]));
+        float xs[3], vs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xs[k] = __fadd_rn(o[k], __fmul_rn(d[k], z));  // rays_o + rays_d * z  (main.py:701)
+            // NDC renders carry the view directions of the world-space rays (main.py:148-162)
+            vs[k] = p.viewdirs ? p.viewdirs[(size_t)ray * 3 + k] : __fdiv_rn(d[k], nrm);
+        }
+        // ---- embedding fragments (nerf_common.h: nerf_pts_col / nerf_view_col) ---------
+        {   // E step 0: coordinate q>>1, frequencies 0..7, sin|cos by q&1
+            const Rev r = to_rev((q & 2) ? xs[1] : xs[0]);
+            float pw = 1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                split_store<NP>(trig_pow2(r, pw, (q & 1) != 0) * act_scale, Eh[0][c], El[0][c], j);
+                pw *= 2.0f;
+            }
+        }
+        {   // E step 1: q<2: coordinate 2 frequencies 0..7; q>=2: frequencies 8,9 of all three + identity
+            const Rev r2 = to_rev(xs[2]);
+            const Rev r0 = to_rev(xs[0]);
+            const Rev r1 = to_rev(xs[1]);
+            float pw = 1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lo_q = trig_pow2(r2, pw, (q & 1) != 0);          // q < 2
+                float hi_q;                                                   // q >= 2
+                if (j < 6) hi_q = trig_pow2(j < 2 ? r0 : (j < 4 ? r1 : r2), (j & 1) ? 512.0f : 256.0f, q == 3);
+                else if (j == 6) hi_q = (q == 3) ? xs[2] : xs[0];
+                else hi_q = (q == 3) ? 0.0f : xs[1];
+                split_store<NP>(((q & 2) ? hi_q : lo_q) * act_scale, Eh[1][c], El[1][c], j);
+                pw *= 2.0f;
+            }
+        }
+        {   // view step: q<3: component q, frequencies j&3, sin|cos by j>>2; q=3: identity
+            const Rev rv = to_rev(q == 0 ? vs[0] : (q == 1 ? vs[1] : vs[2]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = trig_pow2(rv, (float)(1 << (j & 3)), (j >> 2) != 0);
+                const float idv = j < 3 ? vs[j < 3 ? j : 0] : 0.0f;
+                split_store<NP>(((q == 3) ? idv : t) * act_scale, Vh[0][c], Vl[0][c], j);
+            }
+        }
+    }
+}
+
+template <int NP>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
-    static_assert(!MIX || NP == 2, "FP16_FP8 uses the two-part chunk");
     typedef KCfg<NP> C;
     Ring<NP> R;
     R.wimg = p.wimg;
@@ -188,65 +215,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         long long pt[2];
         bool valid[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {  // a lane serves point (lane & 15) of both column tiles
-            const long long pt_raw = (long long)tile * NERF_TILE_PTS + R.wave * NERF_PTS_PER_WAVE + c * 16 + (lane & 15);
-            valid[c] = pt_raw < p.n_pts;
-            pt[c] = valid[c] ? pt_raw : p.n_pts - 1;
-            const int ray = (int)(pt[c] / p.S);
-            const int smp = (int)(pt[c] - (long long)ray * p.S);
-            float o[3], d[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                o[k] = p.rays_o[(size_t)ray * 3 + k];
-                d[k] = p.rays_d[(size_t)ray * 3 + k];
-            }
-            const float z = p.z[(size_t)ray * p.z_stride + smp];
-            // viewdirs = rays_d / ||rays_d||  (main.py:154-156)
-            const float nrm = sqrtf(__fadd_rn(__fadd_rn(d[0] * d[0], d[1] * d[1]), d[2] * d[2]));
-            float xs[3], vs[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                xs[k] = __fadd_rn(o[k], __fmul_rn(d[k], z));  // rays_o + rays_d * z  (main.py:701)
-                // NDC renders carry the view directions of the world-space rays (main.py:148-162)
-                vs[k] = p.viewdirs ? p.viewdirs[(size_t)ray * 3 + k] : __fdiv_rn(d[k], nrm);
-            }
-            // ---- embedding fragments (nerf_common.h: nerf_pts_col / nerf_view_col) ---------
-            {   // E step 0: coordinate q>>1, frequencies 0..7, sin|cos by q&1
-                const Rev r = to_rev((q & 2) ? xs[1] : xs[0]);
-                float pw = 1.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    split_store<NP>(trig_pow2(r, pw, (q & 1) != 0) * act_scale, Eh[0][c], El[0][c], j);
-                    pw *= 2.0f;
-                }
-            }
-            {   // E step 1: q<2: coordinate 2 frequencies 0..7; q>=2: frequencies 8,9 of all three + identity
-                const Rev r2 = to_rev(xs[2]);
-                const Rev r0 = to_rev(xs[0]);
-                const Rev r1 = to_rev(xs[1]);
-                float pw = 1.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float lo_q = trig_pow2(r2, pw, (q & 1) != 0);          // q < 2
-                    float hi_q;                                                   // q >= 2
-                    if (j < 6) hi_q = trig_pow2(j < 2 ? r0 : (j < 4 ? r1 : r2), (j & 1) ? 512.0f : 256.0f, q == 3);
-                    else if (j == 6) hi_q = (q == 3) ? xs[2] : xs[0];
-                    else hi_q = (q == 3) ? 0.0f : xs[1];
-                    split_store<NP>(((q & 2) ? hi_q : lo_q) * act_scale, Eh[1][c], El[1][c], j);
-                    pw *= 2.0f;
-                }
-            }
-            {   // view step: q<3: component q, frequencies j&3, sin|cos by j>>2; q=3: identity
-                const Rev rv = to_rev(q == 0 ? vs[0] : (q == 1 ? vs[1] : vs[2]));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = trig_pow2(rv, (float)(1 << (j & 3)), (j >> 2) != 0);
-                    const float idv = j < 3 ? vs[j < 3 ? j : 0] : 0.0f;
-                    split_store<NP>(((q == 3) ? idv : t) * act_scale, Vh[0][c], Vl[0][c], j);
-                }
-            }
-        }
+        nerf_tile_inputs<NP>(p, tile, R.wave, lane, Eh, El, Vh, Vl, pt, valid);
 
         MlpOut out;
 #pragma unroll
@@ -262,41 +231,34 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
                 A1.h[e][c] = Eh[e][c];
                 A1.l[e][c] = El[e][c];
             }
-        mlp_layer<NP, MIX, 2, 16, NERF_F0_L0, EPI_RELU, 0>(R, A1, Eh, El, A2, p.inv_scale[0], act_scale, neg1, q, out);
+        mlp_layer<NP, 2, 16, NERF_F0_L0, EPI_RELU>(R, A1, Eh, El, A2, p.inv_scale[0], act_scale, neg1, q, out);
         for (int it = 0; it < 3; ++it) {
             if (it == 2) {
                 // L5: [h(256) | E] -> A1, then move to A2 so the two-layer body is reused
-                mlp_layer<NP, MIX, 10, 16, NERF_F0_L5, EPI_RELU, 8>(R, A2, Eh, El, A1, p.inv_scale[5], act_scale, neg1,
+                mlp_layer<NP, 10, 16, NERF_F0_L5, EPI_RELU>(R, A2, Eh, El, A1, p.inv_scale[5], act_scale, neg1,
                                                                     q, out);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         A2.h[i][c] = A1.h[i][c];
-                        if (!MIX) A2.l[i][c] = A1.l[i][c];
-                    }
-                    if (MIX) {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            A2.a[t][c] = A1.a[t][c];
-                            A2.r[t][c] = A1.r[t][c];
-                        }
+                        A2.l[i][c] = A1.l[i][c];
                     }
                 }
             }
             // (L1,L2) (L3,L4) (L6,L7): the fragment run of the pair is contiguous per iteration
             const float inva = p.inv_scale[it == 0 ? 1 : (it == 1 ? 3 : 6)];
             const float invb = p.inv_scale[it == 0 ? 2 : (it == 1 ? 4 : 7)];
-            mlp_layer<NP, MIX, 8, 16, NERF_F0_L1, EPI_RELU, 8>(R, A2, Eh, El, A1, inva, act_scale, neg1, q, out);
-            mlp_layer<NP, MIX, 8, 16, NERF_F0_L1 + 128, EPI_RELU, 8>(R, A1, Eh, El, A2, invb, act_scale, neg1, q, out);
+            mlp_layer<NP, 8, 16, NERF_F0_L1, EPI_RELU>(R, A2, Eh, El, A1, inva, act_scale, neg1, q, out);
+            mlp_layer<NP, 8, 16, NERF_F0_L1 + 128, EPI_RELU>(R, A1, Eh, El, A2, invb, act_scale, neg1, q, out);
         }
         // FA: feature_linear | alpha_linear (no activation) -> A1, sigma
-        mlp_layer<NP, MIX, 8, 17, NERF_F0_FA, EPI_LINEAR_ALPHA, 8>(R, A2, Eh, El, A1, p.inv_scale[8], act_scale, neg1,
+        mlp_layer<NP, 8, 17, NERF_F0_FA, EPI_LINEAR_ALPHA>(R, A2, Eh, El, A1, p.inv_scale[8], act_scale, neg1,
                                                                    q, out);
         // V: [feature | view embedding] -> 128, relu -> A2[0..3]
-        mlp_layer<NP, MIX, 9, 8, NERF_F0_V, EPI_RELU, 8>(R, A1, Vh, Vl, A2, p.inv_scale[9], act_scale, neg1, q, out);
+        mlp_layer<NP, 9, 8, NERF_F0_V, EPI_RELU>(R, A1, Vh, Vl, A2, p.inv_scale[9], act_scale, neg1, q, out);
         // RGB: 128 -> 3 (4 k-steps), then leave the half-used last chunk
-        mlp_layer<NP, MIX, 4, 1, NERF_F0_RGB, EPI_RGB, 4>(R, A2, Eh, El, A1, p.inv_scale[10], act_scale, neg1, q, out);
+        mlp_layer<NP, 4, 1, NERF_F0_RGB, EPI_RGB>(R, A2, Eh, El, A1, p.inv_scale[10], act_scale, neg1, q, out);
         ring_mid<NP>(R);
         R.pre = read_frag<NP>(ring_next_off<NP>(R.use_off) + lane * 16, 0);
         ring_next<NP>(R);
@@ -312,6 +274,57 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
         }
     }
     R2L_WAIT_VMCNT(0);
+}
+
+// ------------------------------------------------------------------------------------
+// FP16_FP8: the hand-scheduled layer chain.  HIP code computes the tile's embedding fragments and stores raw; all
+// eleven layers of the tile are ONE inline-asm block generated by gen/nerf_gen.py (nerf_mlp_asm.inc): fixed register
+// map, fp16 main pass + bf6 x bf6 correction terms, three fp16 passes on the embedding k-steps, 4 x 32 KiB LDS ring fed
+// by LDS-DMA with counted waits, bias / scale table resident in LDS.  The block owns v0-v247, a0-a95, s40-s55; its
+// inputs are the twelve fragment operands (AGPRs), its outputs eight VGPRs: (rgb, sigma) x act_scale of the lane's two
+// points, valid in lane quarter 0.  The generator's CPU emulator checks the stream against a float64 network
+// (tests/test_nerf_gen_cpu.py).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char nerf_chain_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    {   // resident table: per layer 272 f32 bias (act_scale domain) | E8M0 weight scales (nerf_common.h)
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + NERF_CHAIN_STREAM_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(nerf_chain_lds + NERF_CHAIN_RING_BYTES);
+        for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    asm volatile(
+#include "nerf_mlp_pro_asm.inc"
+        :
+        : [wimg] "s"(p.wimg), [wave] "s"(wave)
+        :
+#include "nerf_mlp_pro_clobbers.inc"
+    );
+    const float inv = 1.0f / p.act_scale;
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        f16x8 Eh[2][2], El[2][2], Vh[2][2], Vl[2][2];
+        long long pt[2];
+        bool valid[2];
+        nerf_tile_inputs<2>(p, tile, wave, lane, Eh, El, Vh, Vl, pt, valid);
+        float o0, o1, o2, o3, o4, o5, o6, o7;
+        asm volatile(
+#include "nerf_mlp_asm.inc"
+            : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5),
+              [o6] "=&v"(o6), [o7] "=&v"(o7)
+            : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),
+              [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),
+              [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
+            :
+#include "nerf_mlp_clobbers.inc"
+        );
+        if (lane < 16) {
+            if (valid[0]) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt[0] * 4) = f32x4{o0 * inv, o1 * inv, o2 * inv, o3 * inv};
+            if (valid[1]) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt[1] * 4) = f32x4{o4 * inv, o5 * inv, o6 * inv, o7 * inv};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's refill of the ring
 }
 
 // ====================================================================================
@@ -679,26 +692,27 @@ __global__ __launch_bounds__(256) void nerf_merge_kernel(const float* __restrict
 // ====================================================================================
 // launchers
 // ====================================================================================
-template <int NP, bool MIX>
-static hipError_t launch_mlp(const NerfMlpParams& p, int grid, hipStream_t stream) {
+template <typename K>
+static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds, const NerfMlpParams& p, int grid,
+                                 hipStream_t stream) {
     // the > 64 KiB dynamic-LDS opt-in is per device: a process may drive several GPUs
-    static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp_kernel<NP, MIX>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((nerf_mlp_kernel<NP, MIX>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream) {
-    if (mode == R2L_PREC_FP16_FP8) return launch_mlp<2, true>(p, grid, stream);
-    return mode == R2L_PREC_FP16X3 ? launch_mlp<2, false>(p, grid, stream) : launch_mlp<1, false>(p, grid, stream);
+    static std::atomic<bool> attr_set[3][64];  // zero-initialised; the opt-in call itself is idempotent
+    if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);
+    if (mode == R2L_PREC_FP16X3) return launch_big_lds(&nerf_mlp_kernel<2>, attr_set[1], KCfg<2>::LDS, p, grid, stream);
+    return launch_big_lds(&nerf_mlp_kernel<1>, attr_set[2], KCfg<1>::LDS, p, grid, stream);
 }
 
 hipError_t nerf_launch_ndc_rays(const float* rays_o, const float* rays_d, int n, int H, int W, double focal, float near_,

@@ -353,7 +353,7 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
 // x~_i = x_i - sum_{j<i} b2_j) | per lane quarter (swl1, sw1, swl2, sw2) | pad.
 // Tail: [3,256] W_t / act_scale, then b_t + W_t sum_j b2_j.
 #define R2L_BODY_CHUNK 28672
-static int layer_exponent(const float* w, size_t n) {
+int r2l_layer_exponent(const float* w, size_t n) {
     float m = 0.f;
     for (size_t i = 0; i < n; ++i) {
         const float a = fabsf(w[i]);
@@ -366,7 +366,7 @@ static int layer_exponent(const float* w, size_t n) {
 }
 
 // OCP bf6 = e3m2 (bias 3, max 28, subnormal step 2^-4), round to nearest even, saturating
-static unsigned r2l_f_to_bf6(double v) {
+unsigned r2l_f_to_bf6(double v) {
     const unsigned sgn = signbit(v) ? 32u : 0u;
     const double a = fabs(v);
     if (!(a == a)) return sgn | 31u;
@@ -406,7 +406,7 @@ static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_of
         }
         for (int layer = 0; layer < 2; ++layer) {
             const float* Wl = W[layer];
-            const int e = layer_exponent(Wl, 65536);
+            const int e = r2l_layer_exponent(Wl, 65536);
             if (e < -12 || e > 6)
                 return r2l_set_error(R2L_EINVAL, "body block %d layer %d: max|w| = 2^%d is outside the range the fp16 + bf6 "
                                      "weight split covers (2^-12 .. 2^6); use R2L_PREC_FP16X3", b, layer, e);

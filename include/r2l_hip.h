@@ -223,6 +223,14 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 int nerf_run_network(nerf_ctx* ctx, int which, const float* rays_o_dev, const float* rays_d_dev,
                      const float* z_dev, int z_stride, int S, int n, float* raw_dev, void* stream);
 
+/* Host-only: the R2L_PREC_FP16_FP8 image of one teacher network that nerf_load_weights uploads for
+ * nerf_chain_kernel (the layer chain's weight stream followed by the 16 KiB bias / scale table; layout:
+ * csrc/nerf_capi.hip pack_chain, restated by csrc/gen/nerf_gen.py pack_teacher).  tensors: the 24 state_dict
+ * tensors (model/nerf_raybased.py:357-375).  Returns the image size in bytes (negative on error), copies at
+ * most cap bytes to out; offs[0] receives the byte offset of the table. */
+long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, char* out, long long cap,
+                                     long long* offs);
+
 /* stand-alone scan kernels (all device pointers, f32):
  * raw [n,S,4], z [n,S], rays_d [n,3] -> rgb [n,3], disp [n], acc [n], weights [n,S], depth [n]
  * (weights/depth/disp/acc may be NULL). */
