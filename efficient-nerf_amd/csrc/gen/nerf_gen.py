@@ -481,6 +481,7 @@ class Opts:
         self.lead6 = 5
         self.cap = 3           # issue slots for fillers behind each MFMA
         self.dma_gap = 3       # anchors between two LDS-DMA pieces
+        self.pair = False
         self.__dict__.update(kw)
 
 
@@ -695,7 +696,7 @@ def schedule(opts):
             ins = mfma6(d, bufmap[key], b6(L.src, term, tt, c), V_SC + 2 * (t.li & 1) + term, V_SBA if term == 0 else V_SBL,
                         tag=('m6', T, k, c))
         sch.emit(ins)
-        budget = opts.cap
+        budget = opts.cap if not opts.pair else (0 if c == 0 else 2 * opts.cap)   # pair: fillers only behind the c = 1 MFMA
         while budget > 0:
             r = ready(a)
             if not r:
@@ -778,6 +779,13 @@ def block_stream(opts):
 def emit(dirname, opts):
     setup, _ = setup_ops()
     body = block_stream(opts)
+    drop = getattr(opts, 'drop', ())          # diagnostics only (wrong results): timing knock-outs of instruction classes
+    if drop:
+        def keep(i):
+            if i.kind == 'wait':
+                return not (('lgkm' in drop and 'lgkmcnt' in i.text) or ('vm' in drop and 'vmcnt' in i.text))
+            return i.kind not in drop
+        body = [i for i in body if keep(i)]
     n = {}
     for ins in body:
         n[ins.kind] = n.get(ins.kind, 0) + 1
@@ -838,8 +846,11 @@ def main():
     ap.add_argument('--lead6', type=int, default=5)
     ap.add_argument('--cap', type=int, default=3)
     ap.add_argument('--dma-gap', type=int, default=3)
+    ap.add_argument('--pair', action='store_true', help='fillers only behind the second MFMA of a column-tile pair')
+    ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the emitted '
+                    'text (lgkm, dma, valu, ds, mfma6, mfma16, salu, nop): timing knock-outs, wrong results')
     a = ap.parse_args()
-    opts = Opts(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap)
+    opts = Opts(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap, pair=a.pair, drop=tuple(x for x in a.drop.split(',') if x))
     print('tiles', NT, 'chunks', NCH, 'MFMAs', N_ANCH, 'stream bytes', STREAM_BYTES)
     if a.emit:
         n, body = emit(a.emit, opts)

@@ -446,6 +446,8 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     p.S = S;
     p.n_rays = n;
     p.n_pts = (long long)n * S;
+    if (p.n_pts >= (1ll << 31))   // the kernels index points with 32 bits
+        return r2l_set_error(R2L_EINVAL, "%d rays x %d samples: more than 2^31 points in one call; render fewer rows at a time", n, S);
     p.n_tiles = (int)((p.n_pts + NERF_TILE_PTS - 1) / NERF_TILE_PTS);
     p.act_scale = c->act_scale;
     p.neg1 = -1.0f;

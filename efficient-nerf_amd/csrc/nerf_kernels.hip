@@ -112,61 +112,75 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const ActSet& S, const f1
     for (int i = 0; i < 4; ++i) mlp_epi_pair<NP, EPI, RT>(prev[i >> 1], inv, D, RT - 1, i >> 1, i & 1, act_scale, neg1, out);
 }
 
-// Inputs of one 128-point tile for this lane (a lane serves point (lane & 15) of both column tiles of its wave):
-// pts = rays_o + rays_d * z (main.py:701), view directions (main.py:148-162) and the fragments of both embeddings
-// (nerf_common.h: nerf_pts_col / nerf_view_col), act_scale folded in, as fp16 hi | lo B operands.
-template <int NP>
-__device__ __forceinline__ void nerf_tile_inputs(const NerfMlpParams& p, int tile, int wave, int lane, f16x8 (&Eh)[2][2],
-                                                 f16x8 (&El)[2][2], f16x8 (&Vh)[2][2], f16x8 (&Vl)[2][2],
-                                                 long long (&pt)[2], bool (&valid)[2]) {
-    const int q = lane >> 4;
-    const float act_scale = p.act_scale;
+// Inputs of one 128-point tile for this lane (a lane serves point (lane & 15) of both column tiles of its wave), in two
+// steps so that the chain kernel can fetch the next tile's values before it enters its layer block:
+//   nerf_tile_load   ray origin / direction / depth (and the given view direction) of the lane's two points
+//   nerf_tile_embed  pts = rays_o + rays_d * z (main.py:701), view directions (main.py:148-162) and the fragments of both
+//                    embeddings (nerf_common.h: nerf_pts_col / nerf_view_col), act_scale folded in, fp16 hi | lo B operands
+struct NerfTileRaw {
+    float o[2][3], d[2][3], v[2][3], z[2];
+};
+
+// n_pts < 2^31 (checked by the host): 32-bit point and ray indices
+__device__ __forceinline__ void nerf_tile_load(const NerfMlpParams& p, int tile, int wave, int lane, NerfTileRaw& r) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {  // a lane serves point (lane & 15) of both column tiles
-        const long long pt_raw = (long long)tile * NERF_TILE_PTS + wave * NERF_PTS_PER_WAVE + c * 16 + (lane & 15);
-        valid[c] = pt_raw < p.n_pts;
-        pt[c] = valid[c] ? pt_raw : p.n_pts - 1;
-        const int ray = (int)(pt[c] / p.S);
-        const int smp = (int)(pt[c] - (long long)ray * p.S);
-        float o[3], d[3];
+    for (int c = 0; c < 2; ++c) {
+        const unsigned pt_raw = (unsigned)tile * NERF_TILE_PTS + wave * NERF_PTS_PER_WAVE + c * 16 + (lane & 15);
+        const unsigned last = (unsigned)p.n_pts - 1u;
+        const unsigned pt = pt_raw < last ? pt_raw : last;   // tail lanes repeat the last point (their stores are masked)
+        const unsigned ray = pt / (unsigned)p.S;
+        const unsigned smp = pt - ray * (unsigned)p.S;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            o[k] = p.rays_o[(size_t)ray * 3 + k];
-            d[k] = p.rays_d[(size_t)ray * 3 + k];
+            r.o[c][k] = p.rays_o[(size_t)ray * 3 + k];
+            r.d[c][k] = p.rays_d[(size_t)ray * 3 + k];
+            r.v[c][k] = p.viewdirs ? p.viewdirs[(size_t)ray * 3 + k] : 0.0f;
         }
-        const float z = p.z[(size_t)ray * p.z_stride + smp];
-        // viewdirs = rays_d / ||rays_d||  (main.py:154-156)
+        r.z[c] = p.z[(size_t)ray * p.z_stride + smp];
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void nerf_tile_embed(const NerfMlpParams& p, const NerfTileRaw& r, int lane, f16x8 (&Eh)[2][2],
+                                                f16x8 (&El)[2][2], f16x8 (&Vh)[2][2], f16x8 (&Vl)[2][2]) {
+    const int q = lane >> 4;
+    const float act_scale = p.act_scale;
+    const bool is_cos = (q & 1) != 0;   // odd lane quarters hold cosines in every k-step (nerf_common.h)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float* d = r.d[c];
+        // viewdirs = rays_d / ||rays_d||  (main.py:154-156); NDC renders carry those of the world-space rays (:148-162)
         const float nrm = sqrtf(__fadd_rn(__fadd_rn(d[0] * d[0], d[1] * d[1]), d[2] * d[2]));
         float xs[3], vs[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            xs[k] = __fadd_rn(o[k], __fmul_rn(d[k], z));  // rays_o + rays_d * z  (main.py:701)
-            // NDC renders carry the view directions of the world-space rays (main.py:148-162)
-            vs[k] = p.viewdirs ? p.viewdirs[(size_t)ray * 3 + k] : __fdiv_rn(d[k], nrm);
+            xs[k] = __fadd_rn(r.o[c][k], __fmul_rn(d[k], r.z[c]));  // rays_o + rays_d * z  (main.py:701)
+            vs[k] = p.viewdirs ? r.v[c][k] : __fdiv_rn(d[k], nrm);
         }
-        // ---- embedding fragments (nerf_common.h: nerf_pts_col / nerf_view_col) ---------
+        const Rev r0 = to_rev(xs[0]), r1 = to_rev(xs[1]), r2 = to_rev(xs[2]);
         {   // E step 0: coordinate q>>1, frequencies 0..7, sin|cos by q&1
-            const Rev r = to_rev((q & 2) ? xs[1] : xs[0]);
+            const Rev rr = (q & 2) ? r1 : r0;
             float pw = 1.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                split_store<NP>(trig_pow2(r, pw, (q & 1) != 0) * act_scale, Eh[0][c], El[0][c], j);
+                split_store<NP>(trig_pow2(rr, pw, is_cos) * act_scale, Eh[0][c], El[0][c], j);
                 pw *= 2.0f;
             }
         }
-        {   // E step 1: q<2: coordinate 2 frequencies 0..7; q>=2: frequencies 8,9 of all three + identity
-            const Rev r2 = to_rev(xs[2]);
-            const Rev r0 = to_rev(xs[0]);
-            const Rev r1 = to_rev(xs[1]);
+        {   // E step 1: q<2: coordinate 2, frequencies 0..7; q>=2: frequencies 8,9 of all three, then the identity.
+            // One evaluation per element: the lane quarter selects the argument, not the result.
             float pw = 1.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float lo_q = trig_pow2(r2, pw, (q & 1) != 0);          // q < 2
-                float hi_q;                                                   // q >= 2
-                if (j < 6) hi_q = trig_pow2(j < 2 ? r0 : (j < 4 ? r1 : r2), (j & 1) ? 512.0f : 256.0f, q == 3);
-                else if (j == 6) hi_q = (q == 3) ? xs[2] : xs[0];
-                else hi_q = (q == 3) ? 0.0f : xs[1];
-                split_store<NP>(((q & 2) ? hi_q : lo_q) * act_scale, Eh[1][c], El[1][c], j);
+                const Rev rh = j < 2 ? r0 : (j < 4 ? r1 : r2);                 // q >= 2, j < 6
+                Rev rr;
+                rr.rh = (q & 2) ? rh.rh : r2.rh;
+                rr.rl = (q & 2) ? rh.rl : r2.rl;
+                const float pq = (q & 2) ? ((j & 1) ? 512.0f : 256.0f) : pw;
+                float val = trig_pow2(rr, pq, is_cos);
+                if (j == 6) val = (q & 2) ? (q == 3 ? xs[2] : xs[0]) : val;
+                if (j == 7) val = (q & 2) ? (q == 3 ? 0.0f : xs[1]) : val;
+                split_store<NP>(val * act_scale, Eh[1][c], El[1][c], j);
                 pw *= 2.0f;
             }
         }
@@ -213,9 +227,9 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
     }
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        long long pt[2];
-        bool valid[2];
-        nerf_tile_inputs<NP>(p, tile, R.wave, lane, Eh, El, Vh, Vl, pt, valid);
+        NerfTileRaw traw;
+        nerf_tile_load(p, tile, R.wave, lane, traw);
+        nerf_tile_embed<NP>(p, traw, lane, Eh, El, Vh, Vl);
 
         MlpOut out;
 #pragma unroll
@@ -266,9 +280,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
         if (q == 0) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                if (valid[c]) {
+                const unsigned pt = (unsigned)tile * NERF_TILE_PTS + R.wave * NERF_PTS_PER_WAVE + c * 16 + lane;
+                if (pt < (unsigned)p.n_pts) {
                     f32x4 r4 = {out.rgb[c][0], out.rgb[c][1], out.rgb[c][2], out.alpha[c]};
-                    *reinterpret_cast<f32x4*>(p.raw + (size_t)pt[c] * 4) = r4;
+                    *reinterpret_cast<f32x4*>(p.raw + (size_t)pt * 4) = r4;
                 }
             }
         }
@@ -303,11 +318,13 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
 #include "nerf_mlp_pro_clobbers.inc"
     );
     const float inv = 1.0f / p.act_scale;
+    NerfTileRaw raw;
+    if ((int)blockIdx.x < p.n_tiles) nerf_tile_load(p, blockIdx.x, wave, lane, raw);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         f16x8 Eh[2][2], El[2][2], Vh[2][2], Vl[2][2];
-        long long pt[2];
-        bool valid[2];
-        nerf_tile_inputs<2>(p, tile, wave, lane, Eh, El, Vh, Vl, pt, valid);
+        nerf_tile_embed<2>(p, raw, lane, Eh, El, Vh, Vl);
+        // the next tile's rays and depths travel while this tile's layers run (the values wait in AGPRs)
+        if (tile + (int)gridDim.x < p.n_tiles) nerf_tile_load(p, tile + gridDim.x, wave, lane, raw);
         float o0, o1, o2, o3, o4, o5, o6, o7;
         asm volatile(
 #include "nerf_mlp_asm.inc"
@@ -320,8 +337,9 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
 #include "nerf_mlp_clobbers.inc"
         );
         if (lane < 16) {
-            if (valid[0]) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt[0] * 4) = f32x4{o0 * inv, o1 * inv, o2 * inv, o3 * inv};
-            if (valid[1]) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt[1] * 4) = f32x4{o4 * inv, o5 * inv, o6 * inv, o7 * inv};
+            const unsigned pt0 = (unsigned)tile * NERF_TILE_PTS + wave * NERF_PTS_PER_WAVE + lane, pt1 = pt0 + 16;
+            if (pt0 < (unsigned)p.n_pts) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt0 * 4) = f32x4{o0 * inv, o1 * inv, o2 * inv, o3 * inv};
+            if (pt1 < (unsigned)p.n_pts) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt1 * 4) = f32x4{o4 * inv, o5 * inv, o6 * inv, o7 * inv};
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's refill of the ring
