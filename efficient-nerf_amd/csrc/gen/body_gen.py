@@ -1119,6 +1119,17 @@ def kernel_text(opts):
 
 def emit_inc(path, opts):
     L, pro, body = kernel_text(opts)
+    drop = getattr(opts, 'drop', ())   # diagnostics only (wrong results): timing knock-outs of instruction classes
+    if drop:
+        texts = set()
+        for ins in body:
+            gone = ins.kind in drop or (ins.kind == 'wait' and 'lgkm' in drop and 'lgkmcnt' in ins.text)
+            if gone:
+                texts.add(ins.text)
+        keep_always = ('s_waitcnt vmcnt', 's_barrier')
+        first = L.index('L_block_%=:')
+        last = len(L) - 1 - L[::-1].index('s_sub_u32 %s, %s, 1' % (sreg(S_BLK), sreg(S_BLK)))
+        L = L[:first + 1] + [t for t in L[first + 1:last] if not (t in texts and not t.startswith(keep_always))] + L[last:]
     n = {}
     for ins in body:
         n[ins.kind] = n.get(ins.kind, 0) + 1
@@ -1272,9 +1283,11 @@ def main():
     ap.add_argument('--cap6', type=int, default=3)
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')
+    ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the block loop '
+                    '(lgkm, dma, valu, ds, mfma6, mfma16): timing knock-outs, wrong results')
     a = ap.parse_args()
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, cap16=a.cap16, cap6=a.cap6,
-                skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t))
+                skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t), drop=tuple(x for x in a.drop.split(',') if x))
     if a.emit:
         n = emit_inc(a.emit, opts)
         print('wrote', a.emit, n)

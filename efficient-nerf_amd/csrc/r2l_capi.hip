@@ -138,7 +138,6 @@ struct r2l_ctx {
     float* d_xa;                              // FP16_FP8: head output / body output of one launch slice
     float* d_xb;
     int x_tiles;                              // capacity of d_xa / d_xb in ray tiles
-    int head_np;
     float* d_scratch;
     float* d_z;  // device copy of z
     bool timing;
@@ -241,9 +240,8 @@ static int build_image(r2l_ctx* c, int mode) {
         // head launch: the 32 head chunks of the hi|lo image; body + tail: the v3 stream
         std::vector<char> full;
         // the head stays in the 3-pass fp16 form: a single-pass head alone costs L_inf 2e-4 (1008 high-frequency inputs)
-        c->head_np = 2;
-        pack_image_host(c, c->head_np == 1 ? R2L_PREC_FP16X1 : R2L_PREC_FP16X3, full);
-        img.assign(full.begin(), full.begin() + (size_t)R2L_HEAD_CHUNKS * r2l_chunk_bytes(c->head_np));
+        pack_image_host(c, R2L_PREC_FP16X3, full);   // the head layer runs as three fp16 passes
+        img.assign(full.begin(), full.begin() + (size_t)R2L_HEAD_CHUNKS * r2l_chunk_bytes(2));
         std::vector<char> body;
         int rc = pack_body_v3(c, body, &c->aux_off, &c->tail_off);
         if (rc) return rc;
@@ -639,7 +637,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         ph.xbuf = c->d_xa;
         ph.tile_begin = t0;
         ph.n_tiles = nt;
-        hipError_t e = r2l_launch_head(ph, c->head_np, grid, s);
+        hipError_t e = r2l_launch_head(ph, grid, s);
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
         const float* body_out = c->d_xa;
         if (c->n_block > 0) {

@@ -20,7 +20,7 @@ struct R2LParams {
 };
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*
-hipError_t r2l_launch_head(const R2LParams& p, int np, int grid, hipStream_t stream);      // head layer -> p.xbuf
+hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream);      // head layer -> p.xbuf
 
 // hand-scheduled body (r2l_body.hip): x <- ResMLP blocks(x) on the register image written by the head launch
 struct R2LBodyParams {

@@ -457,24 +457,20 @@ static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream
     return hipGetLastError();
 }
 
-template <int NP>
-static hipError_t launch_head(const R2LParams& p, int grid, hipStream_t stream) {
+// head layer alone (three fp16 passes: a single-pass head costs 2e-4 of the 1e-4 contract) -> p.xbuf
+hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<2>::LDS);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((r2l_resmlp_kernel<NP, true>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    hipLaunchKernelGGL((r2l_resmlp_kernel<2, true>), dim3(grid), dim3(256), KCfg<2>::LDS, stream, p);
     return hipGetLastError();
-}
-
-hipError_t r2l_launch_head(const R2LParams& p, int np, int grid, hipStream_t stream) {
-    return np == 1 ? launch_head<1>(p, grid, stream) : launch_head<2>(p, grid, stream);
 }
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream) {
