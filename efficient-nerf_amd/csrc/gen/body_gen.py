@@ -1130,6 +1130,31 @@ def emit_inc(path, opts):
         first = L.index('L_block_%=:')
         last = len(L) - 1 - L[::-1].index('s_sub_u32 %s, %s, 1' % (sreg(S_BLK), sreg(S_BLK)))
         L = L[:first + 1] + [t for t in L[first + 1:last] if not (t in texts and not t.startswith(keep_always))] + L[last:]
+    if getattr(opts, 'sim32', False):
+        # timing model only (wrong results): every pair of 16x16 MFMAs (column tiles 0, 1) becomes ONE 32x32 MFMA of the
+        # same FLOPs and the same operand registers; everything else stays
+        import re
+        first = L.index('L_block_%=:')
+        out = []
+        for t in L[first:]:
+            m = re.match(r'v_mfma_f32_16x16x32_f16 ([va])\[(\d+):(\d+)\], (v\[\d+:\d+\]), v\[(\d+):(\d+)\], ', t)
+            m6 = re.match(r'v_mfma_scale_f32_16x16x128_f8f6f4 ([va])\[(\d+):(\d+)\], (\S+), a\[(\d+):(\d+)\], \S+ (v\d+), (v\d+) (.*)', t)
+            if m:
+                f_, d0, a_, b0 = m.group(1), int(m.group(2)), m.group(4), int(m.group(5))
+                if (b0 % 64) >= 32:      # column tile 1: folded into its partner
+                    continue
+                d = (d0 // 16) * 16
+                out.append('v_mfma_f32_32x32x16_f16 %s[%d:%d], %s, v[%d:%d], %s[%d:%d]' % (f_, d, d + 15, a_, b0, b0 + 3, f_, d, d + 15))
+            elif m6:
+                f_, d0, a_, b0 = m6.group(1), int(m6.group(2)), m6.group(4).rstrip(','), int(m6.group(5))
+                if ((b0 - 128) // 6) % 2 == 1:
+                    continue
+                d = (d0 // 16) * 16
+                out.append('v_mfma_scale_f32_32x32x64_f8f6f4 %s[%d:%d], %s, a[%d:%d], %s[%d:%d], %s, %s %s' %
+                           (f_, d, d + 15, a_, b0, b0 + 5, f_, d, d + 15, m6.group(7), m6.group(8), m6.group(9)))
+            else:
+                out.append(t)
+        L = L[:first] + out
     n = {}
     for ins in body:
         n[ins.kind] = n.get(ins.kind, 0) + 1
@@ -1283,11 +1308,12 @@ def main():
     ap.add_argument('--cap6', type=int, default=3)
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')
+    ap.add_argument('--sim32', action='store_true', help='timing model only: 32x32 MFMA shapes (wrong results)')
     ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the block loop '
                     '(lgkm, dma, valu, ds, mfma6, mfma16): timing knock-outs, wrong results')
     a = ap.parse_args()
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, cap16=a.cap16, cap6=a.cap6,
-                skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t), drop=tuple(x for x in a.drop.split(',') if x))
+                skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t), drop=tuple(x for x in a.drop.split(',') if x), sim32=a.sim32)
     if a.emit:
         n = emit_inc(a.emit, opts)
         print('wrote', a.emit, n)

@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 d=$root/build_variants/$name
 mkdir -p $d
 cp $root/efficient-nerf_amd/csrc/*.hip $root/efficient-nerf_amd/csrc/*.h $d/
-python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --emit $d/r2l_body_asm.inc "$@" > /dev/null
+python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --emit $d/r2l_body_asm.inc "$@" > /dev/null || exit 1
 sed -i 's#"../../include/r2l_hip.h"#"'$root'/include/r2l_hip.h"#' $d/*.hip
 cd $d
 for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_kernels nerf_capi; do
