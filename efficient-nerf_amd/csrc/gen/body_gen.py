@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled gfx950 body loop of the R2L W256 ResMLP (fp16 main pass + two bf6 x bf6
-correction terms), plus a lane-accurate CPU emulator of the generated stream.
+correction terms, 32x32 MFMA shapes), plus a lane-accurate CPU emulator of the generated stream (isa.py).
 
 What is computed (reference: model/nerf_raybased.py:443-465, ResMLP.forward, 43 blocks):
     x <- x + W2 relu(W1 x + b1) + b2            (activations in the act_scale domain)
@@ -8,77 +8,77 @@ with b2 folded on the host (x~_i = x_i - sum_{j<i} b2_j, b1'_i = b1_i + W1_i sum
 block is  h = relu(W1 x~ + b1'),  x~ += W2 h : the second layer accumulates IN PLACE into the fp32
 residual stream, which is the MFMA C/D operand.
 
-Arithmetic of one Linear(256,256):  y = hi(W) hi(a)              v_mfma_f32_16x16x32_f16      (1 pass)
-                                      + bf6(W - hi(W)) bf6(a)    v_mfma_scale_f32_16x16x128_f8f6f4, e3m2 x e3m2,
+Arithmetic of one Linear(256,256):  y = hi(W) hi(a)              v_mfma_f32_32x32x16_f16      (1 pass)
+                                      + bf6(W - hi(W)) bf6(a)    v_mfma_scale_f32_32x32x64_f8f6f4, e3m2 x e3m2,
                                       + bf6(W) bf6(a - hi(a))    4x the fp16 rate             (2 x 1/4 pass)
 hi = fp16 rounding.  The correction terms need ~3 significant bits; OCP bf6 (e3m2) with one power-of-two scale
 per layer and term (E8M0 operand of the instruction) keeps the network at L_inf ~2e-5 for uniform, Laplace,
 sparse and outlier-laden weights (tools/quant_study.py); e2m3 weights or fp4 do not.
 
-Machine model (one wave64 = 32 rays = 2 column tiles of 16, 4 waves per workgroup, one per SIMD):
-  VGPR   0..63   INh    fp16 B operands of layer 1 (= hi of x~):  c*32 + s*4, s = k-step
+Why 32x32: a wave's in-order issue stalls on LDS-DMA, ds_read and the 32-wide conversions while the LDS array or the
+VALU is busy; an MFMA shadows as many cycles of that as it lasts, and the 32x32 shapes last 32 cycles for the same
+FLOPs per operand byte as two 16x16 ones (profiles/r02_cost_structure.txt: -10 % in a timing model of this loop).
+
+Machine model (one wave64 = 32 rays = ONE column tile of 32, 4 waves per workgroup, one per SIMD; h = lane >> 5):
+  VGPR   0..63   INh    fp16 B operands of layer 1 (= hi of x~): s*4, s = k-step of 16 features
         64..127  Hh     fp16 B operands of layer 2 (= hi of h)
-       128..143  ACC    layer-1 accumulators, 2 buffers x 2 column tiles x 4
-       144..151  BIAS   layer-1 bias of a row tile (C operand of its first MFMA), 2 buffers
-       152..167  HI     fp16 weight fragments (A operand), 4 buffers
-       168..179  A6     bf6 weight operands (A operand of the K=128 MFMA), 2 buffers x 6
-       180..211  LO     fp16 pairs of a - hi(a) of the 8 row tiles being converted, per column tile 16
-       212..231  TMP    epilogue temporaries, per column tile 4 values + 6 conversion outputs
-       232..     addresses / constants
-  AGPR   0..127  X      fp32 residual stream = in-place accumulator of layer 2; X(u,c)+i = feature
-                        16u + 4(lane>>4) + i of ray c*16 + (lane&15)
-       128..175  IN6    bf6 B operands of layer 1: a (t,c) 6 regs each | a - hi(a)
+       128..159  ACC    layer-1 accumulator of a row tile (32 features x 32 rays = 16 registers), 2 buffers (relu in place);
+                        in layer 2, whose accumulator is X, the epilogue's copies of X
+       160..175  BIAS   layer-1 bias of a row tile (C operand of its first MFMA)
+       176..191  HI     fp16 weight fragments (A operand), 4 buffers
+       192..203  A6     bf6 weight operands (A operand of the K=64 MFMA), 2 buffers x 6
+       204..219  LO     fp16 pairs of a - hi(a) of the 2 row tiles being converted
+       220..225  CV     conversion outputs
+       226..     addresses / constants
+  AGPR   0..127  X      fp32 residual stream = in-place accumulator of layer 2; X(u)+r = feature
+                        32u + 8(r/4) + 4h + r%4 of ray lane & 31
+       128..175  IN6    bf6 B operands of layer 1: a (t) 6 regs each | a - hi(a)
        176..223  H6     bf6 B operands of layer 2
 The weight stream goes global -> LDS ring (4 slots x 28 KiB, LDS-DMA, 3 chunks ahead) -> ds_read.
-A chunk = 2 row tiles (32 output features) of one layer: 16 hi fragments (1 KiB) + 8 bf6 operands (1.5 KiB).
+A chunk = 1 row tile (32 output features) of one layer: 16 hi fragments (1 KiB) + 8 bf6 operands (1.5 KiB).
 One counted vmcnt + one s_barrier per chunk (at its middle).
 
-Every instruction is an `Ins` with its assembly text, the registers it reads / writes and a Python
-closure that executes it on the emulator state; `schedule` interleaves the fixed MFMA anchor sequence
-with the filler instructions (LDS reads, epilogue VALU, LDS-DMA, waits) by a small list scheduler.
-`python body_gen.py --emit r2l_body_asm.inc` writes the inline-asm body; the tests run the emulator
-against a float64 reference (tests/test_body_gen_cpu.py).
-
-Hazards the stream must respect by construction (hipcc pads none of them inside an asm statement);
-`check_hazards_stream` enforces them statically:
-  * MFMA result -> any non-accumulate reader: the reader comes >= 2 further MFMAs later;
-  * VALU write -> MFMA operand read: >= 2 instructions in between;
-  * a VALU that writes HALF a register (v_fma_mixlo/hi_f16) must not be followed directly by a reader of that
-    register ("dst-sel forwarding" hazard: the reader sees the stale half);
-  * s_mov m0 -> LDS-DMA: one instruction in between.
+`schedule` interleaves the fixed MFMA anchor sequence with the filler instructions (LDS reads, epilogue VALU, LDS-DMA,
+waits) by a small list scheduler.  `python body_gen.py --emit r2l_body_asm.inc` writes the inline-asm body; the tests
+run the emulator against a float64 reference (tests/test_body_gen_cpu.py).
 """
 import argparse
 import sys
 
 import numpy as np
 
+from isa import (ACT_EXP, RES_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
+                 ds_read_b64, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
+                 v_cvt_pk32_bf6, s_nop, salu, f_to_bf6, pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream,
+                 model_cycles)
+
 # ---------------------------------------------------------------------------------------------
 # register map
 # ---------------------------------------------------------------------------------------------
-NLANE = 64
 V_INH = 0
 V_HH = 64
 V_ACC = 128
-V_BIAS = 144
-V_HI = 152
-V_A6 = 168
-V_LO = 180
-V_TMP = 212
-V_L0 = 232        # lane*16                (LDS bytes 0 .. 65535)
-V_L1 = 233        # lane*16 + 65536
-V_L8A = 234       # lane*8                 (8-byte parts of the bf6 operands)
-V_L8B = 235       # lane*8 + 65536
-V_AUX = 236       # LDS aux base + (lane>>4)*16 (+4096 on odd blocks)
-V_DMAOFF = 237    # wave*7168 + lane*16    (pieces 0..3; V_DMAOFF2 = +4096: pieces 4..6)
-V_DMAOFF2 = 238
-V_AUXOFF = 239    # wave*1024 + lane*16
-V_LANE = 240
-V_SBA = 241       # E8M0 scale of the bf6 activations
-V_SC = 242        # 242,243: E8M0 scales (w - hi | w) of layer 1 of a block; 244,245: of layer 2
-V_SBL = 246       # E8M0 scale of the bf6 activation residuals
-V_CVA = 247       # f32 divisor of the activation conversion
-V_CVL = 248       # f32 divisor of the residual conversion
-N_VGPR_USED = 249
+V_BIAS = 160
+V_HI = 176
+V_A6 = 192
+V_LO = 204
+V_CV = 220
+V_L0 = 226        # lane*16                (LDS bytes 0 .. 65535)
+V_L1 = 227        # lane*16 + 65536
+V_L8A = 228       # lane*8                 (8-byte parts of the bf6 operands)
+V_L8B = 229       # lane*8 + 65536
+V_AUX = 230       # LDS aux base + (lane>>5)*16 (+4096 on odd blocks)
+V_DMAOFF = 231    # wave*7168 + lane*16    (pieces 0..3; V_DMAOFF2 = +4096: pieces 4..6)
+V_DMAOFF2 = 232
+V_AUXOFF = 233    # wave*1024 + lane*16
+V_LANE = 234
+V_SBA = 235       # E8M0 scale of the bf6 activations
+V_SC = 236        # 236,237: E8M0 scales (w - hi | w) of layer 1 of a block; 238,239: of layer 2
+V_SBL = 240       # E8M0 scale of the bf6 activation residuals
+V_CVA = 241       # f32 divisor of the activation conversion
+V_CVL = 242       # f32 divisor of the residual conversion
+N_VGPR_USED = 243
+NHI = 4           # fp16 fragment buffers
 
 A_X = 0
 A_IN6 = 128
@@ -115,41 +115,24 @@ CHUNK = PIECES * 1024      # 28 KiB
 PW = PIECES // 4           # LDS-DMA pieces per wave and chunk
 NSLOT = 4
 LDS_AUX = NSLOT * CHUNK
-AUX_BYTES = 4096           # per block: 256 f32 bias | 4 lane quarters x (swl1, sw1, swl2, sw2) | pad
+AUX_BYTES = 4096           # per block: 256 f32 bias | 4 x (swl1, sw1, swl2, sw2) | pad
 AUX_SCALES = 1024
 LDS_BYTES = LDS_AUX + 2 * AUX_BYTES
-BF6_TOP = 4                # 28 = 1.75 * 2^4
-# activations (act_scale domain, < 2^7) are converted as a / 2^3, their fp16 residuals (< 2^-5) as r * 2^9
-ACT_EXP = 3
-RES_EXP = -9
 
 
-def layer_exponent(W):
-    """e with max|w| in [2^(e-1), 2^e)"""
-    m = float(np.abs(W).max())
-    return int(np.frexp(m)[1]) if m > 0 else -4
+TILES = 16                 # row tiles of a block: layer * 8 + u
 
 
-def weight_exps(e):
-    """power-of-two exponents of the two bf6 weight operands of a layer with weight exponent e:
-    stored (w - hi(w)) / 2^(e-16) and w / 2^(e-4), both < 2^5 in magnitude"""
-    return e - 16, e - 4
+def INH(s):
+    return V_INH + s * 4
 
 
-def INH(s, c):
-    return V_INH + c * 32 + s * 4
+def HH(s):
+    return V_HH + s * 4
 
 
-def HH(s, c):
-    return V_HH + c * 32 + s * 4
-
-
-def ACC(p, c):
-    return V_ACC + p * 8 + c * 4
-
-
-def BIAS(p):
-    return V_BIAS + p * 4
+def ACC(p):
+    return V_ACC + p * 16
 
 
 def HI(b):
@@ -160,120 +143,57 @@ def A6(b):
     return V_A6 + b * 6
 
 
-def LO(c):
-    return V_LO + c * 16
+def X(u):
+    return A_X + u * 16
 
 
-def TMP(c):
-    return V_TMP + c * 10
+def B6(base, term, t):
+    return base + term * 24 + t * 6
 
 
-def X(u, c):
-    return A_X + (u * 2 + c) * 4
-
-
-def B6(base, term, t, c):
-    return base + term * 24 + (t * 2 + c) * 6
-
-
-# order of the four K=128 MFMAs of a row tile: (term, t); term 0 = (w - hi) x bf6(a), 1 = w x bf6(a - hi)
-J_ORDER = [(0, 0), (1, 0), (0, 1), (1, 1)]
+# order of the eight K=64 MFMAs of a row tile: (term, t); term 0 = (w - hi) x bf6(a), 1 = w x bf6(a - hi)
+J_ORDER = [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (1, 3)]
 
 
 # ---------------------------------------------------------------------------------------------
 # layout maps shared with the host packer (r2l_common.h restated; tests compare both sides)
 # ---------------------------------------------------------------------------------------------
-def kappa(s, q, j):
-    """input feature multiplied by element j of lane quarter q of fp16 k-step s (r2l_kappa)"""
-    return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3)
+def kappa(s, h, j):
+    """input feature multiplied by element j of lane half h of fp16 k-step s (r2l_kappa32): the epilogue packs
+    accumulator registers 4g .. 4g+3 (features 32u + 8g + 4h + i) of row tile u into k-step 2u + (g >> 1)"""
+    return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3)
 
 
-def mix_feat(t, q, e):
-    """input feature multiplied by element e (0..31) of lane quarter q of K=128 step t: the conversion takes the
-    16 fp16 pair registers of row tiles 8t .. 8t+7 in order, element e = 4 * (row tile & 7) + accumulator register"""
-    return 16 * (8 * t + (e >> 2)) + 4 * q + (e & 3)
+def mix_feat(t, h, e):
+    """input feature multiplied by element e (0..31) of lane half h of K=64 step t: the conversion takes the 16 fp16
+    pair registers of k-steps 4t .. 4t+3 in order"""
+    return kappa(4 * t + (e >> 3), h, e & 7)
 
 
-def piece_hi(upos, s):
-    return upos * 8 + s
+def piece_hi(s):
+    return s
 
 
-def piece_a6(upos, j):
-    """1 KiB piece with the first 16 B/lane of bf6 operand j of row tile upos"""
-    return 16 + upos * 4 + j
+def piece_a6(j):
+    """1 KiB piece with the first 16 B/lane of bf6 operand j of the row tile"""
+    return 16 + j
 
 
-def piece_a6b(upos, j):
+def piece_a6b(j):
     """(piece, byte offset inside it) of the last 8 B/lane (64 lanes x 8 B = 512 B) of the operand"""
-    return 24 + upos * 2 + (j >> 1), (j & 1) * 512
-
-
-# ---------------------------------------------------------------------------------------------
-# number formats (emulator + python-side packer used by the tests)
-# ---------------------------------------------------------------------------------------------
-def _bf6_table():
-    v = np.zeros(64)
-    for b in range(64):
-        s, e, m = b >> 5, (b >> 2) & 7, b & 3
-        x = (m / 4.0) * 2.0 ** -2 if e == 0 else (1 + m / 4.0) * 2.0 ** (e - 3)
-        v[b] = -x if s else x
-    return v
-
-
-BF6 = _bf6_table()
-_BF6_POS = BF6[:32]           # ascending
-
-
-def f_to_bf6(x):
-    """nearest e3m2 code (ties to even mantissa), saturating at 28; x float array"""
-    x = np.asarray(x, dtype=np.float64)
-    a = np.abs(x)
-    idx = np.searchsorted(_BF6_POS, a).clip(1, 31)
-    lo, hi = _BF6_POS[idx - 1], _BF6_POS[idx]
-    up = (a - lo > hi - a) | ((a - lo == hi - a) & (((idx - 1) & 1) == 1))
-    code = np.where(up, idx, idx - 1)
-    code = np.where(a >= _BF6_POS[31], 31, code)
-    return (code | np.where(np.signbit(x), 32, 0)).astype(np.uint8)
-
-
-def pack6(codes):
-    """[..., 32] 6-bit codes -> [..., 6] uint32, element i at bits [6i, 6i+6) (little endian)"""
-    codes = np.asarray(codes, dtype=np.uint64)
-    out = np.zeros(codes.shape[:-1] + (3,), dtype=np.uint64)
-    for i in range(32):
-        bit = 6 * i
-        w, sh = bit >> 6, bit & 63
-        out[..., w] |= codes[..., i] << np.uint64(sh)
-        if sh > 58:
-            out[..., w + 1] |= codes[..., i] >> np.uint64(64 - sh)
-    return np.ascontiguousarray(out).view(np.uint32).reshape(codes.shape[:-1] + (6,))
-
-
-def unpack6(words):
-    """[..., 6] uint32 -> [..., 32] codes"""
-    words = np.ascontiguousarray(words, dtype=np.uint32)
-    w64 = words.view(np.uint64).reshape(words.shape[:-1] + (3,))
-    out = np.zeros(words.shape[:-1] + (32,), dtype=np.uint8)
-    for i in range(32):
-        bit = 6 * i
-        w, sh = bit >> 6, bit & 63
-        v = w64[..., w] >> np.uint64(sh)
-        if sh > 58:
-            v = v | (w64[..., w + 1] << np.uint64(64 - sh))
-        out[..., i] = (v & np.uint64(63)).astype(np.uint8)
-    return out
+    return 24 + (j >> 1), (j & 1) * 512
 
 
 def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0):
-    """Python restatement of the host packer (r2l_capi.hip pack_body_v4): returns (stream bytes,
+    """Python restatement of the host packer (r2l_capi.hip pack_body_v3): returns (stream bytes,
     aux uint32 [n_block, 1024], total folded bias float64 [256]).  W*: [256, 256] float32 (out, in)."""
     n_block = len(W1s)
     img = np.zeros(n_block * 16 * CHUNK, dtype=np.uint8)
     aux = np.zeros((n_block, AUX_BYTES // 4), dtype=np.uint32)
     Bsum = np.zeros(256, dtype=np.float64)
     lanes = np.arange(64)
-    q = lanes >> 4
-    r = lanes & 15
+    h = lanes >> 5
+    r = lanes & 31
     for b in range(n_block):
         b1f = b1s[b].astype(np.float64) + W1s[b].astype(np.float64) @ Bsum
         aux[b, :256] = (b1f * act_scale).astype(np.float32).view(np.uint32)
@@ -285,301 +205,38 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0):
             for qq in range(4):
                 aux[b, AUX_SCALES // 4 + 4 * qq + 2 * layer] = 0x01010101 * (127 + el)
                 aux[b, AUX_SCALES // 4 + 4 * qq + 2 * layer + 1] = 0x01010101 * (127 + ew)
-            for m in range(8):
-                base = ((b * 2 + layer) * 8 + m) * CHUNK
-                for upos in range(2):
-                    u = 2 * m + upos
-                    rows = 16 * u + r
-                    for s in range(8):
-                        p = base + piece_hi(upos, s) * 1024
-                        frag = np.zeros((64, 8), dtype=np.float16)
-                        for j in range(8):
-                            frag[:, j] = hi[rows, kappa(s, q, j)]
-                        img[p:p + 1024] = frag.view(np.uint8).reshape(-1)
-                    for j, (term, t) in enumerate(J_ORDER):
-                        codes = np.zeros((64, 32), dtype=np.uint8)
-                        for e in range(32):
-                            k = mix_feat(t, q, e)
-                            w = Wl[rows, k].astype(np.float64)
-                            if term == 0:
-                                v = np.ldexp(w - hi[rows, k].astype(np.float64), -el)
-                            else:
-                                v = np.ldexp(w, -ew)
-                            codes[:, e] = f_to_bf6(v)
-                        words = pack6(codes)                       # [64, 6]
-                        p = base + piece_a6(upos, j) * 1024
-                        img[p:p + 1024] = np.ascontiguousarray(words[:, :4]).view(np.uint8).reshape(-1)
-                        pc, off = piece_a6b(upos, j)
-                        p = base + pc * 1024 + off
-                        img[p:p + 512] = np.ascontiguousarray(words[:, 4:]).view(np.uint8).reshape(-1)
+            for u in range(8):
+                base = ((b * 2 + layer) * 8 + u) * CHUNK
+                rows = 32 * u + r
+                for s in range(16):
+                    p = base + piece_hi(s) * 1024
+                    frag = np.zeros((64, 8), dtype=np.float16)
+                    for j in range(8):
+                        frag[:, j] = hi[rows, kappa(s, h, j)]
+                    img[p:p + 1024] = frag.view(np.uint8).reshape(-1)
+                for j, (term, t) in enumerate(J_ORDER):
+                    codes = np.zeros((64, 32), dtype=np.uint8)
+                    for e in range(32):
+                        k = mix_feat(t, h, e)
+                        w = Wl[rows, k].astype(np.float64)
+                        if term == 0:
+                            v = np.ldexp(w - hi[rows, k].astype(np.float64), -el)
+                        else:
+                            v = np.ldexp(w, -ew)
+                        codes[:, e] = f_to_bf6(v)
+                    words = pack6(codes)                       # [64, 6]
+                    p = base + piece_a6(j) * 1024
+                    img[p:p + 1024] = np.ascontiguousarray(words[:, :4]).view(np.uint8).reshape(-1)
+                    pc, off = piece_a6b(j)
+                    p = base + pc * 1024 + off
+                    img[p:p + 512] = np.ascontiguousarray(words[:, 4:]).view(np.uint8).reshape(-1)
         Bsum = Bsum + b2s[b].astype(np.float64)
     return img, aux, Bsum
 
 
 # ---------------------------------------------------------------------------------------------
-# instruction objects
+# LDS-DMA of this kernel's ring
 # ---------------------------------------------------------------------------------------------
-class Ins:
-    __slots__ = ('text', 'kind', 'rd', 'wr', 'emu', 'cost', 'tag', 'partial')
-
-    def __init__(self, text, kind, rd=(), wr=(), emu=None, cost=1, tag='', partial=False):
-        self.text = text
-        self.kind = kind      # 'mfma16' 'mfma6' 'valu' 'ds' 'dma' 'salu' 'wait' 'barrier' 'nop'
-        self.rd = tuple(rd)   # registers read:  ('v', n) / ('a', n)
-        self.wr = tuple(wr)
-        self.emu = emu
-        self.cost = cost      # issue slots (4-cycle units) used by the scheduler's budget
-        self.tag = tag
-        self.partial = partial  # writes 16 bits of its destination (dst-sel forwarding hazard)
-
-
-def vr(n, cnt=1):
-    return [('v', n + i) for i in range(cnt)]
-
-
-def ar(n, cnt=1):
-    return [('a', n + i) for i in range(cnt)]
-
-
-def vreg(n, cnt=1):
-    return 'v%d' % n if cnt == 1 else 'v[%d:%d]' % (n, n + cnt - 1)
-
-
-def areg(n, cnt=1):
-    return 'a%d' % n if cnt == 1 else 'a[%d:%d]' % (n, n + cnt - 1)
-
-
-def sreg(n, cnt=1):
-    return 's%d' % n if cnt == 1 else 's[%d:%d]' % (n, n + cnt - 1)
-
-
-# ---- emulator state ---------------------------------------------------------------------------
-class State:
-    def __init__(self, wave, img, aux, n_block):
-        self.V = np.zeros((256, NLANE), dtype=np.uint32)
-        self.A = np.zeros((256, NLANE), dtype=np.uint32)
-        self.S = {}
-        self.lds = np.zeros(LDS_BYTES, dtype=np.uint8)
-        self.m0 = 0
-        self.wave = wave
-        self.img = img                              # uint8 weight stream
-        self.aux = aux.view(np.uint8).reshape(-1)   # uint8 view of [n_block, 1024] dwords
-        self.n_block = n_block
-        self.pend_ds = []                   # [(first reg, data)] in issue order
-        self.pend_regs = set()
-        self.pend_dma = []                  # [(list of (lds_addr, bytes))] in issue order
-        self.cert = None                    # N of the last vmcnt wait
-        self.lds_pending = np.zeros(LDS_BYTES, dtype=bool)
-        self.n_ins = 0
-        self.errors = []
-
-    def regs(self, file):
-        return self.V if file == 'v' else self.A
-
-    def f32(self, file, n):
-        return self.regs(file)[n].view(np.float32)
-
-    def check_rd(self, ins):
-        for r in ins.rd:
-            if r in self.pend_regs:
-                self.errors.append('ins %d (%s) reads %s%d before its ds_read was waited for' %
-                                   (self.n_ins, ins.text, r[0], r[1]))
-
-    def run(self, stream):
-        for ins in stream:
-            self.check_rd(ins)
-            if ins.emu is not None:
-                ins.emu(self)
-            self.n_ins += 1
-
-
-# ---- builders ----------------------------------------------------------------------------------
-def _halves(regs):
-    """[n, 64] uint32 -> [64, 2n] float32 of the packed f16 halves (low half first)"""
-    return regs.T.copy().view(np.float16).astype(np.float32)
-
-
-def mfma16(dfile, d, a, b, cfile, c, tag=''):
-    """D[dfile d:d+3] = A(v[a:a+3]) x B(v[b:b+3]) + C[cfile c:c+3]"""
-    rf = {'v': vreg, 'a': areg}
-    text = 'v_mfma_f32_16x16x32_f16 %s, %s, %s, %s' % (rf[dfile](d, 4), vreg(a, 4), vreg(b, 4), rf[cfile](c, 4))
-
-    def emu(st):
-        lanes = np.arange(64)
-        Ah = _halves(st.V[a:a + 4])         # [64, 8]
-        Bh = _halves(st.V[b:b + 4])
-        Am = np.zeros((16, 32))
-        Bm = np.zeros((32, 16))
-        for j in range(8):
-            Am[lanes & 15, 8 * (lanes >> 4) + j] = Ah[:, j]
-            Bm[8 * (lanes >> 4) + j, lanes & 15] = Bh[:, j]
-        D = Am @ Bm
-        C = st.regs(cfile)[c:c + 4].view(np.float32).astype(np.float64)   # [4, 64]
-        out = np.zeros((4, 64), dtype=np.float32)
-        for i in range(4):
-            out[i] = (C[i] + D[4 * (lanes >> 4) + i, lanes & 15]).astype(np.float32)
-        st.regs(dfile)[d:d + 4] = out.view(np.uint32)
-
-    rc = vr(c, 4) if cfile == 'v' else ar(c, 4)
-    wd = vr(d, 4) if dfile == 'v' else ar(d, 4)
-    return Ins(text, 'mfma16', rd=vr(a, 4) + vr(b, 4) + rc, wr=wd, emu=emu, tag=tag)
-
-
-def mfma6(dfile, d, a, b_agpr, scale_a, scale_b, tag=''):
-    """D += A(bf6 v[a:a+5], E8M0 v[scale_a]) x B(bf6 a[b:b+5], E8M0 v[scale_b])"""
-    rf = {'v': vreg, 'a': areg}
-    text = ('v_mfma_scale_f32_16x16x128_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0] cbsz:3 blgp:3' %
-            (rf[dfile](d, 4), vreg(a, 6), areg(b_agpr, 6), rf[dfile](d, 4), vreg(scale_a), vreg(scale_b)))
-
-    def emu(st):
-        lanes = np.arange(64)
-        Ac = unpack6(st.V[a:a + 6].T.copy())          # [64, 32]
-        Bc = unpack6(st.A[b_agpr:b_agpr + 6].T.copy())
-        sa = 2.0 ** (int(st.V[scale_a][0] & 0xff) - 127)
-        sb = 2.0 ** (int(st.V[scale_b][0] & 0xff) - 127)
-        Am = np.zeros((16, 128))
-        Bm = np.zeros((128, 16))
-        for e in range(32):
-            Am[lanes & 15, 32 * (lanes >> 4) + e] = BF6[Ac[:, e]] * sa
-            Bm[32 * (lanes >> 4) + e, lanes & 15] = BF6[Bc[:, e]] * sb
-        D = Am @ Bm
-        C = st.regs(dfile)[d:d + 4].view(np.float32).astype(np.float64)
-        out = np.zeros((4, 64), dtype=np.float32)
-        for i in range(4):
-            out[i] = (C[i] + D[4 * (lanes >> 4) + i, lanes & 15]).astype(np.float32)
-        st.regs(dfile)[d:d + 4] = out.view(np.uint32)
-
-    dd = vr(d, 4) if dfile == 'v' else ar(d, 4)
-    return Ins(text, 'mfma6', rd=vr(a, 6) + ar(b_agpr, 6) + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
-
-
-def _ds_read(width, dst, base_v, off, tag):
-    n = width // 4
-    assert 0 <= off < 65536 and off % width == 0
-    text = 'ds_read_b%d %s, %s offset:%d' % (width * 8, vreg(dst, n), vreg(base_v), off)
-
-    def emu(st):
-        addr = st.V[base_v].astype(np.int64) + off
-        data = np.zeros((n, 64), dtype=np.uint32)
-        for l in range(64):
-            a0 = int(addr[l])
-            if st.lds_pending[a0:a0 + width].any():
-                st.errors.append('ins %d (%s): LDS bytes at %d read before their LDS-DMA was certified' %
-                                 (st.n_ins, text, a0))
-            data[:, l] = st.lds[a0:a0 + width].view(np.uint32)
-        st.pend_ds.append((dst, data))
-        st.pend_regs.update(vr(dst, n))
-
-    return Ins(text, 'ds', rd=vr(base_v), wr=vr(dst, n), emu=emu, tag=tag)
-
-
-def ds_read_b128(dst, base_v, off, tag=''):
-    return _ds_read(16, dst, base_v, off, tag)
-
-
-def ds_read_b64(dst, base_v, off, tag=''):
-    return _ds_read(8, dst, base_v, off, tag)
-
-
-def waitcnt_lgkm(n):
-    assert 0 <= n <= 15
-
-    def emu(st):
-        while len(st.pend_ds) > n:
-            dst, data = st.pend_ds.pop(0)
-            st.V[dst:dst + len(data)] = data
-            for r in vr(dst, len(data)):
-                st.pend_regs.discard(r)
-    return Ins('s_waitcnt lgkmcnt(%d)' % n, 'wait', emu=emu)
-
-
-def waitcnt_vm(n):
-    def emu(st):
-        st.cert = n
-    return Ins('s_waitcnt vmcnt(%d)' % n, 'wait', emu=emu)
-
-
-def _land_dma(st, keep):
-    while len(st.pend_dma) > keep:
-        for addr, data in st.pend_dma.pop(0):
-            st.lds[addr:addr + len(data)] = data
-            st.lds_pending[addr:addr + len(data)] = False
-
-
-def barrier():
-    def emu(st):
-        if st.cert is None:
-            st.errors.append('ins %d: s_barrier without a preceding vmcnt wait' % st.n_ins)
-            return
-        _land_dma(st, st.cert)   # every wave waited for all but its `cert` youngest LDS-DMA before arriving
-    return Ins('s_barrier', 'barrier', emu=emu)
-
-
-def valu(text, rd, wr, emu, tag='', partial=False):
-    return Ins(text, 'valu', rd=rd, wr=wr, emu=emu, tag=tag, partial=partial)
-
-
-def v_max0(dst, src):
-    def emu(st):
-        st.V[dst] = np.maximum(st.f32('v', src), np.float32(0)).view(np.uint32)
-    return valu('v_max_f32 %s, 0, %s' % (vreg(dst), vreg(src)), vr(src), vr(dst), emu)
-
-
-def v_accr(vdst, asrc):
-    def emu(st):
-        st.V[vdst] = st.A[asrc]
-    return valu('v_accvgpr_read_b32 %s, %s' % (vreg(vdst), areg(asrc)), ar(asrc), vr(vdst), emu)
-
-
-def v_accw(adst, vsrc):
-    def emu(st):
-        st.A[adst] = st.V[vsrc]
-    return valu('v_accvgpr_write_b32 %s, %s' % (areg(adst), vreg(vsrc)), vr(vsrc), ar(adst), emu)
-
-
-def v_cvt_pk_f16(dst, a, b):
-    def emu(st):
-        lo = st.f32('v', a).astype(np.float16).view(np.uint16).astype(np.uint32)
-        hi = st.f32('v', b).astype(np.float16).view(np.uint16).astype(np.uint32)
-        st.V[dst] = lo | (hi << 16)
-    return valu('v_cvt_pk_f16_f32 %s, %s, %s' % (vreg(dst), vreg(a), vreg(b)), vr(a) + vr(b), vr(dst), emu)
-
-
-def v_resid16(dst, dst_high, hpk, half, t):
-    """half `dst_high` of dst = fp16(t - (float)half(hpk)):  v_fma_mixlo/hi_f16 dst, hpk.f16[half], -1.0 (SGPR), t"""
-    op = 'v_fma_mixhi_f16' if dst_high else 'v_fma_mixlo_f16'
-    sel = ' op_sel:[1,0,0]' if half else ''
-    text = '%s %s, %s, %s, %s%s op_sel_hi:[1,0,0]' % (op, vreg(dst), vreg(hpk), sreg(S_NEG1), vreg(t), sel)
-
-    def emu(st):
-        h = ((st.V[hpk] >> (16 * half)) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
-        r = (st.f32('v', t) - h).astype(np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
-        if dst_high:
-            st.V[dst] = (st.V[dst] & 0x0000ffff) | (r << 16)
-        else:
-            st.V[dst] = (st.V[dst] & 0xffff0000) | r
-    return valu(text, vr(hpk) + vr(t), vr(dst), emu, partial=True)
-
-
-def v_cvt_pk32_bf6(dst, src, scale_v):
-    """v[dst:dst+5] = bf6(f16 v[src:src+15] / f32 v[scale_v]), 32 elements, element i at bits [6i, 6i+6)"""
-    text = 'v_cvt_scalef32_pk32_bf6_f16 %s, %s, %s' % (vreg(dst, 6), vreg(src, 16), vreg(scale_v))
-
-    def emu(st):
-        x = _halves(st.V[src:src + 16]).astype(np.float64)          # [64, 32]
-        sc = st.f32('v', scale_v).astype(np.float64)[:, None]
-        st.V[dst:dst + 6] = pack6(f_to_bf6(x / sc)).T
-    return valu(text, vr(src, 16) + vr(scale_v), vr(dst, 6), emu)
-
-
-def s_nop(n):
-    return Ins('s_nop %d' % n, 'nop', cost=n + 1)
-
-
-def salu(text, emu=None):
-    return Ins(text, 'salu', emu=emu)
-
-
 def dma_piece(i, tag=''):
     """piece i (0..6) of this wave's 7 KiB of a chunk: global_load_lds_dwordx4 v_off, s[S_G:S_G+1] offset:imm
     with LDS destination M0 + imm + lane*16; pieces 4..6 use the +4096 offset register and M0 + 4096."""
@@ -625,19 +282,8 @@ def dma_aux():
 # ---------------------------------------------------------------------------------------------
 # block schedule
 # ---------------------------------------------------------------------------------------------
-class Filler:
-    __slots__ = ('ins', 'earliest', 'deadline', 'chain', 'seq')
-
-    def __init__(self, ins, earliest, deadline, chain):
-        self.ins = ins
-        self.earliest = earliest  # may be issued after anchor #earliest has been emitted
-        self.deadline = deadline  # must be issued before anchor #deadline
-        self.chain = chain        # fillers of one chain keep their order
-        self.seq = 0
-
-
-def slot_of(layer, m):
-    return (layer * 8 + m) % NSLOT
+def slot_of(T):
+    return T % NSLOT
 
 
 def lds_addr(slot, byte_off, width):
@@ -647,67 +293,69 @@ def lds_addr(slot, byte_off, width):
     return (lo, off) if off < 65536 else (hi, off - 65536)
 
 
-def tile_anchors(T):
-    """the 24 MFMAs of a tile as (kind, s or j, c): fp16 k-steps 0..7, the four K=128 MFMA pairs behind
-    k-steps 4..7 (their B operands of the previous layer's last row tiles are converted late)"""
+ORDER = 'tail'   # 'tail': the 16 fp16 MFMAs of a row tile, then its 8 K=64 MFMAs; 'mix': the K=64 ones behind k-steps 8..15
+
+
+def tile_anchors():
+    """the 24 MFMAs of a row tile as (kind, s or j), all on ONE accumulator (an accumulate chain).  The B operands of the
+    previous layer's last row tile are converted late: its k-steps 14, 15 and its K=64 operands (., 3) come last."""
     out = []
-    for s in range(8):
-        out.append(('m16', s, 0))
-        out.append(('m16', s, 1))
-        if s >= 4:
-            out.append(('m6', s - 4, 0))
-            out.append(('m6', s - 4, 1))
+    for s in range(16):
+        out.append(('m16', s))
+        if ORDER == 'mix' and s >= 8:
+            out.append(('m6', s - 8))
+    if ORDER == 'tail':
+        out += [('m6', j) for j in range(8)]
     return out
 
 
 ANCH_PER_TILE = 24
+_POS = {}
 
 
-def anchor_index(T, kind, sj, c):
-    """global anchor number of an MFMA (T may be <0 or >=32: neighbouring block iterations)"""
-    if kind == 'm16':
-        k = sj * 2 + c + 2 * max(0, sj - 4)
-    else:
-        k = (sj + 4) * 2 + 2 + c + 2 * sj
-    return T * ANCH_PER_TILE + k
+def anchor_index(T, kind, sj):
+    """global anchor number of an MFMA (T may be <0 or >=16: neighbouring block iterations)"""
+    if _POS.get('order') != ORDER:
+        _POS.clear()
+        _POS['order'] = ORDER
+        for i, key in enumerate(tile_anchors()):
+            _POS[key] = i
+    return T * ANCH_PER_TILE + _POS[(kind, sj)]
 
 
-def epilogue_ops(T, c):
-    """VALU epilogue of row tile T (block-local tile index, may be -1 = tile 31 of the previous block) for
-    column tile c.  Returns [(Ins, consumer)]; consumer: None | ('hi', s) | ('b6', term, t)."""
-    Tm = T % 32
-    layer, u = Tm >> 4, Tm & 15
-    tb = TMP(c)
-    t = [tb + i for i in range(4)]
-    cv = tb + 4                       # 6 conversion outputs
-    lo = LO(c) + 2 * (u & 7)
+def epilogue_ops(T):
+    """VALU epilogue of row tile T (block-local tile index, may be -1 = tile 15 of the previous block).  Returns
+    [(Ins, consumer)]; consumer: None | ('hi', s) | ('b6', term, t).  Works in the tile's own accumulator registers:
+    relu in place (layer 1), copies of X (layer 2, whose accumulator is X itself)."""
+    Tm = T % TILES
+    layer, u = Tm >> 3, Tm & 7
+    acc = ACC(T & 1)
+    hset, b6 = (HH, A_H6) if layer == 0 else (INH, A_IN6)
     ops = []
-    if layer == 0:
+    for g in range(4):
+        t = [acc + 4 * g + i for i in range(4)]
         for i in range(4):
-            ops.append((v_max0(t[i], ACC(T & 1, c) + i), None))
-        hset, b6 = HH, A_H6
-    else:
-        for i in range(4):
-            ops.append((v_accr(t[i], X(u, c) + i), None))
-        hset, b6 = INH, A_IN6
-    h01 = hset(u >> 1, c) + 2 * (u & 1)
-    h23 = h01 + 1
-    ops.append((v_cvt_pk_f16(h01, t[0], t[1]), ('hi', u >> 1)))
-    ops.append((v_cvt_pk_f16(h23, t[2], t[3]), ('hi', u >> 1)))
-    # half-register writes: low halves first, then the high halves (never two writers of one register back to back)
-    ops.append((v_resid16(lo, 0, h01, 0, t[0]), None))
-    ops.append((v_resid16(lo + 1, 0, h23, 0, t[2]), None))
-    ops.append((v_resid16(lo, 1, h01, 1, t[1]), None))
-    ops.append((v_resid16(lo + 1, 1, h23, 1, t[3]), None))
-    if (u & 7) == 7:
-        tt = u >> 3
-        # 32-wide conversions of the finished group of 8 row tiles; the independent one first (dst-sel forwarding)
-        ops.append((v_cvt_pk32_bf6(cv, hset(4 * tt, c), V_CVA), None))
+            ops.append((v_max0(t[i], t[i]) if layer == 0 else v_accr(t[i], X(u) + 4 * g + i), None))
+        s = 2 * u + (g >> 1)
+        h01 = hset(s) + 2 * (g & 1)
+        h23 = h01 + 1
+        lo = V_LO + (u & 1) * 8 + g * 2
+        ops.append((v_cvt_pk_f16(h01, t[0], t[1]), ('hi', s)))
+        ops.append((v_cvt_pk_f16(h23, t[2], t[3]), ('hi', s)))
+        # half-register writes: low halves first, then the high halves (never two writers of one register back to back)
+        ops.append((v_resid16(lo, 0, h01, 0, t[0], S_NEG1), None))
+        ops.append((v_resid16(lo + 1, 0, h23, 0, t[2], S_NEG1), None))
+        ops.append((v_resid16(lo, 1, h01, 1, t[1], S_NEG1), None))
+        ops.append((v_resid16(lo + 1, 1, h23, 1, t[3], S_NEG1), None))
+    if (u & 1) == 1:
+        tt = u >> 1
+        # 32-wide conversions of the finished pair of row tiles; the independent one first (dst-sel forwarding)
+        ops.append((v_cvt_pk32_bf6(V_CV, hset(4 * tt), V_CVA), None))
         for i in range(6):
-            ops.append((v_accw(B6(b6, 0, tt, c) + i, cv + i), ('b6', 0, tt)))
-        ops.append((v_cvt_pk32_bf6(cv, LO(c), V_CVL), None))
+            ops.append((v_accw(B6(b6, 0, tt) + i, V_CV + i), ('b6', 0, tt)))
+        ops.append((v_cvt_pk32_bf6(V_CV, V_LO, V_CVL), None))
         for i in range(6):
-            ops.append((v_accw(B6(b6, 1, tt, c) + i, cv + i), ('b6', 1, tt)))
+            ops.append((v_accw(B6(b6, 1, tt) + i, V_CV + i), ('b6', 1, tt)))
     return ops
 
 
@@ -738,125 +386,116 @@ class Sched:
 
 
 def build_fillers(it, opts):
-    """fillers of block iteration `it` (anchors numbered it*768 + ...)"""
+    """fillers of block iteration `it` (anchors numbered it*384 + ...)"""
     F = []
-    base_anchor = it * 32 * ANCH_PER_TILE
+    base_anchor = it * TILES * ANCH_PER_TILE
 
-    def A(T, kind, sj, c):
-        return base_anchor + anchor_index(T, kind, sj, c)
+    def A(T, kind, sj):
+        return base_anchor + anchor_index(T, kind, sj)
 
-    for T in range(32):
-        layer, u = T >> 4, T & 15
-        m, upos = u >> 1, u & 1
-        slot = slot_of(layer, m)
-        # --- weight operand reads.  hi fragments in pairs of k-steps (buffers: pair p & 1 of 4): issue order
-        # hi(2p+1), hi(2p) so that the single counted wait in front of k-step 2p covers the pair; the bf6 operands
-        # (2 reads each, buffer (T*4 + j) & 1) are fetched about two k-steps ahead of their MFMA.
-        for p in range(4):
-            g0 = T * 8 + 2 * p
-            gp = g0 - opts.rd_lead
-            earliest = A(gp // 8, 'm16', gp % 8, 1)
-            deadline = A(T, 'm16', 2 * p, 0)
-            grp = []
-            if layer == 0 and p == 0:
-                grp.append(ds_read_b128(BIAS(T & 1), V_AUX, 64 * u, tag=('bias', it, T)))
-            for s_ in (2 * p + 1, 2 * p):
-                bv, off = lds_addr(slot, piece_hi(upos, s_) * 1024, 16)
-                grp.append(ds_read_b128(HI(s_ & 3), bv, off, tag=('hi', it, T, s_)))
-            for ins in grp:
-                F.append(Filler(ins, earliest, deadline, ('rd',)))
-        for j in range(4):
-            gj = T * 4 + j
-            prev = gj - 2                                  # last user of the buffer
-            earliest = max(A(prev // 4, 'm6', prev % 4, 1), A(T, 'm16', 2 + j, 0) - 1)
-            deadline = A(T, 'm6', j, 0)
-            bv, off = lds_addr(slot, piece_a6(upos, j) * 1024, 16)
-            F.append(Filler(ds_read_b128(A6(gj & 1), bv, off, tag=('a6', it, T, j, 0)), earliest, deadline, ('rd6',)))
-            pc, po = piece_a6b(upos, j)
+    for T in range(TILES):
+        layer, u = T >> 3, T & 7
+        slot = slot_of(T)
+        # --- weight operand reads: one ds_read_b128 per fp16 k-step (one MFMA each) into a ring of NHI buffers, two reads
+        # per bf6 operand into two buffers; every read runs `rd_lead` anchors ahead of its MFMA at most
+        if layer == 0:
+            for g in range(4):
+                F.append(Filler(ds_read_b128(V_BIAS + 4 * g, V_AUX, 128 * u + 32 * g, tag=('bias', it, T, g)),
+                                A(T - 1, 'm16', 0), A(T, 'm16', 0), ('rd',)))
+        for s_ in range(16):
+            n = T * 16 + s_
+            prev = n - NHI                                 # last user of the buffer
+            earliest = max(A(prev // 16, 'm16', prev % 16), A(T, 'm16', s_) - opts.rd_lead)
+            bv, off = lds_addr(slot, piece_hi(s_) * 1024, 16)
+            F.append(Filler(ds_read_b128(HI(n % NHI), bv, off, tag=('hi', it, T, s_)), earliest, A(T, 'm16', s_), ('rd',)))
+        for j in range(8):
+            n = T * 8 + j
+            prev = n - 2
+            earliest = max(A(prev // 8, 'm6', prev % 8), A(T, 'm6', j) - opts.rd_lead6)
+            deadline = A(T, 'm6', j)
+            bv, off = lds_addr(slot, piece_a6(j) * 1024, 16)
+            F.append(Filler(ds_read_b128(A6(n & 1), bv, off, tag=('a6', it, T, j, 0)), earliest, deadline, ('rd6',)))
+            pc, po = piece_a6b(j)
             bv, off = lds_addr(slot, pc * 1024 + po, 8)
-            F.append(Filler(ds_read_b64(A6(gj & 1) + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
-        if T == 16:
+            F.append(Filler(ds_read_b64(A6(n & 1) + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
+        if T == 8:
             # this block's layer-2 scales were read during layer 1; flip to the next block's aux slot, then fetch
             # the next block's layer-1 scales (the running layer 1 is over: its scale registers are free)
             F.append(Filler(valu('v_xor_b32 %s, 0x%x, %s' % (vreg(V_AUX), AUX_BYTES, vreg(V_AUX)), vr(V_AUX), vr(V_AUX),
                                  lambda st: st.V.__setitem__(V_AUX, st.V[V_AUX] ^ AUX_BYTES)),
-                            A(T, 'm16', 1, 0), A(T, 'm16', 6, 0), ('auxflip',)))
+                            A(T, 'm16', 1), A(T, 'm16', 12), ('auxflip',)))
             F.append(Filler(ds_read_b64(V_SC, V_AUX, AUX_SCALES, tag=('scale', it + 1, 0)),
-                            A(T, 'm16', 1, 0), A(T + 1, 'm16', 0, 0), ('auxflip',)))
+                            A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
         if T == 1:
             # layer-2 scales of this block (layer 2 of the previous block is over)
             F.append(Filler(ds_read_b64(V_SC + 2, V_AUX, AUX_SCALES + 8, tag=('scale', it, 1)),
-                            A(T, 'm16', 1, 0), A(T + 1, 'm16', 0, 0), ('auxflip',)))
+                            A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
         # --- epilogue of the PREVIOUS tile, under this tile's MFMAs ----------------------------
         Tprev = T - 1
-        pu = (Tprev % 32) & 15
-        nl_T0 = (Tprev - pu) + 16  # first tile of the consuming layer, block-local
-        for c in range(2):
-            e0 = A(T, 'm16', 0, 1) + 1 + c  # two further MFMAs behind the last writer of its accumulator
-            for ins, cons in epilogue_ops(Tprev, c):
-                dl = A(T + 1, 'm16', 0, 0)  # latest: the accumulator buffer is reused by tile T+1
-                if cons is not None:
-                    if cons[0] == 'hi':
-                        first = A(nl_T0, 'm16', cons[1], 0)
-                    else:
-                        first = A(nl_T0, 'm6', J_ORDER.index((cons[1], cons[2])), 0)
-                    dl = min(dl, first - 2)
-                F.append(Filler(ins, e0, dl, ('epi', c)))
-        # --- rendezvous + refill at the middle of each chunk (start of the upos = 1 tile) -------
-        if upos == 1:
-            a0 = A(T, 'm16', 0, 0)
-            ch = ('dma',)
-            F.append(Filler(waitcnt_vm(PW), a0 - 1, a0 + 1, ch))
-            F.append(Filler(barrier(), a0 - 1, a0 + 1, ch))
-            seq = []
-            cidx = layer * 8 + m          # chunk of the block being consumed
-            tgt_slot = (cidx + 3) % NSLOT
-            seq.append(salu('s_add_u32 %s, %s, %s' % (sreg(S_G), sreg(S_W), sreg(S_POS)),
-                            lambda st: st.S.__setitem__(S_G, st.S[S_W] + st.S[S_POS])))
-            seq.append(salu('s_addc_u32 %s, %s, 0' % (sreg(S_G + 1), sreg(S_W + 1))))
-            seq.append(salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_POS), sreg(S_POS), CHUNK),
-                            lambda st: st.S.__setitem__(S_POS, st.S[S_POS] + CHUNK)))
-            seq.append(salu('s_cmp_eq_u32 %s, %s' % (sreg(S_POS), sreg(S_END))))
-            seq.append(salu('s_cselect_b32 %s, 0, %s' % (sreg(S_POS), sreg(S_POS)),
-                            lambda st: st.S.__setitem__(S_POS, 0 if st.S[S_POS] == st.S[S_END] else st.S[S_POS])))
-            if cidx == 0:
-                # aux block of the NEXT block -> the other aux slot; older than this chunk's pieces
-                seq.append(salu('s_add_u32 %s, %s, %s' % (sreg(S_AG), sreg(S_AUXB), sreg(S_AUXPOS)),
-                                lambda st: st.S.__setitem__(S_AG, st.S[S_AUXB] + st.S[S_AUXPOS])))
-                seq.append(salu('s_addc_u32 %s, %s, 0' % (sreg(S_AG + 1), sreg(S_AUXB + 1))))
-                seq.append(salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_AUXPOS), sreg(S_AUXPOS), AUX_BYTES),
-                                lambda st: st.S.__setitem__(S_AUXPOS, st.S[S_AUXPOS] + AUX_BYTES)))
-                seq.append(salu('s_cmp_eq_u32 %s, %s' % (sreg(S_AUXPOS), sreg(S_AUXEND))))
-                seq.append(salu('s_cselect_b32 %s, 0, %s' % (sreg(S_AUXPOS), sreg(S_AUXPOS)),
-                                lambda st: st.S.__setitem__(S_AUXPOS, 0 if st.S[S_AUXPOS] == st.S[S_AUXEND] else st.S[S_AUXPOS])))
-                seq.append(salu('s_mov_b32 m0, %s' % sreg(S_AUXM0), lambda st: setattr(st, 'm0', st.S[S_AUXM0])))
-                seq.append(s_nop(0))
-                seq.append(dma_aux())
-                seq.append(salu('s_xor_b32 %s, %s, 0x%x' % (sreg(S_AUXM0), sreg(S_AUXM0), AUX_BYTES),
-                                lambda st: st.S.__setitem__(S_AUXM0, st.S[S_AUXM0] ^ AUX_BYTES)))
-            seq.append(salu('s_mov_b32 m0, %s' % sreg(S_M0SLOT + tgt_slot),
-                            lambda st, k=S_M0SLOT + tgt_slot: setattr(st, 'm0', st.S[k])))
+        pu = (Tprev % TILES) & 7
+        nl_T0 = (Tprev - pu) + 8  # first tile of the consuming layer, block-local
+        e0 = A(T, 'm16', 0) + 2   # two further MFMAs behind the last writer of the accumulator
+        for ins, cons in epilogue_ops(Tprev):
+            dl = A(T + 1, 'm16', 0)  # latest: the accumulator buffer is reused by tile T+1
+            if cons is not None:
+                if cons[0] == 'hi':
+                    first = A(nl_T0, 'm16', cons[1])
+                else:
+                    first = A(nl_T0, 'm6', J_ORDER.index((cons[1], cons[2])))
+                dl = min(dl, first - 2)
+            F.append(Filler(ins, e0, dl, ('epi',)))
+        # --- rendezvous + refill at the middle of each chunk (= row tile) ------------------------
+        a0 = base_anchor + T * ANCH_PER_TILE + 8
+        ch = ('dma',)
+        F.append(Filler(waitcnt_vm(PW), a0 - 1, a0 + 1, ch))
+        F.append(Filler(barrier(), a0 - 1, a0 + 1, ch))
+        seq = []
+        tgt_slot = (T + 3) % NSLOT
+        seq.append(salu('s_add_u32 %s, %s, %s' % (sreg(S_G), sreg(S_W), sreg(S_POS)),
+                        lambda st: st.S.__setitem__(S_G, st.S[S_W] + st.S[S_POS])))
+        seq.append(salu('s_addc_u32 %s, %s, 0' % (sreg(S_G + 1), sreg(S_W + 1))))
+        seq.append(salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_POS), sreg(S_POS), CHUNK),
+                        lambda st: st.S.__setitem__(S_POS, st.S[S_POS] + CHUNK)))
+        seq.append(salu('s_cmp_eq_u32 %s, %s' % (sreg(S_POS), sreg(S_END))))
+        seq.append(salu('s_cselect_b32 %s, 0, %s' % (sreg(S_POS), sreg(S_POS)),
+                        lambda st: st.S.__setitem__(S_POS, 0 if st.S[S_POS] == st.S[S_END] else st.S[S_POS])))
+        if T == 0:
+            # aux block of the NEXT block -> the other aux slot; older than this chunk's pieces
+            seq.append(salu('s_add_u32 %s, %s, %s' % (sreg(S_AG), sreg(S_AUXB), sreg(S_AUXPOS)),
+                            lambda st: st.S.__setitem__(S_AG, st.S[S_AUXB] + st.S[S_AUXPOS])))
+            seq.append(salu('s_addc_u32 %s, %s, 0' % (sreg(S_AG + 1), sreg(S_AUXB + 1))))
+            seq.append(salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_AUXPOS), sreg(S_AUXPOS), AUX_BYTES),
+                            lambda st: st.S.__setitem__(S_AUXPOS, st.S[S_AUXPOS] + AUX_BYTES)))
+            seq.append(salu('s_cmp_eq_u32 %s, %s' % (sreg(S_AUXPOS), sreg(S_AUXEND))))
+            seq.append(salu('s_cselect_b32 %s, 0, %s' % (sreg(S_AUXPOS), sreg(S_AUXPOS)),
+                            lambda st: st.S.__setitem__(S_AUXPOS, 0 if st.S[S_AUXPOS] == st.S[S_AUXEND] else st.S[S_AUXPOS])))
+            seq.append(salu('s_mov_b32 m0, %s' % sreg(S_AUXM0), lambda st: setattr(st, 'm0', st.S[S_AUXM0])))
             seq.append(s_nop(0))
-            for i in range(PW):
-                if i == 4:
-                    seq.append(salu('s_add_u32 m0, m0, 0x1000', lambda st: setattr(st, 'm0', st.m0 + 4096)))
-                    seq.append(s_nop(0))
-                seq.append(dma_piece(i, tag=('dma', it, T, i)))
-            end = A(T, 'm6', 3, 1)
-            if opts.dma_burst:
-                for ins in seq:
-                    F.append(Filler(ins, a0 - 1, a0 + 1, ch))
-            else:
-                # SALU prelude right behind the barrier, then the pieces spread over the tile's k-steps
-                first_piece = next(i for i, x in enumerate(seq) if x.kind == 'dma' and x.tag)
-                for ins in seq[:first_piece]:
-                    F.append(Filler(ins, a0 - 1, a0 + 4, ch))
-                spots = [A(T, 'm16', s_, 1) for s_ in range(1, 8)]
-                k = 0
-                for ins in seq[first_piece:]:
-                    F.append(Filler(ins, spots[min(k, len(spots) - 1)], end + 1, ch))
-                    if ins.kind == 'dma':
-                        k += 1
+            seq.append(dma_aux())
+            seq.append(salu('s_xor_b32 %s, %s, 0x%x' % (sreg(S_AUXM0), sreg(S_AUXM0), AUX_BYTES),
+                            lambda st: st.S.__setitem__(S_AUXM0, st.S[S_AUXM0] ^ AUX_BYTES)))
+        seq.append(salu('s_mov_b32 m0, %s' % sreg(S_M0SLOT + tgt_slot),
+                        lambda st, k=S_M0SLOT + tgt_slot: setattr(st, 'm0', st.S[k])))
+        seq.append(s_nop(0))
+        for i in range(PW):
+            if i == 4:
+                seq.append(salu('s_add_u32 m0, m0, 0x1000', lambda st: setattr(st, 'm0', st.m0 + 4096)))
+                seq.append(s_nop(0))
+            seq.append(dma_piece(i, tag=('dma', it, T, i)))
+        end = base_anchor + (T + 1) * ANCH_PER_TILE + 6      # well before the next rendezvous
+        if opts.dma_burst:
+            for ins in seq:
+                F.append(Filler(ins, a0 - 1, a0 + 1, ch))
+        else:
+            # SALU prelude right behind the barrier, then the pieces spread over the following MFMAs
+            first_piece = next(i for i, x in enumerate(seq) if x.kind == 'dma' and x.tag)
+            for ins in seq[:first_piece]:
+                F.append(Filler(ins, a0 - 1, a0 + 3, ch))
+            k = 0
+            for ins in seq[first_piece:]:
+                F.append(Filler(ins, a0 + 1 + opts.dma_gap * k, end, ch))
+                if ins.kind == 'dma':
+                    k += 1
     return F
 
 
@@ -877,7 +516,9 @@ def schedule(opts, n_iter=3):
         for i in range(len(ch) - 2, -1, -1):   # a filler must not hold up a successor with an earlier deadline
             ch[i].deadline = min(ch[i].deadline, ch[i + 1].deadline)
     heads = {ch: 0 for ch in chains}
-    total_anchors = n_iter * 32 * ANCH_PER_TILE
+    per_block = TILES * ANCH_PER_TILE
+    total_anchors = n_iter * per_block
+    anchors = tile_anchors()
 
     def ready(pos):
         """chain heads that may issue at anchor position pos, by deadline"""
@@ -903,44 +544,42 @@ def schedule(opts, n_iter=3):
         issue(r[0], -1)
 
     for a in range(total_anchors):
-        it = a // (32 * ANCH_PER_TILE)
-        T = (a // ANCH_PER_TILE) % 32
-        kind, sj, c = tile_anchors(T)[a % ANCH_PER_TILE]
+        it = a // per_block
+        T = (a // ANCH_PER_TILE) % TILES
+        kind, sj = anchors[a % ANCH_PER_TILE]
         while True:  # forced fillers: deadline reached
             r = [f for f in ready(a - 1) if f.deadline <= a]
             if not r:
                 break
             issue(r[0], it)
-        layer, u = T >> 4, T & 15
+        layer, u = T >> 3, T & 7
         hset = INH if layer == 0 else HH
-        if a % (32 * ANCH_PER_TILE) == 0:
+        if a % per_block == 0:
             # loop head: the prefetch issued by the previous iteration's tail -- or by the prologue, which lacks the
             # tail's other reads, so a counted wait would be too generous there -- is drained completely
             sch.emit(it, waitcnt_lgkm(0))
             sch.ds_done = sch.ds_issued
+        dfile, d = ('v', ACC(T & 1)) if layer == 0 else ('a', X(u))
         if kind == 'm16':
             sch.need(it, ('hi', it, T, sj))
-            if layer == 0:
-                d = ACC(T & 1, c)
-                if sj == 0:
-                    sch.need(it, ('bias', it, T))
-                    ins = mfma16('v', d, HI(sj & 3), hset(sj, c), 'v', BIAS(T & 1), tag=('m16', it, T, sj, c))
-                else:
-                    ins = mfma16('v', d, HI(sj & 3), hset(sj, c), 'v', d, tag=('m16', it, T, sj, c))
+            n = T * 16 + sj
+            if layer == 0 and sj == 0:
+                sch.need(it, ('bias', it, T, 3))
+                ins = mfma32_16('v', d, HI(n % NHI), hset(sj), 'v', V_BIAS, tag=('m16', it, T, sj))
             else:
-                d = X(u, c)
-                ins = mfma16('a', d, HI(sj & 3), hset(sj, c), 'a', d, tag=('m16', it, T, sj, c))
+                ins = mfma32_16(dfile, d, HI(n % NHI), hset(sj), dfile, d, tag=('m16', it, T, sj))
             cap = opts.cap16
         else:
-            gj = T * 4 + sj
+            n = T * 8 + sj
             sch.need(it, ('a6', it, T, sj, 1))
             term, t = J_ORDER[sj]
-            if u == 0 and sj == 0 and c == 0:
+            if u == 0 and sj == 0:
                 sch.need(it, ('scale', it, layer))
+            if sj == 0 and ORDER == 'tail' and opts.chain_nop >= 0:
+                sch.emit(it, s_nop(opts.chain_nop))      # fp16 -> scaled MFMA on one accumulator: keep them apart
             b6 = A_IN6 if layer == 0 else A_H6
-            dfile, d = ('v', ACC(T & 1, c)) if layer == 0 else ('a', X(u, c))
-            ins = mfma6(dfile, d, A6(gj & 1), B6(b6, term, t, c), V_SC + 2 * layer + term, V_SBA if term == 0 else V_SBL,
-                        tag=('m6', it, T, sj, c))
+            ins = mfma32_6(dfile, d, A6(n & 1), B6(b6, term, t), V_SC + 2 * layer + term, V_SBA if term == 0 else V_SBL,
+                           tag=('m6', it, T, sj))
             cap = opts.cap6
         if not (kind == 'm6' and J_ORDER[sj][0] in opts.skip_terms):
             sch.emit(it, ins)
@@ -956,11 +595,14 @@ def schedule(opts, n_iter=3):
 
 class Opts:
     def __init__(self, **kw):
-        self.rd_lead = 3
-        self.cap16 = 3
-        self.cap6 = 3
+        self.rd_lead = 4          # anchors (MFMAs of 32 cycles) an fp16 fragment read is issued ahead of its MFMA, at most
+        self.rd_lead6 = 4
+        self.cap16 = 6            # issue slots for fillers behind an MFMA
+        self.cap6 = 6
+        self.dma_gap = 1          # anchors between two LDS-DMA pieces
         self.dma_burst = False
-        self.skip_terms = ()      # diagnostics: drop the K=128 MFMAs of these correction terms (wrong results)
+        self.chain_nop = -1       # s_nop N between the last fp16 and the first K=64 MFMA of a row tile (-1: none)
+        self.skip_terms = ()      # diagnostics: drop the K=64 MFMAs of these correction terms (wrong results)
         self.__dict__.update(kw)
 
 
@@ -979,14 +621,7 @@ def steady_block(opts):
 # ---------------------------------------------------------------------------------------------
 def split_ops(u):
     """standalone split of X row tile u -> the layer-1 operand sets (the layer-2 epilogue without MFMAs)"""
-    ops = []
-    for c in range(2):
-        ops += [ins for ins, _ in epilogue_ops(16 + u, c)]
-    return ops
-
-
-def f32_bits(x):
-    return int(np.array([x], dtype=np.float32).view(np.uint32)[0])
+    return [ins for ins, _ in epilogue_ops(8 + u)]
 
 
 def kernel_text(opts):
@@ -1014,7 +649,7 @@ def kernel_text(opts):
     a('v_add_u32 %s, 0x10000, %s' % (vreg(V_L1), vreg(V_L0)))
     a('v_lshlrev_b32 %s, 3, %s' % (vreg(V_L8A), vreg(V_LANE)))
     a('v_add_u32 %s, 0x10000, %s' % (vreg(V_L8B), vreg(V_L8A)))
-    a('v_lshrrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_LANE)))
+    a('v_lshrrev_b32 %s, 5, %s' % (vreg(V_AUX), vreg(V_LANE)))
     a('v_lshlrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_AUX)))
     a('v_add_u32 %s, 0x%x, %s' % (vreg(V_AUX), LDS_AUX, vreg(V_AUX)))
     a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_T0), sreg(S_WAVE), PW * 1024))        # wave * 7168
@@ -1083,8 +718,8 @@ def kernel_text(opts):
             a('s_add_u32 %s, %s, 0x1000' % (sreg(S_T0 + 4), sreg(S_T0 + 4)))
             a('s_addc_u32 %s, %s, 0' % (sreg(S_T0 + 5), sreg(S_T0 + 5)))
     a('s_waitcnt vmcnt(0)')
-    # initial split of row tiles 0..14 (tile 15's runs at the head of the loop body)
-    for u in range(15):
+    # initial split of row tiles 0..6 (tile 7's runs at the head of the loop body)
+    for u in range(7):
         for ins in split_ops(u):
             a(ins.text)
     for ins in pro:   # LDS reads the loop head expects in flight
@@ -1130,31 +765,6 @@ def emit_inc(path, opts):
         first = L.index('L_block_%=:')
         last = len(L) - 1 - L[::-1].index('s_sub_u32 %s, %s, 1' % (sreg(S_BLK), sreg(S_BLK)))
         L = L[:first + 1] + [t for t in L[first + 1:last] if not (t in texts and not t.startswith(keep_always))] + L[last:]
-    if getattr(opts, 'sim32', False):
-        # timing model only (wrong results): every pair of 16x16 MFMAs (column tiles 0, 1) becomes ONE 32x32 MFMA of the
-        # same FLOPs and the same operand registers; everything else stays
-        import re
-        first = L.index('L_block_%=:')
-        out = []
-        for t in L[first:]:
-            m = re.match(r'v_mfma_f32_16x16x32_f16 ([va])\[(\d+):(\d+)\], (v\[\d+:\d+\]), v\[(\d+):(\d+)\], ', t)
-            m6 = re.match(r'v_mfma_scale_f32_16x16x128_f8f6f4 ([va])\[(\d+):(\d+)\], (\S+), a\[(\d+):(\d+)\], \S+ (v\d+), (v\d+) (.*)', t)
-            if m:
-                f_, d0, a_, b0 = m.group(1), int(m.group(2)), m.group(4), int(m.group(5))
-                if (b0 % 64) >= 32:      # column tile 1: folded into its partner
-                    continue
-                d = (d0 // 16) * 16
-                out.append('v_mfma_f32_32x32x16_f16 %s[%d:%d], %s, v[%d:%d], %s[%d:%d]' % (f_, d, d + 15, a_, b0, b0 + 3, f_, d, d + 15))
-            elif m6:
-                f_, d0, a_, b0 = m6.group(1), int(m6.group(2)), m6.group(4).rstrip(','), int(m6.group(5))
-                if ((b0 - 128) // 6) % 2 == 1:
-                    continue
-                d = (d0 // 16) * 16
-                out.append('v_mfma_scale_f32_32x32x64_f8f6f4 %s[%d:%d], %s, a[%d:%d], %s[%d:%d], %s, %s %s' %
-                           (f_, d, d + 15, a_, b0, b0 + 5, f_, d, d + 15, m6.group(7), m6.group(8), m6.group(9)))
-            else:
-                out.append(t)
-        L = L[:first] + out
     n = {}
     for ins in body:
         n[ins.kind] = n.get(ins.kind, 0) + 1
@@ -1172,14 +782,14 @@ def emit_inc(path, opts):
 def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=True):
     """x_tile_regs: float32 [128, 64] register image of one wave's X.  Returns (X out [128, 64], errors)."""
     pro, body = steady_block(opts)
-    st = State(wave, img, aux, n_block)
+    st = State(wave, img, aux, n_block, LDS_BYTES)
     lanes = np.arange(64, dtype=np.uint32)
     st.V[V_LANE] = lanes
     st.V[V_L0] = lanes * 16
     st.V[V_L1] = lanes * 16 + 65536
     st.V[V_L8A] = lanes * 8
     st.V[V_L8B] = lanes * 8 + 65536
-    st.V[V_AUX] = LDS_AUX + (lanes >> 4) * 16
+    st.V[V_AUX] = LDS_AUX + (lanes >> 5) * 16
     st.V[V_DMAOFF] = wave * PW * 1024 + lanes * 16
     st.V[V_DMAOFF2] = wave * PW * 1024 + lanes * 16 + 4096
     st.V[V_AUXOFF] = wave * 1024 + lanes * 16
@@ -1220,7 +830,7 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     waitcnt_vm(2 * PW).emu(st)
     barrier().emu(st)
     st.A[A_X:A_X + 128] = np.ascontiguousarray(x_tile_regs, dtype=np.float32).view(np.uint32)
-    for u in range(15):
+    for u in range(7):
         st.run(split_ops(u))
     st.run(pro)
     for b in range(n_block):
@@ -1232,88 +842,28 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     return st.A[A_X:A_X + 128].view(np.float32).copy(), errs
 
 
-def check_hazards_stream(stream):
-    """static check with a coarse cycle model (other instructions 4 cycles, an MFMA occupies the matrix
-    pipe 16 cycles and issues when the pipe is free); the rules are listed in the module docstring"""
-    errs = []
-    t = 0
-    pipe_free = 0
-    mf_end = {}       # reg -> end cycle of the MFMA that last wrote it
-    valu_wr = {}      # reg -> instruction index of the last VALU write
-    mf_rd = {}        # reg -> issue cycle of the last MFMA reading it
-    for i, ins in enumerate(stream):
-        if i > 0 and stream[i - 1].partial:
-            touched = set(ins.rd) | (set(ins.wr) if ins.partial else set())
-            if set(stream[i - 1].wr) & touched:
-                errs.append('%d: %s touches a register half-written by the instruction right before it '
-                            '(dst-sel forwarding)' % (i, ins.text))
-        if i > 0 and ins.kind == 'dma' and stream[i - 1].kind == 'salu' and ' m0,' in stream[i - 1].text:
-            errs.append('%d: LDS-DMA right behind an M0 write' % i)
-        if ins.kind in ('mfma16', 'mfma6'):
-            dur = 16
-            start = max(t, pipe_free)
-            d = set(ins.wr)
-            for r in ins.rd:
-                if r in d:
-                    continue  # C operand = D: accumulate chain
-                if r in mf_end and start < mf_end[r] + 24:
-                    errs.append('%d: %s reads %s%d too early behind an MFMA' % (i, ins.text, r[0], r[1]))
-                if r in valu_wr and i - valu_wr[r] < 3:
-                    errs.append('%d: %s reads %s%d written by VALU %d instructions ago' %
-                                (i, ins.text, r[0], r[1], i - valu_wr[r]))
-                mf_rd[r] = start
-            pipe_free = start + dur
-            for r in ins.wr:
-                mf_end[r] = start + dur
-            t = start + 8
-        else:
-            for r in ins.rd:
-                if r in mf_end and t < mf_end[r] + 24:
-                    errs.append('%d: %s reads %s%d %d cycles after its MFMA ended' %
-                                (i, ins.text, r[0], r[1], t - mf_end[r]))
-            for r in ins.wr:
-                if ins.kind == 'valu' and r in mf_rd and t < mf_rd[r] + 12:  # (LDS data lands >= 64 cycles later)
-                    errs.append('%d: %s overwrites %s%d read by an MFMA %d cycles ago' %
-                                (i, ins.text, r[0], r[1], t - mf_rd[r]))
-                if r in mf_end and t < mf_end[r]:
-                    errs.append('%d: %s overwrites %s%d while an MFMA still writes it' % (i, ins.text, r[0], r[1]))
-                if ins.kind == 'valu':
-                    valu_wr[r] = i
-                mf_end.pop(r, None)
-            t += 4 * ins.cost if ins.kind in ('nop',) else 4
-    return errs
-
-
-def model_cycles(body):
-    """coarse issue model: cycles of one block"""
-    t = pipe = 0
-    for ins in body:
-        if ins.kind in ('mfma16', 'mfma6'):
-            st = max(t, pipe)
-            pipe = st + 16
-            t = st + 8
-        elif ins.kind == 'dma':
-            t += 36
-        else:
-            t += 4 * (ins.cost if ins.kind == 'nop' else 1)
-    return max(t, pipe)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--emit', help='write the inline-asm include file')
     ap.add_argument('--dma-burst', action='store_true')
-    ap.add_argument('--rd-lead', type=int, default=3)
-    ap.add_argument('--cap16', type=int, default=3)
-    ap.add_argument('--cap6', type=int, default=3)
+    ap.add_argument('--rd-lead', type=int, default=4)
+    ap.add_argument('--rd-lead6', type=int, default=4)
+    ap.add_argument('--cap16', type=int, default=6)
+    ap.add_argument('--cap6', type=int, default=6)
+    ap.add_argument('--dma-gap', type=int, default=1)
+    ap.add_argument('--chain-nop', type=int, default=-1)
+    ap.add_argument('--order', default=None, choices=['tail', 'mix'])
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')
-    ap.add_argument('--sim32', action='store_true', help='timing model only: 32x32 MFMA shapes (wrong results)')
     ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the block loop '
                     '(lgkm, dma, valu, ds, mfma6, mfma16): timing knock-outs, wrong results')
     a = ap.parse_args()
-    opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, cap16=a.cap16, cap6=a.cap6,
-                skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t), drop=tuple(x for x in a.drop.split(',') if x), sim32=a.sim32)
+    if a.order:
+        global ORDER
+        ORDER = a.order
+    opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap16=a.cap16, cap6=a.cap6, dma_gap=a.dma_gap,
+                chain_nop=a.chain_nop, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
+                drop=tuple(x for x in a.drop.split(',') if x))
     if a.emit:
         n = emit_inc(a.emit, opts)
         print('wrote', a.emit, n)

@@ -1,0 +1,531 @@
+#!/usr/bin/env python3
+"""Instruction objects, number formats, the lane-accurate emulator state and the static hazard check shared by the gfx950
+stream generators (body_gen.py: R2L ResMLP body, 32x32 MFMA shapes; nerf_gen.py: NeRF teacher layer chain, 16x16 shapes).
+
+Every instruction is an `Ins` with its assembly text, the registers it reads / writes and a Python closure that executes
+it on the emulator `State` (64 lanes x 256 VGPRs + 256 AGPRs, LDS bytes, in-order LDS-read and LDS-DMA queues).
+
+Hazards a hand-written stream must respect by construction (hipcc pads nothing inside an asm statement);
+`check_hazards_stream` enforces them statically with a coarse cycle model:
+  * MFMA result -> any non-accumulate reader: the reader comes well after the MFMA has left the pipe;
+  * VALU write -> MFMA operand read: >= 2 instructions in between;
+  * a VALU that writes HALF a register (v_fma_mixlo/hi_f16) must not be followed directly by a reader of that register
+    ("dst-sel forwarding" hazard: the reader sees the stale half);
+  * s_mov m0 -> LDS-DMA: one instruction in between.
+"""
+import numpy as np
+
+NLANE = 64
+BF6_TOP = 4                # 28 = 1.75 * 2^4
+# activations (act_scale domain, < 2^7) are converted as a / 2^3, their fp16 residuals (< 2^-5) as r * 2^9
+ACT_EXP = 3
+RES_EXP = -9
+
+
+def layer_exponent(W):
+    """e with max|w| in [2^(e-1), 2^e)"""
+    m = float(np.abs(W).max())
+    return int(np.frexp(m)[1]) if m > 0 else -4
+
+
+def weight_exps(e):
+    """power-of-two exponents of the two bf6 weight operands of a layer with weight exponent e:
+    stored (w - hi(w)) / 2^(e-16) and w / 2^(e-4), both < 2^5 in magnitude"""
+    return e - 16, e - 4
+
+
+# ---------------------------------------------------------------------------------------------
+# layout maps shared with the host packer (r2l_common.h restated; tests compare both sides)
+# ---------------------------------------------------------------------------------------------
+def kappa16(s, q, j):
+    """input feature multiplied by element j of lane quarter q of fp16 k-step s (r2l_kappa)"""
+    return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3)
+
+
+def mix16(t, q, e):
+    """input feature multiplied by element e (0..31) of lane quarter q of K=128 step t: the conversion takes the
+    16 fp16 pair registers of row tiles 8t .. 8t+7 in order, element e = 4 * (row tile & 7) + accumulator register"""
+    return 16 * (8 * t + (e >> 2)) + 4 * q + (e & 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# number formats (emulator + python-side packer used by the tests)
+# ---------------------------------------------------------------------------------------------
+def _bf6_table():
+    v = np.zeros(64)
+    for b in range(64):
+        s, e, m = b >> 5, (b >> 2) & 7, b & 3
+        x = (m / 4.0) * 2.0 ** -2 if e == 0 else (1 + m / 4.0) * 2.0 ** (e - 3)
+        v[b] = -x if s else x
+    return v
+
+
+BF6 = _bf6_table()
+_BF6_POS = BF6[:32]           # ascending
+
+
+def f_to_bf6(x):
+    """nearest e3m2 code (ties to even mantissa), saturating at 28; x float array"""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.abs(x)
+    idx = np.searchsorted(_BF6_POS, a).clip(1, 31)
+    lo, hi = _BF6_POS[idx - 1], _BF6_POS[idx]
+    up = (a - lo > hi - a) | ((a - lo == hi - a) & (((idx - 1) & 1) == 1))
+    code = np.where(up, idx, idx - 1)
+    code = np.where(a >= _BF6_POS[31], 31, code)
+    return (code | np.where(np.signbit(x), 32, 0)).astype(np.uint8)
+
+
+def pack6(codes):
+    """[..., 32] 6-bit codes -> [..., 6] uint32, element i at bits [6i, 6i+6) (little endian)"""
+    codes = np.asarray(codes, dtype=np.uint64)
+    out = np.zeros(codes.shape[:-1] + (3,), dtype=np.uint64)
+    for i in range(32):
+        bit = 6 * i
+        w, sh = bit >> 6, bit & 63
+        out[..., w] |= codes[..., i] << np.uint64(sh)
+        if sh > 58:
+            out[..., w + 1] |= codes[..., i] >> np.uint64(64 - sh)
+    return np.ascontiguousarray(out).view(np.uint32).reshape(codes.shape[:-1] + (6,))
+
+
+def unpack6(words):
+    """[..., 6] uint32 -> [..., 32] codes"""
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    w64 = words.view(np.uint64).reshape(words.shape[:-1] + (3,))
+    out = np.zeros(words.shape[:-1] + (32,), dtype=np.uint8)
+    for i in range(32):
+        bit = 6 * i
+        w, sh = bit >> 6, bit & 63
+        v = w64[..., w] >> np.uint64(sh)
+        if sh > 58:
+            v = v | (w64[..., w + 1] << np.uint64(64 - sh))
+        out[..., i] = (v & np.uint64(63)).astype(np.uint8)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# instruction objects
+# ---------------------------------------------------------------------------------------------
+class Ins:
+    __slots__ = ('text', 'kind', 'rd', 'wr', 'emu', 'cost', 'tag', 'partial')
+
+    def __init__(self, text, kind, rd=(), wr=(), emu=None, cost=1, tag='', partial=False):
+        self.text = text
+        self.kind = kind      # 'mfma16' 'mfma6' 'valu' 'ds' 'dma' 'salu' 'wait' 'barrier' 'nop'
+        self.rd = tuple(rd)   # registers read:  ('v', n) / ('a', n)
+        self.wr = tuple(wr)
+        self.emu = emu
+        self.cost = cost      # issue slots (4-cycle units) used by the scheduler's budget
+        self.tag = tag
+        self.partial = partial  # writes 16 bits of its destination (dst-sel forwarding hazard)
+
+
+def vr(n, cnt=1):
+    return [('v', n + i) for i in range(cnt)]
+
+
+def ar(n, cnt=1):
+    return [('a', n + i) for i in range(cnt)]
+
+
+def vreg(n, cnt=1):
+    return 'v%d' % n if cnt == 1 else 'v[%d:%d]' % (n, n + cnt - 1)
+
+
+def areg(n, cnt=1):
+    return 'a%d' % n if cnt == 1 else 'a[%d:%d]' % (n, n + cnt - 1)
+
+
+def sreg(n, cnt=1):
+    return 's%d' % n if cnt == 1 else 's[%d:%d]' % (n, n + cnt - 1)
+
+
+
+# ---- emulator state ---------------------------------------------------------------------------
+class State:
+    def __init__(self, wave, img, aux, n_block, lds_bytes):
+        self.V = np.zeros((256, NLANE), dtype=np.uint32)
+        self.A = np.zeros((256, NLANE), dtype=np.uint32)
+        self.S = {}
+        self.lds = np.zeros(lds_bytes, dtype=np.uint8)
+        self.m0 = 0
+        self.wave = wave
+        self.img = img                              # uint8 weight stream
+        self.aux = aux.view(np.uint8).reshape(-1)   # uint8 view of [n_block, 1024] dwords
+        self.n_block = n_block
+        self.pend_ds = []                   # [(first reg, data)] in issue order
+        self.pend_regs = set()
+        self.pend_dma = []                  # [(list of (lds_addr, bytes))] in issue order
+        self.cert = None                    # N of the last vmcnt wait
+        self.lds_pending = np.zeros(lds_bytes, dtype=bool)
+        self.n_ins = 0
+        self.errors = []
+
+    def regs(self, file):
+        return self.V if file == 'v' else self.A
+
+    def f32(self, file, n):
+        return self.regs(file)[n].view(np.float32)
+
+    def check_rd(self, ins):
+        for r in ins.rd:
+            if r in self.pend_regs:
+                self.errors.append('ins %d (%s) reads %s%d before its ds_read was waited for' %
+                                   (self.n_ins, ins.text, r[0], r[1]))
+
+    def run(self, stream):
+        for ins in stream:
+            self.check_rd(ins)
+            if ins.emu is not None:
+                ins.emu(self)
+            self.n_ins += 1
+
+
+
+# ---- builders ----------------------------------------------------------------------------------
+def _halves(regs):
+    """[n, 64] uint32 -> [64, 2n] float32 of the packed f16 halves (low half first)"""
+    return regs.T.copy().view(np.float16).astype(np.float32)
+
+
+def mfma16(dfile, d, a, b, cfile, c, tag=''):
+    """D[dfile d:d+3] = A(v[a:a+3]) x B(v[b:b+3]) + C[cfile c:c+3]"""
+    rf = {'v': vreg, 'a': areg}
+    text = 'v_mfma_f32_16x16x32_f16 %s, %s, %s, %s' % (rf[dfile](d, 4), vreg(a, 4), vreg(b, 4), rf[cfile](c, 4))
+
+    def emu(st):
+        lanes = np.arange(64)
+        Ah = _halves(st.V[a:a + 4])         # [64, 8]
+        Bh = _halves(st.V[b:b + 4])
+        Am = np.zeros((16, 32))
+        Bm = np.zeros((32, 16))
+        for j in range(8):
+            Am[lanes & 15, 8 * (lanes >> 4) + j] = Ah[:, j]
+            Bm[8 * (lanes >> 4) + j, lanes & 15] = Bh[:, j]
+        D = Am @ Bm
+        C = st.regs(cfile)[c:c + 4].view(np.float32).astype(np.float64)   # [4, 64]
+        out = np.zeros((4, 64), dtype=np.float32)
+        for i in range(4):
+            out[i] = (C[i] + D[4 * (lanes >> 4) + i, lanes & 15]).astype(np.float32)
+        st.regs(dfile)[d:d + 4] = out.view(np.uint32)
+
+    rc = vr(c, 4) if cfile == 'v' else ar(c, 4)
+    wd = vr(d, 4) if dfile == 'v' else ar(d, 4)
+    return Ins(text, 'mfma16', rd=vr(a, 4) + vr(b, 4) + rc, wr=wd, emu=emu, tag=tag)
+
+
+def mfma6(dfile, d, a, b_agpr, scale_a, scale_b, tag=''):
+    """D += A(bf6 v[a:a+5], E8M0 v[scale_a]) x B(bf6 a[b:b+5], E8M0 v[scale_b])"""
+    rf = {'v': vreg, 'a': areg}
+    text = ('v_mfma_scale_f32_16x16x128_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0] cbsz:3 blgp:3' %
+            (rf[dfile](d, 4), vreg(a, 6), areg(b_agpr, 6), rf[dfile](d, 4), vreg(scale_a), vreg(scale_b)))
+
+    def emu(st):
+        lanes = np.arange(64)
+        Ac = unpack6(st.V[a:a + 6].T.copy())          # [64, 32]
+        Bc = unpack6(st.A[b_agpr:b_agpr + 6].T.copy())
+        sa = 2.0 ** (int(st.V[scale_a][0] & 0xff) - 127)
+        sb = 2.0 ** (int(st.V[scale_b][0] & 0xff) - 127)
+        Am = np.zeros((16, 128))
+        Bm = np.zeros((128, 16))
+        for e in range(32):
+            Am[lanes & 15, 32 * (lanes >> 4) + e] = BF6[Ac[:, e]] * sa
+            Bm[32 * (lanes >> 4) + e, lanes & 15] = BF6[Bc[:, e]] * sb
+        D = Am @ Bm
+        C = st.regs(dfile)[d:d + 4].view(np.float32).astype(np.float64)
+        out = np.zeros((4, 64), dtype=np.float32)
+        for i in range(4):
+            out[i] = (C[i] + D[4 * (lanes >> 4) + i, lanes & 15]).astype(np.float32)
+        st.regs(dfile)[d:d + 4] = out.view(np.uint32)
+
+    dd = vr(d, 4) if dfile == 'v' else ar(d, 4)
+    return Ins(text, 'mfma6', rd=vr(a, 6) + ar(b_agpr, 6) + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
+
+
+def _ds_read(width, dst, base_v, off, tag):
+    n = width // 4
+    assert 0 <= off < 65536 and off % width == 0
+    text = 'ds_read_b%d %s, %s offset:%d' % (width * 8, vreg(dst, n), vreg(base_v), off)
+
+    def emu(st):
+        addr = st.V[base_v].astype(np.int64) + off
+        data = np.zeros((n, 64), dtype=np.uint32)
+        for l in range(64):
+            a0 = int(addr[l])
+            if st.lds_pending[a0:a0 + width].any():
+                st.errors.append('ins %d (%s): LDS bytes at %d read before their LDS-DMA was certified' %
+                                 (st.n_ins, text, a0))
+            data[:, l] = st.lds[a0:a0 + width].view(np.uint32)
+        st.pend_ds.append((dst, data))
+        st.pend_regs.update(vr(dst, n))
+
+    return Ins(text, 'ds', rd=vr(base_v), wr=vr(dst, n), emu=emu, tag=tag)
+
+
+def ds_read_b128(dst, base_v, off, tag=''):
+    return _ds_read(16, dst, base_v, off, tag)
+
+
+def ds_read_b64(dst, base_v, off, tag=''):
+    return _ds_read(8, dst, base_v, off, tag)
+
+
+def waitcnt_lgkm(n):
+    assert 0 <= n <= 15
+
+    def emu(st):
+        while len(st.pend_ds) > n:
+            dst, data = st.pend_ds.pop(0)
+            st.V[dst:dst + len(data)] = data
+            for r in vr(dst, len(data)):
+                st.pend_regs.discard(r)
+    return Ins('s_waitcnt lgkmcnt(%d)' % n, 'wait', emu=emu)
+
+
+def waitcnt_vm(n):
+    def emu(st):
+        st.cert = n
+    return Ins('s_waitcnt vmcnt(%d)' % n, 'wait', emu=emu)
+
+
+def _land_dma(st, keep):
+    while len(st.pend_dma) > keep:
+        for addr, data in st.pend_dma.pop(0):
+            st.lds[addr:addr + len(data)] = data
+            st.lds_pending[addr:addr + len(data)] = False
+
+
+def barrier():
+    def emu(st):
+        if st.cert is None:
+            st.errors.append('ins %d: s_barrier without a preceding vmcnt wait' % st.n_ins)
+            return
+        _land_dma(st, st.cert)   # every wave waited for all but its `cert` youngest LDS-DMA before arriving
+    return Ins('s_barrier', 'barrier', emu=emu)
+
+
+def valu(text, rd, wr, emu, tag='', partial=False):
+    return Ins(text, 'valu', rd=rd, wr=wr, emu=emu, tag=tag, partial=partial)
+
+
+def v_max0(dst, src):
+    def emu(st):
+        st.V[dst] = np.maximum(st.f32('v', src), np.float32(0)).view(np.uint32)
+    return valu('v_max_f32 %s, 0, %s' % (vreg(dst), vreg(src)), vr(src), vr(dst), emu)
+
+
+def v_accr(vdst, asrc):
+    def emu(st):
+        st.V[vdst] = st.A[asrc]
+    return valu('v_accvgpr_read_b32 %s, %s' % (vreg(vdst), areg(asrc)), ar(asrc), vr(vdst), emu)
+
+
+def v_accw(adst, vsrc):
+    def emu(st):
+        st.A[adst] = st.V[vsrc]
+    return valu('v_accvgpr_write_b32 %s, %s' % (areg(adst), vreg(vsrc)), vr(vsrc), ar(adst), emu)
+
+
+def v_cvt_pk_f16(dst, a, b):
+    def emu(st):
+        lo = st.f32('v', a).astype(np.float16).view(np.uint16).astype(np.uint32)
+        hi = st.f32('v', b).astype(np.float16).view(np.uint16).astype(np.uint32)
+        st.V[dst] = lo | (hi << 16)
+    return valu('v_cvt_pk_f16_f32 %s, %s, %s' % (vreg(dst), vreg(a), vreg(b)), vr(a) + vr(b), vr(dst), emu)
+
+
+def v_resid16(dst, dst_high, hpk, half, t, s_neg1):
+    """half `dst_high` of dst = fp16(t - (float)half(hpk)):  v_fma_mixlo/hi_f16 dst, hpk.f16[half], -1.0 (SGPR s_neg1), t"""
+    op = 'v_fma_mixhi_f16' if dst_high else 'v_fma_mixlo_f16'
+    sel = ' op_sel:[1,0,0]' if half else ''
+    text = '%s %s, %s, %s, %s%s op_sel_hi:[1,0,0]' % (op, vreg(dst), vreg(hpk), sreg(s_neg1), vreg(t), sel)
+
+    def emu(st):
+        h = ((st.V[hpk] >> (16 * half)) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
+        r = (st.f32('v', t) - h).astype(np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+        if dst_high:
+            st.V[dst] = (st.V[dst] & 0x0000ffff) | (r << 16)
+        else:
+            st.V[dst] = (st.V[dst] & 0xffff0000) | r
+    return valu(text, vr(hpk) + vr(t), vr(dst), emu, partial=True)
+
+
+def v_cvt_pk32_bf6(dst, src, scale_v):
+    """v[dst:dst+5] = bf6(f16 v[src:src+15] / f32 v[scale_v]), 32 elements, element i at bits [6i, 6i+6)"""
+    text = 'v_cvt_scalef32_pk32_bf6_f16 %s, %s, %s' % (vreg(dst, 6), vreg(src, 16), vreg(scale_v))
+
+    def emu(st):
+        x = _halves(st.V[src:src + 16]).astype(np.float64)          # [64, 32]
+        sc = st.f32('v', scale_v).astype(np.float64)[:, None]
+        st.V[dst:dst + 6] = pack6(f_to_bf6(x / sc)).T
+    return valu(text, vr(src, 16) + vr(scale_v), vr(dst, 6), emu)
+
+
+def s_nop(n):
+    return Ins('s_nop %d' % n, 'nop', cost=n + 1)
+
+
+def salu(text, emu=None):
+    return Ins(text, 'salu', emu=emu)
+
+
+
+
+# ---- 32x32 shapes (layouts: tools/mfma32_probe.hip) -------------------------------------------------
+# A lane l = row l%32, k-slot (l/32, j); B lane l = column l%32, k-slot (l/32, j); D lane l = column l%32, register r =
+# row 8*(r/4) + 4*(l/32) + r%4
+def _d32_rows():
+    lanes = np.arange(64)
+    return np.stack([8 * (r // 4) + 4 * (lanes >> 5) + r % 4 for r in range(16)])   # [16, 64]
+
+
+_D32_ROWS = _d32_rows()
+
+
+def mfma32_16(dfile, d, a, b, cfile, c, tag=''):
+    """D[dfile d:d+15] = A(v[a:a+3], 32 x 16) x B(v[b:b+3], 16 x 32) + C[cfile c:c+15]: v_mfma_f32_32x32x16_f16"""
+    rf = {'v': vreg, 'a': areg}
+    text = 'v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (rf[dfile](d, 16), vreg(a, 4), vreg(b, 4), rf[cfile](c, 16))
+
+    def emu(st):
+        lanes = np.arange(64)
+        Ah = _halves(st.V[a:a + 4])         # [64, 8]
+        Bh = _halves(st.V[b:b + 4])
+        Am = np.zeros((32, 16))
+        Bm = np.zeros((16, 32))
+        for j in range(8):
+            Am[lanes & 31, 8 * (lanes >> 5) + j] = Ah[:, j]
+            Bm[8 * (lanes >> 5) + j, lanes & 31] = Bh[:, j]
+        D = Am @ Bm
+        C = st.regs(cfile)[c:c + 16].view(np.float32).astype(np.float64)   # [16, 64]
+        out = np.zeros((16, 64), dtype=np.float32)
+        for r in range(16):
+            out[r] = (C[r] + D[_D32_ROWS[r], lanes & 31]).astype(np.float32)
+        st.regs(dfile)[d:d + 16] = out.view(np.uint32)
+
+    rc = vr(c, 16) if cfile == 'v' else ar(c, 16)
+    wd = vr(d, 16) if dfile == 'v' else ar(d, 16)
+    return Ins(text, 'mfma16', rd=vr(a, 4) + vr(b, 4) + rc, wr=wd, emu=emu, tag=tag, cost=1)
+
+
+def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag=''):
+    """D += A(bf6 v[a:a+5], 32 x 64, E8M0 v[scale_a]) x B(bf6 a[b:b+5], 64 x 32, E8M0 v[scale_b]):
+    v_mfma_scale_f32_32x32x64_f8f6f4"""
+    rf = {'v': vreg, 'a': areg}
+    text = ('v_mfma_scale_f32_32x32x64_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0] cbsz:3 blgp:3' %
+            (rf[dfile](d, 16), vreg(a, 6), areg(b_agpr, 6), rf[dfile](d, 16), vreg(scale_a), vreg(scale_b)))
+
+    def emu(st):
+        lanes = np.arange(64)
+        Ac = unpack6(st.V[a:a + 6].T.copy())          # [64, 32]
+        Bc = unpack6(st.A[b_agpr:b_agpr + 6].T.copy())
+        sa = 2.0 ** (int(st.V[scale_a][0] & 0xff) - 127)
+        sb = 2.0 ** (int(st.V[scale_b][0] & 0xff) - 127)
+        Am = np.zeros((32, 64))
+        Bm = np.zeros((64, 32))
+        for e in range(32):
+            Am[lanes & 31, 32 * (lanes >> 5) + e] = BF6[Ac[:, e]] * sa
+            Bm[32 * (lanes >> 5) + e, lanes & 31] = BF6[Bc[:, e]] * sb
+        D = Am @ Bm
+        C = st.regs(dfile)[d:d + 16].view(np.float32).astype(np.float64)
+        out = np.zeros((16, 64), dtype=np.float32)
+        for r in range(16):
+            out[r] = (C[r] + D[_D32_ROWS[r], lanes & 31]).astype(np.float32)
+        st.regs(dfile)[d:d + 16] = out.view(np.uint32)
+
+    dd = vr(d, 16) if dfile == 'v' else ar(d, 16)
+    return Ins(text, 'mfma6', rd=vr(a, 6) + ar(b_agpr, 6) + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
+
+
+# ---------------------------------------------------------------------------------------------
+# list-scheduler items
+# ---------------------------------------------------------------------------------------------
+class Filler:
+    __slots__ = ('ins', 'earliest', 'deadline', 'chain', 'seq')
+
+    def __init__(self, ins, earliest, deadline, chain):
+        self.ins = ins
+        self.earliest = earliest  # may be issued after anchor #earliest has been emitted
+        self.deadline = deadline  # must be issued before anchor #deadline
+        self.chain = chain        # fillers of one chain keep their order
+        self.seq = 0
+
+
+
+def f32_bits(x):
+    return int(np.array([x], dtype=np.float32).view(np.uint32)[0])
+
+
+
+def mfma_cycles(ins):
+    """matrix-pipe cycles of an MFMA: 32 for the 32x32 shapes, 16 for the 16x16 ones"""
+    return 32 if '32x32' in ins.text else 16
+
+
+def check_hazards_stream(stream):
+    """static check with a coarse cycle model (other instructions 4 cycles, an MFMA occupies the matrix
+    pipe 16 cycles and issues when the pipe is free); the rules are listed in the module docstring"""
+    errs = []
+    t = 0
+    pipe_free = 0
+    mf_end = {}       # reg -> end cycle of the MFMA that last wrote it
+    valu_wr = {}      # reg -> instruction index of the last VALU write
+    mf_rd = {}        # reg -> issue cycle of the last MFMA reading it
+    for i, ins in enumerate(stream):
+        if i > 0 and stream[i - 1].partial:
+            touched = set(ins.rd) | (set(ins.wr) if ins.partial else set())
+            if set(stream[i - 1].wr) & touched:
+                errs.append('%d: %s touches a register half-written by the instruction right before it '
+                            '(dst-sel forwarding)' % (i, ins.text))
+        if i > 0 and ins.kind == 'dma' and stream[i - 1].kind == 'salu' and ' m0,' in stream[i - 1].text:
+            errs.append('%d: LDS-DMA right behind an M0 write' % i)
+        if ins.kind in ('mfma16', 'mfma6'):
+            dur = mfma_cycles(ins)
+            start = max(t, pipe_free)
+            d = set(ins.wr)
+            for r in ins.rd:
+                if r in d:
+                    continue  # C operand = D: accumulate chain
+                if r in mf_end and start < mf_end[r] + 24:
+                    errs.append('%d: %s reads %s%d too early behind an MFMA' % (i, ins.text, r[0], r[1]))
+                if r in valu_wr and i - valu_wr[r] < 3:
+                    errs.append('%d: %s reads %s%d written by VALU %d instructions ago' %
+                                (i, ins.text, r[0], r[1], i - valu_wr[r]))
+                mf_rd[r] = start
+            pipe_free = start + dur
+            for r in ins.wr:
+                mf_end[r] = start + dur
+            t = start + 8
+        else:
+            for r in ins.rd:
+                if r in mf_end and t < mf_end[r] + 24:
+                    errs.append('%d: %s reads %s%d %d cycles after its MFMA ended' %
+                                (i, ins.text, r[0], r[1], t - mf_end[r]))
+            for r in ins.wr:
+                if ins.kind == 'valu' and r in mf_rd and t < mf_rd[r] + 12:  # (LDS data lands >= 64 cycles later)
+                    errs.append('%d: %s overwrites %s%d read by an MFMA %d cycles ago' %
+                                (i, ins.text, r[0], r[1], t - mf_rd[r]))
+                if r in mf_end and t < mf_end[r]:
+                    errs.append('%d: %s overwrites %s%d while an MFMA still writes it' % (i, ins.text, r[0], r[1]))
+                if ins.kind == 'valu':
+                    valu_wr[r] = i
+                mf_end.pop(r, None)
+            t += 4 * ins.cost if ins.kind in ('nop',) else 4
+    return errs
+
+
+def model_cycles(body):
+    """coarse issue model: cycles of one block"""
+    t = pipe = 0
+    for ins in body:
+        if ins.kind in ('mfma16', 'mfma6'):
+            st = max(t, pipe)
+            pipe = st + mfma_cycles(ins)
+            t = st + 8
+        elif ins.kind == 'dma':
+            t += 36
+        else:
+            t += 4 * (ins.cost if ins.kind == 'nop' else 1)
+    return max(t, pipe)
+

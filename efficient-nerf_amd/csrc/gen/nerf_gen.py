@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled gfx950 layer chain of the NeRF teacher MLP (model/nerf_raybased.py:377-401,
-NeRF.forward with use_viewdirs, 8 x 256 + view branch): the second instance of the machine of body_gen.py.
+NeRF.forward with use_viewdirs, 8 x 256 + view branch): the 16x16-shape instance of the machine of isa.py (body_gen.py is the 32x32 one).
 
 One straight-line asm block computes all eleven Linear layers for the 128 points of a workgroup tile (a wave owns 32
 points = two column tiles of 16), from the embedding fragments the HIP prologue leaves in AGPRs to raw = (rgb, sigma) in
@@ -15,7 +15,7 @@ points = two column tiles of 16), from the embedding fragments the HIP prologue 
   V      view embedding (AGPR), then Q           1 x 3, 8 + 4                            8          relu         P (k-steps 0..3)
   RGB    P (128 wide)                            4 + 2                                   1          rgb          out
 
-Arithmetic of a 256- (128-) wide source as in body_gen.py: fp16 main pass + bf6(W - hi(W)) x bf6(a) + bf6(W) x bf6(a - hi(a))
+Arithmetic of a 256- (128-) wide source as in the R2L body (body_gen.py): fp16 main pass + bf6(W - hi(W)) x bf6(a) + bf6(W) x bf6(a - hi(a))
 at 4x the fp16 rate.  The embedding k-steps (sines and cosines: not reducible to 3 bits) run as three fp16 passes on hi / lo
 fragments of both operands and come FIRST in a row tile, so a layer's first MFMAs do not wait for the previous layer's last
 epilogue.  Weights are unscaled; every layer carries its two E8M0 scale bytes next to its bias.
@@ -29,7 +29,7 @@ kernel prologue) and ends with the next tile's chunks 0..2 in flight.
 
 `python nerf_gen.py --emit DIR` writes nerf_mlp_asm.inc (the tile block; placeholders %[eh00] ... for the 12 AGPR inputs,
 %[o0] ... %[o7] for the outputs, %[wimg] %[wave]) and nerf_mlp_pro_asm.inc (the ring prologue).  tests/test_nerf_gen_cpu.py
-runs the lane-accurate emulator against a float64 evaluation of the network and the static hazard check of body_gen.py.
+runs the lane-accurate emulator against a float64 evaluation of the network and the static hazard check of isa.py.
 """
 import argparse
 import os
@@ -37,10 +37,10 @@ import sys
 
 import numpy as np
 
-import body_gen as B
-from body_gen import (Ins, vr, ar, vreg, areg, sreg, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accw, v_cvt_pk_f16,
-                      v_cvt_pk32_bf6, s_nop, salu, ds_read_b128, ds_read_b64, f_to_bf6, pack6, layer_exponent,
-                      weight_exps, f32_bits, Filler, check_hazards_stream, kappa, mix_feat)
+import isa as B
+from isa import (Ins, vr, ar, vreg, areg, sreg, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accw, v_cvt_pk_f16,
+                 v_cvt_pk32_bf6, s_nop, salu, ds_read_b128, ds_read_b64, f_to_bf6, pack6, layer_exponent, weight_exps,
+                 f32_bits, Filler, check_hazards_stream, kappa16 as kappa, mix16 as mix_feat)
 
 # ---------------------------------------------------------------------------------------------
 # register map
@@ -367,9 +367,7 @@ def dma_piece(i, pw, tag=''):
 
 class NState(B.State):
     def __init__(self, wave, img, aux):
-        B.State.__init__(self, wave, img, np.zeros((1, 1024), dtype=np.uint32), 0)
-        self.lds = np.zeros(LDS_BYTES, dtype=np.uint8)
-        self.lds_pending = np.zeros(LDS_BYTES, dtype=bool)
+        B.State.__init__(self, wave, img, np.zeros((1, 1024), dtype=np.uint32), 0, LDS_BYTES)
         self.lds[LDS_AUX:LDS_AUX + len(aux)] = aux
         self.out = {}
 

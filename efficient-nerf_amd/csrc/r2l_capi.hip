@@ -340,15 +340,15 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
 }
 
 // ---- FP16_FP8 body stream (gen/body_gen.py pack_body_image is the Python restatement) -------------------
-// Per ResMLP block: 16 chunks of 28 KiB (layer 1: 8, layer 2: 8); chunk m = row tiles 2m, 2m+1; 28 pieces of
-// 1 KiB: piece upos*8 + s = fp16 hi fragment of k-step s (UNSCALED weights, 64 lanes x 16 B);
-// piece 16 + upos*4 + j = the first 16 B/lane of bf6 (e3m2) operand j of the row tile, piece 24 + upos*2 + (j>>1)
+// Per ResMLP block: 16 chunks of 28 KiB (layer 1: 8, layer 2: 8); chunk u = row tile u (32 output features); 28 pieces of
+// 1 KiB: piece s = fp16 hi fragment of k-step s (UNSCALED weights, 64 lanes x 16 B: lane = 32 h + row, elements
+// r2l_kappa32(s, h, j)); piece 16 + j = the first 16 B/lane of bf6 (e3m2) operand j of the row tile, piece 24 + (j>>1)
 // holds the last 8 B/lane of operands j (bytes 0..511) and j+1 (512..1023).  j = (term, t) in the order
-// (0,0) (1,0) (0,1) (1,1): term 0 = (w - hi(w)) / 2^(e-16), term 1 = w / 2^(e-4), e = exponent of the layer's
-// max|w|; 32 elements of 6 bits per lane, element i at bits [6i, 6i+6), element i = input feature
-// r2l_mix_feat(t, lane>>4, i).  The E8M0 scales that undo the shifts travel in the aux block: 4 KiB per block =
+// (0,0) (1,0) (0,1) (1,1) (0,2) (1,2) (0,3) (1,3): term 0 = (w - hi(w)) / 2^(e-16), term 1 = w / 2^(e-4), e = exponent of
+// the layer's max|w|; 32 elements of 6 bits per lane, element i at bits [6i, 6i+6), element i = input feature
+// r2l_mix32(t, h, i).  The E8M0 scales that undo the shifts travel in the aux block: 4 KiB per block =
 // 256 f32 bias of layer 1 (act_scale domain, with the layer-2 biases of all earlier blocks folded in:
-// x~_i = x_i - sum_{j<i} b2_j) | per lane quarter (swl1, sw1, swl2, sw2) | pad.
+// x~_i = x_i - sum_{j<i} b2_j) | 4 x (swl1, sw1, swl2, sw2) | pad.
 // Tail: [3,256] W_t / act_scale, then b_t + W_t sum_j b2_j.
 #define R2L_BODY_CHUNK 28672
 int r2l_layer_exponent(const float* w, size_t n) {
@@ -413,32 +413,29 @@ static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_of
                 aux[256 + 4 * q + 2 * layer] = 0x01010101u * (uint32_t)(127 + el);
                 aux[256 + 4 * q + 2 * layer + 1] = 0x01010101u * (uint32_t)(127 + ew);
             }
-            for (int m = 0; m < 8; ++m) {
-                char* chunk = out.data() + ((size_t)(b * 2 + layer) * 8 + m) * CH;
-                for (int upos = 0; upos < 2; ++upos) {
-                    const int u = 2 * m + upos;
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int q = lane >> 4;
-                        const float* row = Wl + (size_t)(16 * u + (lane & 15)) * 256;
-                        for (int s = 0; s < 8; ++s) {
-                            _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(upos * 8 + s) * 1024 + lane * 16);
-                            for (int j = 0; j < 8; ++j) ph[j] = (_Float16)row[r2l_kappa(s, q, j)];
+            for (int u = 0; u < 8; ++u) {
+                char* chunk = out.data() + ((size_t)(b * 2 + layer) * 8 + u) * CH;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int h = lane >> 5;
+                    const float* row = Wl + (size_t)(32 * u + (lane & 31)) * 256;
+                    for (int s = 0; s < 16; ++s) {
+                        _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)s * 1024 + lane * 16);
+                        for (int j = 0; j < 8; ++j) ph[j] = (_Float16)row[r2l_kappa32(s, h, j)];
+                    }
+                    for (int j = 0; j < 8; ++j) {
+                        const int term = j & 1, t = j >> 1;
+                        uint64_t bits[3] = {0, 0, 0};
+                        for (int el_i = 0; el_i < 32; ++el_i) {
+                            const float w = row[r2l_mix32(t, h, el_i)];
+                            const float hi = (float)(_Float16)w;
+                            const double v = term == 0 ? ldexp((double)w - (double)hi, -el) : ldexp((double)w, -ew);
+                            const uint64_t code = r2l_f_to_bf6(v);
+                            const int bit = 6 * el_i, wd = bit >> 6, sh = bit & 63;
+                            bits[wd] |= code << sh;
+                            if (sh > 58) bits[wd + 1] |= code >> (64 - sh);
                         }
-                        for (int j = 0; j < 4; ++j) {
-                            const int term = j & 1, t = j >> 1;
-                            uint64_t bits[3] = {0, 0, 0};
-                            for (int el_i = 0; el_i < 32; ++el_i) {
-                                const float w = row[r2l_mix_feat(t, q, el_i)];
-                                const float hi = (float)(_Float16)w;
-                                const double v = term == 0 ? ldexp((double)w - (double)hi, -el) : ldexp((double)w, -ew);
-                                const uint64_t code = r2l_f_to_bf6(v);
-                                const int bit = 6 * el_i, wd = bit >> 6, sh = bit & 63;
-                                bits[wd] |= code << sh;
-                                if (sh > 58) bits[wd + 1] |= code >> (64 - sh);
-                            }
-                            memcpy(chunk + (size_t)(16 + upos * 4 + j) * 1024 + lane * 16, bits, 16);
-                            memcpy(chunk + (size_t)(24 + upos * 2 + (j >> 1)) * 1024 + (j & 1) * 512 + lane * 8, &bits[2], 8);
-                        }
+                        memcpy(chunk + (size_t)(16 + j) * 1024 + lane * 16, bits, 16);
+                        memcpy(chunk + (size_t)(24 + (j >> 1)) * 1024 + (j & 1) * 512 + lane * 8, &bits[2], 8);
                     }
                 }
             }

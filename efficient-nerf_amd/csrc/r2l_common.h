@@ -62,6 +62,17 @@ R2L_HD int r2l_chunks_per_tile(int n_block) { return R2L_HEAD_CHUNKS + 2 * n_blo
 // read back as a B fragment: elements 0..3 = registers of row tile 2s, 4..7 = of row tile 2s+1.
 R2L_HD int r2l_kappa(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
 
+// The hand-scheduled body (r2l_body_kernel, FP16_FP8) uses the 32x32 MFMA shapes: a wave's 32 rays are ONE column tile,
+// lane = 32 h + ray; accumulator register r of row tile u (32 features) = feature 32u + 8(r/4) + 4h + r%4.
+// r2l_kappa32(s, h, j): input feature that element j (0..7) of lane half h of fp16 k-step s (0..15, 16 features each)
+// multiplies: registers 4g .. 4g+3 of row tile u go to k-step 2u + (g>>1), elements 4(g&1) .. 4(g&1)+3.
+// r2l_mix32(t, h, e): element e (0..31) of lane half h of K=64 step t = the fp16 k-steps 4t .. 4t+3 in order.
+R2L_HD int r2l_kappa32(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+R2L_HD int r2l_mix32(int t, int h, int e) { return r2l_kappa32(4 * t + (e >> 3), h, e & 7); }
+// register image of x in HBM (head -> body -> tail): [tile][wave][group 0..31][lane 0..63][4] f32, group = 4u + g
+R2L_HD int r2l_x_group(int feature) { return 4 * (feature >> 5) + ((feature >> 3) & 3); }   // of features f .. f+3, f % 4 == 0
+R2L_HD int r2l_x_half(int feature) { return (feature >> 2) & 1; }
+
 // Column of head.0.weight (0..1007, or -1 = zero pad) that element j of lane quarter q of
 // head k-step s (0..31) multiplies.  Reference embedding order per coordinate c is
 // [sin(2^l x) l=0..9, cos(2^l x) l=0..9, x]  (model/nerf_raybased.py:198-208).

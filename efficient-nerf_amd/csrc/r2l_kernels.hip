@@ -379,7 +379,16 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                     x[u][c][r] = v;
                     if (!HEAD_ONLY) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
-                if (HEAD_ONLY || p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
+                if (HEAD_ONLY) {
+                    // register image of the 32x32-shaped body kernel (r2l_common.h r2l_x_group): the four features
+                    // 16u + 4q .. + 3 of ray c*16 + (lane & 15) belong to lane 32 (q & 1) + ray of group 4 (u >> 1) + 2 (u & 1) + (q >> 1)
+                    const int q = lane >> 4;
+                    float* dst = p.xbuf + ((size_t)(tile * R2L_WAVES + R.wave) * 32) * 256 +
+                                 ((4 * (u >> 1) + 2 * (u & 1) + (q >> 1)) * 64 + 32 * (q & 1) + c * 16 + (lane & 15)) * 4;
+                    *reinterpret_cast<f32x4*>(dst) = x[u][c];
+                } else if (p.use_residual) {
+                    *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
+                }
             }
         }
         if constexpr (HEAD_ONLY) continue;

@@ -52,23 +52,22 @@ def fp16x1_error(x, W1s, b1s, W2s, b2s):
 
 
 def to_regs(xs):
-    """[32 rays, 256] -> the wave's register image [128, 64]"""
+    """[32 rays, 256] -> the wave's register image [128, 64]: register 16u + r of lane 32h + ray = feature
+    32u + 8(r/4) + 4h + r%4"""
     regs = np.zeros((128, 64), dtype=np.float32)
     lanes = np.arange(64)
-    for u in range(16):
-        for c in range(2):
-            for i in range(4):
-                regs[(u * 2 + c) * 4 + i] = xs[c * 16 + (lanes & 15), 16 * u + 4 * (lanes >> 4) + i]
+    for u in range(8):
+        for r in range(16):
+            regs[u * 16 + r] = xs[lanes & 31, 32 * u + 8 * (r // 4) + 4 * (lanes >> 5) + r % 4]
     return regs
 
 
 def from_regs(regs):
     xs = np.zeros((32, 256))
     lanes = np.arange(64)
-    for u in range(16):
-        for c in range(2):
-            for i in range(4):
-                xs[c * 16 + (lanes & 15), 16 * u + 4 * (lanes >> 4) + i] = regs[(u * 2 + c) * 4 + i]
+    for u in range(8):
+        for r in range(16):
+            xs[lanes & 31, 32 * u + 8 * (r // 4) + 4 * (lanes >> 5) + r % 4] = regs[u * 16 + r]
     return xs
 
 

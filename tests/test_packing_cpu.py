@@ -141,15 +141,16 @@ def test_fp16_fp8_head_image_and_body_stream(pkg, built_lib):
     el, ew = G.weight_exps(ex)
     aux = buf[offs[0]:offs[0] + G.AUX_BYTES].view(np.uint32)
     assert (aux[256] & 0xff) == 127 + el and (aux[257] & 0xff) == 127 + ew
-    # chunk 3 (row tiles 6, 7) of layer 1, row tile 7, operand j = 1 (w itself, K-step 0): decode lane 37
-    m, upos, j, lane = 3, 1, 1, 37
-    base = m * G.CHUNK
-    lo = buf[base + G.piece_a6(upos, j) * 1024 + lane * 16:][:16]
-    pc, off = G.piece_a6b(upos, j)
+    # chunk 3 (row tile 3: features 96..127) of layer 1, operand j = 1 (w itself, K=64 step 0): decode lane 37
+    import isa
+    u, j, lane = 3, 1, 37
+    base = u * G.CHUNK
+    lo = buf[base + G.piece_a6(j) * 1024 + lane * 16:][:16]
+    pc, off = G.piece_a6b(j)
     hi = buf[base + pc * 1024 + off + lane * 8:][:8]
-    codes = G.unpack6(np.concatenate([lo, hi]).view(np.uint32)[None])[0]
-    vals = G.BF6[codes] * 2.0 ** ew
-    want = np.array([W1[16 * (2 * m + upos) + (lane & 15), G.mix_feat(0, lane >> 4, e)] for e in range(32)])
+    codes = isa.unpack6(np.concatenate([lo, hi]).view(np.uint32)[None])[0]
+    vals = isa.BF6[codes] * 2.0 ** ew
+    want = np.array([W1[32 * u + (lane & 31), G.mix_feat(0, lane >> 5, e)] for e in range(32)])
     assert np.abs(vals - want).max() <= 0.13 * np.abs(want).max()  # e3m2: 2 mantissa bits
     assert np.abs(vals - want).max() > 0
 

@@ -121,8 +121,9 @@ def test_body_kernel_against_reference_layer_activations(g, sd88, pkg, blk):
     S = 16.0
     rays = torch.zeros(128, 256)
     rays[:4] = acts[blk]
-    x = (rays * S).reshape(1, 4, 2, 16, 16, 4, 4).permute(0, 1, 4, 2, 5, 3, 6).reshape(1, 4, 32, 64, 4).contiguous().cuda()
-    out = eng.debug_body(x).cpu().reshape(1, 4, 16, 2, 4, 16, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(128, 256) / S
+    # register image (csrc/r2l_common.h): [wave][group 4u + g][lane 32h + ray][i] = feature 32u + 8g + 4h + i
+    x = (rays * S).reshape(1, 4, 32, 8, 4, 2, 4).permute(0, 1, 3, 4, 5, 2, 6).reshape(1, 4, 32, 64, 4).contiguous().cuda()
+    out = eng.debug_body(x).cpu().reshape(1, 4, 8, 4, 2, 32, 4).permute(0, 1, 5, 2, 3, 4, 6).reshape(128, 256) / S
     got = out[:4] + sd88[f'body.{blk}.body.2.bias']     # the layer-2 bias is folded out of the kernel's x
     err = (got - acts[blk + 1]).abs().max().item()
     print(f'block {blk}: L_inf vs the reference activations {err:.2e} (|x| up to {acts[blk + 1].abs().max():.1f})')

@@ -15,16 +15,16 @@ from efficient_nerf_amd import R2LEngine, PREC_FP16X3, PREC_FP16_FP8
 from oracle import r2l_oracle as O
 
 
-def image_to_rays(x):  # [T,4,32,64,4] -> [T*128, 256]
+def image_to_rays(x):  # [T,4,32,64,4] -> [T*128, 256]; register image of csrc/r2l_common.h (32x32 MFMA shapes)
     T = x.shape[0]
-    x = x.reshape(T, 4, 16, 2, 4, 16, 4)          # tile, wave, u, c, q, r, i
-    x = x.permute(0, 1, 3, 5, 2, 4, 6)            # tile, wave, c, r, u, q, i
+    x = x.reshape(T, 4, 8, 4, 2, 32, 4)           # tile, wave, u, g, h, ray, i: feature 32u + 8g + 4h + i
+    x = x.permute(0, 1, 5, 2, 3, 4, 6)            # tile, wave, ray, u, g, h, i
     return x.reshape(T * 128, 256)
 
 
 def rays_to_image(r):
     T = r.shape[0] // 128
-    x = r.reshape(T, 4, 2, 16, 16, 4, 4).permute(0, 1, 4, 2, 5, 3, 6)
+    x = r.reshape(T, 4, 32, 8, 4, 2, 4).permute(0, 1, 3, 4, 5, 2, 6)
     return x.reshape(T, 4, 32, 64, 4).contiguous()
 
 

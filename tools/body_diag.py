@@ -39,7 +39,7 @@ for k, o in enumerate(outs):
     e = (got - x).abs()
     print(f'run {k}: L_inf {e.max().item():.3e} mean {e.mean().item():.3e} frac>5e-5 {(e > 5e-5).double().mean().item():.4f}')
 e = (image_to_rays(outs[0]).double() / S + Bsum - x).abs()
-er = e.reshape(nt, 4, 2, 16, 16, 16)   # tile, wave, c, ray16, u, f16
+er = e.reshape(nt, 4, 2, 16, 16, 16)   # tile, wave, ray half, ray16, 16-feature group, f16
 print('by row tile u :', ' '.join(f'{v:.1e}' for v in er.amax(dim=(0, 1, 2, 3, 5)).tolist()))
 print('by wave       :', ' '.join(f'{v:.1e}' for v in er.amax(dim=(0, 2, 3, 4, 5)).tolist()))
 print('by col tile   :', ' '.join(f'{v:.1e}' for v in er.amax(dim=(0, 1, 3, 4, 5)).tolist()))

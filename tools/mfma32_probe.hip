@@ -46,6 +46,46 @@ __global__ void k6(const uint8_t* A, const uint8_t* B, float* D, int sa, int sb)
     for (int r = 0; r < 16; ++r) D[(8 * (r / 4) + 4 * h + r % 4) * 32 + m] = d[r];
 }
 
+// accumulate chain across opcodes, as the body kernel issues it: fp16 MFMAs, then scaled bf6 MFMAs on the SAME accumulator,
+// back to back (PAD = 0) or with the pipe drained between all of them (PAD = 1); the results must agree bit for bit
+template <int PAD>
+__global__ void kchain(const uint32_t* in, float* out) {
+    const int l = threadIdx.x;
+    f16x8 a[4], b[4];
+    i32x6 a6[2], b6[2];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            ((uint32_t*)&a[i])[j] = in[((i * 4 + j) * 64 + l)] & 0x3bff3bffu;          // |x| < 2
+            ((uint32_t*)&b[i])[j] = in[((16 + i * 4 + j) * 64 + l)] & 0x3bff3bffu;
+        }
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j) {
+            a6[i][j] = (int)in[((32 + i * 6 + j) * 64 + l)];
+            b6[i][j] = (int)in[((44 + i * 6 + j) * 64 + l)];
+        }
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) d[r] = (float)((l * 16 + r) % 7);
+    const int sc = 0x01010101 * 122;
+#define PADS "s_nop 15\n s_nop 15\n s_nop 15\n"
+    if (PAD)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %5, %0\n" PADS "v_mfma_f32_32x32x16_f16 %0, %2, %6, %0\n" PADS
+                     "v_mfma_f32_32x32x16_f16 %0, %3, %7, %0\n" PADS "v_mfma_f32_32x32x16_f16 %0, %4, %8, %0\n" PADS
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %9, %11, %0, %13, %13 op_sel_hi:[0,0,0] cbsz:3 blgp:3\n" PADS
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %10, %12, %0, %13, %13 op_sel_hi:[0,0,0] cbsz:3 blgp:3\n" PADS
+                     "v_mfma_f32_32x32x16_f16 %0, %1, %6, %0\n" PADS
+                     : "+v"(d) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+                       "v"(a6[0]), "v"(a6[1]), "v"(b6[0]), "v"(b6[1]), "v"(sc));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %5, %0\n v_mfma_f32_32x32x16_f16 %0, %2, %6, %0\n"
+                     "v_mfma_f32_32x32x16_f16 %0, %3, %7, %0\n v_mfma_f32_32x32x16_f16 %0, %4, %8, %0\n"
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %9, %11, %0, %13, %13 op_sel_hi:[0,0,0] cbsz:3 blgp:3\n"
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %10, %12, %0, %13, %13 op_sel_hi:[0,0,0] cbsz:3 blgp:3\n"
+                     "v_mfma_f32_32x32x16_f16 %0, %1, %6, %0\n" PADS
+                     : "+v"(d) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+                       "v"(a6[0]), "v"(a6[1]), "v"(b6[0]), "v"(b6[1]), "v"(sc));
+    for (int r = 0; r < 16; ++r) out[(blockIdx.x * 64 + l) * 16 + r] = d[r];
+}
+
 static float bf6(unsigned c) {   // e3m2, bias 3
     const int s = c >> 5, e = (c >> 2) & 7, m = c & 3;
     const float v = e == 0 ? ldexpf((float)m, -4) : ldexpf(1.0f + m / 4.0f, e - 3);
@@ -90,5 +130,19 @@ int main() {
         }
     printf("v_mfma_scale_f32_32x32x64_f8f6f4 (bf6 x bf6, scales 2^-3 x 2^2): max |D - ref| = %.3g of %.3g (layout %s)\n", e6, mx,
            e6 < 1e-3 * mx ? "confirmed" : "WRONG");
+    // accumulate chain across opcodes
+    const int NB = 2048;
+    std::vector<uint32_t> in(56 * 64);
+    for (auto& x : in) x = ((uint32_t)rand() << 16) ^ (uint32_t)rand();
+    uint32_t* din; float *o0, *o1;
+    hipMalloc(&din, in.size() * 4); hipMalloc(&o0, NB * 64 * 16 * 4); hipMalloc(&o1, NB * 64 * 16 * 4);
+    hipMemcpy(din, in.data(), in.size() * 4, hipMemcpyHostToDevice);
+    kchain<0><<<NB, 64>>>(din, o0);
+    kchain<1><<<NB, 64>>>(din, o1);
+    std::vector<uint32_t> h0(NB * 64 * 16), h1(NB * 64 * 16);
+    hipMemcpy(h0.data(), o0, h0.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), o1, h1.size() * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0;
+    for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
+    printf("accumulate chain f16 x4 -> bf6 x2 -> f16 on one accumulator, back to back vs drained: %zu of %zu words differ\n", bad, h0.size());
     return 0;
 }
