@@ -16,9 +16,21 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   name=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --output-format csv -d $O/pmc_$name -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-teacher > $O/pmc_$name.log 2>&1 || exit 1
   python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv r2l_body > $O/pmc_$name.txt 2>&1
-  python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv 'Lb1EE' >> $O/pmc_$name.txt 2>&1
+  python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv '<2, true>' >> $O/pmc_$name.txt 2>&1
 done
 S_PREC=mix S_REPS=20 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VMEM --output-format csv -d $O/pmc_stress -- python $R/tools/stress.py > $O/pmc_stress.log 2>&1
 grep -h "stress\|MISMATCH" $O/pmc_stress.log > $O/pmc_stress.txt
 python $R/tools/traffic_json.py $O/pmc_FETCH_SIZE/*/*counter_collection.csv $O/pmc_WRITE_SIZE/*/*counter_collection.csv r2l_body fp16_fp8 $O/traffic.json
+# teacher (fp16_fp8): kernel trace + two PMC passes of one 400x400 frame
+export T_PREC=fp16_fp8 T_REP=2
+python $R/tools/bench_teacher.py > $O/teacher_time.txt 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/teacher_trace -- python $R/tools/bench_teacher.py > $O/teacher_trace.log 2>&1 || exit 1
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT"; do
+  name=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --output-format csv -d $O/teacher_pmc_$name -- python $R/tools/bench_teacher.py > $O/teacher_pmc_$name.log 2>&1 || exit 1
+  python $R/tools/pmc_summary.py $O/teacher_pmc_$name/*/*counter_collection.csv nerf_chain > $O/teacher_pmc_$name.txt 2>&1
+done
+# package power and clock while the R2L frame loop runs
+BT_FRAMES=2500 bash $R/tools/power_sample.sh > $O/power.txt 2>&1
 cat $O/bench_n1_fp16_fp8.json
