@@ -37,11 +37,12 @@ extern "C" {
  *   R2L_PREC_FP16X3  hi/lo split of both operands, 3 MFMA passes per k-step
  *                    (ah*wh + ah*wl + al*wh): L_inf vs the fp32 reference ~1e-6;
  *   R2L_PREC_FP16X1  single pass on fp16-rounded operands: L_inf ~4e-4, 3x fewer MFMAs.
- *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the
- *                    block-scaled low-precision MFMA (v_mfma_scale_f32_16x16x128_f8f6f4), L_inf ~3e-5 (< 1e-4):
- *                    R2L: both operands in OCP bf6 (e3m2) at 4x the fp16 rate (1.5 pass-equivalents per
- *                    k-step; head launch -> hand-scheduled body kernel -> tail launch);
- *                    teacher: weights e4m3, activations e5m2 at twice the fp16 rate (2 pass-equivalents). */
+ *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the block-scaled
+ *                    low-precision MFMA (v_mfma_scale_f32_*_f8f6f4) with both operands in OCP bf6 (e3m2)
+ *                    at 4x the fp16 rate: 1.5 pass-equivalents per k-step, L_inf ~3e-5 (< 1e-4).
+ *                    R2L: head launch -> hand-scheduled body kernel (32x32 shapes) -> tail launch;
+ *                    teacher: hand-scheduled layer chain (16x16 shapes; the embedding k-steps stay
+ *                    three fp16 passes).  (The name is historical: round 1 used fp8 terms.) */
 #define R2L_PREC_FP16X3 0
 #define R2L_PREC_FP16X1 1
 #define R2L_PREC_FP16_FP8 2
@@ -138,7 +139,8 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
 long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, int n_block,
                                    char* out, long long cap, long long* offs);
 /* The hand-scheduled body kernel alone (R2L_PREC_FP16_FP8): x_out = ResMLP blocks(x_in) on n_tiles ray
- * tiles in the register-image layout [tile][4][32][64][4] f32 (csrc/r2l_body.hip); parity tests only. */
+ * tiles in the register-image layout [tile][wave 4][group 32][lane 64][4] f32: group 4u + g of lane 32h + ray holds
+ * features 32u + 8g + 4h .. + 3 (csrc/r2l_common.h); parity tests only. */
 int r2l_debug_body(r2l_ctx* ctx, const float* x_in_dev, float* x_out_dev, int n_tiles, void* stream);
 
 /* introspection for bench.py / DESIGN.md */
