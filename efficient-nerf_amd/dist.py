@@ -95,10 +95,12 @@ class RowGather:
 _row_gather = {}
 
 
+_gather_used = {}
+
+
 def gather_backend(device_index, world):
     """which implementation assembled the frames of this process: for bench.py's JSON line"""
-    g = _row_gather.get((device_index, world), 'none')
-    return 'none' if g == 'none' else ('r2l_gather_image (RCCL, C-ABI)' if g is not None else 'torch.distributed all_gather (RCCL)')
+    return _gather_used.get((device_index, world), 'none')
 
 
 def gather_rows(local, H, W, world, group=None, force_collective=False):
@@ -121,9 +123,12 @@ def gather_rows(local, H, W, world, group=None, force_collective=False):
                 print(f'[dist] r2l_gather_image unavailable ({e}); assembling with torch.distributed (RCCL) instead', file=sys.stderr)
                 _row_gather[key] = None
         if _row_gather[key] is not None:
+            _gather_used[key] = 'r2l_gather_image (RCCL, C-ABI)'
             return _row_gather[key].gather(local, H, W)
     F, _, Cc = local.shape
     rank = dist.get_rank(group)
+    _gather_used[(local.device.index, world)] = 'torch.distributed all_gather (%s)' % (
+        'RCCL' if dist.get_backend(group) == 'nccl' else dist.get_backend(group))
     sizes = [(row_shard(H, r, world)[1] - row_shard(H, r, world)[0]) * W for r in range(world)]
     assert local.shape[1] == sizes[rank], (local.shape, sizes[rank])
     mx = max(sizes)
