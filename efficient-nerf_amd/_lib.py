@@ -40,6 +40,8 @@ SIGNATURES = {
     'r2l_debug_pack_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_longlong]),
     'r2l_debug_pack_body_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, _vp, C.c_longlong,
                                                 C.POINTER(C.c_longlong)]),
+    'r2l_set_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
+    'r2l_get_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     'r2l_debug_body': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     'r2l_flops_per_ray': (C.c_longlong, [_vp]),
     'r2l_kernel_flops_per_ray': (C.c_longlong, [_vp]),

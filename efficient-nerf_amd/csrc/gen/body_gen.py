@@ -47,8 +47,8 @@ import sys
 
 import numpy as np
 
-from isa import (ACT_EXP, RES_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
-                 ds_read_b64, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
+from isa import (ACT_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
+                 ds_read_b64, ds_read_b96, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
                  v_cvt_pk32_bf6, s_nop, salu, f_to_bf6, pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream,
                  model_cycles)
 
@@ -72,12 +72,14 @@ V_DMAOFF = 231    # wave*7168 + lane*16    (pieces 0..3; V_DMAOFF2 = +4096: piec
 V_DMAOFF2 = 232
 V_AUXOFF = 233    # wave*1024 + lane*16
 V_LANE = 234
-V_SBA = 235       # E8M0 scale of the bf6 activations
+V_T = 235         # scratch of the exponent arithmetic
 V_SC = 236        # 236,237: E8M0 scales (w - hi | w) of layer 1 of a block; 238,239: of layer 2
-V_SBL = 240       # E8M0 scale of the bf6 activation residuals
-V_CVA = 241       # f32 divisor of the activation conversion
-V_CVL = 242       # f32 divisor of the residual conversion
-N_VGPR_USED = 243
+# activation exponents (one per operand set, calibrated per network: aux block): for the layer that CONSUMES a set the E8M0
+# bytes of a and of a - hi(a), for the epilogue that PRODUCES it the f32 divisors 2^E and 2^(E-12) of the conversions
+V_SB = 240        # 240,241: (a, a - hi(a)) of layer 1's source set | 242,243: of layer 2's
+V_CVD = 244       # 244,245: divisors of the set layer 1 produces (H) | 246,247: of the set layer 2 produces (next IN)
+V_ACT = 248       # 248..250: biased exponents 127 + E of (this block's IN set, its H set, the next block's IN set)
+N_VGPR_USED = 251
 NHI = 4           # fp16 fragment buffers
 
 A_X = 0
@@ -117,6 +119,8 @@ NSLOT = 4
 LDS_AUX = NSLOT * CHUNK
 AUX_BYTES = 4096           # per block: 256 f32 bias | 4 x (swl1, sw1, swl2, sw2) | pad
 AUX_SCALES = 1024
+AUX_ACT = 1088             # (127 + E_in, 127 + E_h, 127 + E_out, 0) as dwords, twice (one copy per lane half)
+RES_SHIFT = 12             # a - hi(a) of an fp16-rounded value is converted 2^12 finer than the value
 LDS_BYTES = LDS_AUX + 2 * AUX_BYTES
 
 
@@ -184,10 +188,13 @@ def piece_a6b(j):
     return 24 + (j >> 1), (j & 1) * 512
 
 
-def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0):
+def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None):
     """Python restatement of the host packer (r2l_capi.hip pack_body_v3): returns (stream bytes,
-    aux uint32 [n_block, 1024], total folded bias float64 [256]).  W*: [256, 256] float32 (out, in)."""
+    aux uint32 [n_block, 1024], total folded bias float64 [256]).  W*: [256, 256] float32 (out, in).
+    act: 2 n_block + 1 activation exponents (IN set of block 0, H set of block 0, IN set of block 1, ...); default ACT_EXP"""
     n_block = len(W1s)
+    if act is None:
+        act = [ACT_EXP] * (2 * n_block + 1)
     img = np.zeros(n_block * 16 * CHUNK, dtype=np.uint8)
     aux = np.zeros((n_block, AUX_BYTES // 4), dtype=np.uint32)
     Bsum = np.zeros(256, dtype=np.float64)
@@ -197,6 +204,9 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0):
     for b in range(n_block):
         b1f = b1s[b].astype(np.float64) + W1s[b].astype(np.float64) @ Bsum
         aux[b, :256] = (b1f * act_scale).astype(np.float32).view(np.uint32)
+        for half in range(2):
+            for i in range(3):
+                aux[b, AUX_ACT // 4 + 4 * half + i] = 127 + act[2 * b + i]
         for layer, Wl in enumerate((W1s[b], W2s[b])):
             Wl = Wl.astype(np.float32)
             hi = Wl.astype(np.float16)
@@ -350,13 +360,27 @@ def epilogue_ops(T):
     if (u & 1) == 1:
         tt = u >> 1
         # 32-wide conversions of the finished pair of row tiles; the independent one first (dst-sel forwarding)
-        ops.append((v_cvt_pk32_bf6(V_CV, hset(4 * tt), V_CVA), None))
+        ops.append((v_cvt_pk32_bf6(V_CV, hset(4 * tt), V_CVD + 2 * layer), None))
         for i in range(6):
             ops.append((v_accw(B6(b6, 0, tt) + i, V_CV + i), ('b6', 0, tt)))
-        ops.append((v_cvt_pk32_bf6(V_CV, V_LO, V_CVL), None))
+        ops.append((v_cvt_pk32_bf6(V_CV, V_LO, V_CVD + 2 * layer + 1), None))
         for i in range(6):
             ops.append((v_accw(B6(b6, 1, tt) + i, V_CV + i), ('b6', 1, tt)))
     return ops
+
+
+def derive_sb(dst, act):
+    """v[dst], v[dst+1] = E8M0 bytes (replicated) of an operand set and of its fp16 residuals, from its biased exponent"""
+    return [v_lshl_or(V_T, act, 8, act), v_lshl_or(dst, V_T, 16, V_T), v_sub_imm(dst + 1, dst, 0x01010101 * RES_SHIFT)]
+
+
+def derive_cv(dst, act):
+    """v[dst], v[dst+1] = f32 divisors 2^E and 2^(E-12) of the two conversions that produce an operand set"""
+    return [v_lshl_imm(dst, 23, act), v_sub_imm(dst + 1, dst, RES_SHIFT << 23)]
+
+
+def read_act(tag):
+    return ds_read_b96(V_ACT, V_AUX, AUX_ACT, tag=tag)
 
 
 class Sched:
@@ -426,6 +450,8 @@ def build_fillers(it, opts):
                             A(T, 'm16', 1), A(T, 'm16', 12), ('auxflip',)))
             F.append(Filler(ds_read_b64(V_SC, V_AUX, AUX_SCALES, tag=('scale', it + 1, 0)),
                             A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
+            # ... and its activation exponents (this block's were used up at tile 1)
+            F.append(Filler(read_act(('act', it + 1)), A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
         if T == 1:
             # layer-2 scales of this block (layer 2 of the previous block is over)
             F.append(Filler(ds_read_b64(V_SC + 2, V_AUX, AUX_SCALES + 8, tag=('scale', it, 1)),
@@ -559,6 +585,16 @@ def schedule(opts, n_iter=3):
             # tail's other reads, so a counted wait would be too generous there -- is drained completely
             sch.emit(it, waitcnt_lgkm(0))
             sch.ds_done = sch.ds_issued
+        if a % ANCH_PER_TILE == 0 and T == 1:
+            # layer 2 of the previous block and its last epilogue are over: the exponents of this block's H set (layer 2
+            # consumes it) and of the set layer 2 produces
+            for ins in derive_sb(V_SB + 2, V_ACT + 1) + derive_cv(V_CVD + 2, V_ACT + 2):
+                sch.emit(it, ins)
+        if a % ANCH_PER_TILE == 0 and T == 9:
+            # layer 1 and its last epilogue are over: the next block's exponents (read behind the aux flip of tile 8)
+            sch.need(it, ('act', it + 1))
+            for ins in derive_sb(V_SB, V_ACT) + derive_cv(V_CVD, V_ACT + 1):
+                sch.emit(it, ins)
         dfile, d = ('v', ACC(T & 1)) if layer == 0 else ('a', X(u))
         if kind == 'm16':
             sch.need(it, ('hi', it, T, sj))
@@ -578,7 +614,7 @@ def schedule(opts, n_iter=3):
             if sj == 0 and ORDER == 'tail' and opts.chain_nop >= 0:
                 sch.emit(it, s_nop(opts.chain_nop))      # fp16 -> scaled MFMA on one accumulator: keep them apart
             b6 = A_IN6 if layer == 0 else A_H6
-            ins = mfma32_6(dfile, d, A6(n & 1), B6(b6, term, t), V_SC + 2 * layer + term, V_SBA if term == 0 else V_SBL,
+            ins = mfma32_6(dfile, d, A6(n & 1), B6(b6, term, t), V_SC + 2 * layer + term, V_SB + 2 * layer + term,
                            tag=('m6', it, T, sj))
             cap = opts.cap6
         if not (kind == 'm6' and J_ORDER[sj][0] in opts.skip_terms):
@@ -604,6 +640,13 @@ class Opts:
         self.chain_nop = -1       # s_nop N between the last fp16 and the first K=64 MFMA of a row tile (-1: none)
         self.skip_terms = ()      # diagnostics: drop the K=64 MFMAs of these correction terms (wrong results)
         self.__dict__.update(kw)
+
+
+def act_prologue():
+    """exponent registers in front of the first tile: layer 1 consumes IN(0) and produces H(0); the initial split of X
+    produces IN(0) with the divisors of the layer-2 epilogue"""
+    return ([read_act(('act', 0)), waitcnt_lgkm(0)] + derive_sb(V_SB, V_ACT) + derive_cv(V_CVD, V_ACT + 1) +
+            derive_cv(V_CVD + 2, V_ACT))
 
 
 def steady_block(opts):
@@ -660,10 +703,6 @@ def kernel_text(opts):
     for k in range(NSLOT):
         a('s_add_u32 %s, %s, 0x%x' % (sreg(S_M0SLOT + k), sreg(S_T0), k * CHUNK))
     a('s_add_u32 %s, %s, 0x%x' % (sreg(S_AUXM0), sreg(S_T0 + 1), LDS_AUX))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBA), 0x01010101 * (127 + ACT_EXP)))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBL), 0x01010101 * (127 + RES_EXP)))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVA), f32_bits(2.0 ** ACT_EXP)))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVL), f32_bits(2.0 ** RES_EXP)))
     a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_END), sreg(S_NBLOCK), 16 * CHUNK))
     a('s_lshl_b32 %s, %s, 12' % (sreg(S_AUXEND), sreg(S_NBLOCK)))
     a('s_mov_b32 %s, 0' % sreg(S_POS))
@@ -702,6 +741,10 @@ def kernel_text(opts):
         L += issue_chunk(k)
     a('s_waitcnt vmcnt(%d)' % (2 * PW))
     a('s_barrier')
+    # activation exponents of block 0 (later blocks and tiles: derived inside the block loop; the last block's "next IN
+    # set" is block 0's, so the state at the end of a tile is the state the next tile starts from)
+    for ins in act_prologue():
+        a(ins.text)
     # ---- tile loop ---------------------------------------------------------------------------
     a('L_tile_%=:')
     # x tile address: xin + tile*131072 + wave*32768 + lane*16  (register image [u*2+c][lane][4])
@@ -793,10 +836,6 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     st.V[V_DMAOFF] = wave * PW * 1024 + lanes * 16
     st.V[V_DMAOFF2] = wave * PW * 1024 + lanes * 16 + 4096
     st.V[V_AUXOFF] = wave * 1024 + lanes * 16
-    st.V[V_SBA] = 0x01010101 * (127 + ACT_EXP)
-    st.V[V_SBL] = 0x01010101 * (127 + RES_EXP)
-    st.V[V_CVA] = f32_bits(2.0 ** ACT_EXP)
-    st.V[V_CVL] = f32_bits(2.0 ** RES_EXP)
     S = st.S
     S[S_W] = 0
     S[S_AUXB] = 0
@@ -829,6 +868,7 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
         issue_chunk(k)
     waitcnt_vm(2 * PW).emu(st)
     barrier().emu(st)
+    st.run(act_prologue())
     st.A[A_X:A_X + 128] = np.ascontiguousarray(x_tile_regs, dtype=np.float32).view(np.uint32)
     for u in range(7):
         st.run(split_ops(u))

@@ -245,7 +245,7 @@ def mfma6(dfile, d, a, b_agpr, scale_a, scale_b, tag=''):
 
 def _ds_read(width, dst, base_v, off, tag):
     n = width // 4
-    assert 0 <= off < 65536 and off % width == 0
+    assert 0 <= off < 65536 and off % (16 if width == 12 else width) == 0
     text = 'ds_read_b%d %s, %s offset:%d' % (width * 8, vreg(dst, n), vreg(base_v), off)
 
     def emu(st):
@@ -269,6 +269,11 @@ def ds_read_b128(dst, base_v, off, tag=''):
 
 def ds_read_b64(dst, base_v, off, tag=''):
     return _ds_read(8, dst, base_v, off, tag)
+
+
+def ds_read_b96(dst, base_v, off, tag=''):
+    ins = _ds_read(12, dst, base_v, off, tag)
+    return ins
 
 
 def waitcnt_lgkm(n):
@@ -360,6 +365,26 @@ def v_cvt_pk32_bf6(dst, src, scale_v):
         sc = st.f32('v', scale_v).astype(np.float64)[:, None]
         st.V[dst:dst + 6] = pack6(f_to_bf6(x / sc)).T
     return valu(text, vr(src, 16) + vr(scale_v), vr(dst, 6), emu)
+
+
+def v_lshl_or(dst, a, sh, b):
+    """dst = (a << sh) | b"""
+    def emu(st):
+        st.V[dst] = ((st.V[a].astype(np.uint64) << np.uint64(sh)).astype(np.uint32)) | st.V[b]
+    return valu('v_lshl_or_b32 %s, %s, %d, %s' % (vreg(dst), vreg(a), sh, vreg(b)), vr(a) + vr(b), vr(dst), emu)
+
+
+def v_sub_imm(dst, src, imm):
+    """dst = src - imm"""
+    def emu(st):
+        st.V[dst] = (st.V[src].astype(np.int64) - imm).astype(np.uint32)
+    return valu('v_subrev_u32 %s, 0x%x, %s' % (vreg(dst), imm, vreg(src)), vr(src), vr(dst), emu)
+
+
+def v_lshl_imm(dst, sh, src):
+    def emu(st):
+        st.V[dst] = (st.V[src].astype(np.uint64) << np.uint64(sh)).astype(np.uint32)
+    return valu('v_lshlrev_b32 %s, %d, %s' % (vreg(dst), sh, vreg(src)), vr(src), vr(dst), emu)
 
 
 def s_nop(n):

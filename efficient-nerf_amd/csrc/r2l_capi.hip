@@ -135,6 +135,10 @@ struct r2l_ctx {
     size_t img_bytes[3];
     char* d_body;                             // FP16_FP8: body stream v3 (r2l_body.hip) | aux blocks | tail
     size_t body_bytes, aux_off, tail_off;
+    std::vector<int> act;                     // FP16_FP8: 2 n_block + 1 activation exponents (packed into the aux blocks)
+    int calib_pending = 0;                    // the next FP16_FP8 render derives them from its own head output (device side)
+    float* d_wcal = nullptr;                  // fp32 W1^T | b1' | W2^T per block for the calibration kernel
+    unsigned* d_stats = nullptr;
     float* d_xa;                              // FP16_FP8: head output / body output of one launch slice
     float* d_xb;
     int x_tiles;                              // capacity of d_xa / d_xb in ray tiles
@@ -213,6 +217,8 @@ void r2l_destroy(r2l_ctx* c) {
     if (c->d_body) (void)hipFree(c->d_body);
     if (c->d_xa) (void)hipFree(c->d_xa);
     if (c->d_xb) (void)hipFree(c->d_xb);
+    if (c->d_wcal) (void)hipFree(c->d_wcal);
+    if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_z) (void)hipFree(c->d_z);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -254,6 +260,31 @@ static int build_image(r2l_ctx* c, int mode) {
         eb = hipMemcpy(c->d_body, body.data(), body.size(), hipMemcpyHostToDevice);
         if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy body stream: %s", hipGetErrorString(eb));
         c->body_bytes = body.size();
+        // calibration operands: per block W1^T | b1' (the folded bias, real units) | W2^T in fp32
+        if (c->n_block > 0) {
+            const size_t per = 2 * 65536 + 256;
+            std::vector<float> wc((size_t)c->n_block * per);
+            for (int b = 0; b < c->n_block; ++b) {
+                const float* W1 = c->host_w[2 + 4 * b].data();
+                const float* W2 = c->host_w[4 + 4 * b].data();
+                const float* auxb = reinterpret_cast<const float*>(body.data() + c->aux_off + (size_t)b * R2L_BODY_AUX_BYTES);
+                float* o = wc.data() + (size_t)b * per;
+                for (int k = 0; k < 256; ++k)
+                    for (int f = 0; f < 256; ++f) {
+                        o[k * 256 + f] = W1[(size_t)f * 256 + k];
+                        o[65536 + 256 + k * 256 + f] = W2[(size_t)f * 256 + k];
+                    }
+                for (int f = 0; f < 256; ++f) o[65536 + f] = auxb[f] / c->act_scale;
+            }
+            if (c->d_wcal) (void)hipFree(c->d_wcal);
+            if (c->d_stats) (void)hipFree(c->d_stats);
+            c->d_wcal = nullptr;
+            c->d_stats = nullptr;
+            eb = hipMalloc((void**)&c->d_wcal, wc.size() * sizeof(float));
+            if (eb == hipSuccess) eb = hipMemcpy(c->d_wcal, wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (eb == hipSuccess) eb = hipMalloc((void**)&c->d_stats, (size_t)(2 * c->n_block + 1) * sizeof(unsigned));
+            if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "calibration operands: %s", hipGetErrorString(eb));
+        }
     } else {
         pack_image_host(c, mode, img);
     }
@@ -402,6 +433,11 @@ static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_of
             const float v = (float)(acc * Sa);
             memcpy(&aux[n], &v, 4);
         }
+        for (int half = 0; half < 2; ++half)      // activation exponents: IN set, H set, next IN set (the last block's: block 0's)
+            for (int i = 0; i < 3; ++i) {
+                const int j = (b == nb - 1 && i == 2) ? 0 : 2 * b + i;
+                aux[R2L_BODY_AUX_ACT / 4 + 4 * half + i] = (uint32_t)(127 + (j < (int)c->act.size() ? c->act[j] : R2L_ACT_EXP));
+            }
         for (int layer = 0; layer < 2; ++layer) {
             const float* Wl = W[layer];
             const int e = r2l_layer_exponent(Wl, 65536);
@@ -479,9 +515,59 @@ int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
             (void)hipFree(c->d_img[m]);
             c->d_img[m] = nullptr;
         }
+    c->act.assign((size_t)2 * c->n_block + 1, R2L_ACT_EXP);
+    c->calib_pending = 1;   // the first FP16_FP8 render measures the activation ranges of these weights
     int rc = build_image(c, c->mode);
     if (rc) return rc;
     c->loaded = true;
+    return R2L_OK;
+}
+
+int r2l_set_act_exponents(r2l_ctx* c, const int* exps, int n) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (!c->loaded) return r2l_set_error(R2L_ESTATE, "r2l_set_act_exponents before r2l_load_weights");
+    if (!exps) {            // back to self-calibration on the next render
+        c->calib_pending = 1;
+        return R2L_OK;
+    }
+    if (n != 2 * c->n_block + 1) return r2l_set_error(R2L_EINVAL, "expected %d exponents, got %d", 2 * c->n_block + 1, n);
+    for (int i = 0; i < n; ++i)
+        if (exps[i] < R2L_ACT_EXP_MIN || exps[i] > R2L_ACT_EXP_MAX)
+            return r2l_set_error(R2L_EINVAL, "exponent %d = %d outside [%d, %d]", i, exps[i], R2L_ACT_EXP_MIN, R2L_ACT_EXP_MAX);
+    c->act.assign(exps, exps + n);
+    c->calib_pending = 0;
+    if (c->d_body) {        // patch the aux blocks of the uploaded stream
+        for (int b = 0; b < c->n_block; ++b) {
+            uint32_t v[8];
+            for (int half = 0; half < 2; ++half) {
+                for (int i = 0; i < 3; ++i) v[4 * half + i] = (uint32_t)(127 + c->act[(b == c->n_block - 1 && i == 2) ? 0 : 2 * b + i]);
+                v[4 * half + 3] = 0;
+            }
+            hipError_t e = hipMemcpy(c->d_body + c->aux_off + (size_t)b * R2L_BODY_AUX_BYTES + R2L_BODY_AUX_ACT, v, sizeof v,
+                                     hipMemcpyHostToDevice);
+            if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy exponents: %s", hipGetErrorString(e));
+        }
+    }
+    return R2L_OK;
+}
+
+int r2l_get_act_exponents(r2l_ctx* c, int* out, int n) {
+    if (!c || !out) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    if (n != 2 * c->n_block + 1) return r2l_set_error(R2L_EINVAL, "expected room for %d exponents, got %d", 2 * c->n_block + 1, n);
+    if (!c->d_body) {
+        for (int i = 0; i < n; ++i) out[i] = i < (int)c->act.size() ? c->act[i] : R2L_ACT_EXP;
+        return R2L_OK;
+    }
+    for (int b = 0; b < c->n_block; ++b) {   // what the kernel reads (after a device-side calibration: only there)
+        uint32_t v[4];
+        hipError_t e = hipMemcpy(v, c->d_body + c->aux_off + (size_t)b * R2L_BODY_AUX_BYTES + R2L_BODY_AUX_ACT, sizeof v,
+                                 hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy exponents: %s", hipGetErrorString(e));
+        out[2 * b] = (int)v[0] - 127;
+        out[2 * b + 1] = (int)v[1] - 127;
+        if (b < c->n_block - 1) out[2 * b + 2] = (int)v[2] - 127;
+    }
+    out[2 * c->n_block] = out[0];   // the tail reads x itself; the slot holds the next tile's first input set
     return R2L_OK;
 }
 
@@ -544,6 +630,12 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     if (!c || !x_in_dev || !x_out_dev || n_tiles < 1) return r2l_set_error(R2L_EINVAL, "bad argument to r2l_debug_body");
     if (!c->loaded || c->mode != R2L_PREC_FP16_FP8 || c->n_block < 1)
         return r2l_set_error(R2L_ESTATE, "r2l_debug_body needs loaded weights, R2L_PREC_FP16_FP8 and n_block >= 1");
+    if (c->calib_pending) {   // as a render would: the exponents of these weights on this input
+        c->calib_pending = 0;
+        hipError_t ec = r2l_launch_calib(x_in_dev, c->d_wcal, c->n_block, n_tiles, c->act_scale, c->d_stats,
+                                         c->d_body + c->aux_off, (hipStream_t)stream);
+        if (ec != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l calibration launch: %s", hipGetErrorString(ec));
+    }
     R2LBodyParams pb;
     pb.wimg = c->d_body;
     pb.aux = c->d_body + c->aux_off;
@@ -637,6 +729,12 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         hipError_t e = r2l_launch_head(ph, grid, s);
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
         const float* body_out = c->d_xa;
+        if (c->n_block > 0 && c->calib_pending) {
+            // activation exponents from this call's own head output: device work in stream order, no host round trip
+            c->calib_pending = 0;
+            e = r2l_launch_calib(c->d_xa, c->d_wcal, c->n_block, nt, c->act_scale, c->d_stats, c->d_body + c->aux_off, s);
+            if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l calibration launch: %s", hipGetErrorString(e));
+        }
         if (c->n_block > 0) {
             R2LBodyParams pb;
             pb.wimg = c->d_body;

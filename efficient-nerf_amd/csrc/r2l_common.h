@@ -69,6 +69,13 @@ R2L_HD int r2l_kappa(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * 
 // r2l_mix32(t, h, e): element e (0..31) of lane half h of K=64 step t = the fp16 k-steps 4t .. 4t+3 in order.
 R2L_HD int r2l_kappa32(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
 R2L_HD int r2l_mix32(int t, int h, int e) { return r2l_kappa32(4 * t + (e >> 3), h, e & 7); }
+// aux block of the body stream (4 KiB per ResMLP block): 256 f32 bias | at 1024: 4 x (swl1, sw1, swl2, sw2) E8M0 |
+// at 1088: the biased activation exponents (127 + E_in, 127 + E_h, 127 + E_out, 0) as dwords, twice
+#define R2L_BODY_AUX_BYTES 4096
+#define R2L_BODY_AUX_ACT 1088
+#define R2L_ACT_EXP 3          // default: activations (act_scale domain) / 2^3 fit bf6
+#define R2L_ACT_EXP_MIN (-8)
+#define R2L_ACT_EXP_MAX 14
 // register image of x in HBM (head -> body -> tail): [tile][wave][group 0..31][lane 0..63][4] f32, group = 4u + g
 R2L_HD int r2l_x_group(int feature) { return 4 * (feature >> 5) + ((feature >> 3) & 3); }   // of features f .. f+3, f % 4 == 0
 R2L_HD int r2l_x_half(int feature) { return (feature >> 2) & 1; }

@@ -165,6 +165,27 @@ class R2LEngine:
             check(lib().r2l_debug_body(self._ctx, dptr(x_in), dptr(out), x_in.shape[0], current_stream()))
         return out
 
+    def act_exponents(self):
+        """The 2 n_block + 1 bf6 activation exponents the FP16_FP8 body kernel uses (x_0, h_0, x_1, ...): measured by
+        the first render after load_state_dict on that render's own rays, or set by set_act_exponents."""
+        n = 2 * self.n_block + 1
+        buf = (C.c_int * n)()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            check(lib().r2l_get_act_exponents(self._ctx, buf, n))
+        return list(buf)
+
+    def set_act_exponents(self, exps=None):
+        """Fix the exponents (list of 2 n_block + 1 ints), or None: measure them again on the next render."""
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            if exps is None:
+                check(lib().r2l_set_act_exponents(self._ctx, None, 0))
+            else:
+                arr = (C.c_int * len(exps))(*[int(e) for e in exps])
+                check(lib().r2l_set_act_exponents(self._ctx, arr, len(exps)))
+        return self
+
     # -- introspection --------------------------------------------------------------
     @property
     def flops_per_ray(self):

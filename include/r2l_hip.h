@@ -143,6 +143,17 @@ long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, i
  * features 32u + 8g + 4h .. + 3 (csrc/r2l_common.h); parity tests only. */
 int r2l_debug_body(r2l_ctx* ctx, const float* x_in_dev, float* x_out_dev, int n_tiles, void* stream);
 
+/* R2L_PREC_FP16_FP8 converts every operand set of the ResMLP body (the input x of block b, its hidden h) to bf6 with
+ * ONE power-of-two scale per set: activations (x act_scale = 16) / 2^E must fit bf6's +-28.  The 2 n_block + 1 exponents
+ * E (x_0, h_0, x_1, h_1, ..., x_n_block) are measured by the library itself: the first R2L_PREC_FP16_FP8 render after
+ * r2l_load_weights evaluates the body in fp32 on a sample of that call's own rays (up to 1,024, behind its head launch)
+ * and writes the exponents into the weight stream before its body launch -- device work in stream order, no host
+ * round trip; other streams must not render with the context until that call has been enqueued.
+ * r2l_set_act_exponents fixes them instead (NULL: measure again on the next render; synchronous host copy),
+ * r2l_get_act_exponents reads back what the kernel uses (synchronous). */
+int r2l_set_act_exponents(r2l_ctx* ctx, const int* exps, int n);
+int r2l_get_act_exponents(r2l_ctx* ctx, int* out, int n);
+
 /* introspection for bench.py / DESIGN.md */
 long long r2l_flops_per_ray(const r2l_ctx* ctx);      /* algorithmic: 2*MACs of the network */
 /* algorithmic flops per ray of the kernel the timing events bracket: the whole network for the single-kernel

@@ -132,3 +132,30 @@ def test_layer_scales_follow_the_weight_exponent():
     ref = ref_blocks(x, *W)
     got = from_regs(out) / 16.0 + W[3][0].astype(np.float64)
     assert np.abs(got - ref).max() < fp16x1_error(x, *W) / 8
+
+
+def test_emulated_stream_with_calibrated_exponents():
+    """Per-set activation exponents (aux block, AUX_ACT): hidden activations 2^-5 smaller and a residual stream 2^3
+    larger than the defaults assume.  With the default exponent 3 the bf6 terms under- / overflow; with exponents
+    matched to the ranges the stream is as accurate as on O(1) data."""
+    nb, wave = 2, 1
+    W1s, b1s, W2s, b2s = make_weights(nb, seed=8)
+    k = -5
+    W1s = [w * np.float32(2.0 ** k) for w in W1s]
+    b1s = [b * np.float32(2.0 ** k) for b in b1s]
+    W2s = [w * np.float32(2.0 ** -k) for w in W2s]
+    W = (W1s, b1s, W2s, b2s)
+    rng = np.random.default_rng(9)
+    x = (8.0 * np.maximum(rng.normal(0, 1, (32, 256)), 0)).astype(np.float32)
+    S = 16.0
+    ref = ref_blocks(x, *W)
+    Bsum = np.sum([b.astype(np.float64) for b in b2s], axis=0)
+    errs = {}
+    for name, act in (('default', None), ('matched', [6, -1, 6, -1, 6])):
+        img, aux, _ = G.pack_body_image(*W, act=act)
+        out, e = G.emulate_tile(G.Opts(), img, aux, to_regs(x * S), nb, wave=wave)
+        assert not e, e[:10]
+        errs[name] = np.abs(from_regs(out) / S + Bsum - ref).max()
+    print('L_inf default exponents %.3g, matched %.3g (|x| up to %.1f)' % (errs['default'], errs['matched'], np.abs(ref).max()))
+    assert errs['matched'] < 2e-5 * np.abs(ref).max()
+    assert errs['matched'] < errs['default'] / 2

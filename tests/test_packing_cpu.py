@@ -162,3 +162,25 @@ def test_pack_rejects_bad_input(pkg, built_lib):
     L = _lib.lib()
     assert L.r2l_debug_pack_host(arr, len(keep), 2, 0, None, 0) < 0  # tensor count does not match n_block
     assert L.r2l_debug_pack_host(arr, len(keep), 1, 7, None, 0) < 0  # bad precision mode
+
+
+def test_fp16_fp8_packers_reject_weights_outside_the_split_range(pkg, built_lib):
+    """The fp16 + bf6 split covers layers with max|w| in [2^-13, 2^6): beyond it the fp16 residual or the bf6 shift would
+    leave their formats, and both packers must say so instead of packing garbage (the caller falls back to fp16x3)."""
+    import ctypes as C
+    from efficient_nerf_amd import _lib
+    L = _lib.lib()
+    sd = O.make_r2l_state(seed=2, netdepth=4)
+    sd['body.0.body.2.weight'] = sd['body.0.body.2.weight'] * 2.0 ** 12
+    keep, arr = _lib.host_ptrs([sd[n] for n in O.r2l_state_names(1)])
+    offs = (C.c_longlong * 2)()
+    assert L.r2l_debug_pack_body_host(arr, len(keep), 1, None, 0, offs) < 0
+    assert b'outside the range' in L.r2l_last_error()
+    from efficient_nerf_amd.teacher import NeRFEngine
+    t = O.make_teacher_state(1)
+    t['pts_linears.3.weight'] = t['pts_linears.3.weight'] * 2.0 ** -12
+    keep, arr = _lib.host_ptrs([t[n] for n in NeRFEngine.STATE_NAMES])
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs) < 0
+    assert b'teacher layer 3' in L.r2l_last_error() and b'outside the range' in L.r2l_last_error()
+    keep, arr = _lib.host_ptrs([O.make_teacher_state(1)[n] for n in NeRFEngine.STATE_NAMES])
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs) > 0
