@@ -1,0 +1,51 @@
+"""Randomised differential check on the GPU box: fp16_fp8 (generated kernels) against fp16x3 (compiler-scheduled kernels)
+on random networks, frame sizes, poses and weight gains; prints the worst difference per family."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import _pkg
+_pkg.load()
+from efficient_nerf_amd import NeRFEngine, R2LEngine, PREC_FP16X3, PREC_FP16_FP8
+from oracle import r2l_oracle as O
+
+rng = np.random.default_rng(int(os.environ.get('SEED', 1)))
+worst = 0.0
+for it in range(int(os.environ.get('N_R2L', 12))):
+    H, W = int(rng.integers(3, 70)), int(rng.integers(3, 70))
+    nb = int(rng.integers(1, 44))
+    gain = float(rng.choice([0.7, 1.0, 1.3] if nb <= 8 else [0.7, 1.0]))   # 1.3 per layer over 40 blocks: |x| ~ 1e3, the
+    # relative error of either mode exceeds any absolute tolerance there
+    sd = O.make_r2l_state(seed=int(rng.integers(1 << 30)), netdepth=2 + 2 * nb)
+    for k in sd:
+        if 'body' in k and k.endswith('weight'):
+            sd[k] = sd[k] * gain
+    c2w = O.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-80, -5)), float(rng.uniform(3, 5)))
+    focal = O.focal_from_angle(W)
+    e3 = R2LEngine(H, W, focal, n_block=nb, precision=PREC_FP16X3).load_state_dict(sd)
+    e8 = R2LEngine(H, W, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    a, b = e3.render(c2w).cpu(), e8.render(c2w).cpu()
+    d = (a - b).abs().max().item()
+    assert torch.isfinite(b).all() and d < 2e-4, (H, W, nb, gain, d)
+    worst = max(worst, d)
+    e3.close(); e8.close()
+print('R2L: worst |fp16_fp8 - fp16x3| = %.3e' % worst)
+worst = 0.0
+for it in range(int(os.environ.get('N_T', 8))):
+    H, W = int(rng.integers(3, 30)), int(rng.integers(3, 30))
+    S0, NI = int(rng.integers(3, 65)), int(rng.integers(1, 129))
+    sds = [O.make_teacher_state(int(rng.integers(1, 1 << 20))) for _ in range(2)]
+    c2w = O.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-80, -5)), float(rng.uniform(3, 5)))
+    focal = O.focal_from_angle(W)
+    outs = []
+    for prec in (PREC_FP16X3, PREC_FP16_FP8):
+        e = NeRFEngine(H, W, focal, N_samples=S0, N_importance=NI, precision=prec).load_state_dicts(*sds)
+        outs.append(e.render(c2w)['rgb_map'].cpu())
+        e.close()
+    d = (outs[0] - outs[1]).abs().max().item()
+    assert torch.isfinite(outs[1]).all() and d < 2e-4, (H, W, S0, NI, d)
+    worst = max(worst, d)
+print('teacher: worst |fp16_fp8 - fp16x3| = %.3e' % worst)
