@@ -243,10 +243,10 @@ def mfma6(dfile, d, a, b_agpr, scale_a, scale_b, tag=''):
     return Ins(text, 'mfma6', rd=vr(a, 6) + ar(b_agpr, 6) + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
 
 
-def _ds_read(width, dst, base_v, off, tag):
+def _ds_read(width, dst, base_v, off, tag, dfile='v'):
     n = width // 4
     assert 0 <= off < 65536 and off % (16 if width == 12 else width) == 0
-    text = 'ds_read_b%d %s, %s offset:%d' % (width * 8, vreg(dst, n), vreg(base_v), off)
+    text = 'ds_read_b%d %s, %s offset:%d' % (width * 8, (vreg if dfile == 'v' else areg)(dst, n), vreg(base_v), off)
 
     def emu(st):
         addr = st.V[base_v].astype(np.int64) + off
@@ -257,14 +257,15 @@ def _ds_read(width, dst, base_v, off, tag):
                 st.errors.append('ins %d (%s): LDS bytes at %d read before their LDS-DMA was certified' %
                                  (st.n_ins, text, a0))
             data[:, l] = st.lds[a0:a0 + width].view(np.uint32)
-        st.pend_ds.append((dst, data))
-        st.pend_regs.update(vr(dst, n))
+        st.pend_ds.append((dfile, dst, data))
+        st.pend_regs.update(regs)
 
-    return Ins(text, 'ds', rd=vr(base_v), wr=vr(dst, n), emu=emu, tag=tag)
+    regs = vr(dst, n) if dfile == 'v' else ar(dst, n)
+    return Ins(text, 'ds', rd=vr(base_v), wr=regs, emu=emu, tag=tag)
 
 
-def ds_read_b128(dst, base_v, off, tag=''):
-    return _ds_read(16, dst, base_v, off, tag)
+def ds_read_b128(dst, base_v, off, tag='', dfile='v'):
+    return _ds_read(16, dst, base_v, off, tag, dfile)
 
 
 def ds_read_b64(dst, base_v, off, tag=''):
@@ -281,9 +282,9 @@ def waitcnt_lgkm(n):
 
     def emu(st):
         while len(st.pend_ds) > n:
-            dst, data = st.pend_ds.pop(0)
-            st.V[dst:dst + len(data)] = data
-            for r in vr(dst, len(data)):
+            dfile, dst, data = st.pend_ds.pop(0)
+            st.regs(dfile)[dst:dst + len(data)] = data
+            for r in (vr if dfile == 'v' else ar)(dst, len(data)):
                 st.pend_regs.discard(r)
     return Ins('s_waitcnt lgkmcnt(%d)' % n, 'wait', emu=emu)
 
@@ -367,6 +368,74 @@ def v_cvt_pk32_bf6(dst, src, scale_v):
     return valu(text, vr(src, 16) + vr(scale_v), vr(dst, 6), emu)
 
 
+def _f32(st, x):
+    """operand value: ('v', n) register, ('s', n) scalar register (float bits in st.S as python float), or a float literal"""
+    if isinstance(x, tuple):
+        if x[0] == 'v':
+            return st.V[x[1]].view(np.float32)
+        return np.full(64, np.float32(st.S[x[1]]), dtype=np.float32)
+    return np.full(64, np.float32(x), dtype=np.float32)
+
+
+def _opnd(x):
+    if isinstance(x, tuple):
+        if x[0] == 'v':
+            return vreg(x[1])
+        return '%%[%s]' % x[1] if isinstance(x[1], str) else sreg(x[1])   # a named scalar = an asm operand of the block
+    if x in (0.0, 0.5, 1.0, 2.0, 4.0, -0.5, -1.0, -2.0, -4.0):
+        return repr(float(x))
+    return '0x%08x' % f32_bits(x)
+
+
+def _rd(*xs):
+    return [x for x in xs if isinstance(x, tuple) and x[0] == 'v']
+
+
+def v_f32_op(op, dst, a, b, tag=''):
+    """dst = a (op) b in f32, one rounding; op in mul / add / sub; a may be a literal / SGPR / VGPR, b a VGPR"""
+    fn = {'mul': np.multiply, 'add': np.add, 'sub': np.subtract}[op]
+
+    def emu(st):
+        st.V[dst] = fn(_f32(st, a), _f32(st, b)).astype(np.float32).view(np.uint32)
+    return valu('v_%s_f32 %s, %s, %s' % (op, vreg(dst), _opnd(a), _opnd(b)), _rd(a, b), vr(dst), emu, tag=tag)
+
+
+def v_fma_f32(dst, a, b, c, neg_c=False):
+    """dst = fma(a, b, +-c): VGPR operands (one rounding)"""
+    def emu(st):
+        x = _f32(st, a).astype(np.float64) * _f32(st, b).astype(np.float64)    # exact in float64
+        st.V[dst] = (x + (-1.0 if neg_c else 1.0) * _f32(st, c).astype(np.float64)).astype(np.float32).view(np.uint32)
+    text = 'v_fma_f32 %s, %s, %s, %s%s' % (vreg(dst), _opnd(a), _opnd(b), '-' if neg_c else '', _opnd(c))
+    return valu(text, _rd(a, b, c), vr(dst), emu)
+
+
+def v_ldexp_f32(dst, a, n):
+    def emu(st):
+        st.V[dst] = np.ldexp(_f32(st, a), n).astype(np.float32).view(np.uint32)
+    return valu('v_ldexp_f32 %s, %s, %d' % (vreg(dst), _opnd(a), n), _rd(a), vr(dst), emu)
+
+
+def v_rndne_f32(dst, a):
+    def emu(st):
+        st.V[dst] = np.rint(_f32(st, a)).astype(np.float32).view(np.uint32)
+    return valu('v_rndne_f32 %s, %s' % (vreg(dst), _opnd(a)), _rd(a), vr(dst), emu)
+
+
+def v_sin_f32(dst, a):
+    """dst = sin(2 pi a): a transcendental (quarter rate); its consumer must not be the next instruction (kind 'trans')"""
+    def emu(st):
+        st.V[dst] = np.sin(2.0 * np.pi * _f32(st, a).astype(np.float64)).astype(np.float32).view(np.uint32)
+    ins = valu('v_sin_f32 %s, %s' % (vreg(dst), _opnd(a)), _rd(a), vr(dst), emu)
+    ins.kind = 'trans'
+    return ins
+
+
+def v_mov_b32(dst, a):
+    def emu(st):
+        st.V[dst] = _f32(st, a).view(np.uint32)
+    return valu('v_mov_b32 %s, %s' % (vreg(dst), _opnd(a)), _rd(a), vr(dst), emu)
+
+
 def v_lshl_or(dst, a, sh, b):
     """dst = (a << sh) | b"""
     def emu(st):
@@ -434,17 +503,17 @@ def mfma32_16(dfile, d, a, b, cfile, c, tag=''):
     return Ins(text, 'mfma16', rd=vr(a, 4) + vr(b, 4) + rc, wr=wd, emu=emu, tag=tag, cost=1)
 
 
-def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag=''):
-    """D += A(bf6 v[a:a+5], 32 x 64, E8M0 v[scale_a]) x B(bf6 a[b:b+5], 64 x 32, E8M0 v[scale_b]):
+def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag='', bfile='a'):
+    """D += A(bf6 v[a:a+5], 32 x 64, E8M0 v[scale_a]) x B(bf6 [bfile] b:b+5, 64 x 32, E8M0 v[scale_b]):
     v_mfma_scale_f32_32x32x64_f8f6f4"""
     rf = {'v': vreg, 'a': areg}
     text = ('v_mfma_scale_f32_32x32x64_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0] cbsz:3 blgp:3' %
-            (rf[dfile](d, 16), vreg(a, 6), areg(b_agpr, 6), rf[dfile](d, 16), vreg(scale_a), vreg(scale_b)))
+            (rf[dfile](d, 16), vreg(a, 6), rf[bfile](b_agpr, 6), rf[dfile](d, 16), vreg(scale_a), vreg(scale_b)))
 
     def emu(st):
         lanes = np.arange(64)
         Ac = unpack6(st.V[a:a + 6].T.copy())          # [64, 32]
-        Bc = unpack6(st.A[b_agpr:b_agpr + 6].T.copy())
+        Bc = unpack6(st.regs(bfile)[b_agpr:b_agpr + 6].T.copy())
         sa = 2.0 ** (int(st.V[scale_a][0] & 0xff) - 127)
         sb = 2.0 ** (int(st.V[scale_b][0] & 0xff) - 127)
         Am = np.zeros((32, 64))
@@ -460,7 +529,8 @@ def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag=''):
         st.regs(dfile)[d:d + 16] = out.view(np.uint32)
 
     dd = vr(d, 16) if dfile == 'v' else ar(d, 16)
-    return Ins(text, 'mfma6', rd=vr(a, 6) + ar(b_agpr, 6) + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
+    rb = ar(b_agpr, 6) if bfile == 'a' else vr(b_agpr, 6)
+    return Ins(text, 'mfma6', rd=vr(a, 6) + rb + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -503,6 +573,8 @@ def check_hazards_stream(stream):
             if set(stream[i - 1].wr) & touched:
                 errs.append('%d: %s touches a register half-written by the instruction right before it '
                             '(dst-sel forwarding)' % (i, ins.text))
+        if i > 0 and stream[i - 1].kind == 'trans' and set(stream[i - 1].wr) & set(ins.rd):
+            errs.append('%d: %s reads the result of the transcendental right before it' % (i, ins.text))
         if i > 0 and ins.kind == 'dma' and stream[i - 1].kind == 'salu' and ' m0,' in stream[i - 1].text:
             errs.append('%d: LDS-DMA right behind an M0 write' % i)
         if ins.kind in ('mfma16', 'mfma6'):
@@ -528,15 +600,15 @@ def check_hazards_stream(stream):
                     errs.append('%d: %s reads %s%d %d cycles after its MFMA ended' %
                                 (i, ins.text, r[0], r[1], t - mf_end[r]))
             for r in ins.wr:
-                if ins.kind == 'valu' and r in mf_rd and t < mf_rd[r] + 12:  # (LDS data lands >= 64 cycles later)
+                if ins.kind in ('valu', 'trans') and r in mf_rd and t < mf_rd[r] + 12:  # (LDS data lands >= 64 cycles later)
                     errs.append('%d: %s overwrites %s%d read by an MFMA %d cycles ago' %
                                 (i, ins.text, r[0], r[1], t - mf_rd[r]))
                 if r in mf_end and t < mf_end[r]:
                     errs.append('%d: %s overwrites %s%d while an MFMA still writes it' % (i, ins.text, r[0], r[1]))
-                if ins.kind == 'valu':
+                if ins.kind in ('valu', 'trans'):
                     valu_wr[r] = i
                 mf_end.pop(r, None)
-            t += 4 * ins.cost if ins.kind in ('nop',) else 4
+            t += 4 * ins.cost if ins.kind in ('nop',) else (16 if ins.kind == 'trans' else 4)
     return errs
 
 
@@ -550,6 +622,10 @@ def model_cycles(body):
             t = st + 8
         elif ins.kind == 'dma':
             t += 36
+        elif ins.kind == 'trans':
+            t += 16
+        elif 'pk32_bf6' in ins.text:
+            t += 32
         else:
             t += 4 * (ins.cost if ins.kind == 'nop' else 1)
     return max(t, pipe)

@@ -239,17 +239,16 @@ static void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
 
 static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img);
 static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
+static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out);
 
 static int build_image(r2l_ctx* c, int mode) {
     std::vector<char> img;
     if (mode == R2L_PREC_FP16_FP8) {
-        // head launch: the 32 head chunks of the hi|lo image; body + tail: the v3 stream
-        std::vector<char> full;
-        // the head stays in the 3-pass fp16 form: a single-pass head alone costs L_inf 2e-4 (1008 high-frequency inputs)
-        pack_image_host(c, R2L_PREC_FP16X3, full);   // the head layer runs as three fp16 passes
-        img.assign(full.begin(), full.begin() + (size_t)R2L_HEAD_CHUNKS * r2l_chunk_bytes(2));
+        // head launch: the stream of r2l_head_kernel; body + tail: the v3 stream
+        int rc = pack_head_v1(c, img);
+        if (rc) return rc;
         std::vector<char> body;
-        int rc = pack_body_v3(c, body, &c->aux_off, &c->tail_off);
+        rc = pack_body_v3(c, body, &c->aux_off, &c->tail_off);
         if (rc) return rc;
         if (c->d_body) {
             (void)hipFree(c->d_body);
@@ -411,6 +410,61 @@ unsigned r2l_f_to_bf6(double v) {
     }
     if (E > 4) return sgn | 31u;
     return sgn | (unsigned)(((E + 3) << 2) | (qn - 4));
+}
+
+// FP16_FP8 head stream of r2l_head_kernel (layout: r2l_common.h r2l_head_col32; restated in gen/head_gen.py pack_head)
+static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
+    out.assign((size_t)R2L_HEAD_STREAM_BYTES + R2L_HEAD_AUX_BYTES, 0);
+    const float* Wh = c->host_w[0].data();   // [256, 1008]
+    const float* bh = c->host_w[1].data();
+    const float Sa = c->act_scale;
+    std::vector<float> Ws((size_t)R2L_WIDTH * R2L_IN);
+    for (size_t i = 0; i < Ws.size(); ++i) Ws[i] = Wh[i] * Sa;   // exact: act_scale is a power of two
+    const int e = r2l_layer_exponent(Ws.data(), Ws.size());
+    if (e < -12 || e > 6)
+        return r2l_set_error(R2L_EINVAL, "head layer: max|w| x act_scale = 2^%d is outside the range the fp16 + bf6 weight "
+                             "split covers (2^-12 .. 2^6); use R2L_PREC_FP16X3", e);
+    const int el = e - 16, ew = e - 4;
+    uint32_t* aux = reinterpret_cast<uint32_t*>(out.data() + R2L_HEAD_STREAM_BYTES);
+    for (int n = 0; n < 256; ++n) {
+        const float v = (float)((double)bh[n] * Sa);
+        memcpy(&aux[n], &v, 4);
+    }
+    for (int q = 0; q < 4; ++q) {
+        aux[256 + 4 * q] = 0x01010101u * (uint32_t)(127 + el);
+        aux[256 + 4 * q + 1] = 0x01010101u * (uint32_t)(127 + ew);
+    }
+    for (int p = 0; p < 16; ++p)
+        for (int u = 0; u < 8; ++u) {
+            char* chunk = out.data() + (size_t)(2 * p + (u >> 2)) * 28672;
+            const int k = u & 3;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int h = lane >> 5;
+                const float* row = Ws.data() + (size_t)(32 * u + (lane & 31)) * R2L_IN;
+                uint64_t bits[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                for (int s = 0; s < 4; ++s) {
+                    _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(4 * k + s) * 1024 + lane * 16);
+                    for (int j = 0; j < 8; ++j) {
+                        const int col = r2l_head_col32(p, s, h, j);
+                        const float w = col < 0 ? 0.f : row[col];
+                        const _Float16 hi = (_Float16)w;
+                        ph[j] = hi;
+                        const int i = 8 * s + j, bit = 6 * i, wd = bit >> 6, sh = bit & 63;
+                        const uint64_t code[2] = {r2l_f_to_bf6(ldexp((double)w - (double)(float)hi, -el)),
+                                                  r2l_f_to_bf6(ldexp((double)w, -ew))};
+                        for (int t = 0; t < 2; ++t) {
+                            bits[t][wd] |= code[t] << sh;
+                            if (sh > 58) bits[t][wd + 1] |= code[t] >> (64 - sh);
+                        }
+                    }
+                }
+                for (int t = 0; t < 2; ++t) {
+                    memcpy(chunk + (size_t)(16 + 2 * k + t) * 1024 + lane * 16, bits[t], 16);
+                    memcpy(chunk + (size_t)(24 + k) * 1024 + t * 512 + lane * 8, &bits[t][2], 8);
+                }
+            }
+        }
+    return R2L_OK;
 }
 
 static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_off, size_t* tail_off) {
@@ -590,7 +644,12 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
         c.host_w.emplace_back(tensors[i], tensors[i] + n);
     }
     std::vector<char> img;
-    pack_image_host(&c, precision_mode, img);
+    if (precision_mode == R2L_PREC_FP16_FP8) {   // the image of this mode's head launch (r2l_head_kernel)
+        int rc = pack_head_v1(&c, img);
+        if (rc) return rc;
+    } else {
+        pack_image_host(&c, precision_mode, img);
+    }
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
 }
@@ -722,7 +781,6 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         const int grid = nt < c->n_cu ? nt : c->n_cu;
         R2LParams ph = p;
         ph.wimg = c->d_img[R2L_PREC_FP16_FP8];
-        ph.chunks_per_tile = R2L_HEAD_CHUNKS;
         ph.xbuf = c->d_xa;
         ph.tile_begin = t0;
         ph.n_tiles = nt;

@@ -69,6 +69,24 @@ R2L_HD int r2l_kappa(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * 
 // r2l_mix32(t, h, e): element e (0..31) of lane half h of K=64 step t = the fp16 k-steps 4t .. 4t+3 in order.
 R2L_HD int r2l_kappa32(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
 R2L_HD int r2l_mix32(int t, int h, int e) { return r2l_kappa32(4 * t + (e >> 3), h, e & 7); }
+// The generated head layer (r2l_head_kernel, FP16_FP8; csrc/gen/head_gen.py): K = 64 group p = point p of the ray;
+// r2l_head_col32(p, s, h, j): column of head.0.weight (or -1 = pad) that element j of lane half h of fp16 k-step s (0..3,
+// 16 features each) of the group multiplies:
+//   s < 3 : coordinate s, frequency j, sin (h = 0) | cos (h = 1)
+//   s = 3 : j < 6: coordinate j >> 1, frequency 8 + (j & 1), sin | cos;  j = 6: x0 | x2;  j = 7: x1 | pad
+// Stream of a tile: 32 chunks of 28 KiB = (point p, row tiles 4m .. 4m+3): piece 4k + s = fp16 fragment of k-step s of
+// the chunk's k-th row tile (weights x act_scale), piece 16 + 2k + t = first 16 B/lane of bf6 operand t (0: (w - hi(w)) /
+// 2^(e-16), 1: w / 2^(e-4)), piece 24 + k = last 8 B/lane of both (t * 512); then 2 KiB: 256 f32 bias x act_scale | at
+// 1024: 4 x (swl, sw, 0, 0) E8M0.
+R2L_HD int r2l_head_col32(int p, int s, int h, int j) {
+    if (s < 3) return (3 * p + s) * R2L_EMBED + (h ? R2L_L : 0) + j;
+    if (j < 6) return (3 * p + (j >> 1)) * R2L_EMBED + (h ? R2L_L : 0) + 8 + (j & 1);
+    if (j == 6) return (3 * p + (h ? 2 : 0)) * R2L_EMBED + 2 * R2L_L;
+    return h ? -1 : (3 * p + 1) * R2L_EMBED + 2 * R2L_L;
+}
+#define R2L_HEAD_STREAM_BYTES (32 * 28672)
+#define R2L_HEAD_AUX_BYTES 2048
+#define R2L_HEAD_LDS (4 * 28672 + R2L_HEAD_AUX_BYTES)
 // aux block of the body stream (4 KiB per ResMLP block): 256 f32 bias | at 1024: 4 x (swl1, sw1, swl2, sw2) E8M0 |
 // at 1088: the biased activation exponents (127 + E_in, 127 + E_h, 127 + E_out, 0) as dwords, twice
 #define R2L_BODY_AUX_BYTES 4096

@@ -1,6 +1,6 @@
 // R2L (neural light field) hot path for MI355X / gfx950, hand-written HIP.
 //
-//   r2l_resmlp_kernel<NP, HEAD_ONLY>
+//   r2l_resmlp_kernel<NP>
 //                          K1+K2+K3 fused: get_rays + 16-point sampling + sinusoidal
 //                          embedding + 88-layer width-256 residual MLP + sigmoid, one
 //                          persistent workgroup per CU, activations resident in registers,
@@ -215,9 +215,7 @@ __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d)
     return (q & 2) ? ((q & 1) ? d : c) : ((q & 1) ? b : a);
 }
 
-// HEAD_ONLY: stop after the head layer and leave relu(head) (act_scale domain, register image
-// [tile][wave][u*2+c][lane][4] f32) in p.xbuf for r2l_body_kernel / r2l_tail_kernel (r2l_body.hip).
-template <int NP, bool HEAD_ONLY = false>
+template <int NP>
 __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     typedef KCfg<NP> C;
     Ring<NP> R;
@@ -367,8 +365,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
         }
 
         // head epilogue: h0 = relu(acc/scale) (scaled domain); keep a copy for the global skip
-        float* scr = HEAD_ONLY ? p.xbuf + ((size_t)(tile * R2L_WAVES + R.wave) * 32) * 256 + lane * 4
-                               : p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
+        float* scr = p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
 #pragma unroll
@@ -377,21 +374,11 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(x[u][c][r] * inv_head, 0.0f);
                     x[u][c][r] = v;
-                    if (!HEAD_ONLY) split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
+                    split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
-                if (HEAD_ONLY) {
-                    // register image of the 32x32-shaped body kernel (r2l_common.h r2l_x_group): the four features
-                    // 16u + 4q .. + 3 of ray c*16 + (lane & 15) belong to lane 32 (q & 1) + ray of group 4 (u >> 1) + 2 (u & 1) + (q >> 1)
-                    const int q = lane >> 4;
-                    float* dst = p.xbuf + ((size_t)(tile * R2L_WAVES + R.wave) * 32) * 256 +
-                                 ((4 * (u >> 1) + 2 * (u & 1) + (q >> 1)) * 64 + 32 * (q & 1) + c * 16 + (lane & 15)) * 4;
-                    *reinterpret_cast<f32x4*>(dst) = x[u][c];
-                } else if (p.use_residual) {
-                    *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
-                }
+                if (p.use_residual) *reinterpret_cast<f32x4*>(scr + (u * 2 + c) * 256) = x[u][c];
             }
         }
-        if constexpr (HEAD_ONLY) continue;
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
@@ -466,19 +453,67 @@ static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream
     return hipGetLastError();
 }
 
-// head layer alone (three fp16 passes: a single-pass head costs 2e-4 of the 1e-4 contract) -> p.xbuf
+// ------------------------------------------------------------------------------------
+// FP16_FP8 head layer: h0 = relu(W_h embedding + b_h) -> p.xbuf (register image of r2l_body_kernel).  HIP code makes the
+// lane's camera ray; the layer itself, embedding included, is ONE inline-asm block per 128-ray tile generated by
+// gen/head_gen.py (r2l_head_asm.inc): the 63 embedding values of point p + 1 are computed in registers under the MFMAs
+// of point p (32x32 shapes, fp16 pass + two bf6 terms), k-outer into the 128 accumulator registers that start from the
+// bias.  The block owns v0-v209, a0-a127, s40-s59, vcc.  The generator's emulator checks the stream against a float64
+// evaluation of the layer (tests/test_head_gen_cpu.py).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void r2l_head_kernel(R2LParams p) {
+    extern __shared__ __attribute__((aligned(16))) char r2l_head_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    {   // resident table: bias x act_scale | E8M0 weight scales
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + R2L_HEAD_STREAM_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(r2l_head_lds + 4 * 28672);
+        if (threadIdx.x < R2L_HEAD_AUX_BYTES / 16) dst[threadIdx.x] = src[threadIdx.x];
+    }
+    __syncthreads();
+    asm volatile(
+#include "r2l_head_pro_asm.inc"
+        :
+        : [wimg] "s"(p.wimg), [wave] "s"(wave)
+        :
+#include "r2l_head_pro_clobbers.inc"
+    );
+    // read-only, wave-uniform: constant address space => scalar loads
+    const __attribute__((address_space(4))) float* zc = (const __attribute__((address_space(4))) float*)p.z;
+    const float z0 = zc[0], z1 = zc[1], z2 = zc[2], z3 = zc[3], z4 = zc[4], z5 = zc[5], z6 = zc[6], z7 = zc[7], z8 = zc[8],
+                z9 = zc[9], z10 = zc[10], z11 = zc[11], z12 = zc[12], z13 = zc[13], z14 = zc[14], z15 = zc[15];
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        // lane 32 h + r serves ray r of the wave (p.tile_begin: this launch is a slice of the call); rays past the end
+        // repeat the last one (the tail launch masks their stores)
+        const int ray_raw = (p.tile_begin + tile) * R2L_TILE_RAYS + wave * R2L_RAYS_PER_WAVE + (lane & 31);
+        const Ray6 r = make_ray(p, ray_raw < p.n_rays ? ray_raw : p.n_rays - 1);
+        float* xout = p.xbuf + ((size_t)(tile * R2L_WAVES + wave) * 32) * 256;
+        asm volatile(
+#include "r2l_head_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave), [xout] "s"(xout), [o0] "v"(r.ox), [o1] "v"(r.oy), [o2] "v"(r.oz),
+              [d0] "v"(r.dx), [d1] "v"(r.dy), [d2] "v"(r.dz), [z0] "s"(z0), [z1] "s"(z1), [z2] "s"(z2), [z3] "s"(z3),
+              [z4] "s"(z4), [z5] "s"(z5), [z6] "s"(z6), [z7] "s"(z7), [z8] "s"(z8), [z9] "s"(z9), [z10] "s"(z10),
+              [z11] "s"(z11), [z12] "s"(z12), [z13] "s"(z13), [z14] "s"(z14), [z15] "s"(z15)
+            :
+#include "r2l_head_clobbers.inc"
+        );
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's refill of the ring and its stores
+}
+
 hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream) {
     static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<2>::LDS);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                R2L_HEAD_LDS);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((r2l_resmlp_kernel<2, true>), dim3(grid), dim3(256), KCfg<2>::LDS, stream, p);
+    hipLaunchKernelGGL(r2l_head_kernel, dim3(grid), dim3(256), R2L_HEAD_LDS, stream, p);
     return hipGetLastError();
 }
 
