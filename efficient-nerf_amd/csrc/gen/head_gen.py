@@ -8,7 +8,8 @@ coordinate) are computed in registers while the previous point's MFMAs run, as B
 One straight-line asm block per 128-ray tile (a wave owns 32 rays, lane = 32h + ray); k-outer:
   for point p = 0..15 (one K = 64 group: 63 features + 1 pad):
       embedding of point p+1 (VALU, under this group's MFMAs): x_c = o_c + d_c z_p, then per value
-          t = 2^l rh, u = t - rint(t), g = u + 2^l rl, sin(2 pi (g + h/4))      (rh + rl = x / 2 pi in two floats, v_sin_f32)
+          t = fma(2^l, rh, h/4), u = t - rint(t), sin(2 pi fma(2^l, rl, u))      (rh + rl = x / 2 pi in two floats;
+          cos(2 pi g) = sin(2 pi (g + 1/4)); 2^l rh + h/4 is exact for |2^l rh| >= 1/4, v_sin_f32 takes turns)
       -> 16 fp16 pair registers (hi), 16 residual pair registers -> two v_cvt_scalef32_pk32_bf6_f16
       for row tile u = 0..7:  X(u) += hi(W) hi(e)  (4 x v_mfma_f32_32x32x16_f16)
                                      + bf6(W - hi(W)) bf6(e) + bf6(W) bf6(e - hi(e))   (2 x v_mfma_scale_f32_32x32x64_f8f6f4)
@@ -61,9 +62,9 @@ N_AGPR_CLOBBER = 128
 S_W, S_XOUT, S_WAVE, S_NEG1, S_M0SAVE = 40, 42, 44, 45, 46
 S_G = 48           # 48,49 LDS-DMA source
 S_WPW = 50         # wave * 7168
-S_C = 51           # 51..53: 1/(2 pi) hi, lo; 54 free
-S_T0 = 56
-N_SGPR_LO, N_SGPR_HI = 40, 60
+S_C = 51           # 51, 52: 1/(2 pi) hi, lo
+S_P2 = 54          # 54..63: 2^l, l = 0..9
+N_SGPR_LO, N_SGPR_HI = 40, 64
 
 PIECES = 28
 CHUNK = PIECES * 1024
@@ -234,17 +235,13 @@ def embed_ops(p):
         grp = vals[i0:i0 + 4]
         T = [V_TT + 3 * k for k in range(len(grp))]
         for k, (e, c, l) in enumerate(grp):
-            ops.append(v_ldexp_f32(T[k], ('v', V_RH + c), l))
+            ops.append(v_fma_f32(T[k], ('v', V_RH + c), ('s', S_P2 + l), ('v', V_BQ)))
         for k in range(len(grp)):
             ops.append(v_rndne_f32(T[k] + 1, ('v', T[k])))
         for k in range(len(grp)):
             ops.append(v_f32_op('sub', T[k], ('v', T[k]), ('v', T[k] + 1)))
         for k, (e, c, l) in enumerate(grp):
-            ops.append(v_ldexp_f32(T[k] + 1, ('v', V_RL + c), l))
-        for k in range(len(grp)):
-            ops.append(v_f32_op('add', T[k], ('v', T[k]), ('v', T[k] + 1)))
-        for k in range(len(grp)):
-            ops.append(v_f32_op('add', T[k], ('v', V_BQ), ('v', T[k])))
+            ops.append(v_fma_f32(T[k], ('v', V_RL + c), ('s', S_P2 + l), ('v', T[k])))
         for k, (e, c, l) in enumerate(grp):
             ops.append(v_sin_f32(V_VAL + e, ('v', T[k])))
     ops.append(v_sel_half(V_VAL + 30, ('v', V_X + 0), ('v', V_X + 2)))
@@ -302,6 +299,7 @@ class Opts:
         self.rd_lead6 = 5
         self.cap = 7
         self.dma_gap = 1
+        self.pair_waits = True    # one lgkmcnt wait for two consecutive fp16 fragments when both reads are out
         self.__dict__.update(kw)
 
 
@@ -370,10 +368,14 @@ class Sched:
             self.ds_index[ins.tag] = self.ds_issued
             self.ds_issued += 1
 
-    def need(self, key):
+    def need(self, key, also=()):
+        """wait for the LDS read `key`; reads in `also` that have been issued ride along (one wait for a run of MFMAs)"""
         idx = self.ds_index[key]
         if idx < self.ds_done:
             return
+        for k2 in also:
+            if k2 in self.ds_index:
+                idx = max(idx, self.ds_index[k2])
         self.emit(waitcnt_lgkm(self.ds_issued - idx - 1))
         self.ds_done = idx + 1
 
@@ -421,7 +423,8 @@ def schedule(opts):
         p, u = ci >> 1, 4 * (ci & 1) + k
         b = p & 1
         if j < 4:
-            sch.need(('hi', ci, k, j))
+            nxt = [('hi', ci, k, j + 1)] if j < 3 and opts.pair_waits else []
+            sch.need(('hi', ci, k, j), nxt)
             ins = mfma32_16('a', X(u), V_HI + (n16 % NHI) * 4, EH(b, j), 'a', X(u), tag=('m16', ci, k, j))
             n16 += 1
         else:
@@ -458,6 +461,8 @@ def setup_ops():
     a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_WPW), sreg(S_WAVE), PW * 1024))
     a('s_mov_b32 %s, 0x%08x' % (sreg(S_C), f32_bits(INV2PI_HI)))
     a('s_mov_b32 %s, 0x%08x' % (sreg(S_C + 1), f32_bits(INV2PI_LO)))
+    for l in range(10):
+        a('s_mov_b32 %s, 0x%08x' % (sreg(S_P2 + l), f32_bits(2.0 ** l)))
     a('s_mov_b32 vcc_lo, 0')
     a('s_mov_b32 vcc_hi, -1')
     for c in range(3):
@@ -501,6 +506,8 @@ def setup_ops():
         st.S[S_WPW] = st.wave * PW * 1024
         st.S[S_C] = float(INV2PI_HI)
         st.S[S_C + 1] = float(INV2PI_LO)
+        for l in range(10):
+            st.S[S_P2 + l] = 2.0 ** l
     return L, emu
 
 
@@ -603,8 +610,9 @@ def main():
     ap.add_argument('--rd-lead6', type=int, default=5)
     ap.add_argument('--cap', type=int, default=7)
     ap.add_argument('--dma-gap', type=int, default=1)
+    ap.add_argument('--no-pair-waits', action='store_true')
     a = ap.parse_args()
-    opts = Opts(rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap=a.cap, dma_gap=a.dma_gap)
+    opts = Opts(rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap=a.cap, dma_gap=a.dma_gap, pair_waits=not a.no_pair_waits)
     if a.emit:
         n, body = emit(a.emit, opts)
         print('wrote', a.emit, n, 'model cycles per tile', model_cycles(body))
