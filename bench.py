@@ -145,7 +145,7 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp16x3': 'f16 (3 fp16 MFMA passes on hi/lo-split operands, fp32 accumulate)',
                                                                                      'fp16x1': 'f16 (1 fp16 MFMA pass, fp32 accumulate)',
-                                                                                     'fp16_fp8': 'f16+bf6 (1 fp16 MFMA pass + both hi/lo correction terms on the block-scaled MFMA in OCP bf6 (e3m2) at 4x the fp16 rate, fp32 accumulate; head layer: 3 fp16 passes)'}[args.precision],
+                                                                                     'fp16_fp8': 'f16+bf6 (1 fp16 MFMA pass + both hi/lo correction terms on the block-scaled MFMA in OCP bf6 (e3m2) at 4x the fp16 rate, fp32 accumulate)'}[args.precision],
         'data': 'synthetic (seeded nn.Linear-init W256D88 weights, pose_spherical test poses, lego intrinsics)',
         'config': {'workload': 'R2L W256D88 lego_noview_800x800 test views, rows sharded across %d GPU(s) + all-gather' % world,
                    'H': H, 'W': W, 'rays_per_gpu_per_step': rows * W * world, 'frames_per_step': world,

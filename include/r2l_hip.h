@@ -40,9 +40,9 @@ extern "C" {
  *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the block-scaled
  *                    low-precision MFMA (v_mfma_scale_f32_*_f8f6f4) with both operands in OCP bf6 (e3m2)
  *                    at 4x the fp16 rate: 1.5 pass-equivalents per k-step, L_inf ~3e-5 (< 1e-4).
- *                    R2L: head launch -> hand-scheduled body kernel (32x32 shapes) -> tail launch;
- *                    teacher: hand-scheduled layer chain (16x16 shapes; the embedding k-steps stay
- *                    three fp16 passes).  (The name is historical: round 1 used fp8 terms.) */
+ *                    R2L: generated head launch -> generated body kernel (32x32 shapes) -> tail launch;
+ *                    teacher: generated layer chain (16x16 shapes; the embedding k-steps stay three
+ *                    fp16 passes).  (The name is historical: round 1 used fp8 terms.) */
 #define R2L_PREC_FP16X3 0
 #define R2L_PREC_FP16X1 1
 #define R2L_PREC_FP16_FP8 2
