@@ -16,7 +16,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   name=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --output-format csv -d $O/pmc_$name -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-teacher > $O/pmc_$name.log 2>&1 || exit 1
   python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv r2l_body > $O/pmc_$name.txt 2>&1
-  python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv '<2, true>' >> $O/pmc_$name.txt 2>&1
+  python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv 'r2l_head' >> $O/pmc_$name.txt 2>&1
 done
 S_PREC=mix S_REPS=20 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VMEM --output-format csv -d $O/pmc_stress -- python $R/tools/stress.py > $O/pmc_stress.log 2>&1
 grep -h "stress\|MISMATCH" $O/pmc_stress.log > $O/pmc_stress.txt
