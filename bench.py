@@ -162,6 +162,11 @@ def main():
                      'whole_path': {'algorithmic_flops_per_ray': flops_per_ray, 'achieved': path_tflops,
                                     'frac': path_tflops / PEAK_FP16_TFLOPS}},
     }
+    if args.precision == 'fp16_fp8':
+        # the exponents the bf6 correction terms were scaled with (measured on the device by the first warm-up render)
+        ex = [int(e) for e in eng.act_exponents()]
+        out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
+                              'meaning': 'per operand set: activations * 2^-E fit OCP bf6 (|v| <= 28)'}
 
     if rank == 0:
         # parity on the bounded CPU sample + CPU baseline (same box, same run)
