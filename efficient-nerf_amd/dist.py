@@ -55,15 +55,34 @@ class RowGather:
         from . import _lib
         self.rank, self.world, self.device = rank, world, torch.device(device)
         idbuf = (C.c_char * 128)()
+        # every step below is agreed on by all ranks before anyone acts on it: a rank that failed alone would otherwise
+        # fall back to torch.distributed while its peers wait inside the RCCL bootstrap
+        err = ''
         if rank == 0:
-            _lib.check(_lib.lib().r2l_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+            try:
+                _lib.check(_lib.lib().r2l_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+            except Exception as e:
+                err = str(e)
         if world > 1:
-            obj = [bytes(idbuf)]
+            obj = [(bytes(idbuf), err)]
             dist.broadcast_object_list(obj, src=0)
-            idbuf = (C.c_char * 128).from_buffer_copy(obj[0])
+            raw, err = obj[0]
+            idbuf = (C.c_char * 128).from_buffer_copy(raw)
+        if err:
+            raise RuntimeError(err)
         self._comm = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().r2l_comm_create(C.byref(self._comm), rank, world, C.cast(idbuf, C.c_void_p)))
+        try:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().r2l_comm_create(C.byref(self._comm), rank, world, C.cast(idbuf, C.c_void_p)))
+        except Exception as e:
+            err = str(e) or repr(e)
+        if world > 1:
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            err = next((e for e in errs if e), '')
+        if err:
+            self.close()
+            raise RuntimeError(err)
         self._out = None
 
     def gather(self, local, H, W):
