@@ -25,7 +25,7 @@ extern __shared__ char smem[];
 
 // SHAPE 0: v_mfma_f32_32x32x16_f16 (32 cycles)   1: v_mfma_scale_f32_32x32x64_f8f6f4 bf6 x bf6 (32 cycles)
 // 2: v_mfma_f32_16x16x32_f16 (16 cycles)
-template <int SHAPE, int ND, int NV>
+template <int SHAPE, int ND, int NV, int ORD>
 __global__ __launch_bounds__(256, 1) void pw(const i32x4* __restrict__ data, int iters, float* sink) {
     i32x4* l = reinterpret_cast<i32x4*>(smem);
     for (int i = threadIdx.x; i < 4096; i += 256) l[i] = data[i];
@@ -57,10 +57,32 @@ __global__ __launch_bounds__(256, 1) void pw(const i32x4* __restrict__ data, int
     for (int i = 0; i < iters; ++i) {
         asm volatile(
             ".macro GRP\n"
+            ".if %c[ord] == 0\n"   // no operand shared between consecutive MFMAs
             MF(c0, a0, b0) MF(c1, a1, b1) MF(c2, a2, b2) MF(c3, a3, b3)
             MF(c0, a4, b5) MF(c1, a5, b6) MF(c2, a6, b7) MF(c3, a7, b4)
             MF(c0, a1, b2) MF(c1, a2, b3) MF(c2, a3, b0) MF(c3, a0, b1)
             MF(c0, a6, b4) MF(c1, a7, b5) MF(c2, a4, b6) MF(c3, a5, b7)
+            ".elseif %c[ord] == 1\n"   // pairs share B
+            MF(c0, a0, b0) MF(c1, a1, b0) MF(c2, a2, b1) MF(c3, a3, b1)
+            MF(c0, a4, b2) MF(c1, a5, b2) MF(c2, a6, b3) MF(c3, a7, b3)
+            MF(c0, a1, b4) MF(c1, a2, b4) MF(c2, a3, b5) MF(c3, a0, b5)
+            MF(c0, a6, b6) MF(c1, a7, b6) MF(c2, a4, b7) MF(c3, a5, b7)
+            ".elseif %c[ord] == 2\n"   // pairs share A
+            MF(c0, a0, b0) MF(c1, a0, b1) MF(c2, a1, b2) MF(c3, a1, b3)
+            MF(c0, a2, b4) MF(c1, a2, b5) MF(c2, a3, b6) MF(c3, a3, b7)
+            MF(c0, a4, b1) MF(c1, a4, b2) MF(c2, a5, b3) MF(c3, a5, b0)
+            MF(c0, a6, b5) MF(c1, a6, b6) MF(c2, a7, b7) MF(c3, a7, b4)
+            ".elseif %c[ord] == 3\n"   // quads share B
+            MF(c0, a0, b0) MF(c1, a1, b0) MF(c2, a2, b0) MF(c3, a3, b0)
+            MF(c0, a4, b1) MF(c1, a5, b1) MF(c2, a6, b1) MF(c3, a7, b1)
+            MF(c0, a1, b2) MF(c1, a2, b2) MF(c2, a3, b2) MF(c3, a0, b2)
+            MF(c0, a6, b3) MF(c1, a7, b3) MF(c2, a4, b3) MF(c3, a5, b3)
+            ".else\n"                  // the same two operands every time
+            MF(c0, a0, b0) MF(c1, a0, b0) MF(c2, a0, b0) MF(c3, a0, b0)
+            MF(c0, a0, b0) MF(c1, a0, b0) MF(c2, a0, b0) MF(c3, a0, b0)
+            MF(c0, a0, b0) MF(c1, a0, b0) MF(c2, a0, b0) MF(c3, a0, b0)
+            MF(c0, a0, b0) MF(c1, a0, b0) MF(c2, a0, b0) MF(c3, a0, b0)
+            ".endif\n"
             ".endm\n"
             "GRP\n GRP\n GRP\n GRP\n"
             ".purgem GRP\n"
@@ -78,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void pw(const i32x4* __restrict__ data, int
               [a0x] "v"(a[0]), [a1x] "v"(a[1]), [a2x] "v"(a[2]), [a3x] "v"(a[3]), [a4x] "v"(a[4]), [a5x] "v"(a[5]),
               [a6x] "v"(a[6]), [a7x] "v"(a[7]), [b0x] "v"(b[0]), [b1x] "v"(b[1]), [b2x] "v"(b[2]), [b3x] "v"(b[3]),
               [b4x] "v"(b[4]), [b5x] "v"(b[5]), [b6x] "v"(b[6]), [b7x] "v"(b[7]),
-              [sc] "v"(sc), [v0] "v"(v0), [v1] "v"(v1), [addr] "v"(addr), [shape] "i"(SHAPE), [nd] "i"(ND), [nv] "i"(NV));
+              [sc] "v"(sc), [v0] "v"(v0), [v1] "v"(v1), [addr] "v"(addr), [shape] "i"(SHAPE), [nd] "i"(ND), [nv] "i"(NV), [ord] "i"(ORD));
     }
     float s = c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3] + v2 + v3 + d0[0] + d1[1];
     if (s == 12345.678f) sink[0] = s;
@@ -98,21 +120,21 @@ static double sclk_mhz() {
     return f.frequency[f.current] / 1e6;
 }
 
-template <int SHAPE, int ND, int NV>
+template <int SHAPE, int ND, int NV, int ORD = 0>
 void run(const char* what, const char* dname, const i32x4* d_data, float* d_sink) {
-    const void* fn = reinterpret_cast<const void*>(&pw<SHAPE, ND, NV>);
+    const void* fn = reinterpret_cast<const void*>(&pw<SHAPE, ND, NV, ORD>);
     hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     const int iters = 2000;   // x 64 MFMAs x 32 (16) cycles = 4.1 (2.0) M cycles: about 2 ms per launch
     const double cyc = (double)iters * 64 * (SHAPE == 2 ? 16 : 32);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    pw<SHAPE, ND, NV><<<256, 256, 65536>>>(d_data, 10, d_sink);
+    pw<SHAPE, ND, NV, ORD><<<256, 256, 65536>>>(d_data, 10, d_sink);
     hipDeviceSynchronize();
     const int launches = 1000;
     hipEventRecord(e0);
-    for (int i = 0; i < launches - 300; ++i) pw<SHAPE, ND, NV><<<256, 256, 65536>>>(d_data, iters, d_sink);
+    for (int i = 0; i < launches - 300; ++i) pw<SHAPE, ND, NV, ORD><<<256, 256, 65536>>>(d_data, iters, d_sink);
     hipEventRecord(e0);   // the last 300 launches are the steady-state window
-    for (int i = 0; i < 300; ++i) pw<SHAPE, ND, NV><<<256, 256, 65536>>>(d_data, iters, d_sink);
+    for (int i = 0; i < 300; ++i) pw<SHAPE, ND, NV, ORD><<<256, 256, 65536>>>(d_data, iters, d_sink);
     hipEventRecord(e1);
     double pw_sum = 0, ck_sum = 0; int n = 0;
     while (hipEventQuery(e1) == hipErrorNotReady) {
@@ -123,8 +145,8 @@ void run(const char* what, const char* dname, const i32x4* d_data, float* d_sink
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double ghz = cyc * 300 / (ms * 1e-3) * 1e-9;
-    printf("%-34s %-8s fillers/MFMA: %d ds_read_b128 %d v_fma   pipe cycles/s %.3f GHz   power %.0f W  sclk %.0f MHz (%d samples)\n",
-           what, dname, ND, NV, ghz, n ? pw_sum / n : 0.0, n ? ck_sum / n : 0.0, n);
+    printf("%-34s %-8s fillers/MFMA: %d ds_read_b128 %d v_fma  order %d   pipe cycles/s %.3f GHz   power %.0f W  sclk %.0f MHz (%d samples)\n",
+           what, dname, ND, NV, ORD, ghz, n ? pw_sum / n : 0.0, n ? ck_sum / n : 0.0, n);
     fflush(stdout);
 }
 
@@ -150,6 +172,15 @@ int main() {
         // for the bf6 shape the same bits are read as 6-bit values: zeros, or every pattern about equally often
         run<1, 0, 0>("v_mfma_scale_f32_32x32x64 bf6", dname, d_data, d_sink);
         if (mode == 2) {
+            // operand order: 1 pairs share B, 2 pairs share A, 3 quads share B, 4 one operand pair throughout
+            run<0, 0, 0, 1>("v_mfma_f32_32x32x16_f16", dname, d_data, d_sink);
+            run<0, 0, 0, 2>("v_mfma_f32_32x32x16_f16", dname, d_data, d_sink);
+            run<0, 0, 0, 3>("v_mfma_f32_32x32x16_f16", dname, d_data, d_sink);
+            run<0, 0, 0, 4>("v_mfma_f32_32x32x16_f16", dname, d_data, d_sink);
+            run<2, 0, 0, 1>("v_mfma_f32_16x16x32_f16", dname, d_data, d_sink);
+            run<2, 0, 0, 4>("v_mfma_f32_16x16x32_f16", dname, d_data, d_sink);
+            run<1, 0, 0, 1>("v_mfma_scale_f32_32x32x64 bf6", dname, d_data, d_sink);
+            run<1, 0, 0, 4>("v_mfma_scale_f32_32x32x64 bf6", dname, d_data, d_sink);
             run<0, 1, 0>("v_mfma_f32_32x32x16_f16", dname, d_data, d_sink);
             run<0, 2, 0>("v_mfma_f32_32x32x16_f16", dname, d_data, d_sink);
             run<0, 0, 2>("v_mfma_f32_32x32x16_f16", dname, d_data, d_sink);
