@@ -43,6 +43,7 @@ SIGNATURES = {
     'r2l_set_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     'r2l_get_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     'r2l_debug_body': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    'r2l_debug_set_fused_tail': (C.c_int, [_vp, C.c_int]),
     'r2l_flops_per_ray': (C.c_longlong, [_vp]),
     'r2l_kernel_flops_per_ray': (C.c_longlong, [_vp]),
     'r2l_weight_image_bytes': (C.c_longlong, [_vp]),

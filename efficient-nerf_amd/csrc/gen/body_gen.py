@@ -79,7 +79,11 @@ V_SC = 236        # 236,237: E8M0 scales (w - hi | w) of layer 1 of a block; 238
 V_SB = 240        # 240,241: (a, a - hi(a)) of layer 1's source set | 242,243: of layer 2's
 V_CVD = 244       # 244,245: divisors of the set layer 1 produces (H) | 246,247: of the set layer 2 produces (next IN)
 V_ACT = 248       # 248..250: biased exponents 127 + E of (this block's IN set, its H set, the next block's IN set)
-N_VGPR_USED = 251
+V_TAILB = 251     # LDS address of the tail table + (lane>>5)*16
+V_BPERM = 252     # (lane ^ 32) * 4: ds_bpermute address of the other lane half
+V_RAYOFF = 253    # lane * 12: byte offset of this lane's ray in the wave's rgb rows
+V_RAY = 254
+N_VGPR_USED = 255
 NHI = 4           # fp16 fragment buffers
 
 A_X = 0
@@ -110,7 +114,12 @@ S_BLK = 69     # block loop counter
 S_T0 = 70      # temporaries 70..75
 S_M0SAVE = 76
 S_TILEOFF = 78  # 78,79
-N_SGPR_LO, N_SGPR_HI = 40, 80
+S_RGB = 80      # 80,81 rgb rows of the launch's first tile (0: store the x image instead of the fused tail)
+S_TAB = 82      # 82,83 tail table
+S_NRAYS = 84
+S_TILE0 = 85    # tile number of the launch's first tile within the call
+S_T1 = 86       # temporaries 86..89
+N_SGPR_LO, N_SGPR_HI = 40, 90
 
 PIECES = 28                # 1 KiB pieces of a chunk
 CHUNK = PIECES * 1024      # 28 KiB
@@ -121,7 +130,9 @@ AUX_BYTES = 4096           # per block: 256 f32 bias | 4 x (swl1, sw1, swl2, sw2
 AUX_SCALES = 1024
 AUX_ACT = 1088             # (127 + E_in, 127 + E_h, 127 + E_out, 0) as dwords, twice (one copy per lane half)
 RES_SHIFT = 12             # a - hi(a) of an fp16-rounded value is converted 2^12 finer than the value
-LDS_BYTES = LDS_AUX + 2 * AUX_BYTES
+LDS_TAIL = LDS_AUX + 2 * AUX_BYTES   # tail table: 3 x 256 f32 (W_t / act_scale) | 2 x (3 folded biases, 0)
+TAIL_BYTES = 4096
+LDS_BYTES = LDS_TAIL + TAIL_BYTES
 
 
 TILES = 16                 # row tiles of a block: layer * 8 + u
@@ -282,7 +293,7 @@ def dma_aux():
             for l in range(64):
                 src = g + int(st.V[V_AUXOFF][l]) + dw
                 dst = st.m0 + dw + l * 16
-                assert LDS_AUX <= dst and dst + 16 <= LDS_BYTES, dst
+                assert LDS_AUX <= dst and dst + 16 <= LDS_TAIL, dst
                 copies.append((dst, st.aux[src:src + 16].copy()))
                 st.lds_pending[dst:dst + 16] = True
         st.pend_dma.append(copies)
@@ -667,10 +678,87 @@ def split_ops(u):
     return [ins for ins, _ in epilogue_ops(8 + u)]
 
 
+def fused_tail_text():
+    """rgb = sigmoid(W_t (x + h) + b_t) of the wave's 32 rays, straight from the residual stream in the AGPRs
+    (model/nerf_raybased.py:539-544 with the global skip of :541; the standalone r2l_tail_kernel computes the same from the
+    stored images).  h, the head output, is read back from xin (the block loop consumed it); a lane sums its 128 features
+    x 3 channels in fp32, ds_bpermute adds the two lane halves, lanes 0..31 store 12 bytes each.  Registers: everything
+    below V_L0 is dead between the last block and the next tile's split."""
+    L = []
+    a = L.append
+    XA, WB, TMP, ACCS, RGBR, BIASR, TR = 0, 128, 176, 180, 186, 190, 194
+    NBUF = 4                                  # groups of weights in flight: 12 ds_read_b128 <= the 4-bit lgkmcnt
+    a('s_add_u32 %s, %s, %s' % (sreg(S_T0 + 4), sreg(S_XIN), sreg(S_TILEOFF)))
+    a('s_addc_u32 %s, %s, %s' % (sreg(S_T0 + 5), sreg(S_XIN + 1), sreg(S_TILEOFF + 1)))
+    for i in range(32):
+        a('global_load_dwordx4 %s, %s, %s offset:%d' % (vreg(XA + 4 * i, 4), vreg(V_L0), sreg(S_T0 + 4, 2), (i % 4) * 1024))
+        if i % 4 == 3:
+            a('s_add_u32 %s, %s, 0x1000' % (sreg(S_T0 + 4), sreg(S_T0 + 4)))
+            a('s_addc_u32 %s, %s, 0' % (sreg(S_T0 + 5), sreg(S_T0 + 5)))
+
+    def rd_w(i):
+        for c in range(3):   # features 8 i + 4 h .. + 3 of channel c
+            a('ds_read_b128 %s, %s offset:%d' % (vreg(WB + 12 * (i % NBUF) + 4 * c, 4), vreg(V_TAILB), 1024 * c + 32 * i))
+
+    for i in range(6):
+        a('v_mov_b32 %s, 0' % vreg(ACCS + i))
+    for i in range(NBUF):
+        rd_w(i)
+    for i in range(32):
+        for k in range(4):
+            a('v_accvgpr_read_b32 %s, %s' % (vreg(TMP + k), areg(A_X + 4 * i + k)))
+        a('s_waitcnt vmcnt(%d)' % (31 - i))
+        for k in range(4):
+            a('v_add_f32 %s, %s, %s' % (vreg(XA + 4 * i + k), vreg(XA + 4 * i + k), vreg(TMP + k)))
+        a('s_waitcnt lgkmcnt(%d)' % (3 * (min(i + NBUF - 1, 31) - i)))
+        for k in range(4):
+            for c in range(3):
+                acc = vreg(ACCS + 2 * c + (k & 1))
+                a('v_fma_f32 %s, %s, %s, %s' % (acc, vreg(XA + 4 * i + k), vreg(WB + 12 * (i % NBUF) + 4 * c + k), acc))
+        if i + NBUF < 32:
+            rd_w(i + NBUF)
+    a('ds_read_b128 %s, %s offset:3072' % (vreg(BIASR, 4), vreg(V_TAILB)))
+    for c in range(3):
+        a('v_add_f32 %s, %s, %s' % (vreg(ACCS + 2 * c), vreg(ACCS + 2 * c), vreg(ACCS + 2 * c + 1)))
+    for c in range(3):
+        a('ds_bpermute_b32 %s, %s, %s' % (vreg(TR + c), vreg(V_BPERM), vreg(ACCS + 2 * c)))
+    a('s_waitcnt lgkmcnt(0)')
+    for c in range(3):
+        a('v_add_f32 %s, %s, %s' % (vreg(TR + c), vreg(TR + c), vreg(ACCS + 2 * c)))
+        a('v_add_f32 %s, %s, %s' % (vreg(TR + c), vreg(TR + c), vreg(BIASR + c)))
+        a('v_mul_f32 %s, 0xbfb8aa3b, %s' % (vreg(TR + c), vreg(TR + c)))      # -log2(e)
+    for c in range(3):
+        a('v_exp_f32 %s, %s' % (vreg(TR + c), vreg(TR + c)))
+    a('s_nop 1')
+    for c in range(3):
+        a('v_add_f32 %s, 1.0, %s' % (vreg(TR + c), vreg(TR + c)))
+    for c in range(3):
+        a('v_rcp_f32 %s, %s' % (vreg(RGBR + c), vreg(TR + c)))
+    a('s_nop 1')
+    # first ray of this wave: ((tile0 + tile) * 4 + wave) * 32; rows of 12 bytes
+    a('s_add_u32 %s, %s, %s' % (sreg(S_T1), sreg(S_TILE), sreg(S_TILE0)))
+    a('s_lshl_b32 %s, %s, 2' % (sreg(S_T1), sreg(S_T1)))
+    a('s_add_u32 %s, %s, %s' % (sreg(S_T1), sreg(S_T1), sreg(S_WAVE)))
+    a('s_lshl_b32 %s, %s, 5' % (sreg(S_T1), sreg(S_T1)))
+    a('v_add_u32 %s, %s, %s' % (vreg(V_RAY), sreg(S_T1), vreg(V_LANE)))
+    a('s_mul_hi_u32 %s, %s, 12' % (sreg(S_T1 + 1), sreg(S_T1)))
+    a('s_mul_i32 %s, %s, 12' % (sreg(S_T1), sreg(S_T1)))
+    a('s_add_u32 %s, %s, %s' % (sreg(S_T1), sreg(S_T1), sreg(S_RGB)))
+    a('s_addc_u32 %s, %s, %s' % (sreg(S_T1 + 1), sreg(S_T1 + 1), sreg(S_RGB + 1)))
+    a('v_cmp_gt_u32 vcc, %s, %s' % (sreg(S_NRAYS), vreg(V_RAY)))
+    a('s_mov_b32 %s, -1' % sreg(S_T1 + 2))
+    a('s_mov_b32 %s, 0' % sreg(S_T1 + 3))
+    a('s_and_b64 exec, vcc, %s' % sreg(S_T1 + 2, 2))                      # lanes 0..31 with a ray inside the call
+    a('global_store_dwordx3 %s, %s, %s' % (vreg(V_RAYOFF), vreg(RGBR, 3), sreg(S_T1, 2)))
+    a('s_mov_b64 exec, -1')
+    return L
+
+
 def kernel_text(opts):
     """asm text of the whole body kernel (one inline-asm statement).  Inputs (asm operands):
     %0 wimg (s64)  %1 aux (s64)  %2 xin (s64)  %3 xout (s64)  %4 n_tiles  %5 n_block  %6 wave  %7 blockIdx.x
-    %8 gridDim.x"""
+    %8 gridDim.x  %9 rgb (s64; 0: store the x image to xout, else the fused tail writes rgb and xout is unused)
+    %10 tail table (s64)  %11 n_rays  %12 number of the launch's first tile"""
     pro, body = steady_block(opts)
     L = []
     a = L.append
@@ -684,6 +772,10 @@ def kernel_text(opts):
     a('s_mov_b32 %s, %%6' % sreg(S_WAVE))
     a('s_mov_b32 %s, %%7' % sreg(S_TILE))
     a('s_mov_b32 %s, %%8' % sreg(S_GRID))
+    a('s_mov_b64 %s, %%9' % sreg(S_RGB, 2))
+    a('s_mov_b64 %s, %%10' % sreg(S_TAB, 2))
+    a('s_mov_b32 %s, %%11' % sreg(S_NRAYS))
+    a('s_mov_b32 %s, %%12' % sreg(S_TILE0))
     a('s_mov_b32 %s, 0xbf800000' % sreg(S_NEG1))
     # lane id, LDS / DMA offsets
     a('v_mbcnt_lo_u32_b32 %s, -1, 0' % vreg(V_LANE))
@@ -694,7 +786,11 @@ def kernel_text(opts):
     a('v_add_u32 %s, 0x10000, %s' % (vreg(V_L8B), vreg(V_L8A)))
     a('v_lshrrev_b32 %s, 5, %s' % (vreg(V_AUX), vreg(V_LANE)))
     a('v_lshlrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_AUX)))
+    a('v_add_u32 %s, 0x%x, %s' % (vreg(V_TAILB), LDS_TAIL, vreg(V_AUX)))
     a('v_add_u32 %s, 0x%x, %s' % (vreg(V_AUX), LDS_AUX, vreg(V_AUX)))
+    a('v_xor_b32 %s, 32, %s' % (vreg(V_BPERM), vreg(V_LANE)))
+    a('v_lshlrev_b32 %s, 2, %s' % (vreg(V_BPERM), vreg(V_BPERM)))
+    a('v_mul_u32_u24 %s, 12, %s' % (vreg(V_RAYOFF), vreg(V_LANE)))
     a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_T0), sreg(S_WAVE), PW * 1024))        # wave * 7168
     a('v_add_u32 %s, %s, %s' % (vreg(V_DMAOFF), sreg(S_T0), vreg(V_L0)))
     a('v_add_u32 %s, 0x1000, %s' % (vreg(V_DMAOFF2), vreg(V_DMAOFF)))
@@ -736,6 +832,10 @@ def kernel_text(opts):
             r.append(dma_piece(i).text)
         return r
 
+    # tail table -> LDS (4 KiB, 1 KiB per wave; the oldest load of the kernel: landed with the first chunk)
+    a('s_add_u32 m0, %s, 0x%x' % (sreg(S_T0 + 1), LDS_TAIL))
+    a('s_nop 0')
+    a('global_load_lds_dwordx4 %s, %s' % (vreg(V_AUXOFF), sreg(S_TAB, 2)))
     L += issue_aux
     for k in range(3):
         L += issue_chunk(k)
@@ -774,10 +874,16 @@ def kernel_text(opts):
     a('s_sub_u32 %s, %s, 1' % (sreg(S_BLK), sreg(S_BLK)))
     a('s_cmp_lg_u32 %s, 0' % sreg(S_BLK))
     a('s_cbranch_scc1 L_block_%=')
-    # drain the prefetch reads, let the last MFMAs retire, store x
+    # drain the prefetch reads, let the last MFMAs retire
     a('s_waitcnt lgkmcnt(0)')
     a('s_nop 15')
     a('s_nop 15')
+    a('s_cmp_eq_u64 %s, 0' % sreg(S_RGB, 2))
+    a('s_cbranch_scc1 L_storex_%=')
+    L += fused_tail_text()
+    a('s_branch L_next_%=')
+    # ---- x image out (r2l_debug_body, networks without the global skip) ------------------------
+    a('L_storex_%=:')
     a('s_add_u32 %s, %s, %s' % (sreg(S_T0 + 4), sreg(S_XOUT), sreg(S_TILEOFF)))
     a('s_addc_u32 %s, %s, %s' % (sreg(S_T0 + 5), sreg(S_XOUT + 1), sreg(S_TILEOFF + 1)))
     for i in range(32):
@@ -785,6 +891,7 @@ def kernel_text(opts):
         if i % 4 == 3:
             a('s_add_u32 %s, %s, 0x1000' % (sreg(S_T0 + 4), sreg(S_T0 + 4)))
             a('s_addc_u32 %s, %s, 0' % (sreg(S_T0 + 5), sreg(S_T0 + 5)))
+    a('L_next_%=:')
     a('s_add_u32 %s, %s, %s' % (sreg(S_TILE), sreg(S_TILE), sreg(S_GRID)))
     a('s_cmp_lt_u32 %s, %s' % (sreg(S_TILE), sreg(S_NTILES)))
     a('s_cbranch_scc1 L_tile_%=')

@@ -136,6 +136,7 @@ struct r2l_ctx {
     char* d_body;                             // FP16_FP8: body stream v3 (r2l_body.hip) | aux blocks | tail
     size_t body_bytes, aux_off, tail_off;
     std::vector<int> act;                     // FP16_FP8: 2 n_block + 1 activation exponents (packed into the aux blocks)
+    int fuse_tail = 1;                        // FP16_FP8 with the global skip: rgb written by the body kernel's fused tail
     int calib_pending = 0;                    // the next FP16_FP8 render derives them from its own head output (device side)
     float* d_wcal = nullptr;                  // fp32 W1^T | b1' | W2^T per block for the calibration kernel
     unsigned* d_stats = nullptr;
@@ -473,7 +474,7 @@ static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_of
     const size_t stream = (size_t)nb * 16 * CH;
     *aux_off = stream;
     *tail_off = stream + (size_t)nb * AUXB;
-    out.assign(*tail_off + (3 * 256 + 4) * sizeof(float), 0);
+    out.assign(*tail_off + 4096, 0);   // the body kernel's fused tail copies 4 KiB of it to LDS
     std::vector<double> Bsum(256, 0.0);
     const float Sa = c->act_scale;
     for (int b = 0; b < nb; ++b) {
@@ -543,6 +544,7 @@ static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_of
             acc += (double)Wt[(size_t)r * 256 + k] * Bsum[k];
         }
         tw[768 + r] = (float)acc;
+        tw[772 + r] = (float)acc;   // second copy: the LDS reads of lanes 32..63 are 16 bytes further on
     }
     return R2L_OK;
 }
@@ -625,6 +627,12 @@ int r2l_get_act_exponents(r2l_ctx* c, int* out, int n) {
     return R2L_OK;
 }
 
+int r2l_debug_set_fused_tail(r2l_ctx* c, int on) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    c->fuse_tail = on ? 1 : 0;
+    return R2L_OK;
+}
+
 // Host-only packing for tests (no GPU): tensors in state_dict order -> chunk stream bytes.
 // Returns the byte count (or a negative code); copies min(count, cap) bytes into out.
 long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_block, int precision_mode, char* out,
@@ -702,6 +710,10 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     pb.xout = x_out_dev;
     pb.n_tiles = n_tiles;
     pb.n_block = c->n_block;
+    pb.rgb = nullptr;
+    pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
+    pb.n_rays = 0;
+    pb.tile_begin = 0;
     hipError_t e = r2l_launch_body(pb, n_tiles < c->n_cu ? n_tiles : c->n_cu, (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
     return R2L_OK;
@@ -787,6 +799,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         hipError_t e = r2l_launch_head(ph, grid, s);
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
         const float* body_out = c->d_xa;
+        bool fused = false;
         if (c->n_block > 0 && c->calib_pending) {
             // activation exponents from this call's own head output: device work in stream order, no host round trip
             c->calib_pending = 0;
@@ -801,6 +814,12 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             pb.xout = c->d_xb;
             pb.n_tiles = nt;
             pb.n_block = c->n_block;
+            // with the global skip the body kernel finishes the rays itself (its fused tail reads h back from xin)
+            fused = c->use_residual && c->fuse_tail;
+            pb.rgb = fused ? p.rgb : nullptr;
+            pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
+            pb.n_rays = p.n_rays;
+            pb.tile_begin = t0;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->timing) {
                 rc = timing_events(c, &e0, &e1);
@@ -812,6 +831,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
             body_out = c->d_xb;
         }
+        if (fused) continue;
         R2LTailParams pt;
         pt.xa = c->use_residual ? c->d_xa : nullptr;
         pt.xb = body_out;
@@ -916,7 +936,8 @@ long long r2l_flops_per_ray(const r2l_ctx* c) {
 }
 long long r2l_kernel_flops_per_ray(const r2l_ctx* c) {
     if (!c) return 0;
-    if (c->mode == R2L_PREC_FP16_FP8) return 2LL * 2LL * c->n_block * R2L_WIDTH * R2L_WIDTH;  // r2l_body_kernel
+    if (c->mode == R2L_PREC_FP16_FP8)   // r2l_body_kernel: the 2 n_block body layers, and the tail layer when it is fused in
+        return 2LL * 2LL * c->n_block * R2L_WIDTH * R2L_WIDTH + (c->use_residual && c->fuse_tail && c->n_block > 0 ? 2LL * 3 * R2L_WIDTH : 0);
     return r2l_flops_per_ray(c);
 }
 long long r2l_weight_image_bytes(const r2l_ctx* c) {

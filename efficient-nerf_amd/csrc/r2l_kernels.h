@@ -27,8 +27,12 @@ struct R2LBodyParams {
     const char* wimg;   // body stream: n_block * 16 chunks of 28 KiB (r2l_capi.hip pack_body_v3)
     const char* aux;    // n_block aux blocks of 4 KiB (bias of layer 1 | E8M0 scales)
     const float* xin;   // [n_tiles, 4, 32, 64, 4] f32
-    float* xout;
+    float* xout;        // x image out; unused when rgb != nullptr
     int n_tiles, n_block;
+    // fused tail (networks with the global skip): rgb rows of the call, nullptr = write the x image instead
+    float* rgb;
+    const float* tail;  // 4 KiB: [3, 256] tail weight / act_scale | 2 x (3 folded biases, 0)
+    int n_rays, tile_begin;
 };
 struct R2LTailParams {
     const float* xa;    // head output (global skip), may be nullptr

@@ -186,6 +186,11 @@ class R2LEngine:
                 check(lib().r2l_set_act_exponents(self._ctx, arr, len(exps)))
         return self
 
+    def _set_fused_tail(self, on):
+        """parity tests: 0 = the three-launch form (body kernel writes x, r2l_tail_kernel finishes the rays)"""
+        check(lib().r2l_debug_set_fused_tail(self._ctx, int(bool(on))))
+        return self
+
     # -- introspection --------------------------------------------------------------
     @property
     def flops_per_ray(self):

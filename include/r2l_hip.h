@@ -142,6 +142,11 @@ long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, i
  * tiles in the register-image layout [tile][wave 4][group 32][lane 64][4] f32: group 4u + g of lane 32h + ray holds
  * features 32u + 8g + 4h .. + 3 (csrc/r2l_common.h); parity tests only. */
 int r2l_debug_body(r2l_ctx* ctx, const float* x_in_dev, float* x_out_dev, int n_tiles, void* stream);
+/* R2L_PREC_FP16_FP8, networks with the global skip: the body kernel ends every ray tile with the tail layer
+ * (rgb = sigmoid(W_t (x + h) + b_t), model/nerf_raybased.py:539-544) straight from its registers.  on = 0 selects the
+ * three-launch form (body kernel writes x, r2l_tail_kernel finishes) that networks without the skip always use;
+ * parity tests compare the two. */
+int r2l_debug_set_fused_tail(r2l_ctx* ctx, int on);
 
 /* R2L_PREC_FP16_FP8 converts every operand set of the ResMLP body (the input x of block b, its hidden h) to bf6 with
  * ONE power-of-two scale per set: activations (x act_scale = 16) / 2^E must fit bf6's +-28.  The 2 n_block + 1 exponents

@@ -28,9 +28,10 @@ def test_bench_line_schema():
     rf = d['roofline']
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12 and 0.05 < rf['frac'] < 1.0
-    # the dominant kernel of the default mode is r2l_body_kernel: the 86 body layers, 2 * 86 * 256^2 flop per ray
-    assert rf['kernel'] == 'r2l_body_kernel' and rf['algorithmic_flops_per_ray'] == 2 * 86 * 65536
-    assert abs(rf['achieved'] - 2 * 86 * 65536 * 640000 / (rf['avg_kernel_ms'] * 1e-3) / 1e12) <= 1e-6 * rf['achieved']
+    # the dominant kernel of the default mode is r2l_body_kernel: the 86 body layers and the fused tail layer,
+    # 2 * (86 * 256^2 + 3 * 256) flop per ray
+    assert rf['kernel'] == 'r2l_body_kernel' and rf['algorithmic_flops_per_ray'] == 2 * (86 * 65536 + 768)
+    assert abs(rf['achieved'] - 2 * (86 * 65536 + 768) * 640000 / (rf['avg_kernel_ms'] * 1e-3) / 1e12) <= 1e-6 * rf['achieved']
     wp = rf['whole_path']
     assert wp['algorithmic_flops_per_ray'] == 11789824 and wp['frac'] <= rf['frac']
     assert abs(wp['achieved'] - 11789824 * 640000 / (d['ms_per_step'] * 1e-3) / 1e12) <= 1e-6 * wp['achieved']
