@@ -138,6 +138,7 @@ struct r2l_ctx {
     std::vector<int> act;                     // FP16_FP8: 2 n_block + 1 activation exponents (packed into the aux blocks)
     int fuse_tail = 1;                        // FP16_FP8 with the global skip: rgb written by the body kernel's fused tail
     int calib_pending = 0;                    // the next FP16_FP8 render derives them from its own head output (device side)
+    int calib_started = 0;                    // maxima of earlier, smaller calls are in d_stats: the next measurement adds to them
     float* d_wcal = nullptr;                  // fp32 W1^T | b1' | W2^T per block for the calibration kernel
     unsigned* d_stats = nullptr;
     float* d_xa;                              // FP16_FP8: head output / body output of one launch slice
@@ -573,6 +574,7 @@ int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
         }
     c->act.assign((size_t)2 * c->n_block + 1, R2L_ACT_EXP);
     c->calib_pending = 1;   // the first FP16_FP8 render measures the activation ranges of these weights
+    c->calib_started = 0;
     int rc = build_image(c, c->mode);
     if (rc) return rc;
     c->loaded = true;
@@ -584,6 +586,7 @@ int r2l_set_act_exponents(r2l_ctx* c, const int* exps, int n) {
     if (!c->loaded) return r2l_set_error(R2L_ESTATE, "r2l_set_act_exponents before r2l_load_weights");
     if (!exps) {            // back to self-calibration on the next render
         c->calib_pending = 1;
+        c->calib_started = 0;
         return R2L_OK;
     }
     if (n != 2 * c->n_block + 1) return r2l_set_error(R2L_EINVAL, "expected %d exponents, got %d", 2 * c->n_block + 1, n);
@@ -700,7 +703,7 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     if (c->calib_pending) {   // as a render would: the exponents of these weights on this input
         c->calib_pending = 0;
         hipError_t ec = r2l_launch_calib(x_in_dev, c->d_wcal, c->n_block, n_tiles, c->act_scale, c->d_stats,
-                                         c->d_body + c->aux_off, (hipStream_t)stream);
+                                         c->d_body + c->aux_off, 0, (hipStream_t)stream);
         if (ec != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l calibration launch: %s", hipGetErrorString(ec));
     }
     R2LBodyParams pb;
@@ -802,8 +805,12 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         bool fused = false;
         if (c->n_block > 0 && c->calib_pending) {
             // activation exponents from this call's own head output: device work in stream order, no host round trip
-            c->calib_pending = 0;
-            e = r2l_launch_calib(c->d_xa, c->d_wcal, c->n_block, nt, c->act_scale, c->d_stats, c->d_body + c->aux_off, s);
+            // a call of fewer than R2L_CALIB_TILES ray tiles is a thin sample: its maxima count, but the measurement stays open
+            // and the next call adds its own (exponents only grow), until one call has filled the sample
+            e = r2l_launch_calib(c->d_xa, c->d_wcal, c->n_block, nt, c->act_scale, c->d_stats, c->d_body + c->aux_off,
+                                 c->calib_started, s);
+            c->calib_started = 1;
+            if (nt >= R2L_CALIB_TILES) c->calib_pending = 0;
             if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l calibration launch: %s", hipGetErrorString(e));
         }
         if (c->n_block > 0) {

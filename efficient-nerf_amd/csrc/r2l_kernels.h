@@ -45,8 +45,10 @@ hipError_t r2l_launch_body(const R2LBodyParams& p, int grid, hipStream_t stream)
 hipError_t r2l_launch_tail(const R2LTailParams& p, hipStream_t stream);
 // activation exponents of the body from the head output of n_tiles ray tiles at xa (register image): stream-ordered,
 // results land in the aux blocks at `aux` (n_block x R2L_BODY_AUX_BYTES); wcal: per block W1^T | b1' | W2^T in fp32
+#define R2L_CALIB_TILES 8   // ray tiles (1,024 rays) the activation-range measurement samples from one call
+// accumulate != 0: keep the maxima already in stats (earlier calls with fewer tiles than the sample)
 hipError_t r2l_launch_calib(const float* xa, const float* wcal, int n_block, int n_tiles, float act_scale, unsigned* stats,
-                            char* aux, hipStream_t stream);
+                            char* aux, int accumulate, hipStream_t stream);
 int r2l_body_lds_bytes();
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,
                                    hipStream_t stream);

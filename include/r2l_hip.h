@@ -153,7 +153,9 @@ int r2l_debug_set_fused_tail(r2l_ctx* ctx, int on);
  * E (x_0, h_0, x_1, h_1, ..., x_n_block) are measured by the library itself: the first R2L_PREC_FP16_FP8 render after
  * r2l_load_weights evaluates the body in fp32 on a sample of that call's own rays (up to 1,024, behind its head launch)
  * and writes the exponents into the weight stream before its body launch -- device work in stream order, no host
- * round trip; other streams must not render with the context until that call has been enqueued.
+ * round trip; other streams must not render with the context until that call has been enqueued.  A call of fewer than
+ * 1,024 rays is a thin sample: its maxima are used and kept, and the following calls add theirs (exponents only grow)
+ * until one call has filled the sample.
  * r2l_set_act_exponents fixes them instead (NULL: measure again on the next render; synchronous host copy),
  * r2l_get_act_exponents reads back what the kernel uses (synchronous). */
 int r2l_set_act_exponents(r2l_ctx* ctx, const int* exps, int n);

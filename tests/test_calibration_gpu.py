@@ -1,0 +1,43 @@
+"""The bf6 activation exponents of R2L_PREC_FP16_FP8 are measured on the first render's own rays (include/r2l_hip.h).
+A first call with fewer rays than the sample must not freeze exponents taken from a handful of rays: the measurement
+stays open and later calls only add to it."""
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_thin_first_call_keeps_the_measurement_open(pkg):
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H, nb = 48, 8
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=21, netdepth=2 + 2 * nb)
+    gain = 1.4                               # growing activations: the ranges differ from ray to ray
+    for k in sd:
+        if k.startswith('body.') and k.endswith('weight'):
+            sd[k] = sd[k] * gain
+    c2w = O.pose_spherical(15., -40., 4.)
+    ro, rd = O.get_rays(H, H, focal, c2w)
+    ro, rd = ro.reshape(-1, 3).float().contiguous().cuda(), rd.reshape(-1, 3).float().contiguous().cuda()
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    one = eng.render_rays(ro[:1].contiguous(), rd[:1].contiguous()).cpu()        # 1 ray: a thin sample
+    e1 = eng.act_exponents()
+    assert (one - ref[:1]).abs().max().item() <= 2e-4
+    full = eng.render_rays(ro, rd).cpu()                                        # 2,304 rays: fills the sample
+    e2 = eng.act_exponents()
+    assert all(b >= a for a, b in zip(e1, e2)), (e1, e2)
+    assert (full - ref).abs().max().item() <= 2e-4
+    # closed now: other rays do not move the exponents, and a repeated call is bit-identical
+    eng.render_rays(ro[500:700].contiguous(), rd[500:700].contiguous())
+    assert eng.act_exponents() == e2
+    assert torch.equal(eng.render_rays(ro, rd).cpu(), full)
+    # a fresh context that sees the full call first ends at exponents no larger than the accumulated ones
+    eng2 = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    eng2.render_rays(ro, rd)
+    e3 = eng2.act_exponents()
+    assert all(b >= a for a, b in zip(e3, e2)), (e3, e2)
+    eng.close()
+    eng2.close()
