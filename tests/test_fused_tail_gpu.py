@@ -52,3 +52,33 @@ def test_fused_tail_writes_only_its_rays(pkg):
         ref = O.r2l_render(sd, H, H, focal, O.pose_spherical(t, -30., 4.), rows=(3, 20))
         assert (out[i] - ref).abs().max().item() <= 1e-4
     eng.close()
+
+
+def test_call_larger_than_one_launch_slice(pkg):
+    """fp16_fp8 renders a call in slices of 8,192 ray tiles (csrc/r2l_capi.hip launch_split): the second slice's tiles
+    must land behind the first slice's rows, and a ray's result must not depend on the slice it falls in"""
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H, nb = 64, 1
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=17, netdepth=2 + 2 * nb)
+    c2w = O.pose_spherical(140., -25., 4.)
+    ro, rd = O.get_rays(H, H, focal, c2w)
+    ro, rd = ro.reshape(-1, 3).float().contiguous().cuda(), rd.reshape(-1, 3).float().contiguous().cuda()
+    n = 8192 * 128 + 300                                     # one full slice + 2.3 tiles
+    idx = torch.arange(n, device='cuda') % ro.shape[0]
+    big_o, big_d = ro[idx].contiguous(), rd[idx].contiguous()
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    frame = eng.render_rays(ro, rd)                          # 4,096 rays; fixes the exponents
+    buf = torch.full((n + 64, 3), -7.0, device='cuda')
+    eng.render_rays(big_o, big_d, out=buf[:n])
+    assert (buf[n:] == -7.0).all()
+    assert torch.equal(buf[:n], frame[idx])                  # every copy of a ray, in either slice, bit for bit
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    assert (frame.cpu() - ref).abs().max().item() <= 1e-4
+    for mode in (0,):                                        # the three-launch form slices the same way
+        eng._set_fused_tail(mode)
+        buf.fill_(-7.0)
+        eng.render_rays(big_o, big_d, out=buf[:n])
+        assert (buf[n:] == -7.0).all()
+        assert (buf[:n] - frame[idx]).abs().max().item() <= 5e-7
+    eng.close()
