@@ -9,6 +9,11 @@ import torch
 import torch.distributed as dist
 
 
+# The hosts of this pool support only dmabuf IPC: without this RCCL / device-tensor sharing across processes fails with
+# `hipIpcGetMemHandle: invalid argument`.  Read by the HIP runtime when it initialises, i.e. at the first device call.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
 def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
