@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torchrun)
 
 A step renders N synthetic 800x800 Blender-style poses: every rank renders its row shard
-(800/N rows) of each of the N frames (fp16_fp8: head launch -> hand-scheduled body launch -> tail
-launch; the other modes: one fused launch), then one RCCL collective (r2l_gather_image) assembles the
+(800/N rows) of each of the N frames (fp16_fp8: head launch -> hand-scheduled body launch, which ends
+every ray tile with the tail layer; the other modes: one fused launch), then one RCCL collective (r2l_gather_image) assembles the
 frames on every rank (weak scaling: 640,000 rays per GPU per step).  Inputs
 (weights, poses) are resident in HBM before the timed region.  The timed region is
 bracketed by barrier + synchronize on both sides, max over ranks; rank 0 prints one JSON
@@ -166,6 +166,7 @@ def main():
         # the exponents the bf6 correction terms were scaled with (measured on the device by the first warm-up render)
         ex = [int(e) for e in eng.act_exponents()]
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
+                              'auto_precision_limit': eng.AUTO_MAX_EXP,   # --precision auto takes fp16_fp8 up to this exponent
                               'meaning': 'per operand set: activations * 2^-E fit OCP bf6 (|v| <= 28)'}
 
     if rank == 0:

@@ -70,7 +70,9 @@ FLAGS = [
     ('--N_rand', dict(type=int, default=4096)), ('--precrop_iters', dict(type=int, default=0)),
     ('--precrop_frac', dict(type=float, default=.5)), ('--no_reload', dict(action=_BOOL)),
     # this front-end's own knobs
-    ('--precision', dict(type=str, default='fp16x3', choices=['fp16x3', 'fp16x1', 'fp16_fp8'])),
+    # auto: fp16_fp8 (fp16 MFMA pass + bf6 correction terms, 1.7x the speed) when the checkpoint's own activation ranges keep
+    # it inside the 1e-4 rgb contract, fp16x3 otherwise (R2LEngine.choose_precision); the teacher takes fp16_fp8
+    ('--precision', dict(type=str, default='fp16x3', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
 ]
@@ -288,13 +290,14 @@ def mse2psnr(mse):
 # ----------------------------------------------------------------------------------------
 # render_path
 # ----------------------------------------------------------------------------------------
-def build_engine(args, hwf, ckpt):
+def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     """Engine for the flags of the reference command line.  Every flag that changes what the reference network
     computes is either honoured or refused: a checkpoint trained with another activation / res_scale / depth must
     not render silently wrong images (ResMLP honours them: model/nerf_raybased.py:443-465)."""
     from . import NeRFEngine, PRECISIONS, R2LEngine, R2LError
     H, W, focal = hwf
-    prec = PRECISIONS[args.precision]
+    auto = args.precision == 'auto'
+    prec = PRECISIONS['fp16_fp8' if auto else args.precision]
     llff_ndc = args.dataset_type == 'llff' and not args.no_ndc
     if args.dataset_type == 'blender':
         near, far = 2., 6.  # main.py:930-931
@@ -325,6 +328,12 @@ def build_engine(args, hwf, ckpt):
         eng = R2LEngine(H, W, focal, near, far, n_sample=args.n_sample_per_ray, L=args.multires,
                         width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec)
         eng.load_state_dict(ckpt['network_fn_state_dict'])
+        if auto:
+            if probe_pose is None and probe_rays is None:
+                raise R2LError('--precision auto needs a pose or rays to measure the activation ranges with')
+            name, top = eng.choose_precision(c2w=probe_pose, rays=probe_rays)
+            if log:
+                log(f'[precision] auto: activation exponents up to {top} (fp16_fp8 up to {eng.AUTO_MAX_EXP}) -> {name}')
         return 'R2L', eng
     if args.model_name == 'nerf':
         if not args.use_viewdirs or args.N_importance <= 0:
@@ -421,7 +430,9 @@ def main(argv=None):
         hwf = (int(H_ / args.render_factor), int(W_ / args.render_factor), f_ / args.render_factor)
         if gt is not None:
             gt = gt[:, :hwf[0], :hwf[1]]
-    kind, eng = build_engine(args, hwf, ckpt)
+    kind, eng = build_engine(args, hwf, ckpt, probe_pose=None if given is not None else poses[0][:3, :4],
+                             probe_rays=None if given is None else (given[0][0].reshape(-1, 3), given[1][0].reshape(-1, 3)),
+                             log=log)
     outdir = args.outdir or os.path.join(args.basedir, args.expname or 'render', 'gen_img')
     if rank == 0:
         os.makedirs(outdir, exist_ok=True)

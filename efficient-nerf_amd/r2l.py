@@ -19,7 +19,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, check, current_stream, dptr, lib
+from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, check, current_stream, dptr, lib
 
 
 def _dev(device=None):
@@ -185,6 +185,41 @@ class R2LEngine:
                 arr = (C.c_int * len(exps))(*[int(e) for e in exps])
                 check(lib().r2l_set_act_exponents(self._ctx, arr, len(exps)))
         return self
+
+    #: largest activation exponent (|a| <= 2^E) at which fp16_fp8 stays inside the 1e-4 rgb contract with margin: W256D88
+    #: networks measured at E = 3 / 4 / 5 differ from fp16x3 by 3-6e-5 / 6e-5-1.0e-4 / 1.5-3e-4 (tools/range_sweep.py,
+    #: profiles/r02_range_sweep.txt)
+    AUTO_MAX_EXP = 3
+
+    def choose_precision(self, c2w=None, rays=None, max_exp=None):
+        """`--precision auto`: fp16_fp8 where the network's own activation ranges allow it, fp16x3 otherwise.  The error of
+        the bf6 correction terms is relative to the residual stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so
+        the choice needs the ranges of THESE weights: a probe render (a band of >= 1,024 rays through the image centre of
+        pose `c2w`, or the middle 4,096 of the given `rays` = (rays_o, rays_d)) lets the library measure its activation
+        exponents; above `max_exp` the context is switched to fp16x3.  Synchronous (reads the exponents back), once per
+        weight load.  Returns (name of the chosen precision, largest exponent)."""
+        max_exp = self.AUTO_MAX_EXP if max_exp is None else int(max_exp)
+        self.set_precision(PREC_FP16_FP8)
+        if self.n_block == 0:
+            return 'fp16_fp8', 0
+        self.set_act_exponents(None)
+        if rays is not None:
+            ro, rd = rays
+            n = min(4096, ro.shape[0])
+            s0 = (ro.shape[0] - n) // 2          # the middle of the set: image centre when the rays are a frame
+            self.render_rays(ro[s0:s0 + n].contiguous().to(self.device, torch.float32),
+                             rd[s0:s0 + n].contiguous().to(self.device, torch.float32))
+        else:
+            if c2w is None:
+                raise R2LError('choose_precision needs a pose or rays to probe with')
+            rows = min(self.H, -(-1024 // self.W))
+            r0 = max(0, (self.H - rows) // 2)
+            self.render(c2w, rows=(r0, r0 + rows))
+        top = max(self.act_exponents())
+        if top > max_exp:
+            self.set_precision(PREC_FP16X3)
+            return 'fp16x3', top
+        return 'fp16_fp8', top
 
     def _set_fused_tail(self, on):
         """parity tests: 0 = the three-launch form (body kernel writes x, r2l_tail_kernel finishes the rays)"""

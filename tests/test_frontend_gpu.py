@@ -191,3 +191,35 @@ def test_cli_rejects_unsupported(pkg, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--model_name', 'R2L'], cwd=ROOT,
                        capture_output=True, text=True)
     assert r.returncode != 0 and 'render_only' in (r.stdout + r.stderr)
+
+
+def test_cli_precision_auto(pkg, tmp_path):
+    """--precision auto measures the checkpoint's activation ranges on a probe render and says what it chose; the same
+    checkpoint through the poses path and the given-rays path, a stress checkpoint (body weights x 1.3, 43 blocks)
+    falls back to fp16x3; every render stays within 1e-4 of the oracle"""
+    from efficient_nerf_amd import frontend as fe
+    H = 32
+    focal = O.focal_from_angle(64) / 2.
+    poses = O.novel_poses(1)
+    for tag, gain, want in (('std', 1.0, 'fp16_fp8'), ('stress', 1.3, 'fp16x3')):
+        sd = O.make_r2l_state(seed=0)
+        for k in sd:
+            if k.startswith('body.') and k.endswith('weight'):
+                sd[k] = sd[k] * gain
+        ck = str(tmp_path / f'{tag}.tar')
+        fe.save_checkpoint(ck, sd)
+        base = ['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256',
+                '--netdepth', '88', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck,
+                '--render_only', '--synthetic_poses', '1', '--H', '64', '--precision', 'auto']
+        log = run_main(base + ['--outdir', str(tmp_path / tag)])
+        assert '[precision] auto' in log and log.split('[precision] auto')[1].splitlines()[0].rstrip().endswith('-> ' + want), log
+        ref = O.r2l_render(sd, H, H, focal, poses[0]).view(H, H, 3).numpy()
+        a = np.load(tmp_path / tag / 'rgbs.npy')
+        assert np.abs(a[0] - ref).max() <= 1e-4
+        if tag == 'std':
+            ro, rd = O.rays_from_dirs(O.camera_dirs(H, H, focal), poses[0][:3, :4])
+            rays = str(tmp_path / 'rays.pt')
+            torch.save({'all_rays_o': ro.reshape(1, -1, 3), 'all_rays_d': rd.reshape(1, -1, 3)}, rays)
+            log = run_main(base + ['--outdir', str(tmp_path / 'g'), '--given_render_path_rays', rays])
+            assert '-> fp16_fp8' in log
+            assert np.abs(np.load(tmp_path / 'g' / 'rgbs.npy')[0] - ref).max() <= 1e-4
