@@ -202,6 +202,26 @@ def main():
                 alt['linf_vs_cpu_oracle'] = (eng.render(poses[0]).cpu()[:n_cpu_rows * W] - ref).abs().max().item()
             out['alt_precision'] = alt
             eng.set_precision(prec)
+        if world == 1 and not args.no_cpu_baseline and args.precision == 'fp16_fp8':
+            # secondary, outside the timed region: SURVEY 8(d)'s stress weights (every body weight x 1.3) through
+            # `--precision auto`: their residual stream is too large for the bf6 terms, the library must notice and take fp16x3
+            ssd = {k: (v * 1.3 if k.startswith('body.') and k.endswith('weight') else v) for k, v in sd.items()}
+            seng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(ssd)
+            chosen, top = seng.choose_precision(c2w=poses[0])
+            band = (H // 2 - 20, H // 2 + 20)
+            sref = O.r2l_render(ssd, H, W, focal, poses[0], rows=band, chunk=16384)
+            sg = seng.render(poses[0], rows=band).cpu()
+            seng.render(poses[1])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s_ in range(3):
+                seng.render(poses[2 + s_])
+            torch.cuda.synchronize()
+            sdt = (time.perf_counter() - t1) / 3
+            out['stress_weights'] = {'body_weight_gain': 1.3, 'max_act_exponent': int(top), 'auto_precision': chosen,
+                                     'linf_vs_cpu_oracle': (sg - sref).abs().max().item(), 'rays_checked': int(sg.shape[0]),
+                                     'value': H * W / sdt, 'unit': 'rays/s'}
+            seng.close()
         if not args.no_teacher and world == 1:
             # secondary, outside the timed region: NeRF teacher coarse+fine (BASELINE config 3)
             from efficient_nerf_amd import NeRFEngine

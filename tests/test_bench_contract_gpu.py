@@ -38,3 +38,7 @@ def test_bench_line_schema():
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['unit'] == 'rays/s' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
     assert d['parity']['within_tolerance'] and d['parity']['linf_vs_cpu_oracle'] <= 1e-4
+    # the stress weights of SURVEY 8(d) must not be rendered with the bf6 terms: the library's own range check decides
+    sw = d['stress_weights']
+    assert sw['auto_precision'] == 'fp16x3' and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
+    assert d['calibration']['max'] <= d['calibration']['auto_precision_limit']     # ... and would keep fp16_fp8 for the standard set
