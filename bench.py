@@ -113,6 +113,11 @@ def main():
 
     for s in range(args.warmup):
         frames = step(s)
+        if s == 0:
+            D.agree_act_exponents(eng)   # N > 1: one set of bf6 exponents for all row shards (measured on the first step)
+    if args.warmup == 0:
+        frames = step(0)                 # untimed: the activation ranges have to be measured and agreed on once
+        D.agree_act_exponents(eng)
     eng.timing(True)
     eng.kernel_time_ms(reset=True)
     D.barrier_sync()
@@ -168,6 +173,17 @@ def main():
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
                               'auto_precision_limit': eng.AUTO_MAX_EXP,   # --precision auto takes fp16_fp8 up to this exponent
                               'meaning': 'per operand set: activations * 2^-E fit OCP bf6 (|v| <= 28)'}
+
+    if world > 1:
+        # the assembled frames of the last step against this rank's own render of all rows of the step's first frame: a
+        # ray's result does not depend on the launch it is in, so the collective's output must match bit for bit
+        last = total_steps - 1
+        own = eng.render_batch(pose_dev[last][0:1])[0]
+        same = bool(torch.equal(frames[0].reshape(-1, 3), own.reshape(-1, 3)))
+        import torch.distributed as dist
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        out['gather_check'] = {'assembled_frame_equals_own_render_on_every_rank': bool(flag.item() == 1)}
 
     if rank == 0:
         # parity on the bounded CPU sample + CPU baseline (same box, same run)

@@ -180,6 +180,24 @@ def all_gather_cat(t, group=None):
     return out
 
 
+def agree_act_exponents(eng, group=None):
+    """R2L_PREC_FP16_FP8 measures its bf6 activation exponents on the first render's own rays (include/r2l_hip.h) -- under
+    row sharding every rank sees other rays and would end with its own set, and the rows of one assembled frame would come
+    from slightly different arithmetic.  Call once after the first render of every rank: the ranks take the element-wise
+    maximum (what one GPU would have measured on all their samples together).  Synchronous; no-op for one rank or for
+    the other precisions."""
+    from ._lib import PREC_FP16_FP8
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or eng.precision != PREC_FP16_FP8 or eng.n_block == 0:
+        return None
+    ex = torch.tensor(eng.act_exponents(), dtype=torch.int32)
+    if dist.get_backend(group) == 'nccl':
+        ex = ex.to(eng.device)
+    dist.all_reduce(ex, op=dist.ReduceOp.MAX, group=group)
+    ex = [int(v) for v in ex.cpu()]
+    eng.set_act_exponents(ex)
+    return ex
+
+
 def barrier_sync():
     if torch.cuda.is_available():
         torch.cuda.synchronize()

@@ -367,18 +367,25 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     from .metrics import ssim_hwc
     rgbs, psnrs, ssims = [], [], []
     n_frames = len(given_rays[0]) if given_rays is not None else len(render_poses)
-    for i in range(n_frames):
-        torch.cuda.synchronize()
-        t0 = time.time()
+
+    def render_local(i):
         if given_rays is not None:
             ro = given_rays[0][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
             rd = given_rays[1][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
             local = eng.render_rays(ro, rd)
-            local = local if kind == 'R2L' else local['rgb_map']
-        elif kind == 'R2L':
-            local = eng.render(render_poses[i][:3, :4], rows=(r0, r1))
-        else:
-            local = eng.render(render_poses[i][:3, :4], rows=(r0, r1))['rgb_map']
+            return local if kind == 'R2L' else local['rgb_map']
+        if kind == 'R2L':
+            return eng.render(render_poses[i][:3, :4], rows=(r0, r1))
+        return eng.render(render_poses[i][:3, :4], rows=(r0, r1))['rgb_map']
+
+    if kind == 'R2L' and world > 1 and n_frames > 0:
+        # fp16_fp8 measures its activation ranges on the first render's own rays: one agreed set for all row shards
+        render_local(0)
+        D.agree_act_exponents(eng)
+    for i in range(n_frames):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        local = render_local(i)
         rgb = D.gather_rows(local[None], H, W, world)[0].view(H, W, 3)
         torch.cuda.synchronize()
         if rank == 0:

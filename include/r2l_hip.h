@@ -155,7 +155,9 @@ int r2l_debug_set_fused_tail(r2l_ctx* ctx, int on);
  * and writes the exponents into the weight stream before its body launch -- device work in stream order, no host
  * round trip; other streams must not render with the context until that call has been enqueued.  A call of fewer than
  * 1,024 rays is a thin sample: its maxima are used and kept, and the following calls add theirs (exponents only grow)
- * until one call has filled the sample.
+ * until one call has filled the sample.  Ranks that render row shards of the same frames see different rays: exchange
+ * the exponents once (r2l_get_act_exponents, element-wise maximum over the ranks, r2l_set_act_exponents; the Python
+ * side does it in dist.agree_act_exponents) so that every shard is rendered with the same arithmetic.
  * r2l_set_act_exponents fixes them instead (NULL: measure again on the next render; synchronous host copy),
  * r2l_get_act_exponents reads back what the kernel uses (synchronous). */
 int r2l_set_act_exponents(r2l_ctx* ctx, const int* exps, int n);

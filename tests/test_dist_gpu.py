@@ -36,3 +36,65 @@ def test_rendered_rows_through_the_collective(pkg):
     got = D.gather_rows(full[None], H, W, 1, force_collective=True)[0]
     assert torch.equal(got, full)
     eng.close()
+
+
+def _agree_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), R2L_DIST_BACKEND='gloo')
+    import _pkg
+    _pkg.load()
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine, dist as D
+    D.init()
+    torch.cuda.set_device(D.local_device(rank))
+    H, nb = 64, 8
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=6, netdepth=2 + 2 * nb)
+    for k in sd:                                   # growing activations: the two row shards see different ranges
+        if k.startswith('body.') and k.endswith('weight'):
+            sd[k] = sd[k] * 1.4
+    c2w = O.pose_spherical(35., -60., 4.)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    r0, r1 = D.row_shard(H, rank, world)
+    eng.render(c2w, rows=(r0, r1))
+    mine = eng.act_exponents()
+    agreed = D.agree_act_exponents(eng)
+    assert agreed == eng.act_exponents() and all(a >= m for a, m in zip(agreed, mine))
+    local = eng.render(c2w, rows=(r0, r1))
+    frame = D.gather_rows(local[None], H, H, world)[0]
+    own = eng.render(c2w)
+    torch.save({'mine': mine, 'agreed': agreed, 'equal': bool(torch.equal(frame, own)), 'frame': frame.cpu()},
+               os.path.join(out_dir, f'r{rank}.pt'))
+    D.barrier_sync()
+    eng.close()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_two_ranks_agree_on_activation_exponents(pkg, tmp_path):
+    """two processes (gloo between them, both on this GPU) render the two row shards of a frame in fp16_fp8: after
+    dist.agree_act_exponents both use the element-wise maximum of what they measured, and the assembled frame equals each
+    rank's own render of all rows bit for bit (bench.py's gather_check, frontend.render_path)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f'r{k}.pt') for k in range(2)]
+    assert r[0]['agreed'] == r[1]['agreed'] == [max(a, b) for a, b in zip(r[0]['mine'], r[1]['mine'])]
+    assert r[0]['equal'] and r[1]['equal'] and torch.equal(r[0]['frame'], r[1]['frame'])
+    ref = O.r2l_render(O_state_14(), 64, 64, O.focal_from_angle(64), O.pose_spherical(35., -60., 4.))
+    assert (r[0]['frame'] - ref).abs().max().item() <= 2e-4
+
+
+def O_state_14():
+    sd = O.make_r2l_state(seed=6, netdepth=18)
+    for k in sd:
+        if k.startswith('body.') and k.endswith('weight'):
+            sd[k] = sd[k] * 1.4
+    return sd
