@@ -62,3 +62,48 @@ def test_create_rand_shards(pkg, tmp_path):
     n2 = create_rand(eng, H, W, focal, n_pose_kd=2, datadir_new=out, i_save=2, split_size=100, stream=RandStream())
     assert n2 == 2 and os.path.exists(os.path.join(out, 'data_6.npy'))
     eng.close()
+
+
+def _rank_create_rand(rank, world, port, out_dir, n_pose, i_save, H):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import _pkg
+    _pkg.load()
+    from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8, dist as D
+    from efficient_nerf_amd.create_data import RandStream, create_rand
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world), R2L_DIST_BACKEND='gloo')
+        D.init()
+        torch.cuda.set_device(D.local_device(rank))
+    focal = O.focal_from_angle(H)
+    eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    n = create_rand(eng, H, H, focal, n_pose_kd=n_pose, datadir_new=out_dir, i_save=i_save, split_size=100,
+                    stream=RandStream(), log=lambda *a, **k: None)
+    assert n == (n_pose // i_save) * (i_save * H * H // 100)
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def test_two_gpu_ranks_write_the_single_rank_directory(pkg, tmp_path):
+    """config 5 sharded by pose over two processes (gloo between them, both on this GPU, the real teacher kernels):
+    the shard directory is byte-identical to the one-rank run, also with i_save % world != 0 over several groups"""
+    import hashlib
+    import socket
+    import torch.multiprocessing as mp
+    H, n_pose, i_save = 12, 7, 3
+    d1, d2 = str(tmp_path / 'w1'), str(tmp_path / 'w2')
+    _rank_create_rand(0, 1, 0, d1, n_pose, i_save, H)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_create_rand, args=(2, port, d2, n_pose, i_save, H), nprocs=2, join=True)
+
+    def digest(d):
+        return {n: hashlib.sha256(open(os.path.join(d, n), 'rb').read()).hexdigest() for n in sorted(os.listdir(d)) if n.endswith('.npy')}
+    a, b = digest(d1), digest(d2)
+    assert len(a) == (n_pose // i_save) * (i_save * H * H // 100) and a == b
