@@ -223,3 +223,35 @@ def test_cli_precision_auto(pkg, tmp_path):
             log = run_main(base + ['--outdir', str(tmp_path / 'g'), '--given_render_path_rays', rays])
             assert '-> fp16_fp8' in log
             assert np.abs(np.load(tmp_path / 'g' / 'rgbs.npy')[0] - ref).max() <= 1e-4
+
+
+def test_r2l_render_only_cli_two_ranks(pkg, tmp_path):
+    """main.py --render_only under torch.distributed.run with two ranks (gloo between them, both on this GPU): rows
+    sharded 17 / 16 (H = 33 is ragged), fp16_fp8 with the exponents agreed between the ranks, one gather per frame;
+    rank 0 writes the frames.  Every frame within 1e-4 of the oracle."""
+    import socket
+    from efficient_nerf_amd import frontend as fe
+    sd = O.make_r2l_state(seed=12, netdepth=14)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    out = str(tmp_path / 'out')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, R2L_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'main.py'),
+                        '--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256',
+                        '--netdepth', '14', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck,
+                        '--render_only', '--synthetic_poses', '3', '--H', '66', '--precision', 'fp16_fp8', '--outdir', out],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'on 2 GPU(s)' in r.stdout
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    H = 33
+    assert rgbs.shape == (3, H, H, 3)
+    focal = O.focal_from_angle(66) / 2.
+    for i, c2w in enumerate(O.novel_poses(3)):
+        ref = O.r2l_render(sd, H, H, focal, c2w).view(H, H, 3).numpy()
+        assert np.abs(rgbs[i] - ref).max() <= 1e-4, i
