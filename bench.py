@@ -76,6 +76,8 @@ def main():
     ap.add_argument('--precision', choices=['fp16x3', 'fp16x1', 'fp16_fp8'], default='fp16_fp8',
                     help='fp16_fp8 (default: fp16 main pass + bf6 correction terms) and fp16x3 meet the <=1e-4 L_inf '
                          'contract (measured 3e-5 / 6e-7, checked in this run against the CPU oracle); fp16x1 (3.5e-4) does not')
+    ap.add_argument('--guard-period', type=int, default=None,
+                    help='fp16_fp8: every k-th body launch runs the range-guard build (library default 8; 1 every launch, 0 never)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-teacher', action='store_true', help='skip the secondary teacher measurement')
     ap.add_argument('--cpu-rays', type=int, default=H * W,
@@ -111,21 +113,29 @@ def main():
         eng.render_batch(pose_dev[s], rows=(r0, r1), out=local)
         return D.gather_rows(local, H, W, world)
 
+    if args.precision == 'fp16_fp8':
+        # untimed, once per weight load: the bf6 activation exponents from EVERY ray of one whole frame (range-guarded
+        # render of test pose 0, every rank the same frame, so all row shards use one set), as `--precision auto` does
+        eng.calibrate_on(c2w=poses[0])
+        D.agree_act_exponents(eng)
+        if args.guard_period is not None:
+            eng.set_guard_period(args.guard_period)
     for s in range(args.warmup):
         frames = step(s)
-        if s == 0:
-            D.agree_act_exponents(eng)   # N > 1: one set of bf6 exponents for all row shards (measured on the first step)
-    if args.warmup == 0:
-        frames = step(0)                 # untimed: the activation ranges have to be measured and agreed on once
-        D.agree_act_exponents(eng)
+    if args.precision == 'fp16_fp8':
+        eng.range_status(reset=True)     # the words below describe the timed steps only
     eng.timing(True)
     eng.kernel_time_ms(reset=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times, no host sync in the loop
     D.barrier_sync()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
+        ev[s - args.warmup].record()
         frames = step(s)
+    ev[args.steps].record()
     D.barrier_sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
     kern_ms, n_launch = eng.kernel_time_ms(reset=True)
     eng.timing(False)
     if world > 1:
@@ -148,6 +158,10 @@ def main():
     out = {
         'metric': 'rays/sec at 800x800 (R2L W256D88)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        # the reference's --benchmark is timeit over frames (main.py:1124-1133); per-step device times (HIP events
+        # on the launch stream, this rank) beside the mean the headline is computed from
+        'median_ms': step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+        'min_ms': step_ms[0], 'max_ms': step_ms[-1],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp16x3': 'f16 (3 fp16 MFMA passes on hi/lo-split operands, fp32 accumulate)',
                                                                                      'fp16x1': 'f16 (1 fp16 MFMA pass, fp32 accumulate)',
                                                                                      'fp16_fp8': 'f16+bf6 (1 fp16 MFMA pass + both hi/lo correction terms on the block-scaled MFMA in OCP bf6 (e3m2) at 4x the fp16 rate, fp32 accumulate)'}[args.precision],
@@ -170,9 +184,14 @@ def main():
     if args.precision == 'fp16_fp8':
         # the exponents the bf6 correction terms were scaled with (measured on the device by the first warm-up render)
         ex = [int(e) for e in eng.act_exponents()]
+        st = eng.range_status()
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
                               'auto_precision_limit': eng.AUTO_MAX_EXP,   # --precision auto takes fp16_fp8 up to this exponent
+                              'measured_on': 'every ray of one 800x800 frame (test pose 0), range-guarded render',
                               'meaning': 'per operand set: activations * 2^-E fit OCP bf6 (|v| <= 28)'}
+        # what the timed steps' own rays did to those scales: h0 of EVERY ray (head launch), all 2 n_block operand sets of
+        # every ray of the guarded launches (r2l_body_guard_kernel); fill 1.0 = bf6's +-28, the calibration aims at 0.571
+        out['range_watch'] = dict(st, guard_period=eng._guard_period, within_calibration=not st['beyond_calibration'])
 
     if world > 1:
         # the assembled frames of the last step against this rank's own render of all rows of the step's first frame: a
@@ -201,8 +220,31 @@ def main():
                                    'kind': 'port',
                                    'sample': '%d rays (rows 0..%d of one 800x800 frame), PyTorch-CPU fp32 eager restatement, %.1f s'
                                              % (n_cpu_rows * W, n_cpu_rows, t_cpu)}
-            out['parity'] = {'linf_vs_cpu_oracle': err, 'psnr_vs_cpu_oracle_db': O.psnr(gpu, ref),
-                             'rays_checked': n_cpu_rows * W, 'tolerance': 1e-4, 'within_tolerance': bool(err <= 1e-4)}
+            # L_inf over >= 3 frames.  Frame 0 is the pose the exponents were measured on; the two others are far
+            # from it on the test path (120 and 240 degrees on) and are checked on every 4th row (160,000 rays each)
+            frames_chk = [{'pose': 0, 'rays': n_cpu_rows * W, 'linf': err, 'psnr_db': O.psnr(gpu, ref), 'calibration_pose': True}]
+            worst = err
+            step_rows = 4 if n_cpu_rows >= H else max(1, 4 * H // n_cpu_rows)
+            for pi in (67, 133):
+                g = eng.render(poses[pi]).cpu().view(H, W, 3)[::step_rows].reshape(-1, 3)
+                r_ = O.r2l_render(sd, H, W, focal, poses[pi], rows=(0, H, step_rows), chunk=16384)
+                e_ = (g - r_).abs().max().item()
+                frames_chk.append({'pose': pi, 'rays': int(g.shape[0]), 'linf': e_, 'psnr_db': O.psnr(g, r_), 'calibration_pose': False})
+                worst = max(worst, e_)
+            out['parity'] = {'linf_vs_cpu_oracle': worst, 'psnr_vs_cpu_oracle_db': min(f['psnr_db'] for f in frames_chk),
+                             'rays_checked': sum(f['rays'] for f in frames_chk), 'frames': frames_chk, 'tolerance': 1e-4,
+                             'within_tolerance': bool(worst <= 1e-4)}
+            # north_star's second tolerance: PSNR delta < 0.01 dB.  No ground truth exists offline; gt* = the oracle's render
+            # under weights perturbed by a fixed seed (a stand-in ~33 dB away, as a trained network is from its ground truth):
+            # | PSNR(gpu, gt*) - PSNR(ref, gt*) | on every 4th row of pose 0 (utils/run_nerf_raybased_helpers.py:19-20)
+            gsd = O.perturbed_state(sd, seed=1234, rel=0.05)
+            gt = O.r2l_render(gsd, H, W, focal, c2w, rows=(0, H, step_rows), chunk=16384)
+            g0 = eng.render(c2w).cpu().view(H, W, 3)[::step_rows].reshape(-1, 3)
+            r0_ = ref.view(-1, W, 3)[::step_rows].reshape(-1, 3) if n_cpu_rows >= H else O.r2l_render(sd, H, W, focal, c2w, rows=(0, H, step_rows), chunk=16384)
+            p_gpu, p_ref = O.psnr(g0, gt), O.psnr(r0_, gt)
+            out['parity']['psnr_delta_db'] = abs(p_gpu - p_ref)
+            out['parity']['psnr_vs_gt_star_db'] = {'gpu': p_gpu, 'reference': p_ref, 'rays': int(gt.shape[0]),
+                                                   'gt_star': 'oracle render, every weight x (1 + 0.05 N(0,1)), seed 1234'}
         if world == 1 and args.precision != 'fp16x3':
             # secondary, outside the timed region: the same frames in the hi/lo-split fp16 mode (fp32-grade result)
             eng.set_precision(PRECISIONS['fp16x3'])
@@ -256,7 +298,7 @@ def main():
                               'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': 2 * 593408 * 256 * th * th / tdt / 1e12,
                               'precision': tprec}
             if not args.no_cpu_baseline:  # parity of that frame against the CPU oracle on a strided ray subset
-                idx = torch.arange(0, th * th, th * th // 256)[:256]
+                idx = torch.arange(0, th * th, th * th // 2048)[:2048]   # 2,048 rays spread over the frame
                 ro, rd = O.get_rays(th, th, O.focal_from_angle(th), poses[1])
                 tref = O.render_rays(O.make_teacher_state(1), O.make_teacher_state(2), ro.reshape(-1, 3)[idx].float(),
                                      rd.reshape(-1, 3)[idx].float(), white_bkgd=True)

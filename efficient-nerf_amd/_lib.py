@@ -4,8 +4,8 @@ import os
 
 PREC_FP16X3 = 0
 PREC_FP16X1 = 1
-PREC_FP16_FP8 = 2  # fp16 main pass + low-precision correction terms (R2L: bf6 at 4x the fp16 rate, hand-scheduled body;
-                   # teacher: e4m3 x e5m2 at 2x)
+PREC_FP16_FP8 = 2  # fp16 main pass + both correction terms in OCP bf6 (e3m2) on the block-scaled MFMA at 4x the fp16 rate:
+                   # generated head / body kernels (R2L), generated layer chain (teacher); the name is historical
 PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -18,6 +18,17 @@ class R2LError(RuntimeError):
 
 _f = C.POINTER(C.c_float)
 _vp = C.c_void_p
+
+
+class RangeStatus(C.Structure):
+    """include/r2l_hip.h r2l_range_status"""
+    _fields_ = [('h0_max', C.c_float), ('h0_fill', C.c_float), ('worst_fill', C.c_float), ('worst_set', C.c_int),
+                ('saturated', C.c_int), ('beyond_calibration', C.c_int), ('launches', C.c_longlong),
+                ('guarded_launches', C.c_longlong)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
 
 # name -> (restype, argtypes); every symbol include/r2l_hip.h declares
 SIGNATURES = {
@@ -42,6 +53,9 @@ SIGNATURES = {
                                                 C.POINTER(C.c_longlong)]),
     'r2l_set_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     'r2l_get_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
+    'r2l_set_guard_period': (C.c_int, [_vp, C.c_int]),
+    'r2l_get_range_status': (C.c_int, [_vp, C.POINTER(RangeStatus), C.c_int]),
+    'r2l_recalibrate': (C.c_int, [_vp, _vp]),
     'r2l_debug_body': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     'r2l_debug_set_fused_tail': (C.c_int, [_vp, C.c_int]),
     'r2l_flops_per_ray': (C.c_longlong, [_vp]),

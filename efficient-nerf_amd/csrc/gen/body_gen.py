@@ -48,7 +48,7 @@ import sys
 import numpy as np
 
 from isa import (ACT_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
-                 ds_read_b64, ds_read_b96, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
+                 ds_read_b64, ds_read_b96, ds_max_u32, v_max3_abs, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
                  v_cvt_pk32_bf6, s_nop, salu, f_to_bf6, pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream,
                  model_cycles)
 
@@ -83,7 +83,8 @@ V_TAILB = 251     # LDS address of the tail table + (lane>>5)*16
 V_BPERM = 252     # (lane ^ 32) * 4: ds_bpermute address of the other lane half
 V_RAYOFF = 253    # lane * 12: byte offset of this lane's ray in the wave's rgb rows
 V_RAY = 254
-N_VGPR_USED = 255
+V_GMAX = 255      # range guard (opts.guard): running max |a| of the operand set being produced, per lane
+N_VGPR_USED = 256
 NHI = 4           # fp16 fragment buffers
 
 A_X = 0
@@ -119,7 +120,8 @@ S_TAB = 82      # 82,83 tail table
 S_NRAYS = 84
 S_TILE0 = 85    # tile number of the launch's first tile within the call
 S_T1 = 86       # temporaries 86..89
-N_SGPR_LO, N_SGPR_HI = 40, 90
+S_GPOS = 90     # range guard: LDS byte address of the maxima row (64 lanes x 4 B) of the operand set being produced
+N_SGPR_LO, N_SGPR_HI = 40, 92
 
 PIECES = 28                # 1 KiB pieces of a chunk
 CHUNK = PIECES * 1024      # 28 KiB
@@ -133,6 +135,11 @@ RES_SHIFT = 12             # a - hi(a) of an fp16-rounded value is converted 2^1
 LDS_TAIL = LDS_AUX + 2 * AUX_BYTES   # tail table: 3 x 256 f32 (W_t / act_scale) | 2 x (3 folded biases, 0)
 TAIL_BYTES = 4096
 LDS_BYTES = LDS_TAIL + TAIL_BYTES
+# range guard (the r2l_body_guard_kernel build of this stream): per operand set (2 per block: IN_b, H_b) one row of 64
+# per-lane maxima of |a| (f32 bits; non-negative floats order as unsigned), accumulated over the tiles of a workgroup
+# by ds_max_u32; the kernel's HIP epilogue reduces the rows and atomicMax-es them into the context's statistics
+LDS_GSTAT = LDS_BYTES
+GSTAT_ROW = 256
 
 
 TILES = 16                 # row tiles of a block: layer * 8 + u
@@ -344,10 +351,22 @@ def anchor_index(T, kind, sj):
     return T * ANCH_PER_TILE + _POS[(kind, sj)]
 
 
-def epilogue_ops(T):
+def guard_flush(tag):
+    """range guard: the per-lane maximum of the operand set just completed joins its LDS row; next set, maximum cleared.
+    V_BPERM = 4 (lane ^ 32) serves as the lane's dword offset inside the row (any bijection of the lanes does)."""
+    return [valu('v_add_u32 %s, %s, %s' % (vreg(V_T), sreg(S_GPOS), vreg(V_BPERM)), vr(V_BPERM), vr(V_T),
+                 lambda st: st.V.__setitem__(V_T, (st.V[V_BPERM] + np.uint32(st.S[S_GPOS])).astype(np.uint32))),
+            ds_max_u32(V_T, V_GMAX, 0, tag=tag),       # S_GPOS carries LDS_GSTAT (beyond a 16-bit offset)
+            salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_GPOS), sreg(S_GPOS), GSTAT_ROW),
+                 lambda st: st.S.__setitem__(S_GPOS, st.S[S_GPOS] + GSTAT_ROW)),
+            valu('v_mov_b32 %s, 0' % vreg(V_GMAX), (), vr(V_GMAX), lambda st: st.V.__setitem__(V_GMAX, np.zeros(64, np.uint32)))]
+
+
+def epilogue_ops(T, guard=False):
     """VALU epilogue of row tile T (block-local tile index, may be -1 = tile 15 of the previous block).  Returns
     [(Ins, consumer)]; consumer: None | ('hi', s) | ('b6', term, t).  Works in the tile's own accumulator registers:
-    relu in place (layer 1), copies of X (layer 2, whose accumulator is X itself)."""
+    relu in place (layer 1), copies of X (layer 2, whose accumulator is X itself).  guard: the values also enter the
+    running maximum of their operand set (2 v_max3_f32 per 4 values)."""
     Tm = T % TILES
     layer, u = Tm >> 3, Tm & 7
     acc = ACC(T & 1)
@@ -357,6 +376,9 @@ def epilogue_ops(T):
         t = [acc + 4 * g + i for i in range(4)]
         for i in range(4):
             ops.append((v_max0(t[i], t[i]) if layer == 0 else v_accr(t[i], X(u) + 4 * g + i), None))
+        if guard:
+            ops.append((v_max3_abs(V_GMAX, t[0], t[1]), None))
+            ops.append((v_max3_abs(V_GMAX, t[2], t[3]), None))
         s = 2 * u + (g >> 1)
         h01 = hset(s) + 2 * (g & 1)
         h23 = h01 + 1
@@ -472,7 +494,10 @@ def build_fillers(it, opts):
         pu = (Tprev % TILES) & 7
         nl_T0 = (Tprev - pu) + 8  # first tile of the consuming layer, block-local
         e0 = A(T, 'm16', 0) + 2   # two further MFMAs behind the last writer of the accumulator
-        for ins, cons in epilogue_ops(Tprev):
+        epi = epilogue_ops(Tprev, opts.guard)
+        if opts.guard and pu == 7:    # the last row tile of a layer: its operand set is complete
+            epi += [(ins, None) for ins in guard_flush(('gmax', it, T))]
+        for ins, cons in epi:
             dl = A(T + 1, 'm16', 0)  # latest: the accumulator buffer is reused by tile T+1
             if cons is not None:
                 if cons[0] == 'hi':
@@ -650,6 +675,7 @@ class Opts:
         self.dma_burst = False
         self.chain_nop = -1       # s_nop N between the last fp16 and the first K=64 MFMA of a row tile (-1: none)
         self.skip_terms = ()      # diagnostics: drop the K=64 MFMAs of these correction terms (wrong results)
+        self.guard = False        # the range-guard build: per operand set the maximum |a| over every ray of the launch
         self.__dict__.update(kw)
 
 
@@ -673,9 +699,9 @@ def steady_block(opts):
 # ---------------------------------------------------------------------------------------------
 # whole-kernel text
 # ---------------------------------------------------------------------------------------------
-def split_ops(u):
+def split_ops(u, guard=False):
     """standalone split of X row tile u -> the layer-1 operand sets (the layer-2 epilogue without MFMAs)"""
-    return [ins for ins, _ in epilogue_ops(8 + u)]
+    return [ins for ins, _ in epilogue_ops(8 + u, guard)]
 
 
 def fused_tail_text():
@@ -862,8 +888,11 @@ def kernel_text(opts):
             a('s_addc_u32 %s, %s, 0' % (sreg(S_T0 + 5), sreg(S_T0 + 5)))
     a('s_waitcnt vmcnt(0)')
     # initial split of row tiles 0..6 (tile 7's runs at the head of the loop body)
+    if opts.guard:
+        a('v_mov_b32 %s, 0' % vreg(V_GMAX))
+        a('s_mov_b32 %s, 0x%x' % (sreg(S_GPOS), LDS_GSTAT))
     for u in range(7):
-        for ins in split_ops(u):
+        for ins in split_ops(u, opts.guard):
             a(ins.text)
     for ins in pro:   # LDS reads the loop head expects in flight
         a(ins.text)
@@ -932,7 +961,7 @@ def emit_inc(path, opts):
 def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=True):
     """x_tile_regs: float32 [128, 64] register image of one wave's X.  Returns (X out [128, 64], errors)."""
     pro, body = steady_block(opts)
-    st = State(wave, img, aux, n_block, LDS_BYTES)
+    st = State(wave, img, aux, n_block, LDS_BYTES + (2 * n_block * GSTAT_ROW if opts.guard else 0))
     lanes = np.arange(64, dtype=np.uint32)
     st.V[V_LANE] = lanes
     st.V[V_L0] = lanes * 16
@@ -977,8 +1006,10 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     barrier().emu(st)
     st.run(act_prologue())
     st.A[A_X:A_X + 128] = np.ascontiguousarray(x_tile_regs, dtype=np.float32).view(np.uint32)
+    st.V[V_BPERM] = (lanes ^ 32) * 4
+    S[S_GPOS] = LDS_GSTAT
     for u in range(7):
-        st.run(split_ops(u))
+        st.run(split_ops(u, opts.guard))
     st.run(pro)
     for b in range(n_block):
         st.run(body)
@@ -986,6 +1017,8 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     errs = list(st.errors)
     if check_hazards:
         errs += check_hazards_stream(body + body)
+    if opts.guard:   # the maxima rows (f32) of the 2 n_block operand sets ride along
+        return st.A[A_X:A_X + 128].view(np.float32).copy(), errs, st.lds[LDS_GSTAT:LDS_GSTAT + 2 * n_block * GSTAT_ROW].view(np.float32).reshape(2 * n_block, 64).copy()
     return st.A[A_X:A_X + 128].view(np.float32).copy(), errs
 
 
@@ -1000,6 +1033,7 @@ def main():
     ap.add_argument('--dma-gap', type=int, default=1)
     ap.add_argument('--chain-nop', type=int, default=-1)
     ap.add_argument('--order', default=None, choices=['tail', 'mix'])
+    ap.add_argument('--guard', action='store_true', help='the range-guard build of the stream (r2l_body_guard_kernel)')
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')
     ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the block loop '
@@ -1009,7 +1043,7 @@ def main():
         global ORDER
         ORDER = a.order
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap16=a.cap16, cap6=a.cap6, dma_gap=a.dma_gap,
-                chain_nop=a.chain_nop, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
+                chain_nop=a.chain_nop, guard=a.guard, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
                 drop=tuple(x for x in a.drop.split(',') if x))
     if a.emit:
         n = emit_inc(a.emit, opts)

@@ -36,7 +36,7 @@ import isa
 from isa import (Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128, ds_read_b64, waitcnt_lgkm,
                  waitcnt_vm, barrier, valu, v_max0, v_accr, v_cvt_pk_f16, v_resid16, v_cvt_pk32_bf6, s_nop, salu, f_to_bf6,
                  pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream, model_cycles, v_f32_op, v_fma_f32,
-                 v_ldexp_f32, v_rndne_f32, v_sin_f32)
+                 v_ldexp_f32, v_rndne_f32, v_sin_f32, v_max3_abs)
 
 # ---------------------------------------------------------------------------------------------
 # register map
@@ -55,6 +55,7 @@ V_L0, V_L1, V_L8A, V_L8B, V_AUX, V_LOFF, V_LANE, V_ST = 196, 197, 198, 199, 200,
 V_SBA, V_SBL, V_CVA, V_CVL = 204, 205, 206, 207
 V_SC = 208         # 208, 209: E8M0 weight scales (w - hi | w)
 N_VGPR_CLOBBER = 210
+V_HMAX = 210       # in/out operand of the block, pinned to v210 by the kernel: running maximum of h0 over the lane's rays
 NHI = 8
 A_X = 0
 N_AGPR_CLOBBER = 128
@@ -532,6 +533,8 @@ def tail_ops():
             ops.append(v_accr(t + r, X(i >> 2) + 4 * (i & 3) + r))
         for r in range(4):
             ops.append(v_max0(t + r, t + r))
+        for r in (0, 2):      # range tracking of every ray (r2l_get_range_status): h0 is the first bf6 operand set of the body
+            ops.append(v_max3_abs(V_HMAX, t + r, t + r + 1))
         ops.append(store_group(i, t))
         if i % 4 == 3 and i < 31:
             ops.append(salu('s_add_u32 %s, %s, 0x1000' % (sreg(S_XOUT), sreg(S_XOUT))))

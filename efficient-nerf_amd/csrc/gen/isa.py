@@ -321,6 +321,28 @@ def v_max0(dst, src):
     return valu('v_max_f32 %s, 0, %s' % (vreg(dst), vreg(src)), vr(src), vr(dst), emu)
 
 
+def v_max3_abs(dst, a, b):
+    """dst = max(dst, |a|, |b|) in f32 (dst >= 0): the running maximum of the range guard"""
+    def emu(st):
+        m = np.maximum(np.abs(st.f32('v', a)), np.abs(st.f32('v', b)))
+        st.V[dst] = np.maximum(st.f32('v', dst), m).astype(np.float32).view(np.uint32)
+    return valu('v_max3_f32 %s, %s, |%s|, |%s|' % (vreg(dst), vreg(dst), vreg(a), vreg(b)), vr(dst) + vr(a) + vr(b), vr(dst), emu)
+
+
+def ds_max_u32(addr_v, data_v, off, tag=''):
+    """LDS[v[addr_v] + off] = max(LDS[...], v[data_v]) as unsigned (no return value; counts in lgkmcnt like a read)"""
+    text = 'ds_max_u32 %s, %s offset:%d' % (vreg(addr_v), vreg(data_v), off)
+
+    def emu(st):
+        addr = st.V[addr_v].astype(np.int64) + off
+        for l in range(64):
+            a0 = int(addr[l])
+            cur = st.lds[a0:a0 + 4].view(np.uint32)[0]
+            st.lds[a0:a0 + 4] = np.array([max(cur, st.V[data_v][l])], dtype=np.uint32).view(np.uint8)
+        st.pend_ds.append(('v', 0, np.zeros((0, 64), dtype=np.uint32)))
+    return Ins(text, 'ds', rd=vr(addr_v) + vr(data_v), emu=emu, tag=tag)
+
+
 def v_accr(vdst, asrc):
     def emu(st):
         st.V[vdst] = st.A[asrc]

@@ -122,6 +122,9 @@ unsigned char r2l_f32_to_e4m3(float v) {
     return sgn | (unsigned char)(((EE + 7) << 3) | (qn - 8));
 }
 
+#define R2L_GUARD_PERIOD_DEFAULT 8   // every 8th body launch runs the range-guard build (and the first after a weight load)
+#define R2L_CALIB_MAX_CALLS 8  // a measurement that only ever sees thin calls (< 1,024 rays) is closed after this many
+
 struct r2l_ctx {
     int H, W, n_block, use_residual, mode;
     double focal;
@@ -139,11 +142,20 @@ struct r2l_ctx {
     int fuse_tail = 1;                        // FP16_FP8 with the global skip: rgb written by the body kernel's fused tail
     int calib_pending = 0;                    // the next FP16_FP8 render derives them from its own head output (device side)
     int calib_started = 0;                    // maxima of earlier, smaller calls are in d_stats: the next measurement adds to them
+    int calib_calls = 0;                      // thin calls the open measurement has seen (closed after R2L_CALIB_MAX_CALLS)
+    // range tracking (r2l_get_range_status): d_range[0] = max h0 of EVERY ray since the last reset (head launch);
+    // d_gstats[2 n_block] = maxima of every operand set over every ray of the guarded body launches since the last reset
+    unsigned* d_range = nullptr;
+    unsigned* d_gstats = nullptr;
+    int guard_period = R2L_GUARD_PERIOD_DEFAULT;
+    long long n_body = 0, n_guarded = 0;      // FP16_FP8 body launches since the last reset / of them guarded
+    long long n_since_load = 0;               // ... since r2l_load_weights (the guard's phase)
+    hipStream_t last_stream = nullptr;        // stream of the newest render: the synchronous host copies wait for it
     float* d_wcal = nullptr;                  // fp32 W1^T | b1' | W2^T per block for the calibration kernel
     unsigned* d_stats = nullptr;
-    float* d_xa;                              // FP16_FP8: head output / body output of one launch slice
-    float* d_xb;
-    int x_tiles;                              // capacity of d_xa / d_xb in ray tiles
+    float* d_xa;                              // FP16_FP8: head output of one launch slice (1 KiB per ray)
+    float* d_xb;                              // body output: only the unfused form (no global skip, r2l_debug_set_fused_tail(0))
+    int x_tiles, xb_tiles;                    // capacity of d_xa / d_xb in ray tiles
     float* d_scratch;
     float* d_z;  // device copy of z
     bool timing;
@@ -154,7 +166,8 @@ struct r2l_ctx {
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
 static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_FP8; }
 #define R2L_N_MODES 3
-#define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head/body/tail launch triple (1 KiB of x per ray, twice)
+#define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head / body launch pair (1 KiB of h0 per ray)
+
 
 int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far_, int n_sample, int L,
                int width, int n_block, int use_residual, int precision_mode) {
@@ -190,7 +203,7 @@ int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far
     c->d_body = nullptr;
     c->body_bytes = c->aux_off = c->tail_off = 0;
     c->d_xa = c->d_xb = nullptr;
-    c->x_tiles = 0;
+    c->x_tiles = c->xb_tiles = 0;
     c->d_scratch = nullptr;
     c->d_z = nullptr;
     c->timing = false;
@@ -221,6 +234,8 @@ void r2l_destroy(r2l_ctx* c) {
     if (c->d_xb) (void)hipFree(c->d_xb);
     if (c->d_wcal) (void)hipFree(c->d_wcal);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_range) (void)hipFree(c->d_range);
+    if (c->d_gstats) (void)hipFree(c->d_gstats);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_z) (void)hipFree(c->d_z);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -240,6 +255,7 @@ static void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
 }
 
 static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img);
+static int ensure_x(r2l_ctx* c, int tiles, bool need_xb);
 static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
 static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out);
 
@@ -285,6 +301,22 @@ static int build_image(r2l_ctx* c, int mode) {
             if (eb == hipSuccess) eb = hipMemcpy(c->d_wcal, wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice);
             if (eb == hipSuccess) eb = hipMalloc((void**)&c->d_stats, (size_t)(2 * c->n_block + 1) * sizeof(unsigned));
             if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "calibration operands: %s", hipGetErrorString(eb));
+        }
+        // range tracking words; the h0 buffer of the context's own frame: nothing is allocated inside a render of <= H x W rays
+        if (!c->d_range) eb = hipMalloc((void**)&c->d_range, 4 * sizeof(unsigned));
+        if (eb == hipSuccess && c->d_gstats) {
+            (void)hipFree(c->d_gstats);
+            c->d_gstats = nullptr;
+        }
+        if (eb == hipSuccess) eb = hipMalloc((void**)&c->d_gstats, (size_t)(2 * c->n_block + 1) * sizeof(unsigned));
+        if (eb == hipSuccess) eb = hipMemset(c->d_range, 0, 4 * sizeof(unsigned));
+        if (eb == hipSuccess) eb = hipMemset(c->d_gstats, 0, (size_t)(2 * c->n_block + 1) * sizeof(unsigned));
+        if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "range tracking words: %s", hipGetErrorString(eb));
+        c->n_body = c->n_guarded = c->n_since_load = 0;
+        {
+            const long long frame_tiles = ((long long)c->H * c->W + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+            int rc = ensure_x(c, (int)(frame_tiles < R2L_SLICE_TILES ? frame_tiles : R2L_SLICE_TILES), false);
+            if (rc) return rc;
         }
     } else {
         pack_image_host(c, mode, img);
@@ -575,6 +607,7 @@ int r2l_load_weights(r2l_ctx* c, const float* const* tensors, int n_tensors) {
     c->act.assign((size_t)2 * c->n_block + 1, R2L_ACT_EXP);
     c->calib_pending = 1;   // the first FP16_FP8 render measures the activation ranges of these weights
     c->calib_started = 0;
+    c->calib_calls = 0;
     int rc = build_image(c, c->mode);
     if (rc) return rc;
     c->loaded = true;
@@ -587,8 +620,10 @@ int r2l_set_act_exponents(r2l_ctx* c, const int* exps, int n) {
     if (!exps) {            // back to self-calibration on the next render
         c->calib_pending = 1;
         c->calib_started = 0;
+        c->calib_calls = 0;
         return R2L_OK;
     }
+    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);   // renders in flight read the aux blocks
     if (n != 2 * c->n_block + 1) return r2l_set_error(R2L_EINVAL, "expected %d exponents, got %d", 2 * c->n_block + 1, n);
     for (int i = 0; i < n; ++i)
         if (exps[i] < R2L_ACT_EXP_MIN || exps[i] > R2L_ACT_EXP_MAX)
@@ -617,6 +652,7 @@ int r2l_get_act_exponents(r2l_ctx* c, int* out, int n) {
         for (int i = 0; i < n; ++i) out[i] = i < (int)c->act.size() ? c->act[i] : R2L_ACT_EXP;
         return R2L_OK;
     }
+    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);   // a calibration enqueued there writes the aux blocks
     for (int b = 0; b < c->n_block; ++b) {   // what the kernel reads (after a device-side calibration: only there)
         uint32_t v[4];
         hipError_t e = hipMemcpy(v, c->d_body + c->aux_off + (size_t)b * R2L_BODY_AUX_BYTES + R2L_BODY_AUX_ACT, sizeof v,
@@ -627,6 +663,73 @@ int r2l_get_act_exponents(r2l_ctx* c, int* out, int n) {
         if (b < c->n_block - 1) out[2 * b + 2] = (int)v[2] - 127;
     }
     out[2 * c->n_block] = out[0];   // the tail reads x itself; the slot holds the next tile's first input set
+    return R2L_OK;
+}
+
+// ---- range tracking ------------------------------------------------------------------------------------
+int r2l_set_guard_period(r2l_ctx* c, int period) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (period < 0) return r2l_set_error(R2L_EINVAL, "guard period %d < 0", period);
+    if (period > 0 && c->n_block > r2l_body_guard_max_blocks())
+        return r2l_set_error(R2L_EINVAL, "the range guard keeps 2 n_block rows of maxima in LDS: n_block <= %d", r2l_body_guard_max_blocks());
+    c->guard_period = period;
+    c->n_since_load = 0;       // the next launch is the first of the new phase: guarded when period > 0
+    return R2L_OK;
+}
+
+static int read_exponents(r2l_ctx* c, std::vector<int>& ex) {
+    ex.assign((size_t)2 * c->n_block + 1, R2L_ACT_EXP);
+    return c->n_block > 0 ? r2l_get_act_exponents(c, ex.data(), (int)ex.size()) : R2L_OK;
+}
+
+int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
+    if (!c || !out) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    memset(out, 0, sizeof *out);
+    out->worst_set = -1;
+    if (!c->loaded || !c->d_range || !c->d_gstats) return r2l_set_error(R2L_ESTATE, "r2l_get_range_status before r2l_load_weights in R2L_PREC_FP16_FP8");
+    std::vector<int> ex;
+    int rc = read_exponents(c, ex);      // synchronises the stream of the newest render
+    if (rc) return rc;
+    const int nset = 2 * c->n_block;
+    std::vector<unsigned> g((size_t)nset + 1);
+    unsigned r[4];
+    hipError_t e = hipMemcpy(r, c->d_range, sizeof r, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(g.data(), c->d_gstats, g.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy range words: %s", hipGetErrorString(e));
+    auto f = [](unsigned u) { float v; memcpy(&v, &u, 4); return v; };
+    const float top = 28.0f;           // largest bf6 (e3m2) magnitude; the calibration aims at <= 16
+    out->h0_max = f(r[0]) / c->act_scale;
+    out->h0_fill = c->n_block > 0 ? ldexpf(f(r[0]), -ex[0]) / top : 0.0f;
+    for (int j = 0; j < nset; ++j) {
+        const float fill = ldexpf(f(g[j]), -ex[j]) / top;
+        if (fill > out->worst_fill) {
+            out->worst_fill = fill;
+            out->worst_set = j;
+        }
+    }
+    const float m = out->h0_fill > out->worst_fill ? out->h0_fill : out->worst_fill;
+    out->saturated = m >= 1.0f;
+    out->beyond_calibration = m > 16.0f / top;
+    out->launches = c->n_body;
+    out->guarded_launches = c->n_guarded;
+    if (reset) {
+        e = hipMemset(c->d_range, 0, sizeof r);
+        if (e == hipSuccess) e = hipMemset(c->d_gstats, 0, g.size() * sizeof(unsigned));
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemset range words: %s", hipGetErrorString(e));
+        c->n_body = c->n_guarded = 0;
+    }
+    return R2L_OK;
+}
+
+int r2l_recalibrate(r2l_ctx* c, void* stream) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (!c->loaded || !c->d_gstats || c->n_block < 1)
+        return r2l_set_error(R2L_ESTATE, "r2l_recalibrate needs loaded weights, R2L_PREC_FP16_FP8 and n_block >= 1");
+    if (c->n_guarded < 1) return r2l_set_error(R2L_ESTATE, "r2l_recalibrate: no guarded launch since the last reset of the range words");
+    hipError_t e = r2l_launch_recalibrate(c->d_gstats, c->d_range, c->n_block, c->d_body + c->aux_off, (hipStream_t)stream);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "recalibration launch: %s", hipGetErrorString(e));
+    c->calib_pending = 0;
+    c->last_stream = (hipStream_t)stream;
     return R2L_OK;
 }
 
@@ -717,6 +820,8 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
     pb.n_rays = 0;
     pb.tile_begin = 0;
+    pb.gstats = c->guard_period == 1 && c->n_block <= r2l_body_guard_max_blocks() ? c->d_gstats : nullptr;
+    c->last_stream = (hipStream_t)stream;
     hipError_t e = r2l_launch_body(pb, n_tiles < c->n_cu ? n_tiles : c->n_cu, (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
     return R2L_OK;
@@ -770,27 +875,35 @@ static int timing_events(r2l_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
     return R2L_OK;
 }
 
-// FP16_FP8: head launch -> hand-scheduled body launch -> tail launch per slice of <= R2L_SLICE_TILES ray tiles;
-// the slices reuse two library-owned x buffers (1 KiB per ray each), stream-ordered.  The timing events bracket
-// the body launch (the dominant kernel).
-static int ensure_x(r2l_ctx* c, int tiles) {
-    if (tiles <= c->x_tiles) return R2L_OK;
-    if (c->d_xa) (void)hipFree(c->d_xa);
-    if (c->d_xb) (void)hipFree(c->d_xb);
-    c->d_xa = c->d_xb = nullptr;
-    c->x_tiles = 0;
-    const size_t bytes = (size_t)tiles * R2L_TILE_RAYS * R2L_WIDTH * sizeof(float);
-    hipError_t e = hipMalloc((void**)&c->d_xa, bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_xb, bytes);
-    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc x buffers (%zu B each): %s", bytes, hipGetErrorString(e));
-    c->x_tiles = tiles;
-    return R2L_OK;
+// FP16_FP8: head launch -> hand-scheduled body launch (which ends every ray tile with the tail layer when the network has
+// the global skip; else -> tail launch) per slice of <= R2L_SLICE_TILES ray tiles; the slices reuse the library-owned h0
+// buffer (1 KiB per ray), stream-ordered.  The timing events bracket the body launch (the dominant kernel).
+static int ensure_x(r2l_ctx* c, int tiles, bool need_xb) {
+    // d_xa is sized for the context's frame at r2l_load_weights; only a call with more rays than H x W (r2l_render_rays,
+    // several poses) grows it -- hipFree synchronises the device, so such a call is not stream-ordered the first time.
+    // d_xb exists only for the unfused form (networks without the global skip; r2l_debug_set_fused_tail(0)).
+    auto grow = [&](float** buf, int* cap) -> int {
+        if (tiles <= *cap) return R2L_OK;
+        if (*buf) (void)hipFree(*buf);
+        *buf = nullptr;
+        *cap = 0;
+        const size_t bytes = (size_t)tiles * R2L_TILE_RAYS * R2L_WIDTH * sizeof(float);
+        hipError_t e = hipMalloc((void**)buf, bytes);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMalloc x buffer (%zu B): %s", bytes, hipGetErrorString(e));
+        *cap = tiles;
+        return R2L_OK;
+    };
+    int rc = grow(&c->d_xa, &c->x_tiles);
+    if (rc == R2L_OK && need_xb) rc = grow(&c->d_xb, &c->xb_tiles);
+    return rc;
 }
 
 static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
     const int slice = p.n_tiles < R2L_SLICE_TILES ? p.n_tiles : R2L_SLICE_TILES;
-    int rc = ensure_x(c, slice);
+    const bool fused_form = c->n_block > 0 && c->use_residual && c->fuse_tail;
+    int rc = ensure_x(c, slice, c->n_block > 0 && !fused_form);
     if (rc) return rc;
+    c->last_stream = s;
     for (int t0 = 0; t0 < p.n_tiles; t0 += R2L_SLICE_TILES) {
         const int nt = p.n_tiles - t0 < R2L_SLICE_TILES ? p.n_tiles - t0 : R2L_SLICE_TILES;
         const int grid = nt < c->n_cu ? nt : c->n_cu;
@@ -799,6 +912,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         ph.xbuf = c->d_xa;
         ph.tile_begin = t0;
         ph.n_tiles = nt;
+        ph.range = c->d_range;     // every ray's h0 enters the running maximum (r2l_get_range_status)
         hipError_t e = r2l_launch_head(ph, grid, s);
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
         const float* body_out = c->d_xa;
@@ -810,7 +924,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             e = r2l_launch_calib(c->d_xa, c->d_wcal, c->n_block, nt, c->act_scale, c->d_stats, c->d_body + c->aux_off,
                                  c->calib_started, s);
             c->calib_started = 1;
-            if (nt >= R2L_CALIB_TILES) c->calib_pending = 0;
+            if (nt >= R2L_CALIB_TILES || ++c->calib_calls >= R2L_CALIB_MAX_CALLS) c->calib_pending = 0;
             if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l calibration launch: %s", hipGetErrorString(e));
         }
         if (c->n_block > 0) {
@@ -827,6 +941,13 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
             pb.n_rays = p.n_rays;
             pb.tile_begin = t0;
+            // range guard: the first launch after a weight load, then every guard_period-th (r2l_set_guard_period)
+            const bool guard = c->guard_period > 0 && c->n_block <= r2l_body_guard_max_blocks() &&
+                               c->n_since_load % c->guard_period == 0;
+            pb.gstats = guard ? c->d_gstats : nullptr;
+            ++c->n_since_load;
+            ++c->n_body;
+            c->n_guarded += guard ? 1 : 0;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (c->timing) {
                 rc = timing_events(c, &e0, &e1);

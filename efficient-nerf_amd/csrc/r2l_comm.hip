@@ -49,7 +49,11 @@ void bind_rccl() {
         h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         if (h) loaded = names[i];
     }
-    if (!h) return;
+    if (!h) {
+        const char* why = dlerror();     // captured here: a later dlerror() returns NULL once the message was consumed
+        g_api.where = why ? why : "dlopen failed without a message";
+        return;
+    }
     g_api.where = loaded;
 #define BIND(f) g_api.f = reinterpret_cast<decltype(g_api.f)>(dlsym(h, "nccl" #f))
     BIND(GetUniqueId); BIND(CommInitRank); BIND(CommDestroy); BIND(AllGather); BIND(Broadcast); BIND(GroupStart); BIND(GroupEnd);
@@ -57,11 +61,12 @@ void bind_rccl() {
 #undef BIND
     g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllGather && g_api.Broadcast &&
                g_api.GroupStart && g_api.GroupEnd && g_api.GetErrorString;
+    if (!g_api.ok) g_api.where = loaded + " lacks one of the nccl* entry points this library binds";
 }
 
 int need_rccl() {
     std::call_once(g_once, bind_rccl);
-    if (!g_api.ok) return r2l_set_error(R2L_ENOGPU, "RCCL is not available (librccl.so could not be bound: %s)", dlerror());
+    if (!g_api.ok) return r2l_set_error(R2L_ENOGPU, "RCCL is not available (librccl.so could not be bound: %s)", g_api.where.c_str());
     return R2L_OK;
 }
 }  // namespace
@@ -89,8 +94,10 @@ int r2l_comm_unique_id(char* id_out128) {
 }
 
 int r2l_comm_create(r2l_comm** out, int rank, int world, const char* id128) {
-    if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return r2l_set_error(R2L_EINVAL, "bad argument to r2l_comm_create");
+    if (!out) return r2l_set_error(R2L_EINVAL, "r2l_comm_create: out is NULL");
     *out = nullptr;
+    if (!id128) return r2l_set_error(R2L_EINVAL, "r2l_comm_create: the 128-byte id is NULL (rank 0 makes it with r2l_comm_unique_id)");
+    if (world < 1 || rank < 0 || rank >= world) return r2l_set_error(R2L_EINVAL, "r2l_comm_create: rank %d is not in [0, world = %d)", rank, world);
     int rc = need_rccl();
     if (rc) return rc;
     ncclUniqueId id;
@@ -120,8 +127,10 @@ static void row_shard(int H, int rank, int world, int* r0, int* r1) {
 
 int r2l_gather_image(r2l_comm* c, const float* local_rows_dev, float* full_image_dev, int n_frames, int H, int row_floats,
                      void* stream) {
-    if (!c || !local_rows_dev || !full_image_dev || n_frames < 1 || H < 1 || row_floats < 1)
-        return r2l_set_error(R2L_EINVAL, "bad argument to r2l_gather_image");
+    if (!c) return r2l_set_error(R2L_EINVAL, "r2l_gather_image: comm is NULL");
+    if (!local_rows_dev || !full_image_dev) return r2l_set_error(R2L_EINVAL, "r2l_gather_image: NULL device pointer");
+    if (n_frames < 1 || H < 1 || row_floats < 1)
+        return r2l_set_error(R2L_EINVAL, "r2l_gather_image: n_frames=%d H=%d row_floats=%d must all be >= 1", n_frames, H, row_floats);
     if (H < c->world) return r2l_set_error(R2L_EINVAL, "H=%d rows cannot be sharded over %d ranks", H, c->world);
     hipStream_t s = (hipStream_t)stream;
     int r0, r1;
@@ -130,20 +139,28 @@ int r2l_gather_image(r2l_comm* c, const float* local_rows_dev, float* full_image
     // ONE grouped launch.  Frame f of the result is full + f*frame; rank r's rows land at its row offset, so the
     // frames come out in [frame][row] order with no copy behind the collective.
     NCHK(g_api.GroupStart(), "ncclGroupStart");
+    // an error inside the bracket must still close it: an open group would silently queue every later collective of the
+    // thread, torch.distributed's included
+    ncclResult_t bad = ncclSuccess;
+    const char* what = "";
     if (H % c->world == 0) {
-        for (int f = 0; f < n_frames; ++f)
-            NCHK(g_api.AllGather(local_rows_dev + (size_t)f * mine, full_image_dev + (size_t)f * frame, mine, ncclFloat, c->comm, s),
-                 "ncclAllGather");
+        for (int f = 0; f < n_frames && bad == ncclSuccess; ++f) {
+            bad = g_api.AllGather(local_rows_dev + (size_t)f * mine, full_image_dev + (size_t)f * frame, mine, ncclFloat, c->comm, s);
+            what = "ncclAllGather";
+        }
     } else {  // ragged shards: every rank broadcasts its rows into place
-        for (int f = 0; f < n_frames; ++f)
-            for (int r = 0; r < c->world; ++r) {
+        for (int f = 0; f < n_frames && bad == ncclSuccess; ++f)
+            for (int r = 0; r < c->world && bad == ncclSuccess; ++r) {
                 int a, b;
                 row_shard(H, r, c->world, &a, &b);
                 float* dst = full_image_dev + (size_t)f * frame + (size_t)a * row_floats;
                 const float* src = r == c->rank ? local_rows_dev + (size_t)f * mine : dst;
-                NCHK(g_api.Broadcast(src, dst, (size_t)(b - a) * row_floats, ncclFloat, r, c->comm, s), "ncclBroadcast");
+                bad = g_api.Broadcast(src, dst, (size_t)(b - a) * row_floats, ncclFloat, r, c->comm, s);
+                what = "ncclBroadcast";
             }
     }
-    NCHK(g_api.GroupEnd(), "ncclGroupEnd");
+    const ncclResult_t ended = g_api.GroupEnd();
+    if (bad != ncclSuccess) return r2l_set_error(R2L_EHIP, "%s: %s", what, g_api.GetErrorString(bad));
+    if (ended != ncclSuccess) return r2l_set_error(R2L_EHIP, "ncclGroupEnd: %s", g_api.GetErrorString(ended));
     return R2L_OK;
 }

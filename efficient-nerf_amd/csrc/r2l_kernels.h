@@ -17,6 +17,7 @@ struct R2LParams {
     float focal, half_w, half_h, act_scale;
     float neg1;  // -1.0f (kept opaque to the compiler: selects v_fma_mix for the hi/lo residuals)
     int W, pix_begin, rays_per_pose, n_rays, n_tiles, n_block, use_residual, chunks_per_tile;
+    unsigned* range;       // head launch: [0] <- atomicMax of the f32 bits of max h0 (act_scale domain) over its rays; nullable
 };
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*
@@ -33,6 +34,9 @@ struct R2LBodyParams {
     float* rgb;
     const float* tail;  // 4 KiB: [3, 256] tail weight / act_scale | 2 x (3 folded biases, 0)
     int n_rays, tile_begin;
+    // range guard: 2 n_block maxima (f32 bits, act_scale domain) of the operand sets IN_0, H_0, IN_1, ... over every ray of
+    // the launch; nullptr = the plain kernel (r2l_body.hip: r2l_body_guard_kernel)
+    unsigned* gstats;
 };
 struct R2LTailParams {
     const float* xa;    // head output (global skip), may be nullptr
@@ -49,7 +53,10 @@ hipError_t r2l_launch_tail(const R2LTailParams& p, hipStream_t stream);
 // accumulate != 0: keep the maxima already in stats (earlier calls with fewer tiles than the sample)
 hipError_t r2l_launch_calib(const float* xa, const float* wcal, int n_block, int n_tiles, float act_scale, unsigned* stats,
                             char* aux, int accumulate, hipStream_t stream);
+// exponents from the range guard's maxima (gstats: 2 n_block sets, act_scale domain) and the head's h0 maximum (range[0])
+hipError_t r2l_launch_recalibrate(const unsigned* gstats, const unsigned* range, int n_block, char* aux, hipStream_t stream);
 int r2l_body_lds_bytes();
+int r2l_body_guard_max_blocks();   // largest n_block whose 2 n_block maxima rows fit the LDS beside the ring
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,
                                    hipStream_t stream);
 hipError_t r2l_launch_embed(const float* x, long long total, int L, float* emb_out,

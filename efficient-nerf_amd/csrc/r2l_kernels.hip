@@ -482,6 +482,8 @@ __global__ __launch_bounds__(256, 1) void r2l_head_kernel(R2LParams p) {
     const __attribute__((address_space(4))) float* zc = (const __attribute__((address_space(4))) float*)p.z;
     const float z0 = zc[0], z1 = zc[1], z2 = zc[2], z3 = zc[3], z4 = zc[4], z5 = zc[5], z6 = zc[6], z7 = zc[7], z8 = zc[8],
                 z9 = zc[9], z10 = zc[10], z11 = zc[11], z12 = zc[12], z13 = zc[13], z14 = zc[14], z15 = zc[15];
+    // running maximum of h0 over this lane's rays of the launch: an in/out operand of the generated block, which names it v210
+    register float hmax asm("v210") = 0.0f;
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         // lane 32 h + r serves ray r of the wave (p.tile_begin: this launch is a slice of the call); rays past the end
         // repeat the last one (the tail launch masks their stores)
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void r2l_head_kernel(R2LParams p) {
         float* xout = p.xbuf + ((size_t)(tile * R2L_WAVES + wave) * 32) * 256;
         asm volatile(
 #include "r2l_head_asm.inc"
-            :
+            : [hmax] "+v"(hmax)
             : [wimg] "s"(p.wimg), [wave] "s"(wave), [xout] "s"(xout), [o0] "v"(r.ox), [o1] "v"(r.oy), [o2] "v"(r.oz),
               [d0] "v"(r.dx), [d1] "v"(r.dy), [d2] "v"(r.dz), [z0] "s"(z0), [z1] "s"(z1), [z2] "s"(z2), [z3] "s"(z3),
               [z4] "s"(z4), [z5] "s"(z5), [z6] "s"(z6), [z7] "s"(z7), [z8] "s"(z8), [z9] "s"(z9), [z10] "s"(z10),
@@ -500,6 +502,12 @@ __global__ __launch_bounds__(256, 1) void r2l_head_kernel(R2LParams p) {
         );
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's refill of the ring and its stores
+    if (p.range != nullptr) {   // every ray of the launch: rays past the end repeat the last one, so they add nothing foreign
+        float m = hmax;
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+        if (lane == 0 && m > 0.0f) atomicMax(p.range, __float_as_uint(m));
+    }
 }
 
 hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream) {

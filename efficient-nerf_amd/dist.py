@@ -55,24 +55,26 @@ class RowGather:
     pre-allocated buffer: no copy follows the collective.  One instance per (process, device); the 128-byte RCCL id
     travels from rank 0 over the torch.distributed process group (host side, once)."""
 
-    def __init__(self, rank, world, device):
+    def __init__(self, rank, world, device, group=None):
         import ctypes as C
         from . import _lib
         self.rank, self.world, self.device = rank, world, torch.device(device)
         idbuf = (C.c_char * 128)()
         # every step below is agreed on by all ranks before anyone acts on it: a rank that failed alone would otherwise
-        # fall back to torch.distributed while its peers wait inside the RCCL bootstrap
+        # fall back to torch.distributed while its peers wait inside the RCCL bootstrap.  Pre-flight: can every rank bind
+        # RCCL at all (r2l_comm_unique_id binds it; only rank 0's id is used)?
         err = ''
-        if rank == 0:
-            try:
-                _lib.check(_lib.lib().r2l_comm_unique_id(C.cast(idbuf, C.c_void_p)))
-            except Exception as e:
-                err = str(e)
+        try:
+            _lib.check(_lib.lib().r2l_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+        except Exception as e:
+            err = str(e) or repr(e)
         if world > 1:
-            obj = [(bytes(idbuf), err)]
-            dist.broadcast_object_list(obj, src=0)
-            raw, err = obj[0]
-            idbuf = (C.c_char * 128).from_buffer_copy(raw)
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+            err = next((e for e in errs if e), '')
+            obj = [bytes(idbuf)]
+            dist.broadcast_object_list(obj, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = (C.c_char * 128).from_buffer_copy(obj[0])
         if err:
             raise RuntimeError(err)
         self._comm = C.c_void_p()
@@ -83,26 +85,30 @@ class RowGather:
             err = str(e) or repr(e)
         if world > 1:
             errs = [None] * world
-            dist.all_gather_object(errs, err)
+            dist.all_gather_object(errs, err, group=group)
             err = next((e for e in errs if e), '')
         if err:
             self.close()
             raise RuntimeError(err)
         self._out = None
 
-    def gather(self, local, H, W):
-        """local [F, rows_local*W, C] f32 on the device -> [F, H*W, C] (a view of the instance's buffer: consume it
-        before the next call)."""
+    def gather(self, local, H, W, out=None):
+        """local [F, rows_local*W, C] f32 on the device -> [F, H*W, C]: `out` when given (a contiguous device tensor the
+        collective writes straight into), else the instance's own buffer, which the NEXT call overwrites -- consume or
+        copy it first (frontend.render_path gathers into its frame stack)."""
         from . import _lib
         F, _, Cc = local.shape
         r0, r1 = row_shard(H, self.rank, self.world)
         assert local.shape[1] == (r1 - r0) * W and local.dtype == torch.float32 and local.is_cuda, local.shape
-        if self._out is None or self._out.shape != (F, H * W, Cc):
-            self._out = torch.empty((F, H * W, Cc), dtype=torch.float32, device=local.device)
+        if out is None:
+            if self._out is None or self._out.shape != (F, H * W, Cc):
+                self._out = torch.empty((F, H * W, Cc), dtype=torch.float32, device=local.device)
+            out = self._out
+        assert out.numel() == F * H * W * Cc and out.is_contiguous() and out.dtype == torch.float32 and out.device == local.device
         with torch.cuda.device(local.device):
-            _lib.check(_lib.lib().r2l_gather_image(self._comm, _lib.dptr(local.contiguous()), _lib.dptr(self._out), F, H, W * Cc,
+            _lib.check(_lib.lib().r2l_gather_image(self._comm, _lib.dptr(local.contiguous()), _lib.dptr(out), F, H, W * Cc,
                                                    _lib.current_stream()))
-        return self._out
+        return out.view(F, H * W, Cc)
 
     def close(self):
         try:
@@ -127,28 +133,42 @@ def gather_backend(device_index, world):
     return _gather_used.get((device_index, world), 'none')
 
 
-def gather_rows(local, H, W, world, group=None, force_collective=False):
+def require_rccl():
+    """R2L_REQUIRE_RCCL=1: the library's own RCCL collective or an error -- never the torch.distributed stand-in
+    (scaling runs: a record must say which implementation it timed, and a run that asked for this one must not time
+    another)"""
+    return os.environ.get('R2L_REQUIRE_RCCL', '0') not in ('', '0')
+
+
+def gather_rows(local, H, W, world, group=None, force_collective=False, out=None):
     """local: [F, rows_local*W, C] slab of F frames rendered by this rank (its row shard).
-    Returns [F, H*W, C] on every rank.  Device tensors under the nccl backend (or world 1 with force_collective:
-    the GPU test of the collective) go through RowGather (RCCL, frame-major output, no copy); the gloo path (CPU
-    tests, rehearsals) gathers once with torch.distributed and reorders on the host side."""
+    Returns [F, H*W, C] on every rank (`out`, when given: the result is written there).  Device tensors under the nccl
+    backend (or world 1 with force_collective: the GPU test of the collective) go through RowGather (RCCL, frame-major
+    output, no copy); the gloo path (CPU tests, rehearsals) gathers once with torch.distributed and reorders on the
+    host side."""
     if world == 1 and not force_collective:
+        if out is not None:
+            out.view(local.shape).copy_(local)
+            return out.view(local.shape)
         return local
     use_rccl = local.is_cuda and (world == 1 or dist.get_backend(group) == 'nccl')
     if use_rccl:
         key = (local.device.index, world)
         if key not in _row_gather:
             try:
-                _row_gather[key] = RowGather(dist.get_rank(group) if world > 1 else 0, world, local.device)
+                _row_gather[key] = RowGather(dist.get_rank(group) if world > 1 else 0, world, local.device, group)
             except Exception as e:  # e.g. RCCL cannot be bound by the library: the same collective through torch.distributed
-                if world == 1:
+                if world == 1 or require_rccl():
                     raise
                 import sys
                 print(f'[dist] r2l_gather_image unavailable ({e}); assembling with torch.distributed (RCCL) instead', file=sys.stderr)
                 _row_gather[key] = None
         if _row_gather[key] is not None:
             _gather_used[key] = 'r2l_gather_image (RCCL, C-ABI)'
-            return _row_gather[key].gather(local, H, W)
+            return _row_gather[key].gather(local, H, W, out=out)
+    if require_rccl() and local.is_cuda:
+        raise RuntimeError('R2L_REQUIRE_RCCL=1 but the process group is %s: r2l_gather_image needs the nccl backend'
+                           % dist.get_backend(group))
     F, _, Cc = local.shape
     rank = dist.get_rank(group)
     _gather_used[(local.device.index, world)] = 'torch.distributed all_gather (%s)' % (
@@ -159,10 +179,15 @@ def gather_rows(local, H, W, world, group=None, force_collective=False):
     if local.shape[1] != mx:
         pad = torch.zeros((F, mx - local.shape[1], Cc), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 1)
-    out = all_gather_cat(local, group).view(world, F, mx, Cc)
+    got = all_gather_cat(local, group).view(world, F, mx, Cc)
     if all(s == mx for s in sizes):
-        return out.permute(1, 0, 2, 3).reshape(F, world * mx, Cc)
-    return torch.cat([out[r, :, :sizes[r]] for r in range(world)], 1)
+        res = got.permute(1, 0, 2, 3).reshape(F, world * mx, Cc)
+    else:
+        res = torch.cat([got[r, :, :sizes[r]] for r in range(world)], 1)
+    if out is not None:
+        out.view(res.shape).copy_(res)
+        return out.view(res.shape)
+    return res
 
 
 def all_gather_cat(t, group=None):
@@ -196,6 +221,24 @@ def agree_act_exponents(eng, group=None):
     ex = [int(v) for v in ex.cpu()]
     eng.set_act_exponents(ex)
     return ex
+
+
+def check_ranges(eng, log=None, group=None):
+    """R2LEngine.check_ranges for row-sharded runs: a rank whose rows left the calibrated bf6 range makes EVERY rank raise
+    its exponents to the common maximum (and fall back together when `--precision auto`'s limit is exceeded), so the rows
+    of one assembled frame never come from different arithmetic.  Returns None or the precision to render the frame
+    again with.  One small all-reduce per call; plain eng.check_ranges for one rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return eng.check_ranges(log=log)
+
+    def any_rank(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend(group) == 'nccl':
+            t = t.to(eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return bool(t.item())
+
+    return eng.check_ranges(log=log, any_rank=any_rank, agree=lambda e: agree_act_exponents(e, group))
 
 
 def barrier_sync():

@@ -70,9 +70,10 @@ FLAGS = [
     ('--N_rand', dict(type=int, default=4096)), ('--precrop_iters', dict(type=int, default=0)),
     ('--precrop_frac', dict(type=float, default=.5)), ('--no_reload', dict(action=_BOOL)),
     # this front-end's own knobs
-    # auto: fp16_fp8 (fp16 MFMA pass + bf6 correction terms, 1.7x the speed) when the checkpoint's own activation ranges keep
-    # it inside the 1e-4 rgb contract, fp16x3 otherwise (R2LEngine.choose_precision); the teacher takes fp16_fp8
-    ('--precision', dict(type=str, default='fp16x3', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'auto'])),
+    # auto (default): fp16_fp8 (fp16 MFMA pass + bf6 correction terms, 1.7x the speed) when the checkpoint's own activation
+    # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
+    # contract, fp16x3 otherwise (R2LEngine.choose_precision / check_ranges); the teacher takes fp16_fp8
+    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
 ]
@@ -333,7 +334,8 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
                 raise R2LError('--precision auto needs a pose or rays to measure the activation ranges with')
             name, top = eng.choose_precision(c2w=probe_pose, rays=probe_rays)
             if log:
-                log(f'[precision] auto: activation exponents up to {top} (fp16_fp8 up to {eng.AUTO_MAX_EXP}) -> {name}')
+                log(f'[precision] auto: activation exponents of every ray of the first frame up to {top} '
+                    f'(fp16_fp8 up to {eng.AUTO_MAX_EXP}) -> {name}')
         return 'R2L', eng
     if args.model_name == 'nerf':
         if not args.use_viewdirs or args.N_importance <= 0:
@@ -365,8 +367,11 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     rank = tdist.get_rank() if tdist.is_initialized() else 0
     r0, r1 = D.row_shard(H, rank, world)
     from .metrics import ssim_hwc
-    rgbs, psnrs, ssims = [], [], []
+    psnrs, ssims = [], []
     n_frames = len(given_rays[0]) if given_rays is not None else len(render_poses)
+    # the frame stack is allocated once and every frame is gathered straight into its slot: the collective's own buffer is
+    # reused from call to call (dist.RowGather.gather), so keeping views of it would keep N copies of the LAST frame
+    rgbs = torch.empty((n_frames, H, W, 3), dtype=torch.float32, device=eng.device)
 
     def render_local(i):
         if given_rays is not None:
@@ -386,11 +391,16 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
         torch.cuda.synchronize()
         t0 = time.time()
         local = render_local(i)
-        rgb = D.gather_rows(local[None], H, W, world)[0].view(H, W, 3)
+        if kind == 'R2L':
+            # fp16_fp8: did this frame's rays stay inside the range the bf6 exponents were measured for?  If not, the
+            # exponents are raised (`auto`: or the context falls back to fp16x3) and the frame is rendered again
+            again = D.check_ranges(eng, log=log if rank == 0 else None)
+            if again is not None:
+                local = render_local(i)
+        rgb = D.gather_rows(local[None], H, W, world, out=rgbs[i])[0].view(H, W, 3)
         torch.cuda.synchronize()
         if rank == 0:
             log(f'[#{i}] frame, rendering done, time for this frame: {time.time() - t0:.4f}s')
-        rgbs.append(rgb)
         if gt_imgs is not None:
             gt = gt_imgs[i].to(rgb.device)
             psnrs.append(mse2psnr(torch.mean((rgb - gt) ** 2)))
@@ -399,7 +409,6 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
             write_png(os.path.join(savedir, f'{i:03d}.png'), to8b(rgb.cpu().numpy()))
             if gt_imgs is not None:  # main.py:340-341
                 write_png(os.path.join(savedir, f'{i:03d}_gt.png'), to8b(gt_imgs[i].cpu().numpy()))
-    rgbs = torch.stack(rgbs, 0)
     misc = {}
     if gt_imgs is not None:
         misc['test_psnr'] = mse2psnr(torch.mean((rgbs - gt_imgs.to(rgbs.device)) ** 2))

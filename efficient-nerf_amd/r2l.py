@@ -186,40 +186,107 @@ class R2LEngine:
                 check(lib().r2l_set_act_exponents(self._ctx, arr, len(exps)))
         return self
 
+    # -- range tracking (include/r2l_hip.h: r2l_range_status) ----------------------------------
+    def set_guard_period(self, period):
+        """0: never run the range-guard build of the body kernel; 1: every launch; k: the first launch and every k-th"""
+        check(lib().r2l_set_guard_period(self._ctx, int(period)))
+        self._guard_period = int(period)
+        return self
+
+    def range_status(self, reset=False):
+        """dict of r2l_range_status: how far the values rendered since the last reset filled the bf6 scales in use
+        (synchronises)"""
+        st = _lib.RangeStatus()
+        with torch.cuda.device(self.device):
+            check(lib().r2l_get_range_status(self._ctx, C.byref(st), int(bool(reset))))
+        return st.as_dict()
+
+    def recalibrate(self):
+        """exponents from the maxima the guarded launches (and every head launch) collected since the last reset"""
+        with torch.cuda.device(self.device):
+            check(lib().r2l_recalibrate(self._ctx, current_stream()))
+        return self
+
+    def calibrate_on(self, c2w=None, rays=None):
+        """Measure the activation exponents on EVERY ray of a whole frame (pose `c2w`) or of the given rays
+        (rays_o, rays_d): one range-guarded render (its own 1,024-ray sample gives provisional exponents, as any first
+        call), then the exponents the full set of rays asks for.  Returns the exponents (synchronises)."""
+        self.set_act_exponents(None)
+        self.range_status(reset=True)
+        period = self._guard_period
+        self.set_guard_period(1)
+        if rays is not None:
+            self.render_rays(rays[0].contiguous().to(self.device, torch.float32), rays[1].contiguous().to(self.device, torch.float32))
+        elif c2w is not None:
+            self.render(c2w)
+        else:
+            raise R2LError('calibrate_on needs a pose or rays')
+        self.recalibrate()
+        self.set_guard_period(period)
+        ex = self.act_exponents()
+        self.range_status(reset=True)
+        return ex
+
+    _guard_period = 8
+
     #: largest activation exponent (|a| <= 2^E) at which fp16_fp8 stays inside the 1e-4 rgb contract with margin: W256D88
-    #: networks measured at E = 3 / 4 / 5 differ from fp16x3 by 3-6e-5 / 6e-5-1.0e-4 / 1.5-3e-4 (tools/range_sweep.py,
+    #: networks measured at E = 3 / 4 / 5 differ from fp16x3 by 3-6e-5 / 6e-5-1.4e-4 / 1.5-3e-4 (tools/range_sweep.py,
     #: profiles/r02_range_sweep.txt)
     AUTO_MAX_EXP = 3
 
     def choose_precision(self, c2w=None, rays=None, max_exp=None):
         """`--precision auto`: fp16_fp8 where the network's own activation ranges allow it, fp16x3 otherwise.  The error of
         the bf6 correction terms is relative to the residual stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so
-        the choice needs the ranges of THESE weights: a probe render (a band of >= 1,024 rays through the image centre of
-        pose `c2w`, or the middle 4,096 of the given `rays` = (rays_o, rays_d)) lets the library measure its activation
-        exponents; above `max_exp` the context is switched to fp16x3.  Synchronous (reads the exponents back), once per
-        weight load.  Returns (name of the chosen precision, largest exponent)."""
+        the choice needs the ranges of THESE weights: `calibrate_on` measures them on every ray of the frame of pose
+        `c2w` (or of the given `rays` = (rays_o, rays_d)); above `max_exp` the context is switched to fp16x3.
+        What is rendered afterwards stays watched (range_status / `check_ranges`).  Synchronous, once per weight load.
+        Returns (name of the chosen precision, largest exponent)."""
         max_exp = self.AUTO_MAX_EXP if max_exp is None else int(max_exp)
         self.set_precision(PREC_FP16_FP8)
         if self.n_block == 0:
             return 'fp16_fp8', 0
-        self.set_act_exponents(None)
-        if rays is not None:
-            ro, rd = rays
-            n = min(4096, ro.shape[0])
-            s0 = (ro.shape[0] - n) // 2          # the middle of the set: image centre when the rays are a frame
-            self.render_rays(ro[s0:s0 + n].contiguous().to(self.device, torch.float32),
-                             rd[s0:s0 + n].contiguous().to(self.device, torch.float32))
-        else:
-            if c2w is None:
-                raise R2LError('choose_precision needs a pose or rays to probe with')
-            rows = min(self.H, -(-1024 // self.W))
-            r0 = max(0, (self.H - rows) // 2)
-            self.render(c2w, rows=(r0, r0 + rows))
-        top = max(self.act_exponents())
+        top = max(self.calibrate_on(c2w=c2w, rays=rays))
+        self._auto_max_exp = max_exp
         if top > max_exp:
             self.set_precision(PREC_FP16X3)
             return 'fp16x3', top
         return 'fp16_fp8', top
+
+    def check_ranges(self, log=None, any_rank=None, agree=None):
+        """After a render in fp16_fp8: did the values stay inside the range the exponents were chosen for?  Returns
+        None when they did.  Otherwise the exponents are raised to what was seen (recalibrate), the precision is
+        switched to fp16x3 when `choose_precision`'s limit is exceeded, and the name of the precision to render the
+        frame AGAIN with is returned (an explicit fp16_fp8 context only warns and keeps its mode).  Synchronises.
+        Row-sharded runs (dist.check_ranges) pass `any_rank` (bool -> True when any rank says so) and `agree` (makes the
+        exponents the element-wise maximum over the ranks), so that every rank takes the same decision."""
+        if self.precision != PREC_FP16_FP8 or self.n_block == 0:
+            return None
+        st = self.range_status()
+        beyond = bool(st['beyond_calibration'])
+        if any_rank is not None:
+            beyond = any_rank(beyond)
+        if not beyond:
+            return None
+        limit = getattr(self, '_auto_max_exp', None)
+        if st['guarded_launches'] > 0 and st['beyond_calibration']:
+            self.recalibrate()
+        elif any_rank is None:   # only the head's running maximum exists: raise the exponents with the next guarded launch
+            self.set_guard_period(self._guard_period)
+        if agree is not None:
+            agree(self)
+        top = max(self.act_exponents()) if (st['guarded_launches'] > 0 or agree is not None) else None
+        self.range_status(reset=True)
+        msg = ('[precision] activations left the calibrated bf6 range (fill %.2f of set %d, h0 fill %.2f%s)' %
+               (st['worst_fill'], st['worst_set'], st['h0_fill'], ', values were clamped' if st['saturated'] else ''))
+        if limit is not None and top is not None and top > limit:
+            self.set_precision(PREC_FP16X3)
+            if log:
+                log(msg + f': exponents now up to {top} > {limit} -> fp16x3')
+            return 'fp16x3'
+        if log:
+            log(msg + (f': exponents raised (up to {top})' if top is not None else ': next launch range-guarded') +
+                ('' if limit is not None else '; explicit fp16_fp8 stays (use --precision auto for the fallback)'))
+        return 'fp16_fp8'
 
     def _set_fused_tail(self, on):
         """parity tests: 0 = the three-launch form (body kernel writes x, r2l_tail_kernel finishes the rays)"""

@@ -163,6 +163,35 @@ int r2l_debug_set_fused_tail(r2l_ctx* ctx, int on);
 int r2l_set_act_exponents(r2l_ctx* ctx, const int* exps, int n);
 int r2l_get_act_exponents(r2l_ctx* ctx, int* out, int n);
 
+/* Range tracking of R2L_PREC_FP16_FP8 (the reference has no counterpart: its fp32 path has no operand ranges,
+ * model/nerf_raybased.py:443-465, 539-544).  The exponents above come from a sample of the first call's rays; whether
+ * they hold for the rays rendered SINCE is measured, not assumed:
+ *   - every head launch adds the largest h0 (= the body's first operand set) of EVERY ray it renders to a running
+ *     maximum (cost: 64 VALU per 128-ray tile);
+ *   - the first body launch after r2l_load_weights and every guard_period-th one afterwards (default 8; 1 = every
+ *     launch, 0 = never) runs the range-guard build of the body kernel: bit-identical results, and per operand set
+ *     (IN_b, H_b: 2 n_block) the maximum |a| over every ray of that launch (r2l_body_guard_kernel: 2 v_max3_f32 per 4
+ *     values, +1.5 % kernel time when it runs).
+ * r2l_get_range_status reads the words (synchronises the stream of the newest render) and relates them to the exponents
+ * in use: fill = max * 16 / 2^E / 28 is the fraction of bf6's +-28 the largest value of a set reached; the calibration
+ * aims at <= 16/28 = 0.571, values beyond 1 were clamped.  reset != 0 clears the words and the launch counters.
+ * r2l_recalibrate (stream-ordered device work) replaces the exponents by those the collected maxima ask for: what the
+ * first call would have measured had it seen every ray of the guarded launches; frames rendered before it with
+ * saturated sets should be rendered again. */
+typedef struct r2l_range_status {
+    float h0_max;            /* largest head output (real units) over every ray since the last reset */
+    float h0_fill;           /* its fill of operand set 0 under the exponents in use */
+    float worst_fill;        /* largest fill over the 2 n_block operand sets of the guarded launches since the reset */
+    int worst_set;           /* its set index (2b: input of block b, 2b+1: hidden layer of block b), -1: no guarded launch */
+    int saturated;           /* a fill reached 1: values were clamped to +-28 */
+    int beyond_calibration;  /* a fill exceeds 16/28: r2l_recalibrate would raise that set's exponent */
+    long long launches;          /* R2L_PREC_FP16_FP8 body launches since the last reset */
+    long long guarded_launches;  /* ... of them range-guarded */
+} r2l_range_status;
+int r2l_set_guard_period(r2l_ctx* ctx, int period);
+int r2l_get_range_status(r2l_ctx* ctx, r2l_range_status* out, int reset);
+int r2l_recalibrate(r2l_ctx* ctx, void* stream);
+
 /* introspection for bench.py / DESIGN.md */
 long long r2l_flops_per_ray(const r2l_ctx* ctx);      /* algorithmic: 2*MACs of the network */
 /* algorithmic flops per ray of the kernel the timing events bracket: the whole network for the single-kernel

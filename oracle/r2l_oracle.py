@@ -195,8 +195,8 @@ def r2l_render(sd, H, W, focal, c2w, near=2., far=6., n_sample=16, L=10, chunk=4
                rows=None, dtype=torch.float32):
     """main.py:401-404 render_func == main.py:300-309: model(embed(sample_test(c2w)))."""
     dirs = camera_dirs(H, W, focal)
-    if rows is not None:
-        dirs = dirs[rows[0]:rows[1]]
+    if rows is not None:   # (r0, r1) or (r0, r1, step): a strided subset of the frame's rows (bench.py's far-pose parity)
+        dirs = dirs[rows[0]:rows[1]:(rows[2] if len(rows) > 2 else 1)]
     z = sampler_z_vals(n_sample, near, far)
     pts = sample_test(dirs, z, c2w[:3, :4])
     outs = []
@@ -441,3 +441,14 @@ def mse2psnr(mse):
 
 def psnr(a, b):
     return mse2psnr(torch.mean((a.double() - b.double())**2))
+
+
+def perturbed_state(sd, seed=1234, rel=0.05):
+    """Stand-in ground truth for the PSNR-delta measurement (no real GT exists offline): the same network
+    with every weight matrix multiplied element-wise by 1 + rel * N(0, 1), fixed seed.  Its render plays the role the
+    ground-truth image plays in the reference's mse2psnr(img2mse(rgb, gt)) (utils/run_nerf_raybased_helpers.py:19-20)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        out[k] = v * (1 + rel * torch.randn(v.shape, generator=g)) if k.endswith('weight') else v.clone()
+    return out

@@ -159,3 +159,36 @@ def test_emulated_stream_with_calibrated_exponents():
     print('L_inf default exponents %.3g, matched %.3g (|x| up to %.1f)' % (errs['default'], errs['matched'], np.abs(ref).max()))
     assert errs['matched'] < 2e-5 * np.abs(ref).max()
     assert errs['matched'] < errs['default'] / 2
+
+
+def test_range_guard_stream_collects_the_maxima_of_every_operand_set():
+    """The guard build of the stream (r2l_body_guard_kernel): same results bit for bit, plus one row of per-lane maxima
+    of |a| per operand set (IN_b = the folded residual stream at block b, H_b = its hidden layer) in LDS -- what the
+    library compares with the calibrated bf6 exponents (r2l_get_range_status)."""
+    nb, wave = 3, 1
+    W = make_weights(nb, seed=4)
+    buf, aux_off, tail_off, _ = cxx_pack(*W)
+    img = buf[:aux_off]
+    aux = buf[aux_off:tail_off].view(np.uint32).reshape(nb, -1)
+    rng = np.random.default_rng(12)
+    x = np.maximum(rng.normal(0, 1.5, (32, 256)), 0).astype(np.float32)
+    S = 16.0
+    plain, e0 = G.emulate_tile(G.Opts(), img, aux, to_regs(x * S), nb, wave=wave)
+    out, e1, rows = G.emulate_tile(G.Opts(guard=True), img, aux, to_regs(x * S), nb, wave=wave)
+    assert not e0 and not e1, (e0 + e1)[:10]
+    assert np.array_equal(plain.view(np.uint32), out.view(np.uint32))
+    # float64 evaluation of the folded blocks: x~_b = x_b - sum_{j<b} b2_j
+    xs = x.astype(np.float64)
+    want = []
+    for W1, b1, W2, b2 in zip(*W):
+        want.append(np.abs(xs).max())
+        h = np.maximum((xs @ W1.astype(np.float64).T) + b1, 0)      # b1' applied to x~ equals b1 applied to x
+        want.append(h.max())
+        xs = xs + h @ W2.astype(np.float64).T + b2
+    b2sum = np.zeros(256)
+    got = rows.max(axis=1) / S
+    for b in range(nb):      # the stream carries x~: compare in x~ units
+        xt = np.abs(ref_blocks(x, *[w[:b] for w in W]) - b2sum).max() if b else np.abs(x).max()
+        assert abs(got[2 * b] - xt) <= 2e-3 * xt, (b, got[2 * b], xt)
+        assert abs(got[2 * b + 1] - want[2 * b + 1]) <= 2e-3 * want[2 * b + 1], (b, got[2 * b + 1], want[2 * b + 1])
+        b2sum = b2sum + W[3][b].astype(np.float64)

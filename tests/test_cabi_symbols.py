@@ -44,3 +44,28 @@ def test_no_oracle_import_in_product():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(dp, f)).read()
                 assert 'oracle' not in txt.replace('the oracle', ''), f
+
+
+def test_collective_entry_points_check_their_arguments(pkg, built_lib):
+    """r2l_comm_* / r2l_gather_image (SURVEY 8(b) seam 3) refuse bad arguments with a code and a message before RCCL is
+    touched -- needs neither a GPU nor a peer (a scaling run's first failure must be readable, not a hang)."""
+    from efficient_nerf_amd import _lib
+    L = _lib.lib()
+    R2L_EINVAL = -1
+    comm = ctypes.c_void_p(0xdead)
+    idbuf = ctypes.create_string_buffer(128)
+    err = lambda: L.r2l_last_error().decode()
+    assert L.r2l_comm_unique_id(None) == R2L_EINVAL and 'NULL' in err()
+    assert L.r2l_comm_create(None, 0, 1, ctypes.cast(idbuf, ctypes.c_void_p)) == R2L_EINVAL and 'out is NULL' in err()
+    assert L.r2l_comm_create(ctypes.byref(comm), 0, 2, None) == R2L_EINVAL and 'id is NULL' in err()
+    assert comm.value is None                                            # cleared on failure
+    for rank, world in ((2, 2), (-1, 2), (0, 0)):
+        assert L.r2l_comm_create(ctypes.byref(comm), rank, world, ctypes.cast(idbuf, ctypes.c_void_p)) == R2L_EINVAL
+        assert 'rank %d is not in [0, world = %d)' % (rank, world) in err()
+    buf = ctypes.c_void_p(0x1000)
+    assert L.r2l_gather_image(None, buf, buf, 1, 8, 24, None) == R2L_EINVAL and 'comm is NULL' in err()
+    L.r2l_comm_destroy(None)                                             # a no-op, as free(NULL)
+    # range tracking entry points on a NULL context
+    st = _lib.RangeStatus()
+    assert L.r2l_get_range_status(None, ctypes.byref(st), 0) == R2L_EINVAL
+    assert L.r2l_set_guard_period(None, 1) == R2L_EINVAL and L.r2l_recalibrate(None, None) == R2L_EINVAL

@@ -25,6 +25,24 @@ def test_rccl_gather_one_rank(pkg):
     assert out2.data_ptr() == out.data_ptr() and torch.equal(out2, local2)
 
 
+def test_gather_into_a_frame_stack_keeps_every_frame(pkg):
+    """frontend.render_path keeps N frames: the collective's own buffer is reused by the next call (a kept view of it
+    would show the LAST frame N times), so each frame is gathered straight into its slot of a pre-allocated stack"""
+    from efficient_nerf_amd import dist as D
+    H, W, N = 6, 5, 4
+    g = torch.Generator().manual_seed(1)
+    frames = [torch.rand(1, H * W, 3, generator=g).cuda() for _ in range(N)]
+    stack = torch.empty((N, H, W, 3), device='cuda')
+    views = [D.gather_rows(f, H, W, 1, force_collective=True, out=stack[i])[0] for i, f in enumerate(frames)]
+    torch.cuda.synchronize()
+    for i in range(N):
+        assert views[i].data_ptr() == stack[i].data_ptr()
+        assert torch.equal(stack[i].reshape(-1, 3), frames[i][0])
+    assert not torch.equal(stack[0], stack[N - 1])
+    reused = [D.gather_rows(f, H, W, 1, force_collective=True)[0] for f in frames]      # without out=: one buffer
+    assert len({r.data_ptr() for r in reused}) == 1
+
+
 def test_rendered_rows_through_the_collective(pkg):
     """a frame rendered as two row ranges, each pushed through the 1-rank collective, equals the full frame"""
     from efficient_nerf_amd import R2LEngine, dist as D

@@ -1,0 +1,170 @@
+"""Range tracking of R2L_PREC_FP16_FP8 (include/r2l_hip.h: r2l_range_status, r2l_set_guard_period, r2l_recalibrate).
+
+The bf6 correction terms are scaled per operand set by exponents measured once; the contract (rgb L_inf <= 1e-4 vs the
+reference, BASELINE.json north_star) must hold for EVERY ray rendered afterwards, at any pose (the reference renders any
+pose with one model call: main.py:300-309).  So the library measures instead of assuming: the head launch tracks h0 of
+every ray, the range-guard build of the body kernel tracks all 2 n_block operand sets of every ray of the launches it
+runs for, and `--precision auto` re-checks after every frame."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_set_maxima(sd, emb, n_block):
+    """float64 maxima of the operand sets the body kernel converts to bf6: IN_b = |x~_b| with x~_b = x_b - sum_{j<b} b2_j
+    (the layer-2 biases are folded on the host, csrc/r2l_capi.hip pack_body_v3), H_b = relu(W1 x_b + b1)"""
+    g = lambda k: sd[k].double()
+    x = torch.relu(emb.double() @ g('head.0.weight').T + g('head.0.bias'))
+    h0max = x.max().item()
+    bsum = torch.zeros(256, dtype=torch.float64)
+    out = []
+    for b in range(n_block):
+        out.append((x - bsum).abs().max().item())
+        h = torch.relu(x @ g(f'body.{b}.body.0.weight').T + g(f'body.{b}.body.0.bias'))
+        out.append(h.max().item())
+        x = x + h @ g(f'body.{b}.body.2.weight').T + g(f'body.{b}.body.2.bias')
+        bsum = bsum + g(f'body.{b}.body.2.bias')
+    return h0max, out
+
+
+def exponent_of(m):
+    """r2l_calib_finalize_kernel: the smallest E with max * 16 / 2^E <= 16"""
+    fr, e = math.frexp(m)
+    return e - 1 if fr == 0.5 else e
+
+
+def frame_embedding(H, W, focal, c2w, idx=None):
+    pts = O.sample_test(O.camera_dirs(H, W, focal), O.sampler_z_vals(16, 2., 6.), torch.as_tensor(c2w)[:3, :4])
+    return O.positional_embed(pts if idx is None else pts[idx])
+
+
+def test_guarded_launch_is_bit_identical_and_measures_every_set(pkg):
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H, nb = 64, 5
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=3, netdepth=2 + 2 * nb)
+    for k in sd:                                  # growing ranges: every set gets its own exponent
+        if k.startswith('body.') and k.endswith('weight'):
+            sd[k] = sd[k] * 1.3
+    c2w = O.pose_spherical(70., -25., 4.)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    ex = eng.calibrate_on(c2w=c2w)                # exponents from every ray of the frame
+    h0max, sets = oracle_set_maxima(sd, frame_embedding(H, H, focal, c2w), nb)
+    for j, m in enumerate(sets):                  # the kernel's maxima carry its own 1e-3-grade rounding: only a maximum
+        want = exponent_of(m)                     # within that of a power of two may land on the other side
+        assert ex[j] == want or abs(m / 2.0 ** round(math.log2(m)) - 1) < 2e-3, (j, ex[j], want, m)
+    eng.set_guard_period(0)
+    plain = eng.render(c2w).cpu()
+    st = eng.range_status(reset=True)
+    assert st['launches'] == 1 and st['guarded_launches'] == 0 and st['worst_set'] == -1
+    assert abs(st['h0_max'] - h0max) <= 2e-3 * h0max          # the head tracks every ray in every launch
+    eng.set_guard_period(1)
+    guarded = eng.render(c2w).cpu()
+    st = eng.range_status(reset=True)
+    assert torch.equal(plain, guarded)
+    assert st['launches'] == 1 and st['guarded_launches'] == 1
+    fills = [m * 16 / 2.0 ** ex[j] / 28 for j, m in enumerate(sets)]
+    assert st['worst_set'] == int(np.argmax(fills)) or abs(st['worst_fill'] - max(fills)) < 2e-3
+    assert abs(st['worst_fill'] - max(fills)) <= 2e-3 and 0.28 < st['worst_fill'] <= 16 / 28 + 1e-3
+    assert not st['saturated'] and not st['beyond_calibration']
+    # every k-th launch: the first after the period is set, then launches k, 2k, ...
+    eng.set_guard_period(3)
+    for _ in range(7):
+        eng.render(c2w)
+    st = eng.range_status(reset=True)
+    assert (st['launches'], st['guarded_launches']) == (7, 3)
+    eng.close()
+
+
+def test_edge_rays_beyond_the_centre_probe_are_caught(pkg):
+    """A network whose activations grow towards the image border (the identity columns of head.0.weight, which carry
+    the point coordinates, scaled up): a probe through the image centre -- how round 2 chose the exponents -- reads too
+    small a range.  Rendering the whole frame with those exponents must raise the flags; check_ranges must raise the
+    exponents and ask for the frame again; calibrate_on must see the border rays in the first place."""
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H, nb = 200, 43
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=0)
+    Wh = sd['head.0.weight'].clone()
+    Wh[:, 20::21] *= 24.0                       # columns c*21 + 20: the coordinates themselves (model/nerf_raybased.py:206)
+    sd['head.0.weight'] = Wh
+    c2w = O.pose_spherical(0., -30., 4.)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    eng.set_guard_period(1)
+    band = (H // 2 - 3, H // 2 + 3)             # 1,200 rays through the centre: the library's own sample only
+    eng.render(c2w, rows=band)
+    probe = eng.act_exponents()
+    eng.range_status(reset=True)
+    eng.render(c2w)                              # the frame under the probe's exponents
+    st = eng.range_status()
+    assert st['beyond_calibration'], st
+    logs = []
+    assert eng.check_ranges(log=logs.append) == 'fp16_fp8' and logs and 'left the calibrated' in logs[0]
+    raised = eng.act_exponents()
+    assert all(b >= a for a, b in zip(probe, raised)) and max(raised) > max(probe), (probe, raised)
+    eng.render(c2w)
+    assert eng.check_ranges() is None            # the second render of the frame is inside the new scales
+    full = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd).calibrate_on(c2w=c2w)
+    assert full == raised, (full, raised)
+    eng.close()
+
+
+def test_auto_falls_back_when_a_later_pose_leaves_the_range(pkg):
+    """`--precision auto` = choose_precision + check_ranges after every frame: exponents forced low (as if the first frame
+    had been a tame one) -> the next frame trips the watch, the context ends in fp16x3 when the limit is exceeded, and the
+    re-rendered frame meets the contract."""
+    from efficient_nerf_amd import PREC_FP16X3, R2LEngine
+    H = 96
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=0)
+    for k in sd:
+        if k.startswith('body.') and k.endswith('weight'):
+            sd[k] = sd[k] * 1.2                   # activation exponents 4..5: beyond fp16_fp8's limit
+    c2w = O.pose_spherical(40., -30., 4.)
+    eng = R2LEngine(H, H, focal).load_state_dict(sd)
+    name, top = eng.choose_precision(c2w=c2w, max_exp=8)      # limit lifted: stays in fp16_fp8 ...
+    assert name == 'fp16_fp8' and top > eng.AUTO_MAX_EXP
+    eng._auto_max_exp = eng.AUTO_MAX_EXP                       # ... then the real limit, with exponents two too small
+    eng.set_act_exponents([e - 2 for e in eng.act_exponents()])
+    eng.set_guard_period(1)
+    eng.range_status(reset=True)
+    eng.render(c2w)
+    logs = []
+    assert eng.check_ranges(log=logs.append) == 'fp16x3', logs
+    assert eng.precision == PREC_FP16X3 and 'fp16x3' in logs[0]
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    assert (eng.render(c2w).cpu() - ref).abs().max().item() <= 1e-4
+    assert eng.check_ranges() is None            # nothing to watch in fp16x3
+    eng.close()
+
+
+def test_calibrate_on_one_pose_holds_the_contract_on_the_whole_test_path(pkg):
+    """Exponents from every ray of ONE 800x800 frame (test pose 0), then eight poses spread over the 200-view test path
+    (load_blender.py:327-333), each checked against the CPU oracle on 2,500 strided rays and watched by the range guard."""
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H = 800
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=0)
+    poses = O.novel_poses(200)[:, :3, :4]
+    eng = R2LEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dict(sd)
+    ex = eng.calibrate_on(c2w=poses[0])
+    assert max(ex) <= eng.AUTO_MAX_EXP
+    eng.set_guard_period(1)
+    idx = torch.arange(0, H * H, H * H // 2500)[:2500]
+    worst, fill = 0.0, 0.0
+    for pi in range(0, 200, 25):
+        rgb = eng.render(poses[pi]).cpu()
+        st = eng.range_status(reset=True)
+        assert not st['saturated'] and not st['beyond_calibration'], (pi, st)
+        fill = max(fill, st['worst_fill'], st['h0_fill'])
+        ref = O.r2l_forward(sd, frame_embedding(H, H, focal, poses[pi], idx))
+        worst = max(worst, (rgb[idx] - ref).abs().max().item())
+    print('8 poses of the test path under pose-0 exponents: L_inf %.2e, largest fill %.3f (calibration aims at 0.571)' % (worst, fill))
+    assert worst <= 1e-4, worst
+    eng.close()
