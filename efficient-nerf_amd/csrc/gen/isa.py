@@ -28,10 +28,11 @@ def layer_exponent(W):
     return int(np.frexp(m)[1]) if m > 0 else -4
 
 
-def weight_exps(e):
-    """power-of-two exponents of the two bf6 weight operands of a layer with weight exponent e:
-    stored (w - hi(w)) / 2^(e-16) and w / 2^(e-4), both < 2^5 in magnitude"""
-    return e - 16, e - 4
+def weight_exps(e, fmt='bf6'):
+    """power-of-two exponents of the two low-precision weight operands of a layer with weight exponent e:
+    bf6: stored (w - hi(w)) / 2^(e-16) and w / 2^(e-4), both < 2^5 in magnitude (bf6 holds 28);
+    e4m3: (w - hi(w)) / 2^(e-20) and w / 2^(e-8), both < 2^9 (e4m3 holds 448)"""
+    return (e - 16, e - 4) if fmt == 'bf6' else (e - 20, e - 8)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -74,6 +75,33 @@ def f_to_bf6(x):
     code = np.where(up, idx, idx - 1)
     code = np.where(a >= _BF6_POS[31], 31, code)
     return (code | np.where(np.signbit(x), 32, 0)).astype(np.uint8)
+
+
+def _e4m3_table():
+    v = np.zeros(128)
+    for b in range(128):
+        e, m = (b >> 3) & 15, b & 7
+        v[b] = (m / 8.0) * 2.0 ** -6 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7)
+    v[127] = np.inf          # 0x7f is NaN; as a search bound it never wins
+    return v
+
+
+E4M3_POS = _e4m3_table()         # ascending magnitudes of codes 0 .. 126 (448), [127] = inf
+E4M3 = np.concatenate([np.where(np.isinf(E4M3_POS), np.nan, E4M3_POS), -np.where(np.isinf(E4M3_POS), np.nan, E4M3_POS)])
+E4M3_TOP = 8                     # 448 = 1.75 * 2^8
+
+
+def f_to_e4m3(x):
+    """nearest OCP e4m3 code (ties to even mantissa), saturating at 448; x float array"""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.abs(x)
+    pos = E4M3_POS[:127]
+    idx = np.searchsorted(pos, a).clip(1, 126)
+    lo, hi = pos[idx - 1], pos[idx]
+    up = (a - lo > hi - a) | ((a - lo == hi - a) & (((idx - 1) & 1) == 1))
+    code = np.where(up, idx, idx - 1)
+    code = np.where(a >= pos[126], 126, code)
+    return (code | np.where(np.signbit(x), 128, 0)).astype(np.uint8)
 
 
 def pack6(codes):
@@ -555,6 +583,54 @@ def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag='', bfile='a'):
     return Ins(text, 'mfma6', rd=vr(a, 6) + rb + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
 
 
+def mfma32_8(dfile, d, a, b_reg, scale_a, scale_b, tag='', bfile='a'):
+    """D += A(e4m3 v[a:a+7], 32 x 64, E8M0 v[scale_a]) x B(e4m3 [bfile] b:b+7, 64 x 32, E8M0 v[scale_b]):
+    v_mfma_scale_f32_32x32x64_f8f6f4 with both operands in OCP fp8 (cbsz:0 blgp:0): 64 matrix-pipe cycles.  Byte e of lane
+    32h + r of A pairs with byte e of lane 32h + c of B (tools/fp8_probe.hip)."""
+    rf = {'v': vreg, 'a': areg}
+    text = ('v_mfma_scale_f32_32x32x64_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0]' %
+            (rf[dfile](d, 16), vreg(a, 8), rf[bfile](b_reg, 8), rf[dfile](d, 16), vreg(scale_a), vreg(scale_b)))
+
+    def emu(st):
+        lanes = np.arange(64)
+        Ac = st.V[a:a + 8].T.copy().view(np.uint8)            # [64, 32]
+        Bc = st.regs(bfile)[b_reg:b_reg + 8].T.copy().view(np.uint8)
+        sa = 2.0 ** (int(st.V[scale_a][0] & 0xff) - 127)
+        sb = 2.0 ** (int(st.V[scale_b][0] & 0xff) - 127)
+        Am = np.zeros((32, 64))
+        Bm = np.zeros((64, 32))
+        for e in range(32):
+            Am[lanes & 31, 32 * (lanes >> 5) + e] = E4M3[Ac[:, e]] * sa
+            Bm[32 * (lanes >> 5) + e, lanes & 31] = E4M3[Bc[:, e]] * sb
+        D = Am @ Bm
+        C = st.regs(dfile)[d:d + 16].view(np.float32).astype(np.float64)
+        out = np.zeros((16, 64), dtype=np.float32)
+        for r in range(16):
+            out[r] = (C[r] + D[_D32_ROWS[r], lanes & 31]).astype(np.float32)
+        st.regs(dfile)[d:d + 16] = out.view(np.uint32)
+
+    dd = vr(d, 16) if dfile == 'v' else ar(d, 16)
+    rb = ar(b_reg, 8) if bfile == 'a' else vr(b_reg, 8)
+    return Ins(text, 'mfma6', rd=vr(a, 8) + rb + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
+
+
+def v_cvt_pk_fp8_f16(dst, dst_high, src_pk, scale_v):
+    """half `dst_high` of v[dst] = the two e4m3 bytes of the packed f16 pair v[src_pk] / f32 v[scale_v] (low f16 -> low
+    byte): v_cvt_scalef32_pk_fp8_f16 [op_sel:[0,0,1]]; writes 16 bits of its destination (dst-sel forwarding hazard)"""
+    text = 'v_cvt_scalef32_pk_fp8_f16 %s, %s, %s%s' % (vreg(dst), vreg(src_pk), vreg(scale_v), ' op_sel:[0,0,1]' if dst_high else '')
+
+    def emu(st):
+        x = _halves(st.V[src_pk:src_pk + 1]).astype(np.float64)     # [64, 2]
+        sc = st.f32('v', scale_v).astype(np.float64)[:, None]
+        c = f_to_e4m3(x / sc).astype(np.uint32)
+        w = c[:, 0] | (c[:, 1] << 8)
+        if dst_high:
+            st.V[dst] = (st.V[dst] & 0x0000ffff) | (w << 16)
+        else:
+            st.V[dst] = (st.V[dst] & 0xffff0000) | w
+    return valu(text, vr(src_pk) + vr(scale_v), vr(dst), emu, partial=True)
+
+
 # ---------------------------------------------------------------------------------------------
 # list-scheduler items
 # ---------------------------------------------------------------------------------------------
@@ -576,8 +652,11 @@ def f32_bits(x):
 
 
 def mfma_cycles(ins):
-    """matrix-pipe cycles of an MFMA: 32 for the 32x32 shapes, 16 for the 16x16 ones"""
-    return 32 if '32x32' in ins.text else 16
+    """matrix-pipe cycles of an MFMA: 32 for the 32x32 shapes (64 with 8-bit operands on the block-scaled instruction: no
+    cbsz / blgp modifier), 16 for the 16x16 ones"""
+    if '32x32' in ins.text:
+        return 64 if 'f8f6f4' in ins.text and 'cbsz' not in ins.text else 32
+    return 16
 
 
 def check_hazards_stream(stream):

@@ -252,41 +252,52 @@ class R2LEngine:
             return 'fp16x3', top
         return 'fp16_fp8', top
 
+    #: fill (fraction of bf6's +-28 the largest value of an operand set reached) beyond which check_ranges raises the
+    #: exponents.  The calibration aims at <= 16/28 = 0.57 on the frame it saw; bf6 represents 16..28 as well as 8..16, so
+    #: other poses may use that headroom (the 200-pose test path of the synthetic weights: up to 0.66) at no loss; at 1.0
+    #: values are clamped and the frame is wrong.
+    FILL_LIMIT = 0.9
+
     def check_ranges(self, log=None, any_rank=None, agree=None):
-        """After a render in fp16_fp8: did the values stay inside the range the exponents were chosen for?  Returns
-        None when they did.  Otherwise the exponents are raised to what was seen (recalibrate), the precision is
-        switched to fp16x3 when `choose_precision`'s limit is exceeded, and the name of the precision to render the
-        frame AGAIN with is returned (an explicit fp16_fp8 context only warns and keeps its mode).  Synchronises.
+        """After a render in fp16_fp8: did the values stay inside the bf6 scales in use?  Returns None when the frame is
+        good: every fill below 1 (nothing was clamped).  Fills beyond FILL_LIMIT raise the exponents for what follows
+        (recalibrate); when values WERE clamped, or when raising the exponents takes them past `choose_precision`'s
+        limit (the context then switches to fp16x3), the name of the precision to render the frame AGAIN with is
+        returned.  An explicit fp16_fp8 context keeps its mode and says so.  Synchronises.
         Row-sharded runs (dist.check_ranges) pass `any_rank` (bool -> True when any rank says so) and `agree` (makes the
         exponents the element-wise maximum over the ranks), so that every rank takes the same decision."""
         if self.precision != PREC_FP16_FP8 or self.n_block == 0:
             return None
         st = self.range_status()
-        beyond = bool(st['beyond_calibration'])
+        fill = max(st['h0_fill'], st['worst_fill'])
+        act, clamped = fill > self.FILL_LIMIT, bool(st['saturated'])
         if any_rank is not None:
-            beyond = any_rank(beyond)
-        if not beyond:
+            act, clamped = any_rank(act), any_rank(clamped)
+        if not act:
             return None
         limit = getattr(self, '_auto_max_exp', None)
-        if st['guarded_launches'] > 0 and st['beyond_calibration']:
+        before = self.act_exponents()
+        if st['guarded_launches'] > 0 and fill > self.FILL_LIMIT:
             self.recalibrate()
-        elif any_rank is None:   # only the head's running maximum exists: raise the exponents with the next guarded launch
+        elif any_rank is None:   # only the head's running maximum exists: the next launch measures every set
             self.set_guard_period(self._guard_period)
         if agree is not None:
             agree(self)
-        top = max(self.act_exponents()) if (st['guarded_launches'] > 0 or agree is not None) else None
+        after = self.act_exponents()
+        top = max(after)
         self.range_status(reset=True)
-        msg = ('[precision] activations left the calibrated bf6 range (fill %.2f of set %d, h0 fill %.2f%s)' %
-               (st['worst_fill'], st['worst_set'], st['h0_fill'], ', values were clamped' if st['saturated'] else ''))
-        if limit is not None and top is not None and top > limit:
+        msg = ('[precision] activations fill %.2f of the bf6 scale of operand set %d (h0: %.2f)%s' %
+               (st['worst_fill'], st['worst_set'], st['h0_fill'], ': values were clamped' if clamped else ''))
+        if limit is not None and top > limit:
             self.set_precision(PREC_FP16X3)
             if log:
-                log(msg + f': exponents now up to {top} > {limit} -> fp16x3')
+                log(msg + f'; exponents now up to {top} > {limit} -> fp16x3, frame rendered again')
             return 'fp16x3'
         if log:
-            log(msg + (f': exponents raised (up to {top})' if top is not None else ': next launch range-guarded') +
-                ('' if limit is not None else '; explicit fp16_fp8 stays (use --precision auto for the fallback)'))
-        return 'fp16_fp8'
+            log(msg + ('; exponents raised (up to %d)' % top if after != before else '; next launch range-guarded') +
+                (', frame rendered again' if clamped else '') +
+                ('' if limit is not None else ' [explicit fp16_fp8: no fallback; --precision auto has one]'))
+        return 'fp16_fp8' if clamped else None
 
     def _set_fused_tail(self, on):
         """parity tests: 0 = the three-launch form (body kernel writes x, r2l_tail_kernel finishes the rays)"""

@@ -171,7 +171,7 @@ int r2l_get_act_exponents(r2l_ctx* ctx, int* out, int n);
  *   - the first body launch after r2l_load_weights and every guard_period-th one afterwards (default 8; 1 = every
  *     launch, 0 = never) runs the range-guard build of the body kernel: bit-identical results, and per operand set
  *     (IN_b, H_b: 2 n_block) the maximum |a| over every ray of that launch (r2l_body_guard_kernel: 2 v_max3_f32 per 4
- *     values, +1.5 % kernel time when it runs).
+ *     values, +1.2 % kernel time when it runs, i.e. +0.15 % at the default period).
  * r2l_get_range_status reads the words (synchronises the stream of the newest render) and relates them to the exponents
  * in use: fill = max * 16 / 2^E / 28 is the fraction of bf6's +-28 the largest value of a set reached; the calibration
  * aims at <= 16/28 = 0.571, values beyond 1 were clamped.  reset != 0 clears the words and the launch counters.
