@@ -6,7 +6,8 @@ PREC_FP16X3 = 0
 PREC_FP16X1 = 1
 PREC_FP16_FP8 = 2  # fp16 main pass + both correction terms in OCP bf6 (e3m2) on the block-scaled MFMA at 4x the fp16 rate:
                    # generated head / body kernels (R2L), generated layer chain (teacher); the name is historical
-PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8}
+PREC_FP16_E4M3 = 3  # R2L only: the same with both correction terms in OCP e4m3 (2.0 pass-equivalents, half the error)
+PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8, 'fp16_e4m3': PREC_FP16_E4M3}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('R2L_LIB_PATH', os.path.join(_HERE, 'libr2l_hip.so'))  # override: ablation builds (tools/)
@@ -23,7 +24,7 @@ _vp = C.c_void_p
 class RangeStatus(C.Structure):
     """include/r2l_hip.h r2l_range_status"""
     _fields_ = [('h0_max', C.c_float), ('h0_fill', C.c_float), ('worst_fill', C.c_float), ('worst_set', C.c_int),
-                ('saturated', C.c_int), ('beyond_calibration', C.c_int), ('launches', C.c_longlong),
+                ('saturated', C.c_int), ('beyond_calibration', C.c_int), ('format_top', C.c_float), ('stream_max', C.c_float), ('launches', C.c_longlong),
                 ('guarded_launches', C.c_longlong)]
 
     def as_dict(self):
@@ -51,6 +52,7 @@ SIGNATURES = {
     'r2l_debug_pack_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_longlong]),
     'r2l_debug_pack_body_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, _vp, C.c_longlong,
                                                 C.POINTER(C.c_longlong)]),
+    'r2l_debug_pack_body_format': (C.c_int, [C.c_int]),
     'r2l_set_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     'r2l_get_act_exponents': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     'r2l_set_guard_period': (C.c_int, [_vp, C.c_int]),

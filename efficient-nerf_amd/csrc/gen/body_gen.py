@@ -48,7 +48,7 @@ import sys
 import numpy as np
 
 from isa import (ACT_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
-                 ds_read_b64, ds_read_b96, ds_max_u32, v_max3_abs, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
+                 ds_read_b64, ds_read_b96, ds_max_u32, v_max3_abs, mfma32_8, v_cvt_pk_fp8_f16, f_to_e4m3, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
                  v_cvt_pk32_bf6, s_nop, salu, f_to_bf6, pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream,
                  model_cycles)
 
@@ -60,9 +60,7 @@ V_HH = 64
 V_ACC = 128
 V_BIAS = 160
 V_HI = 176
-V_A6 = 192
-V_LO = 204
-V_CV = 220
+# V_A6, V_LO, V_CV (192 .. 225): configure()
 V_L0 = 226        # lane*16                (LDS bytes 0 .. 65535)
 V_L1 = 227        # lane*16 + 65536
 V_L8A = 228       # lane*8                 (8-byte parts of the bf6 operands)
@@ -88,9 +86,7 @@ N_VGPR_USED = 256
 NHI = 4           # fp16 fragment buffers
 
 A_X = 0
-A_IN6 = 128
-A_H6 = 176
-N_AGPR_USED = 224
+A_IN6 = 128       # A_H6, N_AGPR_USED: configure()
 
 # SGPRs owned by the body (clobbered); inputs are copied into them at entry
 S_W = 40       # 40,41 weight stream base
@@ -123,23 +119,41 @@ S_T1 = 86       # temporaries 86..89
 S_GPOS = 90     # range guard: LDS byte address of the maxima row (64 lanes x 4 B) of the operand set being produced
 N_SGPR_LO, N_SGPR_HI = 40, 92
 
-PIECES = 28                # 1 KiB pieces of a chunk
-CHUNK = PIECES * 1024      # 28 KiB
-PW = PIECES // 4           # LDS-DMA pieces per wave and chunk
 NSLOT = 4
-LDS_AUX = NSLOT * CHUNK
 AUX_BYTES = 4096           # per block: 256 f32 bias | 4 x (swl1, sw1, swl2, sw2) | pad
 AUX_SCALES = 1024
 AUX_ACT = 1088             # (127 + E_in, 127 + E_h, 127 + E_out, 0) as dwords, twice (one copy per lane half)
 RES_SHIFT = 12             # a - hi(a) of an fp16-rounded value is converted 2^12 finer than the value
-LDS_TAIL = LDS_AUX + 2 * AUX_BYTES   # tail table: 3 x 256 f32 (W_t / act_scale) | 2 x (3 folded biases, 0)
 TAIL_BYTES = 4096
-LDS_BYTES = LDS_TAIL + TAIL_BYTES
-# range guard (the r2l_body_guard_kernel build of this stream): per operand set (2 per block: IN_b, H_b) one row of 64
-# per-lane maxima of |a| (f32 bits; non-negative floats order as unsigned), accumulated over the tiles of a workgroup
-# by ds_max_u32; the kernel's HIP epilogue reduces the rows and atomicMax-es them into the context's statistics
-LDS_GSTAT = LDS_BYTES
-GSTAT_ROW = 256
+# range guard (the r2l_body_guard_kernel build of this stream): per operand set (2 per block: IN_b, H_b) one row of 32
+# maxima of |a| (f32 bits; non-negative floats order as unsigned; lanes l and l + 32 share a word), accumulated over the
+# tiles of a workgroup by ds_max_u32; the kernel's HIP epilogue reduces the rows and atomicMax-es them into the context's
+# statistics
+GSTAT_ROW = 128
+
+
+def configure(fmt):
+    """Format of the two correction terms: 'bf6' (OCP e3m2: 6 registers per K=64 operand, 32 matrix-pipe cycles; the
+    R2L_PREC_FP16_FP8 mode) or 'fp8' (OCP e4m3: 8 registers, 64 cycles; R2L_PREC_FP16_E4M3, one more mantissa bit in all
+    four factors: half the error at 1.33x the MFMA time).  Sets the format-dependent part of the register map, the chunk
+    geometry and the LDS map (module globals: the generators are run once per variant)."""
+    global FMT, NA6, PIECES, CHUNK, PW, LDS_AUX, LDS_TAIL, LDS_BYTES, LDS_GSTAT, V_A6, V_LO, V_CV, A_H6, N_AGPR_USED
+    FMT = fmt
+    NA6 = 6 if fmt == 'bf6' else 8                  # registers of a K=64 operand
+    PIECES = 28 if fmt == 'bf6' else 32             # 1 KiB pieces of a chunk: 16 fp16 fragments + 8 operands of 1.5 | 2 KiB
+    CHUNK = PIECES * 1024
+    PW = PIECES // 4                                # LDS-DMA pieces per wave and chunk
+    LDS_AUX = NSLOT * CHUNK
+    LDS_TAIL = LDS_AUX + 2 * AUX_BYTES              # tail table: 3 x 256 f32 (W_t / act_scale) | 2 x (3 folded biases, 0)
+    LDS_BYTES = LDS_TAIL + TAIL_BYTES
+    LDS_GSTAT = LDS_BYTES
+    V_A6 = 192                                      # weight operands of the K=64 MFMAs, 2 buffers
+    V_LO = V_A6 + 2 * NA6                           # bf6: fp16 residual pairs of 2 row tiles (16); fp8: of one (8)
+    V_CV = V_LO + (16 if fmt == 'bf6' else 8)       # conversion outputs: bf6 6; fp8 4 (values) + 4 (residuals)
+    assert V_CV + (6 if fmt == 'bf6' else 8) <= V_L0
+    A_H6 = A_IN6 + 8 * NA6
+    N_AGPR_USED = A_H6 + 8 * NA6
+    assert N_AGPR_USED <= 256
 
 
 TILES = 16                 # row tiles of a block: layer * 8 + u
@@ -162,7 +176,7 @@ def HI(b):
 
 
 def A6(b):
-    return V_A6 + b * 6
+    return V_A6 + b * NA6
 
 
 def X(u):
@@ -170,7 +184,7 @@ def X(u):
 
 
 def B6(base, term, t):
-    return base + term * 24 + t * 6
+    return base + term * 4 * NA6 + t * NA6
 
 
 # order of the eight K=64 MFMAs of a row tile: (term, t); term 0 = (w - hi) x bf6(a), 1 = w x bf6(a - hi)
@@ -197,19 +211,21 @@ def piece_hi(s):
 
 
 def piece_a6(j):
-    """1 KiB piece with the first 16 B/lane of bf6 operand j of the row tile"""
-    return 16 + j
+    """1 KiB piece with the first 16 B/lane of K=64 operand j of the row tile"""
+    return 16 + j if FMT == 'bf6' else 16 + 2 * j
 
 
 def piece_a6b(j):
-    """(piece, byte offset inside it) of the last 8 B/lane (64 lanes x 8 B = 512 B) of the operand"""
-    return 24 + (j >> 1), (j & 1) * 512
+    """(piece, byte offset inside it) of the rest of the operand: bf6 the last 8 B/lane (64 lanes x 8 B = 512 B), fp8 the
+    second 16 B/lane"""
+    return (24 + (j >> 1), (j & 1) * 512) if FMT == 'bf6' else (17 + 2 * j, 0)
 
 
-def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None):
+def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
     """Python restatement of the host packer (r2l_capi.hip pack_body_v3): returns (stream bytes,
     aux uint32 [n_block, 1024], total folded bias float64 [256]).  W*: [256, 256] float32 (out, in).
     act: 2 n_block + 1 activation exponents (IN set of block 0, H set of block 0, IN set of block 1, ...); default ACT_EXP"""
+    configure(fmt)
     n_block = len(W1s)
     if act is None:
         act = [ACT_EXP] * (2 * n_block + 1)
@@ -229,7 +245,7 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None):
             Wl = Wl.astype(np.float32)
             hi = Wl.astype(np.float16)
             ex = layer_exponent(Wl)
-            el, ew = weight_exps(ex)
+            el, ew = weight_exps(ex, fmt)
             for qq in range(4):
                 aux[b, AUX_SCALES // 4 + 4 * qq + 2 * layer] = 0x01010101 * (127 + el)
                 aux[b, AUX_SCALES // 4 + 4 * qq + 2 * layer + 1] = 0x01010101 * (127 + ew)
@@ -251,13 +267,15 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None):
                             v = np.ldexp(w - hi[rows, k].astype(np.float64), -el)
                         else:
                             v = np.ldexp(w, -ew)
-                        codes[:, e] = f_to_bf6(v)
-                    words = pack6(codes)                       # [64, 6]
+                        codes[:, e] = f_to_bf6(v) if fmt == 'bf6' else f_to_e4m3(v)
+                    # bf6: 6 dwords per lane, little-endian 6-bit fields; fp8: byte e = element e, 8 dwords
+                    words = pack6(codes) if fmt == 'bf6' else np.ascontiguousarray(codes).view(np.uint32)
                     p = base + piece_a6(j) * 1024
                     img[p:p + 1024] = np.ascontiguousarray(words[:, :4]).view(np.uint8).reshape(-1)
                     pc, off = piece_a6b(j)
                     p = base + pc * 1024 + off
-                    img[p:p + 512] = np.ascontiguousarray(words[:, 4:]).view(np.uint8).reshape(-1)
+                    rest = np.ascontiguousarray(words[:, 4:]).view(np.uint8).reshape(-1)
+                    img[p:p + rest.size] = rest
         Bsum = Bsum + b2s[b].astype(np.float64)
     return img, aux, Bsum
 
@@ -353,9 +371,11 @@ def anchor_index(T, kind, sj):
 
 def guard_flush(tag):
     """range guard: the per-lane maximum of the operand set just completed joins its LDS row; next set, maximum cleared.
-    V_BPERM = 4 (lane ^ 32) serves as the lane's dword offset inside the row (any bijection of the lanes does)."""
-    return [valu('v_add_u32 %s, %s, %s' % (vreg(V_T), sreg(S_GPOS), vreg(V_BPERM)), vr(V_BPERM), vr(V_T),
-                 lambda st: st.V.__setitem__(V_T, (st.V[V_BPERM] + np.uint32(st.S[S_GPOS])).astype(np.uint32))),
+    The row has 32 words: lanes l and l + 32 share one (V_BPERM & 0x7c = 4 (lane & 31))."""
+    return [valu('v_and_b32 %s, 0x7c, %s' % (vreg(V_T), vreg(V_BPERM)), vr(V_BPERM), vr(V_T),
+                 lambda st: st.V.__setitem__(V_T, st.V[V_BPERM] & np.uint32(0x7c))),
+            valu('v_add_u32 %s, %s, %s' % (vreg(V_T), sreg(S_GPOS), vreg(V_T)), vr(V_T), vr(V_T),
+                 lambda st: st.V.__setitem__(V_T, (st.V[V_T] + np.uint32(st.S[S_GPOS])).astype(np.uint32))),
             ds_max_u32(V_T, V_GMAX, 0, tag=tag),       # S_GPOS carries LDS_GSTAT (beyond a 16-bit offset)
             salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_GPOS), sreg(S_GPOS), GSTAT_ROW),
                  lambda st: st.S.__setitem__(S_GPOS, st.S[S_GPOS] + GSTAT_ROW)),
@@ -386,11 +406,23 @@ def epilogue_ops(T, guard=False):
         ops.append((v_cvt_pk_f16(h01, t[0], t[1]), ('hi', s)))
         ops.append((v_cvt_pk_f16(h23, t[2], t[3]), ('hi', s)))
         # half-register writes: low halves first, then the high halves (never two writers of one register back to back)
+        if FMT == 'fp8':
+            lo = V_LO + g * 2
         ops.append((v_resid16(lo, 0, h01, 0, t[0], S_NEG1), None))
         ops.append((v_resid16(lo + 1, 0, h23, 0, t[2], S_NEG1), None))
         ops.append((v_resid16(lo, 1, h01, 1, t[1], S_NEG1), None))
         ops.append((v_resid16(lo + 1, 1, h23, 1, t[3], S_NEG1), None))
-    if (u & 1) == 1:
+        if FMT == 'fp8':
+            # four values = one register of each e4m3 operand (byte e = 16 (u & 1) + 4 g + i of K=64 step u >> 1): two
+            # half-register conversions each, never two writers of one register back to back
+            cvh, cvl, tt, r = V_CV + g, V_CV + 4 + g, u >> 1, 4 * (u & 1) + g
+            ops.append((v_cvt_pk_fp8_f16(cvh, 0, h01, V_CVD + 2 * layer), None))
+            ops.append((v_cvt_pk_fp8_f16(cvl, 0, lo, V_CVD + 2 * layer + 1), None))
+            ops.append((v_cvt_pk_fp8_f16(cvh, 1, h23, V_CVD + 2 * layer), None))
+            ops.append((v_cvt_pk_fp8_f16(cvl, 1, lo + 1, V_CVD + 2 * layer + 1), None))
+            ops.append((v_accw(B6(b6, 0, tt) + r, cvh), ('b6', 0, tt)))
+            ops.append((v_accw(B6(b6, 1, tt) + r, cvl), ('b6', 1, tt)))
+    if FMT == 'bf6' and (u & 1) == 1:
         tt = u >> 1
         # 32-wide conversions of the finished pair of row tiles; the independent one first (dst-sel forwarding)
         ops.append((v_cvt_pk32_bf6(V_CV, hset(4 * tt), V_CVD + 2 * layer), None))
@@ -473,8 +505,12 @@ def build_fillers(it, opts):
             bv, off = lds_addr(slot, piece_a6(j) * 1024, 16)
             F.append(Filler(ds_read_b128(A6(n & 1), bv, off, tag=('a6', it, T, j, 0)), earliest, deadline, ('rd6',)))
             pc, po = piece_a6b(j)
-            bv, off = lds_addr(slot, pc * 1024 + po, 8)
-            F.append(Filler(ds_read_b64(A6(n & 1) + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
+            if FMT == 'bf6':
+                bv, off = lds_addr(slot, pc * 1024 + po, 8)
+                F.append(Filler(ds_read_b64(A6(n & 1) + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
+            else:
+                bv, off = lds_addr(slot, pc * 1024 + po, 16)
+                F.append(Filler(ds_read_b128(A6(n & 1) + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
         if T == 8:
             # this block's layer-2 scales were read during layer 1; flip to the next block's aux slot, then fetch
             # the next block's layer-1 scales (the running layer 1 is over: its scale registers are free)
@@ -564,6 +600,7 @@ def build_fillers(it, opts):
 def schedule(opts, n_iter=3):
     """list-schedule n_iter block iterations; returns [(iteration_of_position, Ins)] where the
     position's iteration is that of the surrounding anchors"""
+    configure(opts.fmt)
     sch = Sched(opts)
     fillers = []
     for it in range(n_iter):
@@ -650,9 +687,9 @@ def schedule(opts, n_iter=3):
             if sj == 0 and ORDER == 'tail' and opts.chain_nop >= 0:
                 sch.emit(it, s_nop(opts.chain_nop))      # fp16 -> scaled MFMA on one accumulator: keep them apart
             b6 = A_IN6 if layer == 0 else A_H6
-            ins = mfma32_6(dfile, d, A6(n & 1), B6(b6, term, t), V_SC + 2 * layer + term, V_SB + 2 * layer + term,
-                           tag=('m6', it, T, sj))
-            cap = opts.cap6
+            ins = (mfma32_6 if FMT == 'bf6' else mfma32_8)(dfile, d, A6(n & 1), B6(b6, term, t), V_SC + 2 * layer + term,
+                                                            V_SB + 2 * layer + term, tag=('m6', it, T, sj))
+            cap = opts.cap6 * (1 if FMT == 'bf6' else 2)    # a 64-cycle MFMA shadows twice the issue slots
         if not (kind == 'm6' and J_ORDER[sj][0] in opts.skip_terms):
             sch.emit(it, ins)
         budget = cap
@@ -676,6 +713,7 @@ class Opts:
         self.chain_nop = -1       # s_nop N between the last fp16 and the first K=64 MFMA of a row tile (-1: none)
         self.skip_terms = ()      # diagnostics: drop the K=64 MFMAs of these correction terms (wrong results)
         self.guard = False        # the range-guard build: per operand set the maximum |a| over every ray of the launch
+        self.fmt = 'bf6'          # correction terms: 'bf6' (e3m2 x e3m2) | 'fp8' (e4m3 x e4m3): configure()
         self.__dict__.update(kw)
 
 
@@ -785,10 +823,13 @@ def kernel_text(opts):
     %0 wimg (s64)  %1 aux (s64)  %2 xin (s64)  %3 xout (s64)  %4 n_tiles  %5 n_block  %6 wave  %7 blockIdx.x
     %8 gridDim.x  %9 rgb (s64; 0: store the x image to xout, else the fused tail writes rgb and xout is unused)
     %10 tail table (s64)  %11 n_rays  %12 number of the launch's first tile"""
+    configure(opts.fmt)
     pro, body = steady_block(opts)
     L = []
     a = L.append
     a('s_mov_b32 %s, m0' % sreg(S_M0SAVE))
+    if FMT == 'fp8':   # MODE.FP16_OVFL: conversions to e4m3 clamp at +-448 instead of producing NaN (tools/fp8_probe.hip)
+        a('s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1')
     a('s_mov_b64 %s, %%0' % sreg(S_W, 2))
     a('s_mov_b64 %s, %%1' % sreg(S_AUXB, 2))
     a('s_mov_b64 %s, %%2' % sreg(S_XIN, 2))
@@ -927,6 +968,8 @@ def kernel_text(opts):
     a('L_exit_%=:')
     a('s_waitcnt vmcnt(0) lgkmcnt(0)')
     a('s_barrier')
+    if FMT == 'fp8':
+        a('s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0')
     a('s_mov_b32 m0, %s' % sreg(S_M0SAVE))
     return L, pro, body
 
@@ -960,6 +1003,7 @@ def emit_inc(path, opts):
 # ---------------------------------------------------------------------------------------------
 def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=True):
     """x_tile_regs: float32 [128, 64] register image of one wave's X.  Returns (X out [128, 64], errors)."""
+    configure(opts.fmt)
     pro, body = steady_block(opts)
     st = State(wave, img, aux, n_block, LDS_BYTES + (2 * n_block * GSTAT_ROW if opts.guard else 0))
     lanes = np.arange(64, dtype=np.uint32)
@@ -1018,7 +1062,7 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     if check_hazards:
         errs += check_hazards_stream(body + body)
     if opts.guard:   # the maxima rows (f32) of the 2 n_block operand sets ride along
-        return st.A[A_X:A_X + 128].view(np.float32).copy(), errs, st.lds[LDS_GSTAT:LDS_GSTAT + 2 * n_block * GSTAT_ROW].view(np.float32).reshape(2 * n_block, 64).copy()
+        return st.A[A_X:A_X + 128].view(np.float32).copy(), errs, st.lds[LDS_GSTAT:LDS_GSTAT + 2 * n_block * GSTAT_ROW].view(np.float32).reshape(2 * n_block, 32).copy()
     return st.A[A_X:A_X + 128].view(np.float32).copy(), errs
 
 
@@ -1034,6 +1078,7 @@ def main():
     ap.add_argument('--chain-nop', type=int, default=-1)
     ap.add_argument('--order', default=None, choices=['tail', 'mix'])
     ap.add_argument('--guard', action='store_true', help='the range-guard build of the stream (r2l_body_guard_kernel)')
+    ap.add_argument('--fmt', default='bf6', choices=['bf6', 'fp8'], help='correction terms: bf6 (e3m2) | fp8 (e4m3)')
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')
     ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the block loop '
@@ -1043,7 +1088,7 @@ def main():
         global ORDER
         ORDER = a.order
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap16=a.cap16, cap6=a.cap6, dma_gap=a.dma_gap,
-                chain_nop=a.chain_nop, guard=a.guard, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
+                chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
                 drop=tuple(x for x in a.drop.split(',') if x))
     if a.emit:
         n = emit_inc(a.emit, opts)
@@ -1055,6 +1100,8 @@ def main():
                 f.write(ins.text + '\n')
         print('model cycles per block', model_cycles(body))
 
+
+configure('bf6')
 
 if __name__ == '__main__':
     sys.exit(main())

@@ -125,6 +125,26 @@ unsigned char r2l_f32_to_e4m3(float v) {
 #define R2L_GUARD_PERIOD_DEFAULT 8   // every 8th body launch runs the range-guard build (and the first after a weight load)
 #define R2L_CALIB_MAX_CALLS 8  // a measurement that only ever sees thin calls (< 1,024 rays) is closed after this many
 
+// OCP e4m3fn from a double: round to nearest even, saturating at 448 (what v_cvt_scalef32_pk_fp8_f16 does under
+// MODE.FP16_OVFL, tools/fp8_probe.hip)
+static unsigned char r2l_f_to_e4m3(double v) {
+    const unsigned char sgn = signbit(v) ? 0x80 : 0;
+    const double a = fabs(v);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0) return sgn | 0x7e;
+    int e;
+    frexp(a, &e);
+    int E = e - 1;                                         // a = 1.x * 2^E
+    if (a == 0.0 || E < -6) return sgn | (unsigned char)nearbyint(ldexp(a, 9));   // subnormal step 2^-9 (8 -> min normal)
+    int qn = (int)nearbyint(ldexp(a, 3 - E));              // 8..16
+    if (qn == 16) {
+        qn = 8;
+        ++E;
+    }
+    if (E > 8 || (E == 8 && qn > 14)) return sgn | 0x7e;
+    return sgn | (unsigned char)(((E + 7) << 3) | (qn - 8));
+}
+
 struct r2l_ctx {
     int H, W, n_block, use_residual, mode;
     double focal;
@@ -134,9 +154,10 @@ struct r2l_ctx {
     int n_cu;
     bool loaded;
     std::vector<std::vector<float>> host_w;  // state_dict order
-    char* d_img[3];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
-    size_t img_bytes[3];
-    char* d_body;                             // FP16_FP8: body stream v3 (r2l_body.hip) | aux blocks | tail
+    char* d_img[4];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
+    size_t img_bytes[4];
+    char* d_body;                             // split modes: body stream v3 (r2l_body.hip) | aux blocks | tail
+    int body_mode = -1;                       // ... of this mode (bf6 or e4m3 terms: chunk geometry and operand codes differ)
     size_t body_bytes, aux_off, tail_off;
     std::vector<int> act;                     // FP16_FP8: 2 n_block + 1 activation exponents (packed into the aux blocks)
     int fuse_tail = 1;                        // FP16_FP8 with the global skip: rgb written by the body kernel's fused tail
@@ -164,8 +185,10 @@ struct r2l_ctx {
 };
 
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
-static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_FP8; }
-#define R2L_N_MODES 3
+static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_E4M3; }
+// the modes with the generated head launch + generated body kernel (fp16 main pass + low-precision correction terms)
+static bool split_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3; }
+#define R2L_N_MODES 4
 #define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head / body launch pair (1 KiB of h0 per ray)
 
 
@@ -256,18 +279,19 @@ static void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
 
 static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img);
 static int ensure_x(r2l_ctx* c, int tiles, bool need_xb);
-static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
+static int pack_body_v3(const r2l_ctx* c, int e4m3, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
 static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out);
 
 static int build_image(r2l_ctx* c, int mode) {
     std::vector<char> img;
-    if (mode == R2L_PREC_FP16_FP8) {
-        // head launch: the stream of r2l_head_kernel; body + tail: the v3 stream
+    if (split_mode(mode)) {
+        // head launch: the stream of r2l_head_kernel (bf6 terms in both modes); body + tail: the v3 stream of the mode
         int rc = pack_head_v1(c, img);
         if (rc) return rc;
         std::vector<char> body;
-        rc = pack_body_v3(c, body, &c->aux_off, &c->tail_off);
+        rc = pack_body_v3(c, mode == R2L_PREC_FP16_E4M3, body, &c->aux_off, &c->tail_off);
         if (rc) return rc;
+        c->body_mode = mode;
         if (c->d_body) {
             (void)hipFree(c->d_body);
             c->d_body = nullptr;
@@ -415,6 +439,10 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
 // x~_i = x_i - sum_{j<i} b2_j) | 4 x (swl1, sw1, swl2, sw2) | pad.
 // Tail: [3,256] W_t / act_scale, then b_t + W_t sum_j b2_j.
 #define R2L_BODY_CHUNK 28672
+// R2L_PREC_FP16_E4M3: the same stream with both operands of the correction terms in OCP e4m3: chunks of 32 KiB = 32 pieces;
+// operand j: piece 16 + 2 j = bytes 0..15 of every lane, piece 17 + 2 j = bytes 16..31; byte i = element i;
+// term 0 = (w - hi(w)) / 2^(e-20), term 1 = w / 2^(e-8) (e4m3 holds 448)
+#define R2L_BODY8_CHUNK 32768
 int r2l_layer_exponent(const float* w, size_t n) {
     float m = 0.f;
     for (size_t i = 0; i < n; ++i) {
@@ -501,9 +529,9 @@ static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
     return R2L_OK;
 }
 
-static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_off, size_t* tail_off) {
+static int pack_body_v3(const r2l_ctx* c, int e4m3, std::vector<char>& out, size_t* aux_off, size_t* tail_off) {
     const int nb = c->n_block;
-    const size_t CH = R2L_BODY_CHUNK, AUXB = 4096;
+    const size_t CH = e4m3 ? R2L_BODY8_CHUNK : R2L_BODY_CHUNK, AUXB = 4096;
     const size_t stream = (size_t)nb * 16 * CH;
     *aux_off = stream;
     *tail_off = stream + (size_t)nb * AUXB;
@@ -532,7 +560,7 @@ static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_of
             if (e < -12 || e > 6)
                 return r2l_set_error(R2L_EINVAL, "body block %d layer %d: max|w| = 2^%d is outside the range the fp16 + bf6 "
                                      "weight split covers (2^-12 .. 2^6); use R2L_PREC_FP16X3", b, layer, e);
-            const int el = e - 16, ew = e - 4;
+            const int el = e4m3 ? e - 20 : e - 16, ew = e4m3 ? e - 8 : e - 4;
             for (int q = 0; q < 4; ++q) {
                 aux[256 + 4 * q + 2 * layer] = 0x01010101u * (uint32_t)(127 + el);
                 aux[256 + 4 * q + 2 * layer + 1] = 0x01010101u * (uint32_t)(127 + ew);
@@ -546,7 +574,18 @@ static int pack_body_v3(const r2l_ctx* c, std::vector<char>& out, size_t* aux_of
                         _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)s * 1024 + lane * 16);
                         for (int j = 0; j < 8; ++j) ph[j] = (_Float16)row[r2l_kappa32(s, h, j)];
                     }
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; e4m3 && j < 8; ++j) {
+                        const int term = j & 1, t = j >> 1;
+                        unsigned char codes[32];
+                        for (int el_i = 0; el_i < 32; ++el_i) {
+                            const float w = row[r2l_mix32(t, h, el_i)];
+                            const float hi = (float)(_Float16)w;
+                            codes[el_i] = r2l_f_to_e4m3(term == 0 ? ldexp((double)w - (double)hi, -el) : ldexp((double)w, -ew));
+                        }
+                        memcpy(chunk + (size_t)(16 + 2 * j) * 1024 + lane * 16, codes, 16);
+                        memcpy(chunk + (size_t)(17 + 2 * j) * 1024 + lane * 16, codes + 16, 16);
+                    }
+                    for (int j = 0; !e4m3 && j < 8; ++j) {
                         const int term = j & 1, t = j >> 1;
                         uint64_t bits[3] = {0, 0, 0};
                         for (int el_i = 0; el_i < 32; ++el_i) {
@@ -670,8 +709,8 @@ int r2l_get_act_exponents(r2l_ctx* c, int* out, int n) {
 int r2l_set_guard_period(r2l_ctx* c, int period) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (period < 0) return r2l_set_error(R2L_EINVAL, "guard period %d < 0", period);
-    if (period > 0 && c->n_block > r2l_body_guard_max_blocks())
-        return r2l_set_error(R2L_EINVAL, "the range guard keeps 2 n_block rows of maxima in LDS: n_block <= %d", r2l_body_guard_max_blocks());
+    if (period > 0 && c->n_block > r2l_body_guard_max_blocks(1))
+        return r2l_set_error(R2L_EINVAL, "the range guard keeps 2 n_block rows of maxima in LDS: n_block <= %d", r2l_body_guard_max_blocks(1));
     c->guard_period = period;
     c->n_since_load = 0;       // the next launch is the first of the new phase: guarded when period > 0
     return R2L_OK;
@@ -697,10 +736,13 @@ int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
     if (e == hipSuccess) e = hipMemcpy(g.data(), c->d_gstats, g.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy range words: %s", hipGetErrorString(e));
     auto f = [](unsigned u) { float v; memcpy(&v, &u, 4); return v; };
-    const float top = 28.0f;           // largest bf6 (e3m2) magnitude; the calibration aims at <= 16
+    // largest magnitude of the operand format: bf6 (e3m2) 28, e4m3 448; the calibration aims at <= 16 in both
+    const float top = c->mode == R2L_PREC_FP16_E4M3 ? 448.0f : 28.0f;
     out->h0_max = f(r[0]) / c->act_scale;
     out->h0_fill = c->n_block > 0 ? ldexpf(f(r[0]), -ex[0]) / top : 0.0f;
+    out->stream_max = out->h0_max;
     for (int j = 0; j < nset; ++j) {
+        if (f(g[j]) / c->act_scale > out->stream_max) out->stream_max = f(g[j]) / c->act_scale;
         const float fill = ldexpf(f(g[j]), -ex[j]) / top;
         if (fill > out->worst_fill) {
             out->worst_fill = fill;
@@ -710,6 +752,7 @@ int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
     const float m = out->h0_fill > out->worst_fill ? out->h0_fill : out->worst_fill;
     out->saturated = m >= 1.0f;
     out->beyond_calibration = m > 16.0f / top;
+    out->format_top = top;
     out->launches = c->n_body;
     out->guarded_launches = c->n_guarded;
     if (reset) {
@@ -758,7 +801,7 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
         c.host_w.emplace_back(tensors[i], tensors[i] + n);
     }
     std::vector<char> img;
-    if (precision_mode == R2L_PREC_FP16_FP8) {   // the image of this mode's head launch (r2l_head_kernel)
+    if (split_mode(precision_mode)) {   // the image of this mode's head launch (r2l_head_kernel)
         int rc = pack_head_v1(&c, img);
         if (rc) return rc;
     } else {
@@ -766,6 +809,12 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
     }
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
+}
+
+static thread_local int g_debug_pack_e4m3 = 0;
+int r2l_debug_pack_body_format(int e4m3) {   // which stream r2l_debug_pack_body_host packs: 0 bf6 terms, 1 e4m3 terms
+    g_debug_pack_e4m3 = e4m3 ? 1 : 0;
+    return R2L_OK;
 }
 
 // Host-only: the FP16_FP8 body stream (chunks | aux blocks | tail) of pack_body_v3, for the CPU tests that run
@@ -787,7 +836,7 @@ long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, i
     }
     std::vector<char> img;
     size_t aux_off = 0, tail_off = 0;
-    int rc = pack_body_v3(&c, img, &aux_off, &tail_off);
+    int rc = pack_body_v3(&c, g_debug_pack_e4m3, img, &aux_off, &tail_off);
     if (rc) return rc;
     if (offs) {
         offs[0] = (long long)aux_off;
@@ -801,8 +850,8 @@ long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, i
 // [tile][wave 4][u*2+c 32][lane 64][4] f32 (act_scale domain, layer-2 biases folded: see pack_body_v3).
 int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_tiles, void* stream) {
     if (!c || !x_in_dev || !x_out_dev || n_tiles < 1) return r2l_set_error(R2L_EINVAL, "bad argument to r2l_debug_body");
-    if (!c->loaded || c->mode != R2L_PREC_FP16_FP8 || c->n_block < 1)
-        return r2l_set_error(R2L_ESTATE, "r2l_debug_body needs loaded weights, R2L_PREC_FP16_FP8 and n_block >= 1");
+    if (!c->loaded || !split_mode(c->mode) || c->n_block < 1)
+        return r2l_set_error(R2L_ESTATE, "r2l_debug_body needs loaded weights, R2L_PREC_FP16_FP8 / _E4M3 and n_block >= 1");
     if (c->calib_pending) {   // as a render would: the exponents of these weights on this input
         c->calib_pending = 0;
         hipError_t ec = r2l_launch_calib(x_in_dev, c->d_wcal, c->n_block, n_tiles, c->act_scale, c->d_stats,
@@ -820,7 +869,8 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
     pb.n_rays = 0;
     pb.tile_begin = 0;
-    pb.gstats = c->guard_period == 1 && c->n_block <= r2l_body_guard_max_blocks() ? c->d_gstats : nullptr;
+    pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3;
+    pb.gstats = c->guard_period == 1 && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) ? c->d_gstats : nullptr;
     c->last_stream = (hipStream_t)stream;
     hipError_t e = r2l_launch_body(pb, n_tiles < c->n_cu ? n_tiles : c->n_cu, (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
@@ -830,8 +880,16 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
 int r2l_set_precision(r2l_ctx* c, int mode) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (!mode_ok(mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
+    if (c->loaded && split_mode(mode) && c->d_body && c->body_mode != mode && c->n_block > 0 && !c->calib_pending) {
+        // the other split mode's body stream is about to replace this one: the exponents the device calibrated live only
+        // in its aux blocks -- carry them over (same operand sets, same meaning)
+        std::vector<int> ex((size_t)2 * c->n_block + 1);
+        int rc = r2l_get_act_exponents(c, ex.data(), (int)ex.size());
+        if (rc) return rc;
+        c->act = ex;
+    }
     c->mode = mode;
-    if (c->loaded && !c->d_img[mode]) return build_image(c, mode);
+    if (c->loaded && (!c->d_img[mode] || (split_mode(mode) && c->body_mode != mode))) return build_image(c, mode);
     return R2L_OK;
 }
 
@@ -908,7 +966,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         const int nt = p.n_tiles - t0 < R2L_SLICE_TILES ? p.n_tiles - t0 : R2L_SLICE_TILES;
         const int grid = nt < c->n_cu ? nt : c->n_cu;
         R2LParams ph = p;
-        ph.wimg = c->d_img[R2L_PREC_FP16_FP8];
+        ph.wimg = c->d_img[c->mode];
         ph.xbuf = c->d_xa;
         ph.tile_begin = t0;
         ph.n_tiles = nt;
@@ -941,8 +999,9 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
             pb.n_rays = p.n_rays;
             pb.tile_begin = t0;
+            pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3;
             // range guard: the first launch after a weight load, then every guard_period-th (r2l_set_guard_period)
-            const bool guard = c->guard_period > 0 && c->n_block <= r2l_body_guard_max_blocks() &&
+            const bool guard = c->guard_period > 0 && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) &&
                                c->n_since_load % c->guard_period == 0;
             pb.gstats = guard ? c->d_gstats : nullptr;
             ++c->n_since_load;
@@ -975,7 +1034,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
 }
 
 static int timed_launch(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
-    if (c->mode == R2L_PREC_FP16_FP8) return launch_split(c, p, s);
+    if (split_mode(c->mode)) return launch_split(c, p, s);
     const int grid = p.n_tiles < c->n_cu ? p.n_tiles : c->n_cu;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
@@ -1064,13 +1123,13 @@ long long r2l_flops_per_ray(const r2l_ctx* c) {
 }
 long long r2l_kernel_flops_per_ray(const r2l_ctx* c) {
     if (!c) return 0;
-    if (c->mode == R2L_PREC_FP16_FP8)   // r2l_body_kernel: the 2 n_block body layers, and the tail layer when it is fused in
+    if (split_mode(c->mode))   // r2l_body_kernel: the 2 n_block body layers, and the tail layer when it is fused in
         return 2LL * 2LL * c->n_block * R2L_WIDTH * R2L_WIDTH + (c->use_residual && c->fuse_tail && c->n_block > 0 ? 2LL * 3 * R2L_WIDTH : 0);
     return r2l_flops_per_ray(c);
 }
 long long r2l_weight_image_bytes(const r2l_ctx* c) {
     if (!c) return 0;
-    return (long long)c->img_bytes[c->mode] + (c->mode == R2L_PREC_FP16_FP8 ? (long long)c->body_bytes : 0);
+    return (long long)c->img_bytes[c->mode] + (split_mode(c->mode) ? (long long)c->body_bytes : 0);
 }
 int r2l_rays_per_tile(const r2l_ctx*) { return R2L_TILE_RAYS; }
 

@@ -37,6 +37,7 @@ struct R2LBodyParams {
     // range guard: 2 n_block maxima (f32 bits, act_scale domain) of the operand sets IN_0, H_0, IN_1, ... over every ray of
     // the launch; nullptr = the plain kernel (r2l_body.hip: r2l_body_guard_kernel)
     unsigned* gstats;
+    int e4m3;           // 0: bf6 correction terms (r2l_body_kernel, 28 KiB chunks); 1: e4m3 (r2l_body8_kernel, 32 KiB chunks)
 };
 struct R2LTailParams {
     const float* xa;    // head output (global skip), may be nullptr
@@ -56,7 +57,7 @@ hipError_t r2l_launch_calib(const float* xa, const float* wcal, int n_block, int
 // exponents from the range guard's maxima (gstats: 2 n_block sets, act_scale domain) and the head's h0 maximum (range[0])
 hipError_t r2l_launch_recalibrate(const unsigned* gstats, const unsigned* range, int n_block, char* aux, hipStream_t stream);
 int r2l_body_lds_bytes();
-int r2l_body_guard_max_blocks();   // largest n_block whose 2 n_block maxima rows fit the LDS beside the ring
+int r2l_body_guard_max_blocks(int e4m3);   // largest n_block whose 2 n_block maxima rows fit the LDS beside the ring
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,
                                    hipStream_t stream);
 hipError_t r2l_launch_embed(const float* x, long long total, int L, float* emb_out,

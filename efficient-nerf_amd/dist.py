@@ -211,8 +211,9 @@ def agree_act_exponents(eng, group=None):
     from slightly different arithmetic.  Call once after the first render of every rank: the ranks take the element-wise
     maximum (what one GPU would have measured on all their samples together).  Synchronous; no-op for one rank or for
     the other precisions."""
-    from ._lib import PREC_FP16_FP8
-    if not dist.is_initialized() or dist.get_world_size(group) == 1 or eng.precision != PREC_FP16_FP8 or eng.n_block == 0:
+    from ._lib import PREC_FP16_FP8, PREC_FP16_E4M3
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or eng.precision not in (PREC_FP16_FP8, PREC_FP16_E4M3) \
+            or eng.n_block == 0:
         return None
     ex = torch.tensor(eng.act_exponents(), dtype=torch.int32)
     if dist.get_backend(group) == 'nccl':

@@ -73,7 +73,7 @@ FLAGS = [
     # auto (default): fp16_fp8 (fp16 MFMA pass + bf6 correction terms, 1.7x the speed) when the checkpoint's own activation
     # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
     # contract, fp16x3 otherwise (R2LEngine.choose_precision / check_ranges); the teacher takes fp16_fp8
-    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'auto'])),
+    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
 ]
@@ -335,7 +335,7 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
             name, top = eng.choose_precision(c2w=probe_pose, rays=probe_rays)
             if log:
                 log(f'[precision] auto: activation exponents of every ray of the first frame up to {top} '
-                    f'(fp16_fp8 up to {eng.AUTO_MAX_EXP}) -> {name}')
+                    f'(fp16_fp8 up to {eng.AUTO_MAX_EXP}, fp16_e4m3 up to {eng.AUTO_MAX_EXP_E4M3}) -> {name}')
         return 'R2L', eng
     if args.model_name == 'nerf':
         if not args.use_viewdirs or args.N_importance <= 0:

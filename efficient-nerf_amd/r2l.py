@@ -19,7 +19,10 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, check, current_stream, dptr, lib
+from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, check, current_stream, dptr, lib
+
+SPLIT_MODES = (PREC_FP16_FP8, PREC_FP16_E4M3)   # generated head launch + generated body kernel, calibrated operand scales
+PREC_NAMES = {PREC_FP16X3: 'fp16x3', PREC_FP16X1: 'fp16x1', PREC_FP16_FP8: 'fp16_fp8', PREC_FP16_E4M3: 'fp16_e4m3'}
 
 
 def _dev(device=None):
@@ -224,33 +227,44 @@ class R2LEngine:
         self.recalibrate()
         self.set_guard_period(period)
         ex = self.act_exponents()
-        self.range_status(reset=True)
+        self.stream_max = self.range_status(reset=True)['stream_max']   # largest |activation| of any operand set of those rays
         return ex
 
     _guard_period = 8
 
-    #: largest activation exponent (|a| <= 2^E) at which fp16_fp8 stays inside the 1e-4 rgb contract with margin: W256D88
-    #: networks measured at E = 3 / 4 / 5 differ from fp16x3 by 3-6e-5 / 6e-5-1.4e-4 / 1.5-3e-4 (tools/range_sweep.py,
-    #: profiles/r02_range_sweep.txt)
-    AUTO_MAX_EXP = 3
+    #: `--precision auto`'s ladder: the largest activation exponent (|a| <= 2^E over all operand sets) up to which a mode
+    #: stays inside the 1e-4 rgb contract with margin.  W256D88 networks with every body weight x gain (tools/range_sweep.py,
+    #: profiles/r03_range_sweep.txt), L_inf against fp16x3: bf6 terms 3-6e-5 at E = 3, 6e-5-1.4e-4 at 4; e4m3 terms half of
+    #: that; fp16x3 (6e-7) above.
+    AUTO_MAX_EXP = 3          # fp16_fp8 (bf6 x bf6 terms, 1.5 pass-equivalents)
+    AUTO_MAX_EXP_E4M3 = 4     # fp16_e4m3 (e4m3 x e4m3 terms, 2.0 pass-equivalents)
+
+    def _mode_for(self, top, max_exp=None):
+        lim = self.AUTO_MAX_EXP if max_exp is None else int(max_exp)
+        if top <= lim:
+            return PREC_FP16_FP8
+        if max_exp is None and top <= self.AUTO_MAX_EXP_E4M3:
+            return PREC_FP16_E4M3
+        return PREC_FP16X3
 
     def choose_precision(self, c2w=None, rays=None, max_exp=None):
-        """`--precision auto`: fp16_fp8 where the network's own activation ranges allow it, fp16x3 otherwise.  The error of
-        the bf6 correction terms is relative to the residual stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so
-        the choice needs the ranges of THESE weights: `calibrate_on` measures them on every ray of the frame of pose
-        `c2w` (or of the given `rays` = (rays_o, rays_d)); above `max_exp` the context is switched to fp16x3.
-        What is rendered afterwards stays watched (range_status / `check_ranges`).  Synchronous, once per weight load.
+        """`--precision auto`: the fastest mode the network's own activation ranges allow: fp16_fp8 (bf6 correction terms)
+        up to exponent 3, fp16_e4m3 at 4, fp16x3 above.  The error of the low-precision terms is relative to the residual
+        stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so the choice needs the ranges of THESE weights:
+        `calibrate_on` measures them on every ray of the frame of pose `c2w` (or of the given `rays` = (rays_o, rays_d)).
+        `max_exp` overrides fp16_fp8's limit and disables the middle step (tests).  What is rendered afterwards stays
+        watched (range_status / `check_ranges`).  Synchronous, once per weight load.
         Returns (name of the chosen precision, largest exponent)."""
-        max_exp = self.AUTO_MAX_EXP if max_exp is None else int(max_exp)
         self.set_precision(PREC_FP16_FP8)
         if self.n_block == 0:
             return 'fp16_fp8', 0
         top = max(self.calibrate_on(c2w=c2w, rays=rays))
-        self._auto_max_exp = max_exp
-        if top > max_exp:
-            self.set_precision(PREC_FP16X3)
-            return 'fp16x3', top
-        return 'fp16_fp8', top
+        self._auto = (max_exp,)
+        mode = self._mode_for(top, max_exp)
+        if mode != PREC_FP16_FP8:
+            self.set_precision(mode)          # the exponents travel with a switch between the two split modes
+            self.range_status(reset=True)
+        return PREC_NAMES[mode], top
 
     #: fill (fraction of bf6's +-28 the largest value of an operand set reached) beyond which check_ranges raises the
     #: exponents.  The calibration aims at <= 16/28 = 0.57 on the frame it saw; bf6 represents 16..28 as well as 8..16, so
@@ -266,7 +280,7 @@ class R2LEngine:
         returned.  An explicit fp16_fp8 context keeps its mode and says so.  Synchronises.
         Row-sharded runs (dist.check_ranges) pass `any_rank` (bool -> True when any rank says so) and `agree` (makes the
         exponents the element-wise maximum over the ranks), so that every rank takes the same decision."""
-        if self.precision != PREC_FP16_FP8 or self.n_block == 0:
+        if self.precision not in SPLIT_MODES or self.n_block == 0:
             return None
         st = self.range_status()
         fill = max(st['h0_fill'], st['worst_fill'])
@@ -275,7 +289,7 @@ class R2LEngine:
             act, clamped = any_rank(act), any_rank(clamped)
         if not act:
             return None
-        limit = getattr(self, '_auto_max_exp', None)
+        auto = getattr(self, '_auto', None)
         before = self.act_exponents()
         if st['guarded_launches'] > 0 and fill > self.FILL_LIMIT:
             self.recalibrate()
@@ -286,18 +300,21 @@ class R2LEngine:
         after = self.act_exponents()
         top = max(after)
         self.range_status(reset=True)
-        msg = ('[precision] activations fill %.2f of the bf6 scale of operand set %d (h0: %.2f)%s' %
-               (st['worst_fill'], st['worst_set'], st['h0_fill'], ': values were clamped' if clamped else ''))
-        if limit is not None and top > limit:
-            self.set_precision(PREC_FP16X3)
-            if log:
-                log(msg + f'; exponents now up to {top} > {limit} -> fp16x3, frame rendered again')
-            return 'fp16x3'
+        msg = ('[precision] activations fill %.2f of the %s scale of operand set %d (h0: %.2f)%s' %
+               (st['worst_fill'], 'bf6' if self.precision == PREC_FP16_FP8 else 'e4m3', st['worst_set'], st['h0_fill'],
+                ': values were clamped' if clamped else ''))
+        if auto is not None:
+            mode = self._mode_for(top, auto[0])
+            if mode != self.precision and (mode == PREC_FP16X3 or self.precision == PREC_FP16_FP8):   # never back up the ladder
+                self.set_precision(mode)
+                if log:
+                    log(msg + f'; exponents now up to {top} -> {PREC_NAMES[mode]}, frame rendered again')
+                return PREC_NAMES[mode]
         if log:
             log(msg + ('; exponents raised (up to %d)' % top if after != before else '; next launch range-guarded') +
                 (', frame rendered again' if clamped else '') +
-                ('' if limit is not None else ' [explicit fp16_fp8: no fallback; --precision auto has one]'))
-        return 'fp16_fp8' if clamped else None
+                ('' if auto is not None else ' [explicit precision: no fallback; --precision auto has one]'))
+        return PREC_NAMES[self.precision] if clamped else None
 
     def _set_fused_tail(self, on):
         """parity tests: 0 = the three-launch form (body kernel writes x, r2l_tail_kernel finishes the rays)"""

@@ -43,9 +43,14 @@ extern "C" {
  *                    R2L: generated head launch -> generated body kernel (32x32 shapes) -> tail launch;
  *                    teacher: generated layer chain (16x16 shapes; the embedding k-steps stay three
  *                    fp16 passes).  (The name is historical: round 1 used fp8 terms.) */
+/*   R2L_PREC_FP16_E4M3 (R2L student only) the same machine with both correction terms in OCP e4m3 (3 mantissa bits instead
+ *                    of 2 in all four factors): 2.0 pass-equivalents per k-step, half the error of R2L_PREC_FP16_FP8 -- the
+ *                    mode for networks whose residual stream is too large for the bf6 terms (activation exponent 4:
+ *                    `--precision auto` picks per checkpoint: FP16_FP8 up to exponent 3, FP16_E4M3 at 4, FP16X3 above). */
 #define R2L_PREC_FP16X3 0
 #define R2L_PREC_FP16X1 1
 #define R2L_PREC_FP16_FP8 2
+#define R2L_PREC_FP16_E4M3 3
 
 typedef struct r2l_ctx r2l_ctx;
 typedef struct nerf_ctx nerf_ctx;
@@ -138,6 +143,8 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
  * r2l_load_weights uploads for r2l_body_kernel; offs[0] / offs[1] receive the aux / tail byte offsets. */
 long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, int n_block,
                                    char* out, long long cap, long long* offs);
+/* which stream the call above packs (thread-local): 0 = bf6 terms (R2L_PREC_FP16_FP8, the default), 1 = e4m3 terms */
+int r2l_debug_pack_body_format(int e4m3);
 /* The hand-scheduled body kernel alone (R2L_PREC_FP16_FP8): x_out = ResMLP blocks(x_in) on n_tiles ray
  * tiles in the register-image layout [tile][wave 4][group 32][lane 64][4] f32: group 4u + g of lane 32h + ray holds
  * features 32u + 8g + 4h .. + 3 (csrc/r2l_common.h); parity tests only. */
@@ -184,7 +191,10 @@ typedef struct r2l_range_status {
     float worst_fill;        /* largest fill over the 2 n_block operand sets of the guarded launches since the reset */
     int worst_set;           /* its set index (2b: input of block b, 2b+1: hidden layer of block b), -1: no guarded launch */
     int saturated;           /* a fill reached 1: values were clamped to +-28 */
-    int beyond_calibration;  /* a fill exceeds 16/28: r2l_recalibrate would raise that set's exponent */
+    int beyond_calibration;  /* a fill exceeds 16 / format_top: r2l_recalibrate would raise that set's exponent */
+    float format_top;        /* largest magnitude of the operand format in use: 28 (bf6), 448 (e4m3) */
+    float stream_max;        /* largest |activation| (real units) of any operand set seen since the reset: the error of the
+                              * low-precision terms is proportional to it (`--precision auto` decides on it) */
     long long launches;          /* R2L_PREC_FP16_FP8 body launches since the last reset */
     long long guarded_launches;  /* ... of them range-guarded */
 } r2l_range_status;

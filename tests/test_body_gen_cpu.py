@@ -71,8 +71,9 @@ def from_regs(regs):
     return xs
 
 
-def cxx_pack(W1s, b1s, W2s, b2s):
+def cxx_pack(W1s, b1s, W2s, b2s, e4m3=0):
     nb = len(W1s)
+    _lib.lib().r2l_debug_pack_body_format(e4m3)
     tensors = [np.zeros((256, 1008), np.float32), np.zeros(256, np.float32)]
     for b in range(nb):
         tensors += [W1s[b], b1s[b], W2s[b], b2s[b]]
@@ -84,6 +85,7 @@ def cxx_pack(W1s, b1s, W2s, b2s):
     assert n > 0, _lib.lib().r2l_last_error()
     buf = np.zeros(n, dtype=np.uint8)
     assert _lib.lib().r2l_debug_pack_body_host(arr, len(keep), nb, C.c_void_p(buf.ctypes.data), n, offs) == n
+    _lib.lib().r2l_debug_pack_body_format(0)
     return buf, int(offs[0]), int(offs[1]), tensors
 
 
@@ -98,6 +100,16 @@ def test_cxx_packer_matches_python_restatement():
     Wt, bt = tensors[-2], tensors[-1]
     assert np.allclose(tw[:768].reshape(3, 256) * 16.0, Wt, rtol=0, atol=0)
     assert np.allclose(tw[768:771], bt + Wt.astype(np.float64) @ Bsum, rtol=1e-6, atol=1e-7)
+
+
+def test_cxx_packer_matches_python_restatement_e4m3():
+    W = make_weights(2, seed=5, gain=3.0)
+    buf, aux_off, tail_off, _ = cxx_pack(*W, e4m3=1)
+    img, aux, _ = G.pack_body_image(*W, fmt='fp8')
+    G.configure('bf6')
+    assert aux_off == img.size == 2 * 16 * 32768 and tail_off == aux_off + 2 * G.AUX_BYTES
+    assert np.array_equal(buf[:aux_off], img)
+    assert np.array_equal(buf[aux_off:tail_off].view(np.uint32).reshape(2, -1), aux)
 
 
 @pytest.mark.parametrize('nb,wave,burst', [(1, 0, False), (3, 2, False), (2, 3, True)])
@@ -192,3 +204,37 @@ def test_range_guard_stream_collects_the_maxima_of_every_operand_set():
         assert abs(got[2 * b] - xt) <= 2e-3 * xt, (b, got[2 * b], xt)
         assert abs(got[2 * b + 1] - want[2 * b + 1]) <= 2e-3 * want[2 * b + 1], (b, got[2 * b + 1], want[2 * b + 1])
         b2sum = b2sum + W[3][b].astype(np.float64)
+
+
+def test_e4m3_stream_matches_float64_at_half_the_bf6_error():
+    """The middle precision mode (R2L_PREC_FP16_E4M3): the same machine with both correction terms in OCP e4m3 (8-register
+    operands, 32 KiB chunks, conversions by v_cvt_scalef32_pk_fp8_f16): one more mantissa bit in all four factors."""
+    nb, wave = 2, 2
+    W = make_weights(nb, seed=6)
+    rng = np.random.default_rng(3)
+    x = np.maximum(rng.normal(0, 1, (32, 256)), 0).astype(np.float32)
+    S = 16.0
+    ref = ref_blocks(x, *W)
+    Bsum = np.sum([b.astype(np.float64) for b in W[3]], axis=0)
+    errs = {}
+    for fmt in ('bf6', 'fp8'):
+        img, aux, _ = G.pack_body_image(*W, fmt=fmt)
+        out, e = G.emulate_tile(G.Opts(fmt=fmt), img, aux, to_regs(x * S), nb, wave=wave)
+        assert not e, (fmt, e[:10])
+        errs[fmt] = np.abs(from_regs(out) / S + Bsum - ref).max()
+    G.configure('bf6')
+    print('L_inf after %d blocks: bf6 terms %.3g, e4m3 terms %.3g' % (nb, errs['bf6'], errs['fp8']))
+    assert errs['fp8'] < 0.75 * errs['bf6'] and errs['fp8'] < 1.5e-5 * nb
+
+
+def test_e4m3_guard_stream_is_bit_identical():
+    nb = 2
+    W = make_weights(nb, seed=9)
+    img, aux, _ = G.pack_body_image(*W, fmt='fp8')
+    x = np.maximum(np.random.default_rng(2).normal(0, 1, (32, 256)), 0).astype(np.float32)
+    plain, e0 = G.emulate_tile(G.Opts(fmt='fp8'), img, aux, to_regs(x * 16.0), nb, wave=3)
+    out, e1, rows = G.emulate_tile(G.Opts(fmt='fp8', guard=True), img, aux, to_regs(x * 16.0), nb, wave=3)
+    G.configure('bf6')
+    assert not e0 and not e1, (e0 + e1)[:10]
+    assert np.array_equal(plain.view(np.uint32), out.view(np.uint32))
+    assert abs(rows[0].max() / 16.0 - np.abs(x).max()) < 1e-3 and rows.shape == (2 * nb, 32)

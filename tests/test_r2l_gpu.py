@@ -85,11 +85,12 @@ def test_mirror_objects_materialize(pkg, g):
 
 
 @pytest.mark.parametrize('H', [8, 400, 800])
-@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8'])
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8', 'fp16_e4m3'])
 def test_render_matches_reference_golden(g, engines, H, prec):
     """Full frame vs rgb computed by the reference's modules (model/nerf_raybased.py:76-126, 191-208, 539-544), at
     the reference's own CPU case (8), config 2 (400) and the bench's size (800), in every precision mode that
-    claims the 1e-4 contract -- fp16_fp8 is the bench's mode (head launch + hand-scheduled body + tail)."""
+    claims the 1e-4 contract -- fp16_fp8 is the bench's mode (head launch + hand-scheduled body with the fused tail),
+    fp16_e4m3 the same machine with e4m3 correction terms (`auto`'s middle rung)."""
     from efficient_nerf_amd import PRECISIONS, PREC_FP16X3
     eng = engines[H]
     idx = T(g[f'idx_{H}']).cuda()
@@ -101,7 +102,7 @@ def test_render_matches_reference_golden(g, engines, H, prec):
             assert rgb.shape == (H * H, 3)
             worst = max(worst, np.abs(rgb[idx].cpu().numpy() - g[f'rgb_{H}_{p}']).max())
         print(f'H={H} {prec} L_inf vs reference golden: {worst:.3e}')
-        assert worst <= (TOL_X3 if prec == 'fp16x3' else 6e-5)
+        assert worst <= {'fp16x3': TOL_X3, 'fp16_fp8': 6e-5, 'fp16_e4m3': 4e-5}[prec]
     finally:
         eng.set_precision(PREC_FP16X3)
 
@@ -257,16 +258,31 @@ def test_small_networks_vs_oracle(pkg, n_block, use_residual, gain):
 
 
 def test_linearity_free_properties_full_size(engines, g):
-    """Size-independent checks at the BASELINE 800x800 size: outputs in (0,1), finite,
-    deterministic across launches, and PSNR vs the fp64-evaluated oracle on a strided
-    subset within 0.01 dB of the fp32 reference's own PSNR."""
-    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3
+    """Size-independent checks at the BASELINE 800x800 size: outputs in (0,1), finite, deterministic across launches, and
+    north_star's second tolerance: on a strided subset of the frame, PSNR against a stand-in ground truth (the oracle's
+    render under weights perturbed by a fixed seed, ~33 dB away: utils/run_nerf_raybased_helpers.py:19-20 applied to
+    it) within 0.01 dB of the fp32 reference's own PSNR, in every mode that claims the contract."""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3
     eng = engines[800]
     c2w = T(g['poses'][3])
     a = eng.render(c2w)
     b = eng.render(c2w)
     assert torch.equal(a, b)
     assert torch.isfinite(a).all() and (a > 0).all() and (a < 1).all()
+    idx = torch.arange(0, 800 * 800, 800 * 800 // 4000)[:4000]
+    sd = O.make_r2l_state(0)
+    pts = O.sample_test(O.camera_dirs(800, 800, O.focal_from_angle(800)), T(g['z_vals_800']), c2w[:3, :4])[idx]
+    emb = O.positional_embed(pts, 10)
+    ref = O.r2l_forward(sd, emb)
+    gt = O.r2l_forward(O.perturbed_state(sd), emb)
+    p_ref = O.psnr(ref, gt)
+    assert 25 < p_ref < 45, p_ref
+    for prec in (PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3):
+        eng.set_precision(prec)
+        delta = abs(O.psnr(eng.render(c2w).cpu()[idx], gt) - p_ref)
+        print(f'precision {prec}: PSNR vs gt* {p_ref:.3f} dB (reference), delta {delta:.2e} dB')
+        assert delta < 0.01, (prec, delta)
+    eng.set_precision(PREC_FP16X3)
     # the bench's default mode at the bench's size: deterministic, finite, and within the contract of
     # the fp16x3 frame everywhere (640,000 rays), row ranges and pose batches agree bit for bit
     eng.set_precision(PREC_FP16_FP8)

@@ -135,33 +135,39 @@ def test_edge_rays_beyond_the_centre_probe_are_caught(pkg):
     eng.close()
 
 
-def test_auto_falls_back_when_a_later_pose_leaves_the_range(pkg):
+@pytest.mark.parametrize('gain,want', [(1.12, 'fp16_e4m3'), (1.3, 'fp16x3')])
+def test_auto_falls_back_when_a_later_pose_leaves_the_range(pkg, gain, want):
     """`--precision auto` = choose_precision + check_ranges after every frame: exponents forced low (as if the first frame
-    had been a tame one) -> the next frame trips the watch, the context ends in fp16x3 when the limit is exceeded, and the
-    re-rendered frame meets the contract."""
-    from efficient_nerf_amd import PREC_FP16X3, R2LEngine
+    had been a tame one) -> the next frame trips the watch, the context moves down the ladder (fp16_fp8 -> fp16_e4m3 at
+    exponent 4 -> fp16x3 above), and the re-rendered frame meets the contract."""
+    from efficient_nerf_amd import PRECISIONS, R2LEngine
     H = 96
     focal = O.focal_from_angle(H)
     sd = O.make_r2l_state(seed=0)
     for k in sd:
         if k.startswith('body.') and k.endswith('weight'):
-            sd[k] = sd[k] * 1.2                   # activation exponents 4..5: beyond fp16_fp8's limit
+            sd[k] = sd[k] * gain                  # activation exponents 4 (gain 1.12) / 5-6 (1.3): beyond fp16_fp8's limit
     c2w = O.pose_spherical(40., -30., 4.)
     eng = R2LEngine(H, H, focal).load_state_dict(sd)
     name, top = eng.choose_precision(c2w=c2w, max_exp=8)      # limit lifted: stays in fp16_fp8 ...
     assert name == 'fp16_fp8' and top > eng.AUTO_MAX_EXP
-    eng._auto_max_exp = eng.AUTO_MAX_EXP                       # ... then the real limit, with exponents two too small
+    eng._auto = (None,)                                        # ... then the real ladder, with exponents two too small
     eng.set_act_exponents([e - 2 for e in eng.act_exponents()])
     eng.set_guard_period(1)
     eng.range_status(reset=True)
     eng.render(c2w)
     logs = []
-    assert eng.check_ranges(log=logs.append) == 'fp16x3', logs
-    assert eng.precision == PREC_FP16X3 and 'fp16x3' in logs[0]
+    assert eng.check_ranges(log=logs.append) == want, logs
+    assert eng.precision == PRECISIONS[want] and want in logs[0]
     ref = O.r2l_render(sd, H, H, focal, c2w)
     assert (eng.render(c2w).cpu() - ref).abs().max().item() <= 1e-4
-    assert eng.check_ranges() is None            # nothing to watch in fp16x3
+    assert eng.check_ranges() is None            # inside the scales now (fp16x3 has none to watch)
+    # straight through choose_precision: the same rung
+    eng2 = R2LEngine(H, H, focal).load_state_dict(sd)
+    assert eng2.choose_precision(c2w=c2w)[0] == want
+    assert (eng2.render(c2w).cpu() - ref).abs().max().item() <= 1e-4
     eng.close()
+    eng2.close()
 
 
 def test_calibrate_on_one_pose_holds_the_contract_on_the_whole_test_path(pkg):

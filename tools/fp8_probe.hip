@@ -30,10 +30,11 @@ static int e4m3_enc(float x) {
     return s | best;
 }
 
-__global__ void k_cvt(const uint32_t* src, uint32_t* out, float scale) {
+__global__ void k_cvt(const uint32_t* src, uint32_t* out, float scale, int ovfl) {
     const int l = threadIdx.x;
     const uint32_t s0 = src[l * 2], s1 = src[l * 2 + 1];
     uint32_t d = 0xdeadbeef;
+    if (ovfl) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 2" ::: "memory");   // MODE.FP16_OVFL
     asm volatile(
         "v_cvt_scalef32_pk_fp8_f16 %0, %1, %3\n\t"
         "s_nop 1\n\t"
@@ -117,19 +118,23 @@ int main() {
     hipMalloc((void**)&ds, sizeof vals); hipMalloc((void**)&dout, sizeof out);
     hipMemcpy(ds, vals, sizeof vals, hipMemcpyHostToDevice);
     const float scales[3] = {1.0f, 4.0f, 0.125f};
-    for (int sc = 0; sc < 3; ++sc) {
-        k_cvt<<<1, 64>>>(ds, dout, scales[sc]);
+    for (int sc = 0; sc < 6; ++sc) {
+        const int ovfl = sc >= 3;
+        const float scale = scales[sc % 3];
+        k_cvt<<<1, 64>>>(ds, dout, scale, ovfl);
         hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost);
         int bad_div = 0, bad_mul = 0;
         for (int l = 0; l < 64; ++l)
             for (int i = 0; i < 4; ++i) {
                 const int got = (out[l] >> (8 * i)) & 0xff;
                 const float x = (float)vals[l][i];
-                bad_div += got != e4m3_enc(x / scales[sc]);
-                bad_mul += got != e4m3_enc(x * scales[sc]);
+                if (got != e4m3_enc(x / scale) && bad_div++ < 3)
+                    printf("    lane %d el %d: %.9g / %g -> code 0x%02x (%g), host rule 0x%02x (%g)\n", l, i, x, scale, got, e4m3_val(got),
+                           e4m3_enc(x / scale), e4m3_val(e4m3_enc(x / scale)));
+                bad_mul += got != e4m3_enc(x * scale);
             }
-        printf("cvt_scalef32_pk_fp8_f16 scale %g: byte i = element i (low half first, op_sel[2] = high half), RNE, saturating: "
-               "%d mismatches if dst = fp8(src / scale), %d if dst = fp8(src * scale)\n", scales[sc], bad_div, bad_mul);
+        printf("cvt_scalef32_pk_fp8_f16 scale %g, MODE.FP16_OVFL %d: byte i = element i (low half first, op_sel[2] = high half), RNE, saturating: "
+               "%d mismatches if dst = fp8(src / scale), %d if dst = fp8(src * scale)\n", scale, ovfl, bad_div, bad_mul);
         if (sc == 0) {
             printf("  lane 20 (rounding):");
             for (int i = 0; i < 4; ++i) printf(" %g->%g", (float)vals[20][i], e4m3_val((out[20] >> (8 * i)) & 0xff));
