@@ -30,5 +30,11 @@ if 'SQ_WAVE_CYCLES' in mean:
     for n in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_LDS'):
         if n in mean:
             print(f'  {n}/SQ_WAVE_CYCLES = {mean[n]/wc:.3f}')
+    for n in ('SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_LDS_CMD_FIFO_FULL',
+              'SQ_LDS_DATA_FIFO_FULL'):
+        if n in mean:
+            print(f'  {n}/SQ_WAVE_CYCLES = {mean[n]/wc:.3f}')
+    if 'SQ_VALU_MFMA_COEXEC_CYCLES' in mean:
+        print(f'  SQ_VALU_MFMA_COEXEC_CYCLES / (4 SQ_WAVE_CYCLES) = {mean["SQ_VALU_MFMA_COEXEC_CYCLES"]/(4*wc):.3f}')
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in mean:
         print(f'  MFMA busy / wave cycles = {mean["SQ_VALU_MFMA_BUSY_CYCLES"]/(4*wc):.3f} (quad-cycle corrected)')
