@@ -6,7 +6,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 d=$root/build_variants/$name
 mkdir -p $d
-cp $root/efficient-nerf_amd/csrc/*.hip $root/efficient-nerf_amd/csrc/*.h $d/
+cp $root/efficient-nerf_amd/csrc/*.hip $root/efficient-nerf_amd/csrc/*.h $root/efficient-nerf_amd/csrc/*.inc $d/
 python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --emit $d/r2l_body_asm.inc "$@" > /dev/null || exit 1
 sed -i 's#"../../include/r2l_hip.h"#"'$root'/include/r2l_hip.h"#' $d/*.hip
 cd $d
