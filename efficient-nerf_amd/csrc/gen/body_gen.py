@@ -48,7 +48,8 @@ import sys
 import numpy as np
 
 from isa import (ACT_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
-                 ds_read_b64, ds_read_b96, ds_max_u32, v_max3_abs, mfma32_8, v_cvt_pk_fp8_f16, f_to_e4m3, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
+                 ds_read_b64, ds_read_b96, ds_max_u32, ds_write_b128, ds_write_b64, v_max3_abs, mfma32_8, v_cvt_pk_fp8_f16,
+                 f_to_e4m3, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
                  v_cvt_pk32_bf6, s_nop, salu, f_to_bf6, pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream,
                  model_cycles)
 
@@ -59,8 +60,7 @@ V_INH = 0
 V_HH = 64
 V_ACC = 128
 V_BIAS = 160
-V_HI = 176
-# V_A6, V_LO, V_CV (192 .. 225): configure()
+# V_HI, V_A6, V_LO, V_CV (176 .. 225): configure()
 V_L0 = 226        # lane*16                (LDS bytes 0 .. 65535)
 V_L1 = 227        # lane*16 + 65536
 V_L8A = 228       # lane*8                 (8-byte parts of the bf6 operands)
@@ -83,7 +83,7 @@ V_RAYOFF = 253    # lane * 12: byte offset of this lane's ray in the wave's rgb 
 V_RAY = 254
 V_GMAX = 255      # range guard (opts.guard): running max |a| of the operand set being produced, per lane
 N_VGPR_USED = 256
-NHI = 4           # fp16 fragment buffers
+# NHI (fp16 fragment buffers): configure()
 
 A_X = 0
 A_IN6 = 128       # A_H6, N_AGPR_USED: configure()
@@ -130,33 +130,57 @@ TAIL_BYTES = 4096
 # tiles of a workgroup by ds_max_u32; the kernel's HIP epilogue reduces the rows and atomicMax-es them into the context's
 # statistics
 GSTAT_ROW = 128
-
+DMA6 = False      # --dma6 (bf6r): a wave's share as 6 x dwordx4, the sixth overlapping the fifth by 512 B, instead of 5 + 2 x dword
 
 def configure(fmt):
-    """Format of the two correction terms: 'bf6' (OCP e3m2: 6 registers per K=64 operand, 32 matrix-pipe cycles; the
-    R2L_PREC_FP16_FP8 mode) or 'fp8' (OCP e4m3: 8 registers, 64 cycles; R2L_PREC_FP16_E4M3, one more mantissa bit in all
-    four factors: half the error at 1.33x the MFMA time).  Sets the format-dependent part of the register map, the chunk
-    geometry and the LDS map (module globals: the generators are run once per variant)."""
-    global FMT, NA6, PIECES, CHUNK, PW, LDS_AUX, LDS_TAIL, LDS_BYTES, LDS_GSTAT, V_A6, V_LO, V_CV, A_H6, N_AGPR_USED
-    FMT = fmt
-    NA6 = 6 if fmt == 'bf6' else 8                  # registers of a K=64 operand
-    PIECES = 28 if fmt == 'bf6' else 32             # 1 KiB pieces of a chunk: 16 fp16 fragments + 8 operands of 1.5 | 2 KiB
-    CHUNK = PIECES * 1024
-    PW = PIECES // 4                                # LDS-DMA pieces per wave and chunk
-    LDS_AUX = NSLOT * CHUNK
+    """Format of the two correction terms and source of the bf6(W) operand:
+      'bf6'   OCP e3m2 x e3m2 (6 registers per K=64 operand, 32 matrix-pipe cycles), all 8 operands of a row tile streamed:
+              28 KiB chunks (the round-2 kernel; kept as the reference build of the A/B);
+      'bf6r'  the same arithmetic, but the four bf6(W) operands of a row tile (term 1: W x (a - hi(a))) are neither streamed
+              nor read from LDS: every wave converts them from the fp16 fragments it holds for its own MFMAs (four
+              v_cvt_scalef32_pk32_bf6_f16 per row tile, each in the shadow of a 32-cycle MFMA): 22 KiB chunks, -21 % of the
+              L2 -> LDS stream AND of the LDS reads, no LDS traffic added (R2L_PREC_FP16_FP8 since round 3).  The fragment
+              ring has 8 buffers (a K=64 step's four fragments are 16 consecutive registers), the layer-1 bias is read
+              straight into the accumulator, the streamed bf6 operands go through AGPRs;
+      'fp8'   OCP e4m3 x e4m3 (8 registers, 64 cycles; R2L_PREC_FP16_E4M3, one more mantissa bit in all four factors: half
+              the error at 1.33x the MFMA time), all operands streamed: 32 KiB chunks.
+    Sets the format-dependent part of the register map, the chunk geometry and the LDS map (module globals: the generators
+    are run once per variant)."""
+    global FMT, WREG, NA6, NHI, PIECES, CHUNK, SLOT, WAVE_BYTES, PW, LDS_AUX, LDS_TAIL, LDS_BYTES, LDS_GSTAT
+    global V_HI, V_A6, A_A6, V_LO, V_CV, V_WCV, V_WSC, V_DMAOFF4, A_H6, N_AGPR_USED, ORDER
+    WREG = fmt == 'bf6r'
+    FMT = 'bf6' if WREG else fmt
+    NA6 = 6 if FMT == 'bf6' else 8                  # registers of a K=64 operand
+    PIECES = 28 if FMT == 'bf6' else 32             # KiB of a chunk with all operands: 16 fp16 fragments + 8 x 1.5 | 2 KiB
+    CHUNK = 22 * 1024 if WREG else PIECES * 1024    # bytes of a chunk in the stream = LDS stride of the ring
+    SLOT = CHUNK
+    WAVE_BYTES = CHUNK // 4                         # a wave's share of a chunk: bf6r 5 x 1 KiB + 2 x 256 B
+    PW = (6 if DMA6 else 7) if WREG else PIECES // 4   # LDS-DMA instructions per wave and chunk
+    LDS_AUX = NSLOT * SLOT
     LDS_TAIL = LDS_AUX + 2 * AUX_BYTES              # tail table: 3 x 256 f32 (W_t / act_scale) | 2 x (3 folded biases, 0)
     LDS_BYTES = LDS_TAIL + TAIL_BYTES
     LDS_GSTAT = LDS_BYTES
-    V_A6 = 192                                      # weight operands of the K=64 MFMAs, 2 buffers
-    V_LO = V_A6 + 2 * NA6                           # bf6: fp16 residual pairs of 2 row tiles (16); fp8: of one (8)
-    V_CV = V_LO + (16 if fmt == 'bf6' else 8)       # conversion outputs: bf6 6; fp8 4 (values) + 4 (residuals)
-    assert V_CV + (6 if fmt == 'bf6' else 8) <= V_L0
+    if WREG:
+        NHI = 8                                     # fragment buffers: two groups of four = the sources of two conversions
+        V_HI = 160                                  # 160..191 (the bias registers are gone: read straight into ACC)
+        V_LO, V_CV, V_WCV, V_WSC, V_DMAOFF4 = 192, 208, 214, 220, 222
+        V_A6, A_A6 = None, 224                      # streamed bf6 operands (term 0): 2 buffers in AGPRs
+        ORDER = 'group'
+    else:
+        NHI = 4
+        V_HI = 176
+        V_A6 = 192                                  # weight operands of the K=64 MFMAs, 2 buffers
+        V_LO = V_A6 + 2 * NA6                       # bf6: fp16 residual pairs of 2 row tiles (16); fp8: of one (8)
+        V_CV = V_LO + (16 if FMT == 'bf6' else 8)   # conversion outputs: bf6 6; fp8 4 (values) + 4 (residuals)
+        assert V_CV + (6 if FMT == 'bf6' else 8) <= V_L0
+        ORDER = ORDER_BASE
     A_H6 = A_IN6 + 8 * NA6
-    N_AGPR_USED = A_H6 + 8 * NA6
+    N_AGPR_USED = A_H6 + 8 * NA6 + (12 if WREG else 0)
     assert N_AGPR_USED <= 256
 
 
 TILES = 16                 # row tiles of a block: layer * 8 + u
+BIAS_AT = 17               # bf6r: anchor of a tile from which the NEXT tile's bias may be read into its accumulator buffer
 
 
 def INH(s):
@@ -176,7 +200,8 @@ def HI(b):
 
 
 def A6(b):
-    return V_A6 + b * NA6
+    """buffer b of the streamed K=64 weight operands: (file, first register)"""
+    return ('a', A_A6 + b * NA6) if WREG else ('v', V_A6 + b * NA6)
 
 
 def X(u):
@@ -206,19 +231,28 @@ def mix_feat(t, h, e):
     return kappa(4 * t + (e >> 3), h, e & 7)
 
 
-def piece_hi(s):
-    return s
+def off_hi(s):
+    """byte offset inside a chunk (stream and ring slot alike) of the fp16 fragment of k-step s (1 KiB, lane * 16)"""
+    return s * 1024
 
 
-def piece_a6(j):
-    """1 KiB piece with the first 16 B/lane of K=64 operand j of the row tile"""
-    return 16 + j if FMT == 'bf6' else 16 + 2 * j
+def off_a6(j):
+    """(offset of the first 16 B/lane, offset of the rest) of K=64 operand j = (term, t) = J_ORDER[j] inside its ring slot.
+    bf6: the rest is 8 B/lane (512 B); fp8: another 16 B/lane.  bf6r: only the term-0 operands exist in the stream; they
+    follow the fragments back to back, 1,536 B each (1 KiB of lane * 16, then 512 B of lane * 8)."""
+    term, t = J_ORDER[j]
+    if WREG:
+        assert term == 0
+        base = 16 * 1024 + t * 1536
+        return base, base + 1024
+    if FMT == 'bf6':
+        return (16 + j) * 1024, (24 + (j >> 1)) * 1024 + (j & 1) * 512
+    return (16 + 2 * j) * 1024, (17 + 2 * j) * 1024
 
 
-def piece_a6b(j):
-    """(piece, byte offset inside it) of the rest of the operand: bf6 the last 8 B/lane (64 lanes x 8 B = 512 B), fp8 the
-    second 16 B/lane"""
-    return (24 + (j >> 1), (j & 1) * 512) if FMT == 'bf6' else (17 + 2 * j, 0)
+def in_stream(j):
+    """is operand j part of the weight stream (False: made on chip, bf6r term 1)"""
+    return not (WREG and J_ORDER[j][0] == 1)
 
 
 def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
@@ -245,7 +279,7 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
             Wl = Wl.astype(np.float32)
             hi = Wl.astype(np.float16)
             ex = layer_exponent(Wl)
-            el, ew = weight_exps(ex, fmt)
+            el, ew = weight_exps(ex, FMT)
             for qq in range(4):
                 aux[b, AUX_SCALES // 4 + 4 * qq + 2 * layer] = 0x01010101 * (127 + el)
                 aux[b, AUX_SCALES // 4 + 4 * qq + 2 * layer + 1] = 0x01010101 * (127 + ew)
@@ -253,12 +287,14 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
                 base = ((b * 2 + layer) * 8 + u) * CHUNK
                 rows = 32 * u + r
                 for s in range(16):
-                    p = base + piece_hi(s) * 1024
+                    p = base + off_hi(s)
                     frag = np.zeros((64, 8), dtype=np.float16)
                     for j in range(8):
                         frag[:, j] = hi[rows, kappa(s, h, j)]
                     img[p:p + 1024] = frag.view(np.uint8).reshape(-1)
                 for j, (term, t) in enumerate(J_ORDER):
+                    if not in_stream(j):
+                        continue
                     codes = np.zeros((64, 32), dtype=np.uint8)
                     for e in range(32):
                         k = mix_feat(t, h, e)
@@ -267,15 +303,13 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
                             v = np.ldexp(w - hi[rows, k].astype(np.float64), -el)
                         else:
                             v = np.ldexp(w, -ew)
-                        codes[:, e] = f_to_bf6(v) if fmt == 'bf6' else f_to_e4m3(v)
+                        codes[:, e] = f_to_bf6(v) if FMT == 'bf6' else f_to_e4m3(v)
                     # bf6: 6 dwords per lane, little-endian 6-bit fields; fp8: byte e = element e, 8 dwords
-                    words = pack6(codes) if fmt == 'bf6' else np.ascontiguousarray(codes).view(np.uint32)
-                    p = base + piece_a6(j) * 1024
-                    img[p:p + 1024] = np.ascontiguousarray(words[:, :4]).view(np.uint8).reshape(-1)
-                    pc, off = piece_a6b(j)
-                    p = base + pc * 1024 + off
+                    words = pack6(codes) if FMT == 'bf6' else np.ascontiguousarray(codes).view(np.uint32)
+                    o1, o2 = off_a6(j)
+                    img[base + o1:base + o1 + 1024] = np.ascontiguousarray(words[:, :4]).view(np.uint8).reshape(-1)
                     rest = np.ascontiguousarray(words[:, 4:]).view(np.uint8).reshape(-1)
-                    img[p:p + rest.size] = rest
+                    img[base + o2:base + o2 + rest.size] = rest
         Bsum = Bsum + b2s[b].astype(np.float64)
     return img, aux, Bsum
 
@@ -284,26 +318,31 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
 # LDS-DMA of this kernel's ring
 # ---------------------------------------------------------------------------------------------
 def dma_piece(i, tag=''):
-    """piece i (0..6) of this wave's 7 KiB of a chunk: global_load_lds_dwordx4 v_off, s[S_G:S_G+1] offset:imm
-    with LDS destination M0 + imm + lane*16; pieces 4..6 use the +4096 offset register and M0 + 4096."""
-    voffr = V_DMAOFF if i < 4 else V_DMAOFF2
-    imm = 1024 * (i & 3)
-    text = 'global_load_lds_dwordx4 %s, %s offset:%d' % (vreg(voffr), sreg(S_G, 2), imm)
+    """piece i of this wave's share of a chunk: global_load_lds_dwordx4 v_off, s[S_G:S_G+1] offset:imm with LDS destination
+    M0 + imm + lane*16; pieces 4.. use the second offset register and M0 + 4096.  bf6r: a wave moves 5,632 B = pieces 0..4
+    of 1 KiB and pieces 5, 6 of 256 B (global_load_lds_dword: 4 bytes per lane; dwordx3 does not pack, tools/dma12_probe.hip)."""
+    if WREG and DMA6 and i == 5:
+        voffr, width, imm = V_DMAOFF2, 16, 512                         # overlaps piece 4 by 512 B: the same bytes twice
+    elif WREG and i >= 5:
+        voffr, width, imm = V_DMAOFF4, 4, 1024 + 256 * (i - 5)        # relative to M0 + 4096 / the + 4096 offset register
+    else:
+        voffr, width, imm = (V_DMAOFF if i < 4 else V_DMAOFF2), 16, 1024 * (i & 3)
+    text = 'global_load_lds_dword%s %s, %s offset:%d' % ('x4' if width == 16 else '', vreg(voffr), sreg(S_G, 2), imm)
 
     def emu(st):
         copies = []
         g = st.S[S_G]
         for w in range(4):
-            dw = (w - st.wave) * PW * 1024
+            dw = (w - st.wave) * WAVE_BYTES
             for l in range(64):
                 src = g + int(st.V[voffr][l]) + dw + imm
-                dst = st.m0 + dw + imm + l * 16
-                assert 0 <= dst and dst + 16 <= LDS_AUX, dst
-                assert 0 <= src and src + 16 <= len(st.img), src
-                copies.append((dst, st.img[src:src + 16].copy()))
-                st.lds_pending[dst:dst + 16] = True
+                dst = st.m0 + dw + imm + l * width
+                assert 0 <= dst and dst + width <= LDS_AUX, dst
+                assert 0 <= src and src + width <= len(st.img), src
+                copies.append((dst, st.img[src:src + width].copy()))
+                st.lds_pending[dst:dst + width] = True
         st.pend_dma.append(copies)
-    return Ins(text, 'dma', rd=vr(voffr), emu=emu, cost=8, tag=tag)
+    return Ins(text, 'dma', rd=vr(voffr), emu=emu, cost=8 if width == 16 else 4, tag=tag)
 
 
 def dma_aux():
@@ -334,18 +373,25 @@ def slot_of(T):
 
 def lds_addr(slot, byte_off, width):
     """(base VGPR, immediate offset) of byte `byte_off` of ring slot `slot` for a per-lane width of 16 or 8 bytes"""
-    off = slot * CHUNK + byte_off
+    off = slot * SLOT + byte_off
     lo, hi = (V_L0, V_L1) if width == 16 else (V_L8A, V_L8B)
     return (lo, off) if off < 65536 else (hi, off - 65536)
 
 
-ORDER = 'tail'   # 'tail': the 16 fp16 MFMAs of a row tile, then its 8 K=64 MFMAs; 'mix': the K=64 ones behind k-steps 8..15
+ORDER_BASE = 'tail'   # 'tail': the 16 fp16 MFMAs of a row tile, then its 8 K=64 MFMAs; 'mix': the K=64 ones behind k-steps
+                      # 8..15; bf6r always runs 'group': per K=64 step t its four fp16 MFMAs, then (1, t), then (0, t)
+ORDER = ORDER_BASE
 
 
 def tile_anchors():
     """the 24 MFMAs of a row tile as (kind, s or j), all on ONE accumulator (an accumulate chain).  The B operands of the
     previous layer's last row tile are converted late: its k-steps 14, 15 and its K=64 operands (., 3) come last."""
     out = []
+    if ORDER == 'group':     # bf6r: K=64 step t = fp16 k-steps 4t .. 4t+3, then term 1 (operand converted from them), then term 0
+        for t in range(4):
+            out += [('m16', 4 * t + i) for i in range(4)]
+            out += [('m6', J_ORDER.index((1, t))), ('m6', J_ORDER.index((0, t)))]
+        return out
     for s in range(16):
         out.append(('m16', s))
         if ORDER == 'mix' and s >= 8:
@@ -444,6 +490,13 @@ def derive_cv(dst, act):
     return [v_lshl_imm(dst, 23, act), v_sub_imm(dst + 1, dst, RES_SHIFT << 23)]
 
 
+def derive_wsc(dst, sc):
+    """v[dst] = 2^(E - 127) as f32 from the replicated E8M0 byte in v[sc] (bf6r: divisor of the bf6(W) conversion)"""
+    return [valu('v_and_b32 %s, 0xff, %s' % (vreg(V_T), vreg(sc)), vr(sc), vr(V_T),
+                 lambda st: st.V.__setitem__(V_T, st.V[sc] & np.uint32(0xff))),
+            v_lshl_imm(dst, 23, V_T)]
+
+
 def read_act(tag):
     return ds_read_b96(V_ACT, V_AUX, AUX_ACT, tag=tag)
 
@@ -487,30 +540,68 @@ def build_fillers(it, opts):
         slot = slot_of(T)
         # --- weight operand reads: one ds_read_b128 per fp16 k-step (one MFMA each) into a ring of NHI buffers, two reads
         # per bf6 operand into two buffers; every read runs `rd_lead` anchors ahead of its MFMA at most
-        if layer == 0:
+        if layer == 0 and not WREG:
             for g in range(4):
                 F.append(Filler(ds_read_b128(V_BIAS + 4 * g, V_AUX, 128 * u + 32 * g, tag=('bias', it, T, g)),
                                 A(T - 1, 'm16', 0), A(T, 'm16', 0), ('rd',)))
+        if layer == 0 and WREG:
+            # no bias registers: the bias is read straight into the tile's accumulator buffer, which the epilogue of tile
+            # T - 2 (same buffer) has left by anchor BIAS_AT of tile T - 1 (its deadline is pulled in accordingly)
+            for g in range(4):
+                F.append(Filler(ds_read_b128(ACC(T & 1) + 4 * g, V_AUX, 128 * u + 32 * g, tag=('bias', it, T, g)),
+                                A(T - 1, 'm16', 0) + BIAS_AT, A(T, 'm16', 0), ('rd',)))
+        def cvt_window(TT, t):
+            """bf6r: (anchor behind which conversion t of tile TT may issue = its predecessor's MFMA has read the operand
+            register, anchor before which it must issue = two instructions ahead of its own MFMA)"""
+            pm = A(TT, 'm6', J_ORDER.index((1, t - 1))) if t else A(TT - 1, 'm6', J_ORDER.index((1, 3)))
+            if TT % TILES == 0 and t == 0:
+                pm = max(pm, A(TT, 'm16', 0) - 1)      # the block's divisor is derived at the loop head
+            return pm + 1, A(TT, 'm16', 4 * t + 2)
+
         for s_ in range(16):
             n = T * 16 + s_
             prev = n - NHI                                 # last user of the buffer
             earliest = max(A(prev // 16, 'm16', prev % 16), A(T, 'm16', s_) - opts.rd_lead)
-            bv, off = lds_addr(slot, piece_hi(s_) * 1024, 16)
-            F.append(Filler(ds_read_b128(HI(n % NHI), bv, off, tag=('hi', it, T, s_)), earliest, A(T, 'm16', s_), ('rd',)))
+            deadline = A(T, 'm16', s_)
+            if WREG:
+                # the buffer is also a source of the conversion of its group (prev's K=64 step), and the whole group of this
+                # fragment must be on its way when its own conversion may issue
+                TP, tp = prev // 16, (prev % 16) >> 2
+                earliest = max(A(TP, 'm16', prev % 16), cvt_window(TP, tp)[1], A(T, 'm16', s_) - opts.rd_lead - 4)
+                deadline = min(deadline, cvt_window(T, s_ >> 2)[0])
+            bv, off = lds_addr(slot, off_hi(s_), 16)
+            F.append(Filler(ds_read_b128(HI(n % NHI), bv, off, tag=('hi', it, T, s_)), earliest, deadline, ('rd',)))
         for j in range(8):
-            n = T * 8 + j
-            prev = n - 2
-            earliest = max(A(prev // 8, 'm6', prev % 8), A(T, 'm6', j) - opts.rd_lead6)
-            deadline = A(T, 'm6', j)
-            bv, off = lds_addr(slot, piece_a6(j) * 1024, 16)
-            F.append(Filler(ds_read_b128(A6(n & 1), bv, off, tag=('a6', it, T, j, 0)), earliest, deadline, ('rd6',)))
-            pc, po = piece_a6b(j)
-            if FMT == 'bf6':
-                bv, off = lds_addr(slot, pc * 1024 + po, 8)
-                F.append(Filler(ds_read_b64(A6(n & 1) + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
+            if not in_stream(j):
+                continue
+            n = T * 4 + (j >> 1) if WREG else T * 8 + j
+            prevj = [jj for jj in range(8) if in_stream(jj)]
+            k = prevj.index(j)
+            # the buffer's last user: the operand two before this one in stream order
+            if k >= 2:
+                pa = A(T, 'm6', prevj[k - 2])
             else:
-                bv, off = lds_addr(slot, pc * 1024 + po, 16)
-                F.append(Filler(ds_read_b128(A6(n & 1) + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
+                pa = A(T - 1, 'm6', prevj[len(prevj) - 2 + k])
+            earliest = max(pa, A(T, 'm6', j) - opts.rd_lead6)
+            deadline = A(T, 'm6', j)
+            o1, o2 = off_a6(j)
+            fl, reg = A6(n & 1)
+            bv, off = lds_addr(slot, o1, 16)
+            F.append(Filler(ds_read_b128(reg, bv, off, tag=('a6', it, T, j, 0), dfile=fl), earliest, deadline, ('rd6',)))
+            if FMT == 'bf6':
+                bv, off = lds_addr(slot, o2, 8)
+                F.append(Filler(ds_read_b64(reg + 4, bv, off, tag=('a6', it, T, j, 1), dfile=fl), earliest, deadline, ('rd6',)))
+            else:
+                bv, off = lds_addr(slot, o2, 16)
+                F.append(Filler(ds_read_b128(reg + 4, bv, off, tag=('a6', it, T, j, 1)), earliest, deadline, ('rd6',)))
+        if WREG:
+            # bf6(W / 2^(e-4)) of K=64 step t from the four fragments the wave holds for its own fp16 MFMAs: after the last of
+            # them has landed and the previous conversion's MFMA has read the operand register; two instructions before its MFMA
+            for t in range(4):
+                e, d = cvt_window(T, t)
+                if 'wcvt' in getattr(opts, 'drop', ()):       # diagnostics (wrong results): what the conversions cost
+                    continue
+                F.append(Filler(v_cvt_pk32_bf6(V_WCV, HI(4 * (t & 1)), V_WSC + layer), e, d, ('wcv',), needs=(('hi', it, T, 4 * t + 3),)))
         if T == 8:
             # this block's layer-2 scales were read during layer 1; flip to the next block's aux slot, then fetch
             # the next block's layer-1 scales (the running layer 1 is over: its scale registers are free)
@@ -535,6 +626,8 @@ def build_fillers(it, opts):
             epi += [(ins, None) for ins in guard_flush(('gmax', it, T))]
         for ins, cons in epi:
             dl = A(T + 1, 'm16', 0)  # latest: the accumulator buffer is reused by tile T+1
+            if WREG and ((T + 1) % TILES) < 8:
+                dl = A(T, 'm16', 0) + BIAS_AT     # ... whose bias is read into it from this anchor on
             if cons is not None:
                 if cons[0] == 'hi':
                     first = A(nl_T0, 'm16', cons[1])
@@ -631,6 +724,8 @@ def schedule(opts, n_iter=3):
 
     def issue(f, it):
         ins = f.ins
+        for key in f.needs:
+            sch.need(it, key)
         if ins.kind == 'ds':
             sch.ds_index[ins.tag] = sch.ds_issued
         sch.emit(it, ins)
@@ -658,6 +753,13 @@ def schedule(opts, n_iter=3):
             # tail's other reads, so a counted wait would be too generous there -- is drained completely
             sch.emit(it, waitcnt_lgkm(0))
             sch.ds_done = sch.ds_issued
+            if WREG:   # f32 divisor 2^(e-4) of this block's layer-1 conversions, from the E8M0 byte its MFMAs use
+                for ins in derive_wsc(V_WSC, V_SC + 1):
+                    sch.emit(it, ins)
+        if WREG and a % ANCH_PER_TILE == 0 and T == 2:
+            sch.need(it, ('scale', it, 1))          # ... and of its layer-2 conversions (tiles 8..15; scales read during tile 1)
+            for ins in derive_wsc(V_WSC + 1, V_SC + 3):
+                sch.emit(it, ins)
         if a % ANCH_PER_TILE == 0 and T == 1:
             # layer 2 of the previous block and its last epilogue are over: the exponents of this block's H set (layer 2
             # consumes it) and of the set layer 2 produces
@@ -674,21 +776,27 @@ def schedule(opts, n_iter=3):
             n = T * 16 + sj
             if layer == 0 and sj == 0:
                 sch.need(it, ('bias', it, T, 3))
-                ins = mfma32_16('v', d, HI(n % NHI), hset(sj), 'v', V_BIAS, tag=('m16', it, T, sj))
+                ins = mfma32_16('v', d, HI(n % NHI), hset(sj), 'v', d if WREG else V_BIAS, tag=('m16', it, T, sj))
             else:
                 ins = mfma32_16(dfile, d, HI(n % NHI), hset(sj), dfile, d, tag=('m16', it, T, sj))
             cap = opts.cap16
         else:
-            n = T * 8 + sj
-            sch.need(it, ('a6', it, T, sj, 1))
             term, t = J_ORDER[sj]
-            if u == 0 and sj == 0:
+            n = T * 4 + t if WREG else T * 8 + sj
+            if in_stream(sj):
+                sch.need(it, ('a6', it, T, sj, 1))
+            if u == 0 and (kind, sj) == [x for x in anchors if x[0] == 'm6'][0]:
                 sch.need(it, ('scale', it, layer))
             if sj == 0 and ORDER == 'tail' and opts.chain_nop >= 0:
                 sch.emit(it, s_nop(opts.chain_nop))      # fp16 -> scaled MFMA on one accumulator: keep them apart
             b6 = A_IN6 if layer == 0 else A_H6
-            ins = (mfma32_6 if FMT == 'bf6' else mfma32_8)(dfile, d, A6(n & 1), B6(b6, term, t), V_SC + 2 * layer + term,
-                                                            V_SB + 2 * layer + term, tag=('m6', it, T, sj))
+            if FMT == 'fp8':
+                ins = mfma32_8(dfile, d, A6(n & 1)[1], B6(b6, term, t), V_SC + 2 * layer + term, V_SB + 2 * layer + term,
+                               tag=('m6', it, T, sj))
+            else:
+                fl, reg = ('v', V_WCV) if not in_stream(sj) else A6(n & 1)     # bf6r term 1: the operand just converted
+                ins = mfma32_6(dfile, d, reg, B6(b6, term, t), V_SC + 2 * layer + term, V_SB + 2 * layer + term,
+                               tag=('m6', it, T, sj), afile=fl)
             cap = opts.cap6 * (1 if FMT == 'bf6' else 2)    # a 64-cycle MFMA shadows twice the issue slots
         if not (kind == 'm6' and J_ORDER[sj][0] in opts.skip_terms):
             sch.emit(it, ins)
@@ -751,6 +859,7 @@ def fused_tail_text():
     L = []
     a = L.append
     XA, WB, TMP, ACCS, RGBR, BIASR, TR = 0, 128, 176, 180, 186, 190, 194
+    v_lane, v_rayoff, v_ray = V_LANE, V_RAYOFF, V_RAY
     NBUF = 4                                  # groups of weights in flight: 12 ds_read_b128 <= the 4-bit lgkmcnt
     a('s_add_u32 %s, %s, %s' % (sreg(S_T0 + 4), sreg(S_XIN), sreg(S_TILEOFF)))
     a('s_addc_u32 %s, %s, %s' % (sreg(S_T0 + 5), sreg(S_XIN + 1), sreg(S_TILEOFF + 1)))
@@ -804,16 +913,16 @@ def fused_tail_text():
     a('s_lshl_b32 %s, %s, 2' % (sreg(S_T1), sreg(S_T1)))
     a('s_add_u32 %s, %s, %s' % (sreg(S_T1), sreg(S_T1), sreg(S_WAVE)))
     a('s_lshl_b32 %s, %s, 5' % (sreg(S_T1), sreg(S_T1)))
-    a('v_add_u32 %s, %s, %s' % (vreg(V_RAY), sreg(S_T1), vreg(V_LANE)))
+    a('v_add_u32 %s, %s, %s' % (vreg(v_ray), sreg(S_T1), vreg(v_lane)))
     a('s_mul_hi_u32 %s, %s, 12' % (sreg(S_T1 + 1), sreg(S_T1)))
     a('s_mul_i32 %s, %s, 12' % (sreg(S_T1), sreg(S_T1)))
     a('s_add_u32 %s, %s, %s' % (sreg(S_T1), sreg(S_T1), sreg(S_RGB)))
     a('s_addc_u32 %s, %s, %s' % (sreg(S_T1 + 1), sreg(S_T1 + 1), sreg(S_RGB + 1)))
-    a('v_cmp_gt_u32 vcc, %s, %s' % (sreg(S_NRAYS), vreg(V_RAY)))
+    a('v_cmp_gt_u32 vcc, %s, %s' % (sreg(S_NRAYS), vreg(v_ray)))
     a('s_mov_b32 %s, -1' % sreg(S_T1 + 2))
     a('s_mov_b32 %s, 0' % sreg(S_T1 + 3))
     a('s_and_b64 exec, vcc, %s' % sreg(S_T1 + 2, 2))                      # lanes 0..31 with a ray inside the call
-    a('global_store_dwordx3 %s, %s, %s' % (vreg(V_RAYOFF), vreg(RGBR, 3), sreg(S_T1, 2)))
+    a('global_store_dwordx3 %s, %s, %s' % (vreg(v_rayoff), vreg(RGBR, 3), sreg(S_T1, 2)))
     a('s_mov_b64 exec, -1')
     return L
 
@@ -858,13 +967,17 @@ def kernel_text(opts):
     a('v_xor_b32 %s, 32, %s' % (vreg(V_BPERM), vreg(V_LANE)))
     a('v_lshlrev_b32 %s, 2, %s' % (vreg(V_BPERM), vreg(V_BPERM)))
     a('v_mul_u32_u24 %s, 12, %s' % (vreg(V_RAYOFF), vreg(V_LANE)))
-    a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_T0), sreg(S_WAVE), PW * 1024))        # wave * 7168
+    a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_T0), sreg(S_WAVE), WAVE_BYTES))        # this wave's share of a chunk
     a('v_add_u32 %s, %s, %s' % (vreg(V_DMAOFF), sreg(S_T0), vreg(V_L0)))
     a('v_add_u32 %s, 0x1000, %s' % (vreg(V_DMAOFF2), vreg(V_DMAOFF)))
+    if WREG:   # pieces 5, 6 move 4 bytes per lane: wave * share + 4096 + lane * 4
+        a('v_lshlrev_b32 %s, 2, %s' % (vreg(V_DMAOFF4), vreg(V_LANE)))
+        a('v_add_u32 %s, %s, %s' % (vreg(V_DMAOFF4), sreg(S_T0), vreg(V_DMAOFF4)))
+        a('v_add_u32 %s, 0x1000, %s' % (vreg(V_DMAOFF4), vreg(V_DMAOFF4)))
     a('s_lshl_b32 %s, %s, 10' % (sreg(S_T0 + 1), sreg(S_WAVE)))                 # wave * 1024
     a('v_add_u32 %s, %s, %s' % (vreg(V_AUXOFF), sreg(S_T0 + 1), vreg(V_L0)))
     for k in range(NSLOT):
-        a('s_add_u32 %s, %s, 0x%x' % (sreg(S_M0SLOT + k), sreg(S_T0), k * CHUNK))
+        a('s_add_u32 %s, %s, 0x%x' % (sreg(S_M0SLOT + k), sreg(S_T0), k * SLOT))
     a('s_add_u32 %s, %s, 0x%x' % (sreg(S_AUXM0), sreg(S_T0 + 1), LDS_AUX))
     a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_END), sreg(S_NBLOCK), 16 * CHUNK))
     a('s_lshl_b32 %s, %s, 12' % (sreg(S_AUXEND), sreg(S_NBLOCK)))
@@ -1013,8 +1126,10 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     st.V[V_L8A] = lanes * 8
     st.V[V_L8B] = lanes * 8 + 65536
     st.V[V_AUX] = LDS_AUX + (lanes >> 5) * 16
-    st.V[V_DMAOFF] = wave * PW * 1024 + lanes * 16
-    st.V[V_DMAOFF2] = wave * PW * 1024 + lanes * 16 + 4096
+    st.V[V_DMAOFF] = wave * WAVE_BYTES + lanes * 16
+    st.V[V_DMAOFF2] = wave * WAVE_BYTES + 4096 + lanes * 16
+    if WREG:
+        st.V[V_DMAOFF4] = wave * WAVE_BYTES + 4096 + lanes * 4
     st.V[V_AUXOFF] = wave * 1024 + lanes * 16
     S = st.S
     S[S_W] = 0
@@ -1024,7 +1139,7 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     S[S_END] = n_block * 16 * CHUNK
     S[S_AUXEND] = n_block * AUX_BYTES
     for k in range(NSLOT):
-        S[S_M0SLOT + k] = wave * PW * 1024 + k * CHUNK
+        S[S_M0SLOT + k] = wave * WAVE_BYTES + k * SLOT
     S[S_AUXM0] = LDS_AUX + wave * 1024
 
     def issue_aux():
@@ -1078,15 +1193,20 @@ def main():
     ap.add_argument('--chain-nop', type=int, default=-1)
     ap.add_argument('--order', default=None, choices=['tail', 'mix'])
     ap.add_argument('--guard', action='store_true', help='the range-guard build of the stream (r2l_body_guard_kernel)')
-    ap.add_argument('--fmt', default='bf6', choices=['bf6', 'fp8'], help='correction terms: bf6 (e3m2) | fp8 (e4m3)')
+    ap.add_argument('--fmt', default='bf6', choices=['bf6', 'bf6r', 'fp8'],
+                    help='correction terms: bf6 (e3m2, all operands streamed) | bf6r (bf6(W) converted from the fp16 fragments in registers) | fp8 (e4m3)')
+    ap.add_argument('--dma6', action='store_true', help='bf6r: 6 x dwordx4 per wave and chunk (512 B moved twice) instead of 5 x dwordx4 + 2 x dword')
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')
     ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the block loop '
-                    '(lgkm, dma, valu, ds, mfma6, mfma16): timing knock-outs, wrong results')
+                    '(lgkm, dma, valu, ds, mfma6, mfma16, wcvt): timing knock-outs, wrong results')
     a = ap.parse_args()
     if a.order:
-        global ORDER
-        ORDER = a.order
+        global ORDER_BASE
+        ORDER_BASE = a.order
+    if a.dma6:
+        global DMA6
+        DMA6 = True
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap16=a.cap16, cap6=a.cap6, dma_gap=a.dma_gap,
                 chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
                 drop=tuple(x for x in a.drop.split(',') if x))

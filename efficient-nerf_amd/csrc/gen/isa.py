@@ -296,8 +296,8 @@ def ds_read_b128(dst, base_v, off, tag='', dfile='v'):
     return _ds_read(16, dst, base_v, off, tag, dfile)
 
 
-def ds_read_b64(dst, base_v, off, tag=''):
-    return _ds_read(8, dst, base_v, off, tag)
+def ds_read_b64(dst, base_v, off, tag='', dfile='v'):
+    return _ds_read(8, dst, base_v, off, tag, dfile)
 
 
 def ds_read_b96(dst, base_v, off, tag=''):
@@ -369,6 +369,28 @@ def ds_max_u32(addr_v, data_v, off, tag=''):
             st.lds[a0:a0 + 4] = np.array([max(cur, st.V[data_v][l])], dtype=np.uint32).view(np.uint8)
         st.pend_ds.append(('v', 0, np.zeros((0, 64), dtype=np.uint32)))
     return Ins(text, 'ds', rd=vr(addr_v) + vr(data_v), emu=emu, tag=tag)
+
+
+def _ds_write(width, addr_v, data_v, off, tag):
+    n = width // 4
+    assert 0 <= off < 65536 and off % width == 0
+    text = 'ds_write_b%d %s, %s offset:%d' % (width * 8, vreg(addr_v), vreg(data_v, n), off)
+
+    def emu(st):
+        addr = st.V[addr_v].astype(np.int64) + off
+        for l in range(64):
+            a0 = int(addr[l])
+            st.lds[a0:a0 + width] = st.V[data_v:data_v + n, l].copy().view(np.uint8)
+        st.pend_ds.append(('v', 0, np.zeros((0, 64), dtype=np.uint32)))      # counts in lgkmcnt like a read
+    return Ins(text, 'ds', rd=vr(addr_v) + vr(data_v, n), emu=emu, tag=tag)
+
+
+def ds_write_b128(addr_v, data_v, off, tag=''):
+    return _ds_write(16, addr_v, data_v, off, tag)
+
+
+def ds_write_b64(addr_v, data_v, off, tag=''):
+    return _ds_write(8, addr_v, data_v, off, tag)
 
 
 def v_accr(vdst, asrc):
@@ -553,16 +575,16 @@ def mfma32_16(dfile, d, a, b, cfile, c, tag=''):
     return Ins(text, 'mfma16', rd=vr(a, 4) + vr(b, 4) + rc, wr=wd, emu=emu, tag=tag, cost=1)
 
 
-def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag='', bfile='a'):
-    """D += A(bf6 v[a:a+5], 32 x 64, E8M0 v[scale_a]) x B(bf6 [bfile] b:b+5, 64 x 32, E8M0 v[scale_b]):
+def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag='', bfile='a', afile='v'):
+    """D += A(bf6 [afile] a:a+5, 32 x 64, E8M0 v[scale_a]) x B(bf6 [bfile] b:b+5, 64 x 32, E8M0 v[scale_b]):
     v_mfma_scale_f32_32x32x64_f8f6f4"""
     rf = {'v': vreg, 'a': areg}
     text = ('v_mfma_scale_f32_32x32x64_f8f6f4 %s, %s, %s, %s, %s, %s op_sel_hi:[0,0,0] cbsz:3 blgp:3' %
-            (rf[dfile](d, 16), vreg(a, 6), rf[bfile](b_agpr, 6), rf[dfile](d, 16), vreg(scale_a), vreg(scale_b)))
+            (rf[dfile](d, 16), rf[afile](a, 6), rf[bfile](b_agpr, 6), rf[dfile](d, 16), vreg(scale_a), vreg(scale_b)))
 
     def emu(st):
         lanes = np.arange(64)
-        Ac = unpack6(st.V[a:a + 6].T.copy())          # [64, 32]
+        Ac = unpack6(st.regs(afile)[a:a + 6].T.copy())          # [64, 32]
         Bc = unpack6(st.regs(bfile)[b_agpr:b_agpr + 6].T.copy())
         sa = 2.0 ** (int(st.V[scale_a][0] & 0xff) - 127)
         sb = 2.0 ** (int(st.V[scale_b][0] & 0xff) - 127)
@@ -580,7 +602,8 @@ def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag='', bfile='a'):
 
     dd = vr(d, 16) if dfile == 'v' else ar(d, 16)
     rb = ar(b_agpr, 6) if bfile == 'a' else vr(b_agpr, 6)
-    return Ins(text, 'mfma6', rd=vr(a, 6) + rb + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
+    ra = ar(a, 6) if afile == 'a' else vr(a, 6)
+    return Ins(text, 'mfma6', rd=ra + rb + dd + vr(scale_a) + vr(scale_b), wr=dd, emu=emu, tag=tag)
 
 
 def mfma32_8(dfile, d, a, b_reg, scale_a, scale_b, tag='', bfile='a'):
@@ -635,14 +658,15 @@ def v_cvt_pk_fp8_f16(dst, dst_high, src_pk, scale_v):
 # list-scheduler items
 # ---------------------------------------------------------------------------------------------
 class Filler:
-    __slots__ = ('ins', 'earliest', 'deadline', 'chain', 'seq')
+    __slots__ = ('ins', 'earliest', 'deadline', 'chain', 'seq', 'needs')
 
-    def __init__(self, ins, earliest, deadline, chain):
+    def __init__(self, ins, earliest, deadline, chain, needs=()):
         self.ins = ins
         self.earliest = earliest  # may be issued after anchor #earliest has been emitted
         self.deadline = deadline  # must be issued before anchor #deadline
         self.chain = chain        # fillers of one chain keep their order
         self.seq = 0
+        self.needs = needs        # tags of LDS operations that must have completed (counted lgkmcnt in front of it)
 
 
 

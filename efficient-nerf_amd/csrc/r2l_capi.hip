@@ -185,6 +185,7 @@ struct r2l_ctx {
 };
 
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
+enum { R2L_STREAM_BF6 = 0, R2L_STREAM_E4M3 = 1, R2L_STREAM_BF6R = 2 };   // body stream layouts (pack_body_v3)
 static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_E4M3; }
 // the modes with the generated head launch + generated body kernel (fp16 main pass + low-precision correction terms)
 static bool split_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3; }
@@ -289,7 +290,8 @@ static int build_image(r2l_ctx* c, int mode) {
         int rc = pack_head_v1(c, img);
         if (rc) return rc;
         std::vector<char> body;
-        rc = pack_body_v3(c, mode == R2L_PREC_FP16_E4M3, body, &c->aux_off, &c->tail_off);
+        rc = pack_body_v3(c, mode == R2L_PREC_FP16_E4M3 ? R2L_STREAM_E4M3 : (R2L_BF6_CHUNK == 28672 ? R2L_STREAM_BF6 : R2L_STREAM_BF6R),
+                          body, &c->aux_off, &c->tail_off);
         if (rc) return rc;
         c->body_mode = mode;
         if (c->d_body) {
@@ -439,6 +441,12 @@ static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img) 
 // x~_i = x_i - sum_{j<i} b2_j) | 4 x (swl1, sw1, swl2, sw2) | pad.
 // Tail: [3,256] W_t / act_scale, then b_t + W_t sum_j b2_j.
 #define R2L_BODY_CHUNK 28672
+// Round-3 experiment "bf6r" (gen/body_gen.py configure; -DR2L_BF6R_STREAM): the term-1 operands bf6(W) are neither streamed
+// nor read from LDS -- every wave converts them from the fp16 fragments it holds for its own MFMAs
+// (v_cvt_scalef32_pk32_bf6_f16).  Chunk = 22 KiB: 16 fp16 fragments, then the four term-0 operands (w - hi(w)) / 2^(e-16) back
+// to back, 1,536 B each: 1 KiB of (lane x 16 B), then 512 B of (lane x 8 B).  Parity green on hardware, 5 % slower than the
+// 28 KiB stream above, which therefore stays the shipping form (profiles/r03_dma_experiments.txt).
+#define R2L_BODYW_CHUNK 22528
 // R2L_PREC_FP16_E4M3: the same stream with both operands of the correction terms in OCP e4m3: chunks of 32 KiB = 32 pieces;
 // operand j: piece 16 + 2 j = bytes 0..15 of every lane, piece 17 + 2 j = bytes 16..31; byte i = element i;
 // term 0 = (w - hi(w)) / 2^(e-20), term 1 = w / 2^(e-8) (e4m3 holds 448)
@@ -529,9 +537,10 @@ static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
     return R2L_OK;
 }
 
-static int pack_body_v3(const r2l_ctx* c, int e4m3, std::vector<char>& out, size_t* aux_off, size_t* tail_off) {
+static int pack_body_v3(const r2l_ctx* c, int fmt, std::vector<char>& out, size_t* aux_off, size_t* tail_off) {
     const int nb = c->n_block;
-    const size_t CH = e4m3 ? R2L_BODY8_CHUNK : R2L_BODY_CHUNK, AUXB = 4096;
+    const int e4m3 = fmt == R2L_STREAM_E4M3, wconv = fmt == R2L_STREAM_BF6R;
+    const size_t CH = e4m3 ? R2L_BODY8_CHUNK : (wconv ? R2L_BODYW_CHUNK : R2L_BODY_CHUNK), AUXB = 4096;
     const size_t stream = (size_t)nb * 16 * CH;
     *aux_off = stream;
     *tail_off = stream + (size_t)nb * AUXB;
@@ -597,8 +606,15 @@ static int pack_body_v3(const r2l_ctx* c, int e4m3, std::vector<char>& out, size
                             bits[wd] |= code << sh;
                             if (sh > 58) bits[wd + 1] |= code >> (64 - sh);
                         }
-                        memcpy(chunk + (size_t)(16 + j) * 1024 + lane * 16, bits, 16);
-                        memcpy(chunk + (size_t)(24 + (j >> 1)) * 1024 + (j & 1) * 512 + lane * 8, &bits[2], 8);
+                        if (wconv) {
+                            if (term == 1) continue;          // made on chip
+                            char* op = chunk + 16384 + (size_t)t * 1536;
+                            memcpy(op + lane * 16, bits, 16);
+                            memcpy(op + 1024 + lane * 8, &bits[2], 8);
+                        } else {
+                            memcpy(chunk + (size_t)(16 + j) * 1024 + lane * 16, bits, 16);
+                            memcpy(chunk + (size_t)(24 + (j >> 1)) * 1024 + (j & 1) * 512 + lane * 8, &bits[2], 8);
+                        }
                     }
                 }
             }
@@ -812,8 +828,9 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
 }
 
 static thread_local int g_debug_pack_e4m3 = 0;
-int r2l_debug_pack_body_format(int e4m3) {   // which stream r2l_debug_pack_body_host packs: 0 bf6 terms, 1 e4m3 terms
-    g_debug_pack_e4m3 = e4m3 ? 1 : 0;
+int r2l_debug_pack_body_format(int fmt) {   // which stream r2l_debug_pack_body_host packs: R2L_STREAM_*
+    if (fmt < 0 || fmt > 2) return r2l_set_error(R2L_EINVAL, "stream format %d", fmt);
+    g_debug_pack_e4m3 = fmt;
     return R2L_OK;
 }
 

@@ -84,6 +84,15 @@ R2L_HD int r2l_head_col32(int p, int s, int h, int j) {
     if (j == 6) return (3 * p + (h ? 2 : 0)) * R2L_EMBED + 2 * R2L_L;
     return h ? -1 : (3 * p + 1) * R2L_EMBED + 2 * R2L_L;
 }
+// Body stream of R2L_PREC_FP16_FP8 (r2l_capi.hip pack_body_v3, gen/body_gen.py configure): 28 KiB chunks, every operand of the
+// correction terms streamed ('bf6').  -DR2L_BF6R_STREAM builds the round-3 experiment 'bf6r' (22 KiB chunks: the bf6(W) operands
+// are converted from the fp16 fragments in registers; generate the two r2l_body*_asm.inc with `body_gen.py --fmt bf6r`): parity
+// green, 5 % slower (the 64 conversions per block are 32 VALU cycles each and do not hide: profiles/r03_dma_experiments.txt).
+#ifdef R2L_BF6R_STREAM
+#define R2L_BF6_CHUNK 22528
+#else
+#define R2L_BF6_CHUNK 28672
+#endif
 #define R2L_HEAD_STREAM_BYTES (32 * 28672)
 #define R2L_HEAD_AUX_BYTES 2048
 #define R2L_HEAD_LDS (4 * 28672 + R2L_HEAD_AUX_BYTES)

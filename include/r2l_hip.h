@@ -143,8 +143,10 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
  * r2l_load_weights uploads for r2l_body_kernel; offs[0] / offs[1] receive the aux / tail byte offsets. */
 long long r2l_debug_pack_body_host(const float* const* tensors, int n_tensors, int n_block,
                                    char* out, long long cap, long long* offs);
-/* which stream the call above packs (thread-local): 0 = bf6 terms (R2L_PREC_FP16_FP8, the default), 1 = e4m3 terms */
-int r2l_debug_pack_body_format(int e4m3);
+/* which stream the call above packs (thread-local): 0 = R2L_PREC_FP16_FP8's (bf6 terms, 28 KiB chunks; the default),
+ * 1 = R2L_PREC_FP16_E4M3's (32 KiB chunks), 2 = the 'bf6r' experiment (bf6 terms, the bf6(W) operands converted on chip from
+ * the fp16 fragments: 22 KiB chunks; csrc/r2l_common.h R2L_BF6R_STREAM) */
+int r2l_debug_pack_body_format(int fmt);
 /* The hand-scheduled body kernel alone (R2L_PREC_FP16_FP8): x_out = ResMLP blocks(x_in) on n_tiles ray
  * tiles in the register-image layout [tile][wave 4][group 32][lane 64][4] f32: group 4u + g of lane 32h + ray holds
  * features 32u + 8g + 4h .. + 3 (csrc/r2l_common.h); parity tests only. */

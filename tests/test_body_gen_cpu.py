@@ -72,6 +72,8 @@ def from_regs(regs):
 
 
 def cxx_pack(W1s, b1s, W2s, b2s, e4m3=0):
+    """the C++ packer's stream: 0 = bf6 terms, all operands streamed (the shipping form), 1 = e4m3 terms, 2 = the bf6r
+    experiment (22 KiB chunks)"""
     nb = len(W1s)
     _lib.lib().r2l_debug_pack_body_format(e4m3)
     tensors = [np.zeros((256, 1008), np.float32), np.zeros(256, np.float32)]
@@ -108,6 +110,11 @@ def test_cxx_packer_matches_python_restatement_e4m3():
     img, aux, _ = G.pack_body_image(*W, fmt='fp8')
     G.configure('bf6')
     assert aux_off == img.size == 2 * 16 * 32768 and tail_off == aux_off + 2 * G.AUX_BYTES
+    bw, aw, tw, _ = cxx_pack(*W, e4m3=2)            # the bf6r experiment's stream
+    imgw, auxw, _ = G.pack_body_image(*W, fmt='bf6r')
+    G.configure('bf6')
+    assert aw == imgw.size == 2 * 16 * 22528 and np.array_equal(bw[:aw], imgw)
+    assert np.array_equal(bw[aw:tw].view(np.uint32).reshape(2, -1), auxw)
     assert np.array_equal(buf[:aux_off], img)
     assert np.array_equal(buf[aux_off:tail_off].view(np.uint32).reshape(2, -1), aux)
 
@@ -238,3 +245,29 @@ def test_e4m3_guard_stream_is_bit_identical():
     assert not e0 and not e1, (e0 + e1)[:10]
     assert np.array_equal(plain.view(np.uint32), out.view(np.uint32))
     assert abs(rows[0].max() / 16.0 - np.abs(x).max()) < 1e-3 and rows.shape == (2 * nb, 32)
+
+
+@pytest.mark.parametrize('nb,wave,guard', [(2, 0, False), (3, 3, False), (2, 1, True)])
+def test_bf6r_stream_converts_the_weight_operands_from_registers(nb, wave, guard):
+    """R2L_PREC_FP16_FP8's stream since round 3 ('bf6r'): the four bf6(W) operands of a chunk are not streamed (22 KiB chunks
+    instead of 28); each wave converts one of them from the chunk's fp16 fragments and stores it to LDS behind the chunk's
+    existing barrier.  Same arithmetic up to the double rounding bf6(fp16(w)) vs bf6(w)."""
+    W = make_weights(nb, seed=20 + nb)
+    rng = np.random.default_rng(4)
+    x = np.maximum(rng.normal(0, 1, (32, 256)), 0).astype(np.float32)
+    S = 16.0
+    ref = ref_blocks(x, *W)
+    Bsum = np.sum([b.astype(np.float64) for b in W[3]], axis=0)
+    img0, aux0, _ = G.pack_body_image(*W, fmt='bf6')
+    out0, e0 = G.emulate_tile(G.Opts(), img0, aux0, to_regs(x * S), nb, wave=wave)
+    img, aux, _ = G.pack_body_image(*W, fmt='bf6r')
+    assert img.size == nb * 16 * 22 * 1024 and np.array_equal(aux, aux0)
+    res = G.emulate_tile(G.Opts(fmt='bf6r', guard=guard), img, aux, to_regs(x * S), nb, wave=wave)
+    G.configure('bf6')
+    out, e1 = res[0], res[1]
+    assert not e0 and not e1, (e0 + e1)[:10]
+    err = np.abs(from_regs(out) / S + Bsum - ref).max()
+    err0 = np.abs(from_regs(out0) / S + Bsum - ref).max()
+    print('L_inf after %d blocks: streamed bf6(W) %.3g, converted on chip %.3g; difference between the two %.3g'
+          % (nb, err0, err, np.abs(from_regs(out) - from_regs(out0)).max() / S))
+    assert err < 2.5e-5 * nb and err < 1.15 * err0 + 1e-6

@@ -116,8 +116,8 @@ def test_packed_stream_decodes_to_weights(pkg, built_lib, mode, np_):
 def test_fp16_fp8_head_image_and_body_stream(pkg, built_lib):
     """R2L_PREC_FP16_FP8 streams two images: the head launch reads the stream of r2l_debug_pack_host(mode 2) (pinned
     against the generator's Python restatement in tests/test_head_gen_cpu.py), the body kernel the 28 KiB-chunk stream of
-    r2l_debug_pack_body_host (pinned in tests/test_body_gen_cpu.py).  Here: sizes, scale bytes, and the bf6 codes decode
-    to the weights they stand for."""
+    r2l_debug_pack_body_host (16 fp16 fragments + 8 bf6 operands; pinned in tests/test_body_gen_cpu.py).  Here: sizes,
+    scale bytes, and the bf6 codes decode to the weights they stand for."""
     import ctypes as C
     import os
     import sys
@@ -133,22 +133,25 @@ def test_fp16_fp8_head_image_and_body_stream(pkg, built_lib):
     n = _lib.lib().r2l_debug_pack_body_host(arr, len(keep), n_block, None, 0, offs)
     buf = np.zeros(n, dtype=np.uint8)
     assert _lib.lib().r2l_debug_pack_body_host(arr, len(keep), n_block, C.c_void_p(buf.ctypes.data), n, offs) == n
-    assert offs[0] == n_block * 16 * G.CHUNK and offs[1] == offs[0] + n_block * G.AUX_BYTES
+    G.configure('bf6')
+    assert G.CHUNK == 28672 and offs[0] == n_block * 16 * G.CHUNK and offs[1] == offs[0] + n_block * G.AUX_BYTES
     W1 = sd['body.0.body.0.weight'].float().numpy()
     ex = G.layer_exponent(W1)
     el, ew = G.weight_exps(ex)
     aux = buf[offs[0]:offs[0] + G.AUX_BYTES].view(np.uint32)
     assert (aux[256] & 0xff) == 127 + el and (aux[257] & 0xff) == 127 + ew
-    # chunk 3 (row tile 3: features 96..127) of layer 1, operand j = 1 (w itself, K=64 step 0): decode lane 37
+    # chunk 3 (row tile 3: features 96..127) of layer 1, operand j = 2 (w - hi(w), K=64 step 1): decode lane 37
     import isa
-    u, j, lane = 3, 1, 37
+    u, j, lane = 3, 2, 37
     base = u * G.CHUNK
-    lo = buf[base + G.piece_a6(j) * 1024 + lane * 16:][:16]
-    pc, off = G.piece_a6b(j)
-    hi = buf[base + pc * 1024 + off + lane * 8:][:8]
+    o1, o2 = G.off_a6(j)
+    lo = buf[base + o1 + lane * 16:][:16]
+    hi = buf[base + o2 + lane * 8:][:8]
+    G.configure('bf6')
     codes = isa.unpack6(np.concatenate([lo, hi]).view(np.uint32)[None])[0]
-    vals = isa.BF6[codes] * 2.0 ** ew
-    want = np.array([W1[32 * u + (lane & 31), G.mix_feat(0, lane >> 5, e)] for e in range(32)])
+    vals = isa.BF6[codes] * 2.0 ** el
+    w = np.array([W1[32 * u + (lane & 31), G.mix_feat(1, lane >> 5, e)] for e in range(32)])
+    want = w.astype(np.float64) - w.astype(np.float16).astype(np.float64)
     assert np.abs(vals - want).max() <= 0.13 * np.abs(want).max()  # e3m2: 2 mantissa bits
     assert np.abs(vals - want).max() > 0
 

@@ -8,11 +8,15 @@ d=$root/build_variants/$name
 mkdir -p $d
 cp $root/efficient-nerf_amd/csrc/*.hip $root/efficient-nerf_amd/csrc/*.h $root/efficient-nerf_amd/csrc/*.inc $d/
 python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --emit $d/r2l_body_asm.inc "$@" > /dev/null || exit 1
+python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --guard --emit $d/r2l_body_guard_asm.inc "$@" > /dev/null || exit 1
 sed -i 's#"../../include/r2l_hip.h"#"'$root'/include/r2l_hip.h"#' $d/*.hip
 cd $d
+# a variant generated with `--fmt bf6r` streams 22 KiB chunks: its packer and LDS size are selected at compile time
+DEF=""
+case " $* " in *" --fmt bf6r "*) DEF="-DR2L_BF6R_STREAM";; esac
 for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_kernels nerf_capi; do
-  if [ $f = r2l_body ] || [ ! -f $root/efficient-nerf_amd/csrc/$f.o ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -c $f.hip -o $f.o
+  if [ $f = r2l_body ] || [ $f = r2l_capi -a -n "$DEF" ] || [ ! -f $root/efficient-nerf_amd/csrc/$f.o ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $DEF -c $f.hip -o $f.o
   else cp $root/efficient-nerf_amd/csrc/$f.o $f.o; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build_variants/libr2l_$name.so r2l_kernels.o r2l_body.o r2l_capi.o r2l_comm.o nerf_kernels.o nerf_capi.o -ldl

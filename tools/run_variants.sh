@@ -3,9 +3,6 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 for rep in 1 2; do for v in default $VARIANTS; do
-  # a variant whose name starts with "legacy" streams round 2's 28 KiB chunks (all bf6 operands streamed)
-  if [ $v = default ]; then python $R/tools/body_time.py
-  elif [ ${v#legacy} != $v ]; then R2L_LEGACY_BF6_STREAM=1 R2L_LIB_PATH=$R/build_variants/libr2l_$v.so python $R/tools/body_time.py
-  else R2L_LIB_PATH=$R/build_variants/libr2l_$v.so python $R/tools/body_time.py; fi
+  if [ $v = default ]; then python $R/tools/body_time.py; else R2L_LIB_PATH=$R/build_variants/libr2l_$v.so python $R/tools/body_time.py; fi
 done; done 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/variants.log
 cat $R/gpurun_out/variants.log
