@@ -349,7 +349,20 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
         eng = NeRFEngine(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance,
                          multires=args.multires, multires_views=args.multires_views, white_bkgd=args.white_bkgd,
                          precision=prec, ndc=llff_ndc, lindisp=args.lindisp)  # main.py:160-162, 525-528, 679-680
+        if args.precision == 'fp16_e4m3':
+            raise R2LError('--precision fp16_e4m3 is a mode of the R2L student (the teacher has fp16x3, fp16_fp8, fp16x1)')
         eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
+        if auto:
+            # the chain's bf6 terms run under fixed activation exponents: measured against fp16x3 on the first frame's own rays
+            from .teacher import get_rays
+            if probe_rays is not None:
+                ro, rd = (t.to(eng.device, torch.float32) for t in probe_rays)
+            else:
+                ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, probe_pose, device=eng.device))
+            name, diff = eng.choose_precision(ro, rd)
+            if log:
+                log(f'[precision] auto: fp16_fp8 differs from fp16x3 by {diff:.1e} on {min(4096, ro.shape[0])} rays of the first '
+                    f'frame (limit {eng.AUTO_MAX_DIFF:.0e}) -> {name}')
         return 'nerf', eng
     raise R2LError(f'model_name={args.model_name} is not a render path of this build')
 

@@ -148,6 +148,7 @@ class NeRFEngine:
             check(lib().nerf_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
                                     self.N_samples, self.N_importance, int(multires), int(multires_views),
                                     int(bool(white_bkgd)), int(precision)))
+        self.precision = int(precision)
         # main.py:676-678 / helpers:293 evaluated with the host's torch, as the reference does
         if z_coarse is None:
             t_vals = torch.linspace(0., 1., steps=self.N_samples)
@@ -207,6 +208,34 @@ class NeRFEngine:
     def set_precision(self, precision):
         with torch.cuda.device(self.device):
             check(lib().nerf_set_precision(self._ctx, int(precision)))
+        self.precision = int(precision)
+
+    #: `--precision auto`: largest rgb difference between fp16_fp8 (bf6 correction terms under FIXED exponents: the layer
+    #: chain has no calibration) and fp16x3 on a probe of the caller's own rays that still selects fp16_fp8.  The contract is
+    #: 1e-4 against the reference; fp16x3 is within 2e-7 of it, the synthetic teacher within 1e-6 in fp16_fp8.
+    AUTO_MAX_DIFF = 2e-5
+
+    def choose_precision(self, rays_o, rays_d, max_diff=None):
+        """`--precision auto` for the teacher: the layer chain's bf6 terms use fixed activation exponents (|a| x 16 / 2^3 must
+        fit bf6's +-28, i.e. hidden activations up to ~14), so whether THESE weights suit them is measured: up to 4,096 of
+        the given rays, spread over the set, are rendered coarse + fine in both precisions; fp16_fp8 is kept when rgb, disp
+        and acc agree with fp16x3 within `max_diff`, else the context stays in fp16x3.  Returns (name, largest difference).
+        Synchronous, once per weight load."""
+        from ._lib import PREC_FP16_FP8
+        max_diff = self.AUTO_MAX_DIFF if max_diff is None else float(max_diff)
+        n = rays_o.shape[0]
+        idx = torch.arange(0, n, max(1, n // 4096), device=rays_o.device)[:4096]
+        ro, rd = rays_o[idx].contiguous(), rays_d[idx].contiguous()
+        self.set_precision(PREC_FP16X3)
+        ref = self.render_rays(ro, rd)
+        ref = {k: ref[k].clone() for k in ('rgb_map', 'acc_map')}
+        self.set_precision(PREC_FP16_FP8)
+        got = self.render_rays(ro, rd)
+        diff = max(float((got[k] - ref[k]).abs().max()) for k in ref)
+        if not (diff <= max_diff):          # NaN included
+            self.set_precision(PREC_FP16X3)
+            return 'fp16x3', diff
+        return 'fp16_fp8', diff
 
     def _outs(self, n):
         dev = self.device
