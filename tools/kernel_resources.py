@@ -26,8 +26,9 @@ with tempfile.TemporaryDirectory() as d:
             rows.append((name, g('vgpr_count'), g('agpr_count'), g('vgpr_spill_count'), g('sgpr_spill_count'),
                          g('private_segment_fixed_size'), g('group_segment_fixed_size')))
 out = ['# gfx950 resource usage of every kernel (hipcc -S metadata, ROCm 7.2; tools/kernel_resources.py)', '',
-       'The bench-default path (R2L_PREC_FP16_FP8) launches `r2l_resmlp_kernel<2, true>` (head), `r2l_body_kernel`, '
-       '`r2l_tail_kernel`; the teacher in that mode `nerf_chain_kernel`.',
+       'The bench-default path (R2L_PREC_FP16_FP8) launches `r2l_head_kernel` and `r2l_body_kernel` (which ends every ray tile '
+       'with the tail layer; every 8th launch its range-guard build `r2l_body_guard_kernel`); R2L_PREC_FP16_E4M3 '
+       '`r2l_body8_kernel` / `r2l_body8_guard_kernel`; the teacher in fp16_fp8 `nerf_chain_kernel`.',
        'The 24 / 48 B of scratch are the by-value kernel argument block indexed dynamically (`c2w_host`), not spills.', '',
        'kernel | vgpr_count (arch+acc) | agpr | vgpr_spill | sgpr_spill | scratch bytes | static LDS',
        '---|---|---|---|---|---|---']
