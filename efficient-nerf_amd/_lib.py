@@ -7,7 +7,9 @@ PREC_FP16X1 = 1
 PREC_FP16_FP8 = 2  # fp16 main pass + both correction terms in OCP bf6 (e3m2) on the block-scaled MFMA at 4x the fp16 rate:
                    # generated head / body kernels (R2L), generated layer chain (teacher); the name is historical
 PREC_FP16_E4M3 = 3  # R2L only: the same with both correction terms in OCP e4m3 (2.0 pass-equivalents, half the error)
-PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8, 'fp16_e4m3': PREC_FP16_E4M3}
+PREC_FP16X3_ASM = 4  # R2L only: fp16x3's three fp16 passes on the generated body kernel's machine (no scales, nothing to calibrate)
+PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8, 'fp16_e4m3': PREC_FP16_E4M3,
+              'fp16x3_asm': PREC_FP16X3_ASM}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('R2L_LIB_PATH', os.path.join(_HERE, 'libr2l_hip.so'))  # override: ablation builds (tools/)

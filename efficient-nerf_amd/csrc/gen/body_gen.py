@@ -147,11 +147,13 @@ def configure(fmt):
     Sets the format-dependent part of the register map, the chunk geometry and the LDS map (module globals: the generators
     are run once per variant)."""
     global FMT, WREG, NA6, NHI, PIECES, CHUNK, SLOT, WAVE_BYTES, PW, LDS_AUX, LDS_TAIL, LDS_BYTES, LDS_GSTAT
-    global V_HI, V_A6, A_A6, V_LO, V_CV, V_WCV, V_WSC, V_DMAOFF4, A_H6, N_AGPR_USED, ORDER
+    global V_HI, V_HL, V_A6, A_A6, V_LO, V_CV, V_WCV, V_WSC, V_DMAOFF4, A_H6, N_AGPR_USED, ORDER, ANCH_PER_TILE, A_INL, A_HLO
     WREG = fmt == 'bf6r'
     FMT = 'bf6' if WREG else fmt
+    ANCH_PER_TILE = 48 if FMT == 'f16' else 24      # MFMAs of a row tile
     NA6 = 6 if FMT == 'bf6' else 8                  # registers of a K=64 operand
     PIECES = 28 if FMT == 'bf6' else 32             # KiB of a chunk with all operands: 16 fp16 fragments + 8 x 1.5 | 2 KiB
+                                                    # (f16: 16 hi + 16 lo fragments)
     CHUNK = 22 * 1024 if WREG else PIECES * 1024    # bytes of a chunk in the stream = LDS stride of the ring
     SLOT = CHUNK
     WAVE_BYTES = CHUNK // 4                         # a wave's share of a chunk: bf6r 5 x 1 KiB + 2 x 256 B
@@ -166,6 +168,14 @@ def configure(fmt):
         V_LO, V_CV, V_WCV, V_WSC, V_DMAOFF4 = 192, 208, 214, 220, 222
         V_A6, A_A6 = None, 224                      # streamed bf6 operands (term 0): 2 buffers in AGPRs
         ORDER = 'group'
+    elif FMT == 'f16':
+        # R2L_PREC_FP16X3 on this machine: three fp16 passes per k-step, hi(W) hi(a) + hi(W) lo(a) + lo(W) hi(a), lo = the fp16
+        # rounding residual (exact products, no scales, no calibration: the correction terms are as good as fp16 allows).
+        # The lo B operands live in the AGPRs the bf6 sets leave free; a second fragment ring holds lo(W).
+        NHI = 4
+        V_HI, V_HL, V_LO, V_CV = 176, 192, 208, 216
+        V_A6, ORDER = None, 'f16'
+        A_INL, A_HLO = 128, 192                     # lo(a) B operands of layer 1 / layer 2: + 4 s
     else:
         NHI = 4
         V_HI = 176
@@ -175,7 +185,7 @@ def configure(fmt):
         assert V_CV + (6 if FMT == 'bf6' else 8) <= V_L0
         ORDER = ORDER_BASE
     A_H6 = A_IN6 + 8 * NA6
-    N_AGPR_USED = A_H6 + 8 * NA6 + (12 if WREG else 0)
+    N_AGPR_USED = 256 if FMT == 'f16' else A_H6 + 8 * NA6 + (12 if WREG else 0)
     assert N_AGPR_USED <= 256
 
 
@@ -250,6 +260,11 @@ def off_a6(j):
     return (16 + 2 * j) * 1024, (17 + 2 * j) * 1024
 
 
+def off_lo(s):
+    """f16: byte offset inside a chunk of the lo(W) fragment of k-step s"""
+    return (16 + s) * 1024
+
+
 def in_stream(j):
     """is operand j part of the weight stream (False: made on chip, bf6r term 1)"""
     return not (WREG and J_ORDER[j][0] == 1)
@@ -292,6 +307,14 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
                     for j in range(8):
                         frag[:, j] = hi[rows, kappa(s, h, j)]
                     img[p:p + 1024] = frag.view(np.uint8).reshape(-1)
+                if FMT == 'f16':
+                    lo16 = (Wl.astype(np.float64) - hi.astype(np.float64)).astype(np.float16)     # fp16(w - hi(w))
+                    for s in range(16):
+                        frag = np.zeros((64, 8), dtype=np.float16)
+                        for j in range(8):
+                            frag[:, j] = lo16[rows, kappa(s, h, j)]
+                        img[base + off_lo(s):base + off_lo(s) + 1024] = frag.view(np.uint8).reshape(-1)
+                    continue
                 for j, (term, t) in enumerate(J_ORDER):
                     if not in_stream(j):
                         continue
@@ -387,6 +410,10 @@ def tile_anchors():
     """the 24 MFMAs of a row tile as (kind, s or j), all on ONE accumulator (an accumulate chain).  The B operands of the
     previous layer's last row tile are converted late: its k-steps 14, 15 and its K=64 operands (., 3) come last."""
     out = []
+    if ORDER == 'f16':       # three fp16 passes per k-step on one accumulate chain
+        for s in range(16):
+            out += [('m16', s), ('mhl', s), ('mlh', s)]
+        return out
     if ORDER == 'group':     # bf6r: K=64 step t = fp16 k-steps 4t .. 4t+3, then term 1 (operand converted from them), then term 0
         for t in range(4):
             out += [('m16', 4 * t + i) for i in range(4)]
@@ -401,7 +428,7 @@ def tile_anchors():
     return out
 
 
-ANCH_PER_TILE = 24
+# ANCH_PER_TILE (MFMAs of a row tile: 24, f16: 48): configure()
 _POS = {}
 
 
@@ -452,12 +479,16 @@ def epilogue_ops(T, guard=False):
         ops.append((v_cvt_pk_f16(h01, t[0], t[1]), ('hi', s)))
         ops.append((v_cvt_pk_f16(h23, t[2], t[3]), ('hi', s)))
         # half-register writes: low halves first, then the high halves (never two writers of one register back to back)
-        if FMT == 'fp8':
+        if FMT in ('fp8', 'f16'):
             lo = V_LO + g * 2
         ops.append((v_resid16(lo, 0, h01, 0, t[0], S_NEG1), None))
         ops.append((v_resid16(lo + 1, 0, h23, 0, t[2], S_NEG1), None))
         ops.append((v_resid16(lo, 1, h01, 1, t[1], S_NEG1), None))
         ops.append((v_resid16(lo + 1, 1, h23, 1, t[3], S_NEG1), None))
+        if FMT == 'f16':   # the residual pairs ARE the lo B operand of k-step s: registers 2 (g & 1), + 1
+            lset = A_HLO if layer == 0 else A_INL
+            ops.append((v_accw(lset + 4 * s + 2 * (g & 1), lo), ('lo', s)))
+            ops.append((v_accw(lset + 4 * s + 2 * (g & 1) + 1, lo + 1), ('lo', s)))
         if FMT == 'fp8':
             # four values = one register of each e4m3 operand (byte e = 16 (u & 1) + 4 g + i of K=64 step u >> 1): two
             # half-register conversions each, never two writers of one register back to back
@@ -563,6 +594,11 @@ def build_fillers(it, opts):
             prev = n - NHI                                 # last user of the buffer
             earliest = max(A(prev // 16, 'm16', prev % 16), A(T, 'm16', s_) - opts.rd_lead)
             deadline = A(T, 'm16', s_)
+            if FMT == 'f16':   # hi(W) of k-step s feeds two MFMAs; a second ring streams lo(W)
+                earliest = max(A(prev // 16, 'mhl', prev % 16), A(T, 'm16', s_) - 3 * opts.rd_lead)
+                bv, off = lds_addr(slot, off_lo(s_), 16)
+                F.append(Filler(ds_read_b128(V_HL + 4 * (n % NHI), bv, off, tag=('hl', it, T, s_)),
+                                max(A(prev // 16, 'mlh', prev % 16), A(T, 'mlh', s_) - 3 * opts.rd_lead), A(T, 'mlh', s_), ('rdl',)))
             if WREG:
                 # the buffer is also a source of the conversion of its group (prev's K=64 step), and the whole group of this
                 # fragment must be on its way when its own conversion may issue
@@ -572,7 +608,7 @@ def build_fillers(it, opts):
             bv, off = lds_addr(slot, off_hi(s_), 16)
             F.append(Filler(ds_read_b128(HI(n % NHI), bv, off, tag=('hi', it, T, s_)), earliest, deadline, ('rd',)))
         for j in range(8):
-            if not in_stream(j):
+            if not in_stream(j) or FMT == 'f16':
                 continue
             n = T * 4 + (j >> 1) if WREG else T * 8 + j
             prevj = [jj for jj in range(8) if in_stream(jj)]
@@ -608,11 +644,12 @@ def build_fillers(it, opts):
             F.append(Filler(valu('v_xor_b32 %s, 0x%x, %s' % (vreg(V_AUX), AUX_BYTES, vreg(V_AUX)), vr(V_AUX), vr(V_AUX),
                                  lambda st: st.V.__setitem__(V_AUX, st.V[V_AUX] ^ AUX_BYTES)),
                             A(T, 'm16', 1), A(T, 'm16', 12), ('auxflip',)))
-            F.append(Filler(ds_read_b64(V_SC, V_AUX, AUX_SCALES, tag=('scale', it + 1, 0)),
-                            A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
-            # ... and its activation exponents (this block's were used up at tile 1)
-            F.append(Filler(read_act(('act', it + 1)), A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
-        if T == 1:
+            if FMT != 'f16':
+                F.append(Filler(ds_read_b64(V_SC, V_AUX, AUX_SCALES, tag=('scale', it + 1, 0)),
+                                A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
+                # ... and its activation exponents (this block's were used up at tile 1)
+                F.append(Filler(read_act(('act', it + 1)), A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
+        if T == 1 and FMT != 'f16':
             # layer-2 scales of this block (layer 2 of the previous block is over)
             F.append(Filler(ds_read_b64(V_SC + 2, V_AUX, AUX_SCALES + 8, tag=('scale', it, 1)),
                             A(T, 'm16', 1), A(T + 1, 'm16', 0), ('auxflip',)))
@@ -631,12 +668,14 @@ def build_fillers(it, opts):
             if cons is not None:
                 if cons[0] == 'hi':
                     first = A(nl_T0, 'm16', cons[1])
+                elif cons[0] == 'lo':
+                    first = A(nl_T0, 'mhl', cons[1])
                 else:
                     first = A(nl_T0, 'm6', J_ORDER.index((cons[1], cons[2])))
                 dl = min(dl, first - 2)
             F.append(Filler(ins, e0, dl, ('epi',)))
         # --- rendezvous + refill at the middle of each chunk (= row tile) ------------------------
-        a0 = base_anchor + T * ANCH_PER_TILE + 8
+        a0 = base_anchor + T * ANCH_PER_TILE + ANCH_PER_TILE // 3
         ch = ('dma',)
         F.append(Filler(waitcnt_vm(PW), a0 - 1, a0 + 1, ch))
         F.append(Filler(barrier(), a0 - 1, a0 + 1, ch))
@@ -673,7 +712,7 @@ def build_fillers(it, opts):
                 seq.append(salu('s_add_u32 m0, m0, 0x1000', lambda st: setattr(st, 'm0', st.m0 + 4096)))
                 seq.append(s_nop(0))
             seq.append(dma_piece(i, tag=('dma', it, T, i)))
-        end = base_anchor + (T + 1) * ANCH_PER_TILE + 6      # well before the next rendezvous
+        end = base_anchor + (T + 1) * ANCH_PER_TILE + ANCH_PER_TILE // 4      # well before the next rendezvous
         if opts.dma_burst:
             for ins in seq:
                 F.append(Filler(ins, a0 - 1, a0 + 1, ch))
@@ -760,18 +799,27 @@ def schedule(opts, n_iter=3):
             sch.need(it, ('scale', it, 1))          # ... and of its layer-2 conversions (tiles 8..15; scales read during tile 1)
             for ins in derive_wsc(V_WSC + 1, V_SC + 3):
                 sch.emit(it, ins)
-        if a % ANCH_PER_TILE == 0 and T == 1:
+        if FMT != 'f16' and a % ANCH_PER_TILE == 0 and T == 1:
             # layer 2 of the previous block and its last epilogue are over: the exponents of this block's H set (layer 2
             # consumes it) and of the set layer 2 produces
             for ins in derive_sb(V_SB + 2, V_ACT + 1) + derive_cv(V_CVD + 2, V_ACT + 2):
                 sch.emit(it, ins)
-        if a % ANCH_PER_TILE == 0 and T == 9:
+        if FMT != 'f16' and a % ANCH_PER_TILE == 0 and T == 9:
             # layer 1 and its last epilogue are over: the next block's exponents (read behind the aux flip of tile 8)
             sch.need(it, ('act', it + 1))
             for ins in derive_sb(V_SB, V_ACT) + derive_cv(V_CVD, V_ACT + 1):
                 sch.emit(it, ins)
         dfile, d = ('v', ACC(T & 1)) if layer == 0 else ('a', X(u))
-        if kind == 'm16':
+        if kind in ('mhl', 'mlh'):      # f16: hi(W) x lo(a) | lo(W) x hi(a)
+            n = T * 16 + sj
+            if kind == 'mhl':
+                lset = A_INL if layer == 0 else A_HLO
+                ins = mfma32_16(dfile, d, HI(n % NHI), lset + 4 * sj, dfile, d, tag=(kind, it, T, sj), bfile='a')
+            else:
+                sch.need(it, ('hl', it, T, sj))
+                ins = mfma32_16(dfile, d, V_HL + 4 * (n % NHI), hset(sj), dfile, d, tag=(kind, it, T, sj))
+            cap = opts.cap16
+        elif kind == 'm16':
             sch.need(it, ('hi', it, T, sj))
             n = T * 16 + sj
             if layer == 0 and sj == 0:
@@ -828,6 +876,8 @@ class Opts:
 def act_prologue():
     """exponent registers in front of the first tile: layer 1 consumes IN(0) and produces H(0); the initial split of X
     produces IN(0) with the divisors of the layer-2 epilogue"""
+    if FMT == 'f16':
+        return []
     return ([read_act(('act', 0)), waitcnt_lgkm(0)] + derive_sb(V_SB, V_ACT) + derive_cv(V_CVD, V_ACT + 1) +
             derive_cv(V_CVD + 2, V_ACT))
 
@@ -1193,8 +1243,9 @@ def main():
     ap.add_argument('--chain-nop', type=int, default=-1)
     ap.add_argument('--order', default=None, choices=['tail', 'mix'])
     ap.add_argument('--guard', action='store_true', help='the range-guard build of the stream (r2l_body_guard_kernel)')
-    ap.add_argument('--fmt', default='bf6', choices=['bf6', 'bf6r', 'fp8'],
-                    help='correction terms: bf6 (e3m2, all operands streamed) | bf6r (bf6(W) converted from the fp16 fragments in registers) | fp8 (e4m3)')
+    ap.add_argument('--fmt', default='bf6', choices=['bf6', 'bf6r', 'fp8', 'f16'],
+                    help='correction terms: bf6 (e3m2, all operands streamed) | bf6r (bf6(W) converted from the fp16 fragments in registers) | fp8 (e4m3) | '
+                         'f16 (three fp16 passes: R2L_PREC_FP16X3 on this machine)')
     ap.add_argument('--dma6', action='store_true', help='bf6r: 6 x dwordx4 per wave and chunk (512 B moved twice) instead of 5 x dwordx4 + 2 x dword')
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')

@@ -154,8 +154,8 @@ struct r2l_ctx {
     int n_cu;
     bool loaded;
     std::vector<std::vector<float>> host_w;  // state_dict order
-    char* d_img[4];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
-    size_t img_bytes[4];
+    char* d_img[5];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
+    size_t img_bytes[5];
     char* d_body;                             // split modes: body stream v3 (r2l_body.hip) | aux blocks | tail
     int body_mode = -1;                       // ... of this mode (bf6 or e4m3 terms: chunk geometry and operand codes differ)
     size_t body_bytes, aux_off, tail_off;
@@ -185,11 +185,17 @@ struct r2l_ctx {
 };
 
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
-enum { R2L_STREAM_BF6 = 0, R2L_STREAM_E4M3 = 1, R2L_STREAM_BF6R = 2 };   // body stream layouts (pack_body_v3)
-static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_E4M3; }
-// the modes with the generated head launch + generated body kernel (fp16 main pass + low-precision correction terms)
-static bool split_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3; }
-#define R2L_N_MODES 4
+enum { R2L_STREAM_BF6 = 0, R2L_STREAM_E4M3 = 1, R2L_STREAM_BF6R = 2, R2L_STREAM_F16 = 3 };   // body stream layouts (pack_body_v3)
+static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16X3_ASM; }
+// the modes with the generated head launch + generated body kernel
+static bool split_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16X3_ASM; }
+// ... of them those with low-precision correction terms in the body: calibrated operand scales, range tracking
+static bool scaled_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3; }
+static int stream_of(int mode) {
+    return mode == R2L_PREC_FP16_E4M3 ? R2L_STREAM_E4M3 : mode == R2L_PREC_FP16X3_ASM ? R2L_STREAM_F16 :
+           (R2L_BF6_CHUNK == 28672 ? R2L_STREAM_BF6 : R2L_STREAM_BF6R);
+}
+#define R2L_N_MODES 5
 #define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head / body launch pair (1 KiB of h0 per ray)
 
 
@@ -290,8 +296,7 @@ static int build_image(r2l_ctx* c, int mode) {
         int rc = pack_head_v1(c, img);
         if (rc) return rc;
         std::vector<char> body;
-        rc = pack_body_v3(c, mode == R2L_PREC_FP16_E4M3 ? R2L_STREAM_E4M3 : (R2L_BF6_CHUNK == 28672 ? R2L_STREAM_BF6 : R2L_STREAM_BF6R),
-                          body, &c->aux_off, &c->tail_off);
+        rc = pack_body_v3(c, stream_of(mode), body, &c->aux_off, &c->tail_off);
         if (rc) return rc;
         c->body_mode = mode;
         if (c->d_body) {
@@ -539,8 +544,8 @@ static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
 
 static int pack_body_v3(const r2l_ctx* c, int fmt, std::vector<char>& out, size_t* aux_off, size_t* tail_off) {
     const int nb = c->n_block;
-    const int e4m3 = fmt == R2L_STREAM_E4M3, wconv = fmt == R2L_STREAM_BF6R;
-    const size_t CH = e4m3 ? R2L_BODY8_CHUNK : (wconv ? R2L_BODYW_CHUNK : R2L_BODY_CHUNK), AUXB = 4096;
+    const int e4m3 = fmt == R2L_STREAM_E4M3, wconv = fmt == R2L_STREAM_BF6R, f16 = fmt == R2L_STREAM_F16;
+    const size_t CH = (e4m3 || f16) ? R2L_BODY8_CHUNK : (wconv ? R2L_BODYW_CHUNK : R2L_BODY_CHUNK), AUXB = 4096;
     const size_t stream = (size_t)nb * 16 * CH;
     *aux_off = stream;
     *tail_off = stream + (size_t)nb * AUXB;
@@ -583,6 +588,13 @@ static int pack_body_v3(const r2l_ctx* c, int fmt, std::vector<char>& out, size_
                         _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)s * 1024 + lane * 16);
                         for (int j = 0; j < 8; ++j) ph[j] = (_Float16)row[r2l_kappa32(s, h, j)];
                     }
+                    for (int s = 0; f16 && s < 16; ++s) {      // FP16X3_ASM: pieces 16 + s = the fp16 residuals w - hi(w)
+                        _Float16* pl = reinterpret_cast<_Float16*>(chunk + (size_t)(16 + s) * 1024 + lane * 16);
+                        for (int j = 0; j < 8; ++j) {
+                            const float w = row[r2l_kappa32(s, h, j)];
+                            pl[j] = (_Float16)((double)w - (double)(float)(_Float16)w);
+                        }
+                    }
                     for (int j = 0; e4m3 && j < 8; ++j) {
                         const int term = j & 1, t = j >> 1;
                         unsigned char codes[32];
@@ -594,7 +606,7 @@ static int pack_body_v3(const r2l_ctx* c, int fmt, std::vector<char>& out, size_
                         memcpy(chunk + (size_t)(16 + 2 * j) * 1024 + lane * 16, codes, 16);
                         memcpy(chunk + (size_t)(17 + 2 * j) * 1024 + lane * 16, codes + 16, 16);
                     }
-                    for (int j = 0; !e4m3 && j < 8; ++j) {
+                    for (int j = 0; !e4m3 && !f16 && j < 8; ++j) {
                         const int term = j & 1, t = j >> 1;
                         uint64_t bits[3] = {0, 0, 0};
                         for (int el_i = 0; el_i < 32; ++el_i) {
@@ -741,7 +753,9 @@ int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
     if (!c || !out) return r2l_set_error(R2L_EINVAL, "NULL argument");
     memset(out, 0, sizeof *out);
     out->worst_set = -1;
-    if (!c->loaded || !c->d_range || !c->d_gstats) return r2l_set_error(R2L_ESTATE, "r2l_get_range_status before r2l_load_weights in R2L_PREC_FP16_FP8");
+    if (!c->loaded || !c->d_range || !c->d_gstats || !scaled_mode(c->mode))
+        return r2l_set_error(R2L_ESTATE, "r2l_get_range_status needs loaded weights and R2L_PREC_FP16_FP8 / R2L_PREC_FP16_E4M3 "
+                                         "(the other modes have no operand scales to watch)");
     std::vector<int> ex;
     int rc = read_exponents(c, ex);      // synchronises the stream of the newest render
     if (rc) return rc;
@@ -869,7 +883,7 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     if (!c || !x_in_dev || !x_out_dev || n_tiles < 1) return r2l_set_error(R2L_EINVAL, "bad argument to r2l_debug_body");
     if (!c->loaded || !split_mode(c->mode) || c->n_block < 1)
         return r2l_set_error(R2L_ESTATE, "r2l_debug_body needs loaded weights, R2L_PREC_FP16_FP8 / _E4M3 and n_block >= 1");
-    if (c->calib_pending) {   // as a render would: the exponents of these weights on this input
+    if (c->calib_pending && scaled_mode(c->mode)) {   // as a render would: the exponents of these weights on this input
         c->calib_pending = 0;
         hipError_t ec = r2l_launch_calib(x_in_dev, c->d_wcal, c->n_block, n_tiles, c->act_scale, c->d_stats,
                                          c->d_body + c->aux_off, 0, (hipStream_t)stream);
@@ -886,8 +900,8 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
     pb.n_rays = 0;
     pb.tile_begin = 0;
-    pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3;
-    pb.gstats = c->guard_period == 1 && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) ? c->d_gstats : nullptr;
+    pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3 ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
+    pb.gstats = c->guard_period == 1 && scaled_mode(c->mode) && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) ? c->d_gstats : nullptr;
     c->last_stream = (hipStream_t)stream;
     hipError_t e = r2l_launch_body(pb, n_tiles < c->n_cu ? n_tiles : c->n_cu, (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
@@ -897,7 +911,8 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
 int r2l_set_precision(r2l_ctx* c, int mode) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (!mode_ok(mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
-    if (c->loaded && split_mode(mode) && c->d_body && c->body_mode != mode && c->n_block > 0 && !c->calib_pending) {
+    if (c->loaded && split_mode(mode) && scaled_mode(c->body_mode) && c->d_body && c->body_mode != mode && c->n_block > 0 &&
+        !c->calib_pending) {
         // the other split mode's body stream is about to replace this one: the exponents the device calibrated live only
         // in its aux blocks -- carry them over (same operand sets, same meaning)
         std::vector<int> ex((size_t)2 * c->n_block + 1);
@@ -992,7 +1007,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
         const float* body_out = c->d_xa;
         bool fused = false;
-        if (c->n_block > 0 && c->calib_pending) {
+        if (c->n_block > 0 && c->calib_pending && scaled_mode(c->mode)) {
             // activation exponents from this call's own head output: device work in stream order, no host round trip
             // a call of fewer than R2L_CALIB_TILES ray tiles is a thin sample: its maxima count, but the measurement stays open
             // and the next call adds its own (exponents only grow), until one call has filled the sample
@@ -1016,9 +1031,9 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
             pb.n_rays = p.n_rays;
             pb.tile_begin = t0;
-            pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3;
+            pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3 ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
             // range guard: the first launch after a weight load, then every guard_period-th (r2l_set_guard_period)
-            const bool guard = c->guard_period > 0 && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) &&
+            const bool guard = c->guard_period > 0 && scaled_mode(c->mode) && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) &&
                                c->n_since_load % c->guard_period == 0;
             pb.gstats = guard ? c->d_gstats : nullptr;
             ++c->n_since_load;

@@ -37,7 +37,8 @@ struct R2LBodyParams {
     // range guard: 2 n_block maxima (f32 bits, act_scale domain) of the operand sets IN_0, H_0, IN_1, ... over every ray of
     // the launch; nullptr = the plain kernel (r2l_body.hip: r2l_body_guard_kernel)
     unsigned* gstats;
-    int e4m3;           // 0: bf6 correction terms (r2l_body_kernel, 28 KiB chunks); 1: e4m3 (r2l_body8_kernel, 32 KiB chunks)
+    int e4m3;           // 0: bf6 correction terms (r2l_body_kernel, 28 KiB chunks); 1: e4m3 (r2l_body8_kernel, 32 KiB chunks);
+                        // 2: three fp16 passes (r2l_bodyx_kernel, 32 KiB chunks: R2L_PREC_FP16X3_ASM; no guard build)
 };
 struct R2LTailParams {
     const float* xa;    // head output (global skip), may be nullptr

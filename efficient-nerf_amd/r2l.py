@@ -19,10 +19,11 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, check, current_stream, dptr, lib
+from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, check, current_stream, dptr, lib
 
 SPLIT_MODES = (PREC_FP16_FP8, PREC_FP16_E4M3)   # generated head launch + generated body kernel, calibrated operand scales
-PREC_NAMES = {PREC_FP16X3: 'fp16x3', PREC_FP16X1: 'fp16x1', PREC_FP16_FP8: 'fp16_fp8', PREC_FP16_E4M3: 'fp16_e4m3'}
+PREC_NAMES = {PREC_FP16X3: 'fp16x3', PREC_FP16X1: 'fp16x1', PREC_FP16_FP8: 'fp16_fp8', PREC_FP16_E4M3: 'fp16_e4m3',
+              PREC_FP16X3_ASM: 'fp16x3_asm'}
 
 
 def _dev(device=None):

@@ -271,3 +271,25 @@ def test_bf6r_stream_converts_the_weight_operands_from_registers(nb, wave, guard
     print('L_inf after %d blocks: streamed bf6(W) %.3g, converted on chip %.3g; difference between the two %.3g'
           % (nb, err0, err, np.abs(from_regs(out) - from_regs(out0)).max() / S))
     assert err < 2.5e-5 * nb and err < 1.15 * err0 + 1e-6
+
+
+@pytest.mark.parametrize('nb,wave', [(2, 0), (3, 3)])
+def test_f16_stream_three_fp16_passes(nb, wave):
+    """R2L_PREC_FP16X3 on the body's machine ('f16'): hi(W) hi(a) + hi(W) lo(a) + lo(W) hi(a) as three fp16 MFMAs per
+    k-step on one accumulate chain, lo = the fp16 rounding residual (lo(W) streamed as a second set of fragments, lo(a)
+    kept as B operands in AGPRs): no scales, no calibration, fp32-grade result."""
+    W = make_weights(nb, seed=30 + nb)
+    rng = np.random.default_rng(6)
+    x = np.maximum(rng.normal(0, 1, (32, 256)), 0).astype(np.float32)
+    S = 16.0
+    ref = ref_blocks(x, *W)
+    Bsum = np.sum([b.astype(np.float64) for b in W[3]], axis=0)
+    img, aux, _ = G.pack_body_image(*W, fmt='f16')
+    assert img.size == nb * 16 * 32768
+    out, e = G.emulate_tile(G.Opts(fmt='f16'), img, aux, to_regs(x * S), nb, wave=wave)
+    G.configure('bf6')
+    assert not e, e[:10]
+    err = np.abs(from_regs(out) / S + Bsum - ref).max()
+    print('L_inf after %d blocks: three fp16 passes %.3g (one pass: %.3g)' % (nb, err, fp16x1_error(x, *W)))
+    # lo(W) of weights ~ 2^-5 is an fp16 subnormal (2^-24 grid): ~2^-20 relative per product instead of 2^-22
+    assert err < 2e-6 * nb and err < fp16x1_error(x, *W) / 100

@@ -25,5 +25,5 @@ for i in range(n):
     t0 = time.time(); eng.render_batch(poses[i % 8:i % 8 + 1]); torch.cuda.synchronize(); ts.append(time.time() - t0)
 kt, kn = eng.kernel_time_ms()
 ts.sort()
-print(f'{os.path.basename(os.environ.get("R2L_LIB_PATH", "default"))}: frame median {ts[len(ts)//2]*1e3:.3f} ms min {ts[0]*1e3:.3f} ms '
+print(f'{os.path.basename(os.environ.get("R2L_LIB_PATH", "default"))} {os.environ.get("BT_PREC", "fp16_fp8")}: frame median {ts[len(ts)//2]*1e3:.3f} ms min {ts[0]*1e3:.3f} ms '
       f'= {H*H/ts[len(ts)//2]:.3e} rays/s; timed kernel mean {kt/max(kn,1):.3f} ms', flush=True)
