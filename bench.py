@@ -69,9 +69,9 @@ def measured_traffic(precision):
 
 
 def middle_rung(torch, O, R2LEngine, sd, poses, focal):
-    """secondary, outside the timed region: a W256D88 network with every body weight x 1.2 (activation exponent 4: beyond
+    """secondary, outside the timed region: a W256D88 network with every body weight x 1.12 (activation exponent 4: beyond
     the bf6 terms' reach) through `--precision auto`: must come out as fp16_e4m3, inside 1e-4 of the CPU oracle, at its rate"""
-    msd = {k: (v * 1.2 if k.startswith('body.') and k.endswith('weight') else v) for k, v in sd.items()}
+    msd = {k: (v * 1.12 if k.startswith('body.') and k.endswith('weight') else v) for k, v in sd.items()}
     eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(msd)
     chosen, top = eng.choose_precision(c2w=poses[0])
     band = (H // 2 - 20, H // 2 + 20)
@@ -85,7 +85,7 @@ def middle_rung(torch, O, R2LEngine, sd, poses, focal):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / 5
     st = eng.range_status()
-    out = {'body_weight_gain': 1.2, 'max_act_exponent': int(top), 'auto_precision': chosen,
+    out = {'body_weight_gain': 1.12, 'max_act_exponent': int(top), 'auto_precision': chosen,
            'linf_vs_cpu_oracle': (got - ref).abs().max().item(), 'rays_checked': int(got.shape[0]), 'value': H * W / dt,
            'unit': 'rays/s', 'ms_per_frame': dt * 1e3, 'worst_fill': st['worst_fill']}
     eng.close()
@@ -97,7 +97,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--precision', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3'], default='fp16_fp8',
+    ap.add_argument('--precision', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm'], default='fp16_fp8',
                     help='fp16_fp8 (default: fp16 main pass + bf6 correction terms) and fp16x3 meet the <=1e-4 L_inf '
                          'contract (measured 3e-5 / 6e-7, checked in this run against the CPU oracle); fp16x1 (3.5e-4) does not')
     ap.add_argument('--guard-period', type=int, default=None,
@@ -177,7 +177,7 @@ def main():
     avg_kernel_s = kern_ms / max(n_launch, 1) / 1e3
     achieved = kflops_per_ray * rays_per_launch / avg_kernel_s / 1e12
     # fp16-MFMA pass equivalents per k-step: fp16_fp8 = 1 fp16 pass + two bf6 terms at 4x the fp16 rate
-    passes = {'fp16x3': 3, 'fp16x1': 1, 'fp16_fp8': 1.5, 'fp16_e4m3': 2.0}[args.precision]
+    passes = {'fp16x3': 3, 'fp16x1': 1, 'fp16_fp8': 1.5, 'fp16_e4m3': 2.0, 'fp16x3_asm': 3}[args.precision]
     path_tflops = flops_per_ray * rays_per_step * args.steps / dt / world / 1e12   # per GPU, everything in the step
 
     out = {
@@ -190,7 +190,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp16x3': 'f16 (3 fp16 MFMA passes on hi/lo-split operands, fp32 accumulate)',
                                                                                      'fp16x1': 'f16 (1 fp16 MFMA pass, fp32 accumulate)',
                                                                                      'fp16_fp8': 'f16+bf6 (1 fp16 MFMA pass + both hi/lo correction terms on the block-scaled MFMA in OCP bf6 (e3m2) at 4x the fp16 rate, fp32 accumulate)',
-                                                                                     'fp16_e4m3': 'f16+e4m3 (1 fp16 MFMA pass + both hi/lo correction terms on the block-scaled MFMA in OCP e4m3 at 2x the fp16 rate, fp32 accumulate)'}[args.precision],
+                                                                                     'fp16_e4m3': 'f16+e4m3 (1 fp16 MFMA pass + both hi/lo correction terms on the block-scaled MFMA in OCP e4m3 at 2x the fp16 rate, fp32 accumulate)',
+                                                                                     'fp16x3_asm': 'f16 (3 fp16 MFMA passes on hi/lo-split operands in the generated body kernel; head launch with bf6 terms; fp32 accumulate)'}[args.precision],
         'data': 'synthetic (seeded nn.Linear-init W256D88 weights, pose_spherical test poses, lego intrinsics)',
         'config': {'workload': 'R2L W256D88 lego_noview_800x800 test views, rows sharded across %d GPU(s) + all-gather' % world,
                    'H': H, 'W': W, 'rays_per_gpu_per_step': rows * W * world, 'frames_per_step': world,
@@ -199,7 +200,7 @@ def main():
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP16_TFLOPS, 'traffic': measured_traffic(args.precision),
                      'kernel': {'fp16x3': 'r2l_resmlp_kernel<2, false, false>', 'fp16x1': 'r2l_resmlp_kernel<1, false, false>',
-                                'fp16_fp8': 'r2l_body_kernel', 'fp16_e4m3': 'r2l_body8_kernel'}[args.precision],
+                                'fp16_fp8': 'r2l_body_kernel', 'fp16_e4m3': 'r2l_body8_kernel', 'fp16x3_asm': 'r2l_bodyx_kernel'}[args.precision],
                      'avg_kernel_ms': avg_kernel_s * 1e3, 'launches': n_launch,
                      'algorithmic_flops_per_ray': kflops_per_ray, 'executed_mfma_passes': passes,
                      'executed_frac': achieved * passes / PEAK_FP16_TFLOPS,
@@ -287,7 +288,7 @@ def main():
             out['alt_precision'] = alt
             eng.set_precision(prec)
         if world == 1 and not args.no_cpu_baseline and args.precision == 'fp16_fp8':
-            # the middle rung of `--precision auto` on the networks it is for (body weights x 1.2: activation exponent 4)
+            # the middle rung of `--precision auto` on the networks it is for (body weights x 1.12: activation exponent 4)
             out['e4m3_mode'] = middle_rung(torch, O, R2LEngine, sd, poses, focal)
             # secondary, outside the timed region: SURVEY 8(d)'s stress weights (every body weight x 1.3) through
             # `--precision auto`: their residual stream is too large for the bf6 terms, the library must notice and take fp16x3

@@ -49,7 +49,7 @@ import numpy as np
 
 from isa import (ACT_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
                  ds_read_b64, ds_read_b96, ds_max_u32, ds_write_b128, ds_write_b64, v_max3_abs, mfma32_8, v_cvt_pk_fp8_f16,
-                 f_to_e4m3, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
+                 f_to_e4m3, v_mul_lit, v_fmac_lit, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
                  v_cvt_pk32_bf6, s_nop, salu, f_to_bf6, pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream,
                  model_cycles)
 
@@ -130,6 +130,12 @@ TAIL_BYTES = 4096
 # tiles of a workgroup by ds_max_u32; the kernel's HIP epilogue reduces the rows and atomicMax-es them into the context's
 # statistics
 GSTAT_ROW = 128
+# f16: the stream holds W x 2^F16_WSHIFT (hi and lo fragments alike; exact), so that lo(W) of weights ~ 2^-5 is a normal fp16
+# number instead of a subnormal on the 2^-24 grid; the accumulators carry the factor, the epilogue takes it out (layer 1: one
+# v_mul_f32 behind the relu; layer 2: X += acc / 2^F16_WSHIFT as one v_fmac_f32).  Layer 2 of this format accumulates W2 h in a
+# fresh accumulator and joins X ONCE per row tile: 48 MFMAs rounding at ulp(X) each are what would dominate its error otherwise.
+F16_WSHIFT = 8
+V_XT = 216        # f16: 8 temporaries of the layer-2 epilogue (X values on their way through the VALU)
 DMA6 = False      # --dma6 (bf6r): a wave's share as 6 x dwordx4, the sixth overlapping the fifth by 512 B, instead of 5 + 2 x dword
 
 def configure(fmt):
@@ -286,14 +292,16 @@ def pack_body_image(W1s, b1s, W2s, b2s, act_scale=16.0, act=None, fmt='bf6'):
     r = lanes & 31
     for b in range(n_block):
         b1f = b1s[b].astype(np.float64) + W1s[b].astype(np.float64) @ Bsum
-        aux[b, :256] = (b1f * act_scale).astype(np.float32).view(np.uint32)
+        aux[b, :256] = (b1f * act_scale * (2.0 ** F16_WSHIFT if FMT == 'f16' else 1.0)).astype(np.float32).view(np.uint32)
         for half in range(2):
             for i in range(3):
                 aux[b, AUX_ACT // 4 + 4 * half + i] = 127 + act[2 * b + i]
         for layer, Wl in enumerate((W1s[b], W2s[b])):
             Wl = Wl.astype(np.float32)
-            hi = Wl.astype(np.float16)
             ex = layer_exponent(Wl)
+            if FMT == 'f16':
+                Wl = Wl * np.float32(2.0 ** F16_WSHIFT)
+            hi = Wl.astype(np.float16)
             el, ew = weight_exps(ex, FMT)
             for qq in range(4):
                 aux[b, AUX_SCALES // 4 + 4 * qq + 2 * layer] = 0x01010101 * (127 + el)
@@ -455,7 +463,7 @@ def guard_flush(tag):
             valu('v_mov_b32 %s, 0' % vreg(V_GMAX), (), vr(V_GMAX), lambda st: st.V.__setitem__(V_GMAX, np.zeros(64, np.uint32)))]
 
 
-def epilogue_ops(T, guard=False):
+def epilogue_ops(T, guard=False, split=False):
     """VALU epilogue of row tile T (block-local tile index, may be -1 = tile 15 of the previous block).  Returns
     [(Ins, consumer)]; consumer: None | ('hi', s) | ('b6', term, t).  Works in the tile's own accumulator registers:
     relu in place (layer 1), copies of X (layer 2, whose accumulator is X itself).  guard: the values also enter the
@@ -467,8 +475,24 @@ def epilogue_ops(T, guard=False):
     ops = []
     for g in range(4):
         t = [acc + 4 * g + i for i in range(4)]
-        for i in range(4):
-            ops.append((v_max0(t[i], t[i]) if layer == 0 else v_accr(t[i], X(u) + 4 * g + i), None))
+        if FMT == 'f16' and layer == 1:
+            # x <- x + acc / 2^F16_WSHIFT through temporaries (split: the ray tile's initial split, nothing to add yet)
+            a_ = t
+            t = [V_XT + 4 * (g & 1) + i for i in range(4)]
+            for i in range(4):
+                ops.append((v_accr(t[i], X(u) + 4 * g + i), None))
+            for i in range(4):
+                if not split:
+                    ops.append((v_fmac_lit(t[i], 2.0 ** -F16_WSHIFT, a_[i]), None))
+            for i in range(4):
+                if not split:
+                    ops.append((v_accw(X(u) + 4 * g + i, t[i]), None))
+        else:
+            for i in range(4):
+                ops.append((v_max0(t[i], t[i]) if layer == 0 else v_accr(t[i], X(u) + 4 * g + i), None))
+            if FMT == 'f16':       # the accumulator carries the weight stream's factor
+                for i in range(4):
+                    ops.append((v_mul_lit(t[i], t[i], 2.0 ** -F16_WSHIFT), None))
         if guard:
             ops.append((v_max3_abs(V_GMAX, t[0], t[1]), None))
             ops.append((v_max3_abs(V_GMAX, t[2], t[3]), None))
@@ -809,7 +833,7 @@ def schedule(opts, n_iter=3):
             sch.need(it, ('act', it + 1))
             for ins in derive_sb(V_SB, V_ACT) + derive_cv(V_CVD, V_ACT + 1):
                 sch.emit(it, ins)
-        dfile, d = ('v', ACC(T & 1)) if layer == 0 else ('a', X(u))
+        dfile, d = ('v', ACC(T & 1)) if layer == 0 or FMT == 'f16' else ('a', X(u))
         if kind in ('mhl', 'mlh'):      # f16: hi(W) x lo(a) | lo(W) x hi(a)
             n = T * 16 + sj
             if kind == 'mhl':
@@ -825,6 +849,8 @@ def schedule(opts, n_iter=3):
             if layer == 0 and sj == 0:
                 sch.need(it, ('bias', it, T, 3))
                 ins = mfma32_16('v', d, HI(n % NHI), hset(sj), 'v', d if WREG else V_BIAS, tag=('m16', it, T, sj))
+            elif FMT == 'f16' and sj == 0:      # layer 2: a fresh accumulator (its bias is folded into later layer-1 biases)
+                ins = mfma32_16('v', d, HI(n % NHI), hset(sj), '0', 0, tag=('m16', it, T, sj))
             else:
                 ins = mfma32_16(dfile, d, HI(n % NHI), hset(sj), dfile, d, tag=('m16', it, T, sj))
             cap = opts.cap16
@@ -897,7 +923,21 @@ def steady_block(opts):
 # ---------------------------------------------------------------------------------------------
 def split_ops(u, guard=False):
     """standalone split of X row tile u -> the layer-1 operand sets (the layer-2 epilogue without MFMAs)"""
-    return [ins for ins, _ in epilogue_ops(8 + u, guard)]
+    return [ins for ins, _ in epilogue_ops(8 + u, guard, split=True)]
+
+
+def f16_join_ops(u, p):
+    """f16: X row tile u += accumulator buffer p / 2^F16_WSHIFT (the join of a layer-2 row tile, outside the loop schedule)"""
+    ops = []
+    for i in range(16):
+        ops += [v_accr(V_XT + (i & 7), X(u) + i), v_fmac_lit(V_XT + (i & 7), 2.0 ** -F16_WSHIFT, ACC(p) + i), v_accw(X(u) + i, V_XT + (i & 7))]
+    return ops
+
+
+def f16_clear_ops():
+    """f16: the loop head joins "tile 15 of the previous block" into X row tile 7: nothing in front of the first block"""
+    return [valu('v_mov_b32 %s, 0' % vreg(ACC(1) + i), (), vr(ACC(1) + i),
+                 (lambda i_: lambda st: st.V.__setitem__(ACC(1) + i_, np.zeros(64, np.uint32)))(i)) for i in range(16)]
 
 
 def fused_tail_text():
@@ -1098,6 +1138,9 @@ def kernel_text(opts):
     for u in range(7):
         for ins in split_ops(u, opts.guard):
             a(ins.text)
+    if FMT == 'f16':
+        for ins in f16_clear_ops():
+            a(ins.text)
     for ins in pro:   # LDS reads the loop head expects in flight
         a(ins.text)
     a('s_mov_b32 %s, %s' % (sreg(S_BLK), sreg(S_NBLOCK)))
@@ -1111,6 +1154,10 @@ def kernel_text(opts):
     a('s_waitcnt lgkmcnt(0)')
     a('s_nop 15')
     a('s_nop 15')
+    if FMT == 'f16':      # the last row tile of the last block joins X here (inside the loop: at the head of the next block)
+        for ins in f16_join_ops(7, 1):
+            a(ins.text)
+        a('s_nop 1')
     a('s_cmp_eq_u64 %s, 0' % sreg(S_RGB, 2))
     a('s_cbranch_scc1 L_storex_%=')
     L += fused_tail_text()
@@ -1219,10 +1266,14 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     S[S_GPOS] = LDS_GSTAT
     for u in range(7):
         st.run(split_ops(u, opts.guard))
+    if FMT == 'f16':
+        st.run(f16_clear_ops())
     st.run(pro)
     for b in range(n_block):
         st.run(body)
     waitcnt_lgkm(0).emu(st)
+    if FMT == 'f16':
+        st.run(f16_join_ops(7, 1))
     errs = list(st.errors)
     if check_hazards:
         errs += check_hazards_stream(body + body)

@@ -349,6 +349,25 @@ def v_max0(dst, src):
     return valu('v_max_f32 %s, 0, %s' % (vreg(dst), vreg(src)), vr(src), vr(dst), emu)
 
 
+def v_mul_lit(dst, src, lit):
+    """dst = lit * src, lit an f32 literal (a power of two here: exact)"""
+    bits = int(np.float32(lit).view(np.uint32))
+
+    def emu(st):
+        st.V[dst] = (st.f32('v', src) * np.float32(lit)).astype(np.float32).view(np.uint32)
+    return valu('v_mul_f32 %s, 0x%08x, %s' % (vreg(dst), bits, vreg(src)), vr(src), vr(dst), emu)
+
+
+def v_fmac_lit(dst, lit, src):
+    """dst += lit * src (one rounding), lit an f32 literal"""
+    bits = int(np.float32(lit).view(np.uint32))
+
+    def emu(st):
+        st.V[dst] = (st.f32('v', dst).astype(np.float64) + np.float64(np.float32(lit)) * st.f32('v', src).astype(np.float64)
+                     ).astype(np.float32).view(np.uint32)
+    return valu('v_fmac_f32 %s, 0x%08x, %s' % (vreg(dst), bits, vreg(src)), vr(dst) + vr(src), vr(dst), emu)
+
+
 def v_max3_abs(dst, a, b):
     """dst = max(dst, |a|, |b|) in f32 (dst >= 0): the running maximum of the range guard"""
     def emu(st):
@@ -551,7 +570,7 @@ _D32_ROWS = _d32_rows()
 
 def mfma32_16(dfile, d, a, b, cfile, c, tag='', bfile='v'):
     """D[dfile d:d+15] = A(v[a:a+3], 32 x 16) x B([bfile] b:b+3, 16 x 32) + C[cfile c:c+15]: v_mfma_f32_32x32x16_f16"""
-    rf = {'v': vreg, 'a': areg}
+    rf = {'v': vreg, 'a': areg, '0': lambda c_, n_: '0'}      # cfile '0': the inline constant 0 (a fresh accumulator)
     text = 'v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (rf[dfile](d, 16), vreg(a, 4), rf[bfile](b, 4), rf[cfile](c, 16))
 
     def emu(st):
@@ -564,13 +583,13 @@ def mfma32_16(dfile, d, a, b, cfile, c, tag='', bfile='v'):
             Am[lanes & 31, 8 * (lanes >> 5) + j] = Ah[:, j]
             Bm[8 * (lanes >> 5) + j, lanes & 31] = Bh[:, j]
         D = Am @ Bm
-        C = st.regs(cfile)[c:c + 16].view(np.float32).astype(np.float64)   # [16, 64]
+        C = np.zeros((16, 64)) if cfile == '0' else st.regs(cfile)[c:c + 16].view(np.float32).astype(np.float64)   # [16, 64]
         out = np.zeros((16, 64), dtype=np.float32)
         for r in range(16):
             out[r] = (C[r] + D[_D32_ROWS[r], lanes & 31]).astype(np.float32)
         st.regs(dfile)[d:d + 16] = out.view(np.uint32)
 
-    rc = vr(c, 16) if cfile == 'v' else ar(c, 16)
+    rc = [] if cfile == '0' else vr(c, 16) if cfile == 'v' else ar(c, 16)
     wd = vr(d, 16) if dfile == 'v' else ar(d, 16)
     rb = vr(b, 4) if bfile == 'v' else ar(b, 4)
     return Ins(text, 'mfma16', rd=vr(a, 4) + rb + rc, wr=wd, emu=emu, tag=tag, cost=1)

@@ -552,6 +552,9 @@ static int pack_body_v3(const r2l_ctx* c, int fmt, std::vector<char>& out, size_
     out.assign(*tail_off + 4096, 0);   // the body kernel's fused tail copies 4 KiB of it to LDS
     std::vector<double> Bsum(256, 0.0);
     const float Sa = c->act_scale;
+    // FP16X3_ASM: the stream holds W x 2^8 (exact), so that the residuals of weights ~ 2^-5 are normal fp16 numbers; the
+    // accumulators (hence the bias) carry the factor, the kernel's epilogue takes it out (gen/body_gen.py F16_WSHIFT)
+    const float wsc = f16 ? 256.0f : 1.0f;
     for (int b = 0; b < nb; ++b) {
         const float* W[2] = {c->host_w[2 + 4 * b].data(), c->host_w[4 + 4 * b].data()};
         const float* b1 = c->host_w[3 + 4 * b].data();
@@ -560,7 +563,7 @@ static int pack_body_v3(const r2l_ctx* c, int fmt, std::vector<char>& out, size_
         for (int n = 0; n < 256; ++n) {
             double acc = b1[n];
             for (int k = 0; k < 256; ++k) acc += (double)W[0][(size_t)n * 256 + k] * Bsum[k];
-            const float v = (float)(acc * Sa);
+            const float v = (float)(acc * Sa * wsc);
             memcpy(&aux[n], &v, 4);
         }
         for (int half = 0; half < 2; ++half)      // activation exponents: IN set, H set, next IN set (the last block's: block 0's)
@@ -586,12 +589,12 @@ static int pack_body_v3(const r2l_ctx* c, int fmt, std::vector<char>& out, size_
                     const float* row = Wl + (size_t)(32 * u + (lane & 31)) * 256;
                     for (int s = 0; s < 16; ++s) {
                         _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)s * 1024 + lane * 16);
-                        for (int j = 0; j < 8; ++j) ph[j] = (_Float16)row[r2l_kappa32(s, h, j)];
+                        for (int j = 0; j < 8; ++j) ph[j] = (_Float16)(row[r2l_kappa32(s, h, j)] * wsc);
                     }
                     for (int s = 0; f16 && s < 16; ++s) {      // FP16X3_ASM: pieces 16 + s = the fp16 residuals w - hi(w)
                         _Float16* pl = reinterpret_cast<_Float16*>(chunk + (size_t)(16 + s) * 1024 + lane * 16);
                         for (int j = 0; j < 8; ++j) {
-                            const float w = row[r2l_kappa32(s, h, j)];
+                            const float w = row[r2l_kappa32(s, h, j)] * wsc;
                             pl[j] = (_Float16)((double)w - (double)(float)(_Float16)w);
                         }
                     }

@@ -264,7 +264,8 @@ class R2LEngine:
         mode = self._mode_for(top, max_exp)
         if mode != PREC_FP16_FP8:
             self.set_precision(mode)          # the exponents travel with a switch between the two split modes
-            self.range_status(reset=True)
+            if mode in SPLIT_MODES:
+                self.range_status(reset=True)
         return PREC_NAMES[mode], top
 
     #: fill (fraction of bf6's +-28 the largest value of an operand set reached) beyond which check_ranges raises the

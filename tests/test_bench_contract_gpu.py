@@ -38,6 +38,20 @@ def test_bench_line_schema():
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['unit'] == 'rays/s' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
     assert d['parity']['within_tolerance'] and d['parity']['linf_vs_cpu_oracle'] <= 1e-4
+    # SURVEY 8(d)'s protocol: per-step device times beside the mean, L_inf over >= 3 frames (one of them the pose the
+    # exponents were measured on, the others not), north_star's second tolerance (PSNR delta < 0.01 dB)
+    assert 0 < d['min_ms'] <= d['median_ms'] <= d['max_ms'] and d['median_ms'] <= 1.05 * d['ms_per_step']
+    fr = d['parity']['frames']
+    assert len(fr) >= 3 and len({f['pose'] for f in fr}) == len(fr) and any(not f['calibration_pose'] for f in fr)
+    assert all(f['linf'] <= 1e-4 and f['rays'] >= 2400 for f in fr) and d['parity']['rays_checked'] == sum(f['rays'] for f in fr)
+    assert d['parity']['psnr_delta_db'] < 0.01
+    # every ray of the timed steps was watched (h0; the guarded launches among them: every operand set): nothing clamped
+    rw = d['range_watch']
+    assert rw['saturated'] == 0 and rw['launches'] == 2 and 0 < rw['h0_fill'] < 1 and rw['worst_fill'] < 1
+    assert d['calibration']['measured_on'].startswith('every ray')
+    # the middle rung of the ladder on the networks it is for
+    em = d['e4m3_mode']
+    assert em['auto_precision'] == 'fp16_e4m3' and em['max_act_exponent'] == 4 and em['linf_vs_cpu_oracle'] <= 1e-4
     # the stress weights of SURVEY 8(d) must not be rendered with the bf6 terms: the library's own range check decides
     sw = d['stress_weights']
     assert sw['auto_precision'] == 'fp16x3' and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4

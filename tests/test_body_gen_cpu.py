@@ -291,5 +291,5 @@ def test_f16_stream_three_fp16_passes(nb, wave):
     assert not e, e[:10]
     err = np.abs(from_regs(out) / S + Bsum - ref).max()
     print('L_inf after %d blocks: three fp16 passes %.3g (one pass: %.3g)' % (nb, err, fp16x1_error(x, *W)))
-    # lo(W) of weights ~ 2^-5 is an fp16 subnormal (2^-24 grid): ~2^-20 relative per product instead of 2^-22
-    assert err < 2e-6 * nb and err < fp16x1_error(x, *W) / 100
+    # the stream holds W x 2^8, so that lo(W) of weights ~ 2^-5 is a normal fp16 number (not one on the 2^-24 subnormal grid)
+    assert err < 4e-7 * nb and err < fp16x1_error(x, *W) / 500
