@@ -49,7 +49,7 @@ import numpy as np
 
 from isa import (ACT_EXP, Ins, State, Filler, vr, ar, vreg, areg, sreg, mfma32_16, mfma32_6, ds_read_b128,
                  ds_read_b64, ds_read_b96, ds_max_u32, ds_write_b128, ds_write_b64, v_max3_abs, mfma32_8, v_cvt_pk_fp8_f16,
-                 f_to_e4m3, v_mul_lit, v_fmac_lit, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
+                 f_to_e4m3, v_mul_lit, v_fmac_lit, global_load_x4_a, ds_write_b128_stage, v_lshl_or, v_sub_imm, v_lshl_imm, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accr, v_accw, v_cvt_pk_f16, v_resid16,
                  v_cvt_pk32_bf6, s_nop, salu, f_to_bf6, pack6, layer_exponent, weight_exps, f32_bits, check_hazards_stream,
                  model_cycles)
 
@@ -117,7 +117,15 @@ S_NRAYS = 84
 S_TILE0 = 85    # tile number of the launch's first tile within the call
 S_T1 = 86       # temporaries 86..89
 S_GPOS = 90     # range guard: LDS byte address of the maxima row (64 lanes x 4 B) of the operand set being produced
-N_SGPR_LO, N_SGPR_HI = 40, 92
+S_G2 = 92       # 92,93 staged transfer: S_G + 4096 (pieces 4..6 of a wave's share)
+N_SGPR_LO, N_SGPR_HI = 40, 94
+# Staged transfer of the weight stream (Opts.stage, bf6 only: its 32 free AGPRs): instead of LDS-DMA a wave loads its share of
+# chunk T + 3 into 28 AGPRs (7 x global_load_dwordx4) at the rendezvous of row tile T and stores it into the ring at the next
+# rendezvous (s_waitcnt vmcnt(0), then per piece ds_write_b128 from the AGPRs followed by the load of the piece of the chunk
+# after); the barrier of a rendezvous certifies the stores of the one before.  An LDS-DMA instruction holds the wave's issue
+# for 60 .. 185 cycles on this kernel (profiles/r02_cost_structure.txt: no LDS-DMA = -33 % time); a load + a 16-byte store
+# hold it for ~20.
+A_STG = 224
 
 NSLOT = 4
 AUX_BYTES = 4096           # per block: 256 f32 bias | 4 x (swl1, sw1, swl2, sw2) | pad
@@ -395,6 +403,44 @@ def dma_aux():
     return Ins(text, 'dma', rd=vr(V_AUXOFF), emu=emu, cost=8)
 
 
+def stage_g2():
+    """S_G2 = S_G + 4096: source of pieces 4..6 (the load's immediate reaches +-4 KiB)"""
+    return [salu('s_add_u32 %s, %s, 0x1000' % (sreg(S_G2), sreg(S_G)), lambda st: st.S.__setitem__(S_G2, st.S[S_G] + 4096)),
+            salu('s_addc_u32 %s, %s, 0' % (sreg(S_G2 + 1), sreg(S_G + 1)))]
+
+
+def stage_load(i, tag=''):
+    """piece i of this wave's share of the chunk at S_G -> staging AGPRs"""
+    return global_load_x4_a(A_STG + 4 * i, V_DMAOFF, S_G if i < 4 else S_G2, 1024 * (i & 3), tag=tag)
+
+
+def stage_write(i, slot, tag=''):
+    """staging AGPRs of piece i -> ring slot `slot` (V_DMAOFF2 = V_DMAOFF + 64 KiB reaches slot 3)"""
+    off = slot * SLOT + 1024 * i
+    base, off = (V_DMAOFF, off) if off < 65536 else (V_DMAOFF2, off - 65536)
+    return ds_write_b128_stage(base, A_STG + 4 * i, off, WAVE_BYTES, tag=tag)
+
+
+def stage_prologue_ops():
+    """ring prologue of the staged transfer: chunks 0, 1 in slots 0, 1 for everybody, chunk 2 on its way to the staging
+    registers (the state every rendezvous leaves behind)"""
+    def next_chunk():
+        return [salu('s_add_u32 %s, %s, %s' % (sreg(S_G), sreg(S_W), sreg(S_POS)),
+                     lambda st: st.S.__setitem__(S_G, st.S[S_W] + st.S[S_POS])),
+                salu('s_addc_u32 %s, %s, 0' % (sreg(S_G + 1), sreg(S_W + 1))),
+                salu('s_add_u32 %s, %s, 0x%x' % (sreg(S_POS), sreg(S_POS), CHUNK),
+                     lambda st: st.S.__setitem__(S_POS, st.S[S_POS] + CHUNK)),
+                salu('s_cmp_eq_u32 %s, %s' % (sreg(S_POS), sreg(S_END))),
+                salu('s_cselect_b32 %s, 0, %s' % (sreg(S_POS), sreg(S_POS)),
+                     lambda st: st.S.__setitem__(S_POS, 0 if st.S[S_POS] == st.S[S_END] else st.S[S_POS]))] + stage_g2()
+    ops = []
+    for c in range(3):
+        ops += next_chunk() + [stage_load(i) for i in range(PW)]
+        if c < 2:
+            ops += [waitcnt_vm(0)] + [stage_write(i, c) for i in range(PW)]
+    return ops + [waitcnt_lgkm(0), barrier()]
+
+
 # ---------------------------------------------------------------------------------------------
 # block schedule
 # ---------------------------------------------------------------------------------------------
@@ -578,8 +624,9 @@ class Sched:
         idx = self.ds_index[key]
         if idx < self.ds_done:
             return
-        self.emit(it, waitcnt_lgkm(self.ds_issued - idx - 1))
-        self.ds_done = idx + 1
+        n = min(15, self.ds_issued - idx - 1)         # the counter has 4 bits; waiting for more is always right
+        self.emit(it, waitcnt_lgkm(n))
+        self.ds_done = self.ds_issued - n
 
 
 def build_fillers(it, opts):
@@ -701,7 +748,7 @@ def build_fillers(it, opts):
         # --- rendezvous + refill at the middle of each chunk (= row tile) ------------------------
         a0 = base_anchor + T * ANCH_PER_TILE + ANCH_PER_TILE // 3
         ch = ('dma',)
-        F.append(Filler(waitcnt_vm(PW), a0 - 1, a0 + 1, ch))
+        F.append(Filler(waitcnt_vm(0 if opts.stage else PW), a0 - 1, a0 + 1, ch))
         F.append(Filler(barrier(), a0 - 1, a0 + 1, ch))
         seq = []
         tgt_slot = (T + 3) % NSLOT
@@ -728,27 +775,33 @@ def build_fillers(it, opts):
             seq.append(dma_aux())
             seq.append(salu('s_xor_b32 %s, %s, 0x%x' % (sreg(S_AUXM0), sreg(S_AUXM0), AUX_BYTES),
                             lambda st: st.S.__setitem__(S_AUXM0, st.S[S_AUXM0] ^ AUX_BYTES)))
-        seq.append(salu('s_mov_b32 m0, %s' % sreg(S_M0SLOT + tgt_slot),
-                        lambda st, k=S_M0SLOT + tgt_slot: setattr(st, 'm0', st.S[k])))
-        seq.append(s_nop(0))
-        for i in range(PW):
-            if i == 4:
-                seq.append(salu('s_add_u32 m0, m0, 0x1000', lambda st: setattr(st, 'm0', st.m0 + 4096)))
-                seq.append(s_nop(0))
-            seq.append(dma_piece(i, tag=('dma', it, T, i)))
+        if opts.stage:
+            seq += stage_g2()
+            for i in range(PW):       # the chunk that arrived -> slot of chunk T + 2, then the same registers take chunk T + 3
+                seq.append(stage_write(i, (T + 2) % NSLOT, tag=('stw', it, T, i)))
+                seq.append(stage_load(i, tag=('dma', it, T, i)))
+        else:
+            seq.append(salu('s_mov_b32 m0, %s' % sreg(S_M0SLOT + tgt_slot),
+                            lambda st, k=S_M0SLOT + tgt_slot: setattr(st, 'm0', st.S[k])))
+            seq.append(s_nop(0))
+            for i in range(PW):
+                if i == 4:
+                    seq.append(salu('s_add_u32 m0, m0, 0x1000', lambda st: setattr(st, 'm0', st.m0 + 4096)))
+                    seq.append(s_nop(0))
+                seq.append(dma_piece(i, tag=('dma', it, T, i)))
         end = base_anchor + (T + 1) * ANCH_PER_TILE + ANCH_PER_TILE // 4      # well before the next rendezvous
         if opts.dma_burst:
             for ins in seq:
                 F.append(Filler(ins, a0 - 1, a0 + 1, ch))
         else:
             # SALU prelude right behind the barrier, then the pieces spread over the following MFMAs
-            first_piece = next(i for i, x in enumerate(seq) if x.kind == 'dma' and x.tag)
+            first_piece = next(i for i, x in enumerate(seq) if x.kind in ('dma', 'vload', 'ds') and x.tag)
             for ins in seq[:first_piece]:
                 F.append(Filler(ins, a0 - 1, a0 + 3, ch))
             k = 0
             for ins in seq[first_piece:]:
                 F.append(Filler(ins, a0 + 1 + opts.dma_gap * k, end, ch))
-                if ins.kind == 'dma':
+                if ins.kind in ('dma', 'vload'):
                     k += 1
     return F
 
@@ -896,6 +949,7 @@ class Opts:
         self.skip_terms = ()      # diagnostics: drop the K=64 MFMAs of these correction terms (wrong results)
         self.guard = False        # the range-guard build: per operand set the maximum |a| over every ray of the launch
         self.fmt = 'bf6'          # correction terms: 'bf6' (e3m2 x e3m2) | 'fp8' (e4m3 x e4m3): configure()
+        self.stage = False        # weight stream through staging AGPRs + ds_write_b128 instead of LDS-DMA (bf6 only)
         self.__dict__.update(kw)
 
 
@@ -914,7 +968,7 @@ def steady_block(opts):
     the loop is entered), in their issue order."""
     out = schedule(opts, 3)
     body = [ins for it, ins in out if it == 1]
-    pro = [ins for it, ins in out if it == 0 and ins.kind == 'ds' and ins.tag[1] == 1]
+    pro = [ins for it, ins in out if it == 0 and ins.kind == 'ds' and ins.tag[0] != 'stw' and ins.tag[1] == 1]
     return pro, body
 
 
@@ -1059,7 +1113,7 @@ def kernel_text(opts):
     a('v_mul_u32_u24 %s, 12, %s' % (vreg(V_RAYOFF), vreg(V_LANE)))
     a('s_mul_i32 %s, %s, 0x%x' % (sreg(S_T0), sreg(S_WAVE), WAVE_BYTES))        # this wave's share of a chunk
     a('v_add_u32 %s, %s, %s' % (vreg(V_DMAOFF), sreg(S_T0), vreg(V_L0)))
-    a('v_add_u32 %s, 0x1000, %s' % (vreg(V_DMAOFF2), vreg(V_DMAOFF)))
+    a('v_add_u32 %s, 0x%x, %s' % (vreg(V_DMAOFF2), 0x10000 if opts.stage else 0x1000, vreg(V_DMAOFF)))
     if WREG:   # pieces 5, 6 move 4 bytes per lane: wave * share + 4096 + lane * 4
         a('v_lshlrev_b32 %s, 2, %s' % (vreg(V_DMAOFF4), vreg(V_LANE)))
         a('v_add_u32 %s, %s, %s' % (vreg(V_DMAOFF4), sreg(S_T0), vreg(V_DMAOFF4)))
@@ -1107,10 +1161,14 @@ def kernel_text(opts):
     a('s_nop 0')
     a('global_load_lds_dwordx4 %s, %s' % (vreg(V_AUXOFF), sreg(S_TAB, 2)))
     L += issue_aux
-    for k in range(3):
-        L += issue_chunk(k)
-    a('s_waitcnt vmcnt(%d)' % (2 * PW))
-    a('s_barrier')
+    if opts.stage:
+        assert FMT == 'bf6' and not WREG and A_H6 + 8 * NA6 <= A_STG
+        L += [ins.text for ins in stage_prologue_ops()]
+    else:
+        for k in range(3):
+            L += issue_chunk(k)
+        a('s_waitcnt vmcnt(%d)' % (2 * PW))
+        a('s_barrier')
     # activation exponents of block 0 (later blocks and tiles: derived inside the block loop; the last block's "next IN
     # set" is block 0's, so the state at the end of a tile is the state the next tile starts from)
     for ins in act_prologue():
@@ -1190,7 +1248,8 @@ def emit_inc(path, opts):
     if drop:
         texts = set()
         for ins in body:
-            gone = ins.kind in drop or (ins.kind == 'wait' and 'lgkm' in drop and 'lgkmcnt' in ins.text)
+            gone = (ins.kind in drop or (ins.kind == 'wait' and 'lgkm' in drop and 'lgkmcnt' in ins.text) or
+                    ('stw' in drop and ins.text.startswith('ds_write_b128')))
             if gone:
                 texts.add(ins.text)
         keep_always = ('s_waitcnt vmcnt', 's_barrier')
@@ -1224,7 +1283,7 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
     st.V[V_L8B] = lanes * 8 + 65536
     st.V[V_AUX] = LDS_AUX + (lanes >> 5) * 16
     st.V[V_DMAOFF] = wave * WAVE_BYTES + lanes * 16
-    st.V[V_DMAOFF2] = wave * WAVE_BYTES + 4096 + lanes * 16
+    st.V[V_DMAOFF2] = wave * WAVE_BYTES + (65536 if opts.stage else 4096) + lanes * 16
     if WREG:
         st.V[V_DMAOFF4] = wave * WAVE_BYTES + 4096 + lanes * 4
     st.V[V_AUXOFF] = wave * 1024 + lanes * 16
@@ -1256,10 +1315,13 @@ def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=Tru
             dma_piece(i).emu(st)
 
     issue_aux()
-    for k in range(3):
-        issue_chunk(k)
-    waitcnt_vm(2 * PW).emu(st)
-    barrier().emu(st)
+    if opts.stage:
+        st.run(stage_prologue_ops())
+    else:
+        for k in range(3):
+            issue_chunk(k)
+        waitcnt_vm(2 * PW).emu(st)
+        barrier().emu(st)
     st.run(act_prologue())
     st.A[A_X:A_X + 128] = np.ascontiguousarray(x_tile_regs, dtype=np.float32).view(np.uint32)
     st.V[V_BPERM] = (lanes ^ 32) * 4
@@ -1297,6 +1359,7 @@ def main():
     ap.add_argument('--fmt', default='bf6', choices=['bf6', 'bf6r', 'fp8', 'f16'],
                     help='correction terms: bf6 (e3m2, all operands streamed) | bf6r (bf6(W) converted from the fp16 fragments in registers) | fp8 (e4m3) | '
                          'f16 (three fp16 passes: R2L_PREC_FP16X3 on this machine)')
+    ap.add_argument('--stage', action='store_true', help='bf6: the weight stream through 28 staging AGPRs + ds_write_b128 instead of LDS-DMA')
     ap.add_argument('--dma6', action='store_true', help='bf6r: 6 x dwordx4 per wave and chunk (512 B moved twice) instead of 5 x dwordx4 + 2 x dword')
     ap.add_argument('--dump', help='write the loop body as plain text')
     ap.add_argument('--skip-terms', default='', help='diagnostics only: comma list of correction terms to drop')
@@ -1310,7 +1373,7 @@ def main():
         global DMA6
         DMA6 = True
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap16=a.cap16, cap6=a.cap6, dma_gap=a.dma_gap,
-                chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
+                chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, stage=a.stage, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
                 drop=tuple(x for x in a.drop.split(',') if x))
     if a.emit:
         n = emit_inc(a.emit, opts)

@@ -185,6 +185,9 @@ class State:
         self.pend_ds = []                   # [(first reg, data)] in issue order
         self.pend_regs = set()
         self.pend_dma = []                  # [(list of (lds_addr, bytes))] in issue order
+        self.pend_vload = []                # register loads in flight: [(file, first reg, data, source)] in issue order
+        self.pend_stage = []                # staged ds_writes not yet certified by a barrier: [(lgkm token, copies)]
+        self.stage_src = {}                 # first staging register -> per-lane global byte address it was loaded from
         self.cert = None                    # N of the last vmcnt wait
         self.lds_pending = np.zeros(lds_bytes, dtype=bool)
         self.n_ins = 0
@@ -320,7 +323,58 @@ def waitcnt_lgkm(n):
 def waitcnt_vm(n):
     def emu(st):
         st.cert = n
+        if st.pend_vload and n != 0:
+            st.errors.append('ins %d: counted vmcnt(%d) with register loads in flight (not modelled)' % (st.n_ins, n))
+        while st.pend_vload and n == 0:
+            file, dst, data = st.pend_vload.pop(0)
+            st.regs(file)[dst:dst + len(data)] = data
+            for r in (vr if file == 'v' else ar)(dst, len(data)):
+                st.pend_regs.discard(r)
     return Ins('s_waitcnt vmcnt(%d)' % n, 'wait', emu=emu)
+
+
+def global_load_x4_a(adst, voff, sbase, imm, tag=''):
+    """a[adst:adst+3] <- 16 bytes per lane of the weight stream at s[sbase:sbase+1] + v[voff] + imm (vmcnt)"""
+    assert -4096 <= imm < 4096
+    text = 'global_load_dwordx4 %s, %s, %s offset:%d' % (areg(adst, 4), vreg(voff), sreg(sbase, 2), imm)
+
+    def emu(st):
+        src = st.S[sbase] + st.V[voff].astype(np.int64) + imm
+        data = np.zeros((4, 64), dtype=np.uint32)
+        for l in range(64):
+            assert 0 <= src[l] and src[l] + 16 <= len(st.img), src[l]
+            data[:, l] = st.img[int(src[l]):int(src[l]) + 16].view(np.uint32)
+        st.pend_vload.append(('a', adst, data))
+        st.pend_regs.update(ar(adst, 4))
+        st.stage_src[adst] = src.copy()
+    return Ins(text, 'vload', rd=vr(voff), wr=ar(adst, 4), emu=emu, tag=tag)
+
+
+def ds_write_b128_stage(addr_v, asrc, off, wave_bytes, tag=''):
+    """one staged piece of a ring slot: ds_write_b128 v[addr_v] + off <- a[asrc:asrc+3].  The three other waves of the
+    workgroup do the same with their shares (wave_bytes apart, in the stream and in the slot alike); the bytes count as
+    written for everybody behind the next barrier, which this wave may only enter with the write complete (lgkmcnt)."""
+    assert 0 <= off < 65536 and off % 16 == 0
+    text = 'ds_write_b128 %s, %s offset:%d' % (vreg(addr_v), areg(asrc, 4), off)
+
+    def emu(st):
+        addr = st.V[addr_v].astype(np.int64) + off
+        src = st.stage_src[asrc]
+        copies = []
+        for w in range(4):
+            dw = (w - st.wave) * wave_bytes
+            for l in range(64):
+                dst = int(addr[l]) + dw
+                if w == st.wave:
+                    data = st.A[asrc:asrc + 4, l].copy().view(np.uint8)
+                else:
+                    data = st.img[int(src[l]) + dw:int(src[l]) + dw + 16].copy()
+                copies.append((dst, data))
+                st.lds_pending[dst:dst + 16] = True
+        token = ('v', 0, np.zeros((0, 64), dtype=np.uint32))      # counts in lgkmcnt like a read
+        st.pend_ds.append(token)
+        st.pend_stage.append((token, copies))
+    return Ins(text, 'ds', rd=vr(addr_v) + ar(asrc, 4), emu=emu, tag=tag)
 
 
 def _land_dma(st, keep):
@@ -336,6 +390,13 @@ def barrier():
             st.errors.append('ins %d: s_barrier without a preceding vmcnt wait' % st.n_ins)
             return
         _land_dma(st, st.cert)   # every wave waited for all but its `cert` youngest LDS-DMA before arriving
+        for token, copies in st.pend_stage:
+            if any(token is e for e in st.pend_ds):
+                st.errors.append('ins %d: s_barrier with a staged ds_write still in flight (lgkmcnt)' % st.n_ins)
+            for addr, data in copies:
+                st.lds[addr:addr + len(data)] = data
+                st.lds_pending[addr:addr + len(data)] = False
+        st.pend_stage = []
     return Ins('s_barrier', 'barrier', emu=emu)
 
 

@@ -293,3 +293,22 @@ def test_f16_stream_three_fp16_passes(nb, wave):
     print('L_inf after %d blocks: three fp16 passes %.3g (one pass: %.3g)' % (nb, err, fp16x1_error(x, *W)))
     # the stream holds W x 2^8, so that lo(W) of weights ~ 2^-5 is a normal fp16 number (not one on the 2^-24 subnormal grid)
     assert err < 4e-7 * nb and err < fp16x1_error(x, *W) / 500
+
+
+@pytest.mark.parametrize('nb,wave,guard', [(2, 0, False), (3, 2, False), (2, 3, True)])
+def test_staged_stream_is_bit_identical_to_the_lds_dma_stream(nb, wave, guard):
+    """Opts.stage: the weight stream travels through 28 staging AGPRs (global_load_dwordx4, one row tile later
+    ds_write_b128 into the ring; the barrier of a rendezvous certifies the stores of the one before) instead of LDS-DMA.
+    Same bytes in the same ring slots, same MFMAs: bit-identical results; the emulator checks that no LDS byte is read
+    before the barrier that certifies it, that no staging register is stored before its load was waited for and that no
+    barrier is entered with a staged store in flight."""
+    W = make_weights(nb, seed=40 + nb)
+    rng = np.random.default_rng(12)
+    x = np.maximum(rng.normal(0, 1, (32, 256)), 0).astype(np.float32)
+    img, aux, _ = G.pack_body_image(*W)
+    r0 = G.emulate_tile(G.Opts(guard=guard), img, aux, to_regs(x * 16.0), nb, wave=wave)
+    r1 = G.emulate_tile(G.Opts(guard=guard, stage=True), img, aux, to_regs(x * 16.0), nb, wave=wave)
+    assert not r0[1] and not r1[1], (r0[1][:5], r1[1][:5])
+    assert np.array_equal(r0[0], r1[0])
+    if guard:
+        assert np.array_equal(r0[2], r1[2])
