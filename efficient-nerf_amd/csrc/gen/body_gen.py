@@ -795,12 +795,15 @@ def build_fillers(it, opts):
                 F.append(Filler(ins, a0 - 1, a0 + 1, ch))
         else:
             # SALU prelude right behind the barrier, then the pieces spread over the following MFMAs
+            # 4 waves x 7 pieces of 1 KiB right behind the barrier ask the 64 B/clk path into the CU for 128 B/clk; at one piece
+            # per three MFMAs the waves wait less (bf6: -0.7 % kernel time, profiles/r03_dma_experiments.txt item 6)
+            gap = opts.dma_gap if opts.dma_gap is not None else (3 if FMT == 'bf6' and not WREG and not opts.stage else 1)
             first_piece = next(i for i, x in enumerate(seq) if x.kind in ('dma', 'vload', 'ds') and x.tag)
             for ins in seq[:first_piece]:
                 F.append(Filler(ins, a0 - 1, a0 + 3, ch))
             k = 0
             for ins in seq[first_piece:]:
-                F.append(Filler(ins, a0 + 1 + opts.dma_gap * k, end, ch))
+                F.append(Filler(ins, a0 + 1 + gap * k, end, ch))
                 if ins.kind in ('dma', 'vload'):
                     k += 1
     return F
@@ -943,7 +946,7 @@ class Opts:
         self.rd_lead6 = 4
         self.cap16 = 6            # issue slots for fillers behind an MFMA
         self.cap6 = 6
-        self.dma_gap = 1          # anchors between two LDS-DMA pieces
+        self.dma_gap = None       # anchors between two LDS-DMA pieces (None: 3 for the bf6 stream, else 1)
         self.dma_burst = False
         self.chain_nop = -1       # s_nop N between the last fp16 and the first K=64 MFMA of a row tile (-1: none)
         self.skip_terms = ()      # diagnostics: drop the K=64 MFMAs of these correction terms (wrong results)
@@ -1352,7 +1355,7 @@ def main():
     ap.add_argument('--rd-lead6', type=int, default=4)
     ap.add_argument('--cap16', type=int, default=6)
     ap.add_argument('--cap6', type=int, default=6)
-    ap.add_argument('--dma-gap', type=int, default=1)
+    ap.add_argument('--dma-gap', type=int, default=None)
     ap.add_argument('--chain-nop', type=int, default=-1)
     ap.add_argument('--order', default=None, choices=['tail', 'mix'])
     ap.add_argument('--guard', action='store_true', help='the range-guard build of the stream (r2l_body_guard_kernel)')

@@ -67,17 +67,37 @@ S_C = 51           # 51, 52: 1/(2 pi) hi, lo
 S_P2 = 54          # 54..63: 2^l, l = 0..9
 N_SGPR_LO, N_SGPR_HI = 40, 64
 
-PIECES = 28
-CHUNK = PIECES * 1024
-PW = PIECES // 4
 NSLOT = 4
-LDS_AUX = NSLOT * CHUNK
 AUX_BYTES = 2048           # 256 f32 bias (x act_scale) | at 1024: (swl, sw, 0, 0) x 4
 AUX_SCALES = 1024
-LDS_BYTES = LDS_AUX + AUX_BYTES
 NPT = 16                   # points per ray = K = 64 groups
 NCH = 2 * NPT              # chunks per tile
-STREAM_BYTES = NCH * CHUNK
+
+
+def configure(fmt):
+    """'bf6': fp16 pass + two bf6 terms (R2L_PREC_FP16_FP8 / _E4M3: the embedding's ranges are fixed, bf6 serves both);
+    'f16': three fp16 passes per k-step, hi(W) hi(e) + hi(W) lo(e) + lo(W) hi(e) with lo = the fp16 rounding residual
+    (R2L_PREC_FP16X3_ASM: no low-precision term anywhere on the ray's path).  f16 streams lo(W) as a second set of
+    fragments (32 KiB chunks: pieces 16 + 4 k + s), keeps lo(e) where bf6 keeps its converted operands, and reads lo(W)
+    through a second ring of fragment buffers."""
+    global FMT, PIECES, CHUNK, PW, LDS_AUX, LDS_BYTES, STREAM_BYTES, ANCH_PER_RT, ANCH_PER_CHUNK, N_ANCH, NHI, NHL, V_HL, V_EL, NAME
+    FMT = fmt
+    PIECES = 32 if fmt == 'f16' else 28
+    CHUNK = PIECES * 1024
+    PW = PIECES // 4
+    LDS_AUX = NSLOT * CHUNK
+    LDS_BYTES = LDS_AUX + AUX_BYTES
+    STREAM_BYTES = NCH * CHUNK
+    ANCH_PER_RT = 12 if fmt == 'f16' else 6          # MFMAs of a row tile per point: 4 k-steps x 3 | 4 fp16 + 2 K=64
+    ANCH_PER_CHUNK = 4 * ANCH_PER_RT
+    N_ANCH = NCH * ANCH_PER_CHUNK
+    NHI = 6 if fmt == 'f16' else 8                   # hi(W) fragment buffers at V_HI
+    NHL, V_HL = 5, 176                               # f16: lo(W) fragment buffers (176..195)
+    V_EL = 112                                       # f16: lo(e) B operands, 2 buffers x 16 (112..143)
+    NAME = 'r2l_headx' if fmt == 'f16' else 'r2l_head'
+
+
+configure('bf6')
 EMB_EXP = -1               # embedding values (|sin|, |cos| <= 1, |x| < 14) / 2^-1 fit bf6; residuals 2^-12 finer
 RES_SHIFT = 12
 INV2PI_HI = np.float32(0.15915494)
@@ -95,6 +115,10 @@ def EH(b, s):
 
 def E6(b, term):
     return V_E6 + b * 12 + term * 6
+
+
+def EL(b, s):
+    return V_EL + b * 16 + s * 4
 
 
 def head_col(p, s, h, j):
@@ -121,9 +145,10 @@ def piece_a6b(k, t):
     return 24 + k, t * 512
 
 
-def pack_head(W, b, act_scale=16.0):
+def pack_head(W, b, act_scale=16.0, fmt='bf6'):
     """(stream bytes of one tile [STREAM_BYTES], aux bytes [AUX_BYTES]) from head.0.weight [256, 1008], head.0.bias [256]:
     Python restatement of r2l_capi.hip pack_head_v1"""
+    configure(fmt)
     Ws = (W.astype(np.float64) * act_scale).astype(np.float32)          # exact: act_scale is a power of two
     hi = Ws.astype(np.float16)
     el, ew = weight_exps(layer_exponent(Ws))
@@ -147,6 +172,12 @@ def pack_head(W, b, act_scale=16.0):
             for s in range(4):
                 o = base + piece_hi(k, s) * 1024
                 img[o:o + 1024] = np.ascontiguousarray(wh[:, s, :]).view(np.uint8).reshape(-1)
+            if FMT == 'f16':      # pieces 16 + 4 k + s: fp16(w - hi(w))
+                wl = (wv.astype(np.float64) - wh.astype(np.float64)).astype(np.float16)
+                for s in range(4):
+                    o = base + (16 + piece_hi(k, s)) * 1024
+                    img[o:o + 1024] = np.ascontiguousarray(wl[:, s, :]).view(np.uint8).reshape(-1)
+                continue
             w64, h64 = wv.reshape(64, 32).astype(np.float64), wh.reshape(64, 32).astype(np.float64)
             for t, v in enumerate((np.ldexp(w64 - h64, -el), np.ldexp(w64, -ew))):
                 words = pack6(f_to_bf6(v))
@@ -251,7 +282,9 @@ def embed_ops(p):
         ops.append(v_cvt_pk_f16(EH(b, 0) + i, V_VAL + 2 * i, V_VAL + 2 * i + 1))
     for half in range(2):   # half-register writes: all low halves, then all high halves
         for i in range(16):
-            ops.append(v_resid16(V_LO + i, half, EH(b, 0) + i, half, V_VAL + 2 * i + half, S_NEG1))
+            ops.append(v_resid16((EL(b, 0) if FMT == 'f16' else V_LO) + i, half, EH(b, 0) + i, half, V_VAL + 2 * i + half, S_NEG1))
+    if FMT == 'f16':        # the residual pairs ARE the lo B operands
+        return ops
     ops.append(v_cvt_pk32_bf6(E6(b, 0), EH(b, 0), V_CVA))
     ops.append(v_cvt_pk32_bf6(E6(b, 1), V_LO, V_CVL))
     return ops
@@ -260,12 +293,14 @@ def embed_ops(p):
 # ---------------------------------------------------------------------------------------------
 # schedule of one tile
 # ---------------------------------------------------------------------------------------------
-ANCH_PER_CHUNK = 24          # 4 row tiles x (4 fp16 + 2 K=64)
-N_ANCH = NCH * ANCH_PER_CHUNK
+# ANCH_PER_CHUNK (bf6: 24 = 4 row tiles x (4 fp16 + 2 K=64); f16: 48 = 4 x 4 k-steps x 3), N_ANCH: configure()
 
 
 def anchor(ci, k, kind, sj):
-    """anchor number of MFMA (kind, s or t) of the k-th row tile of chunk ci"""
+    """anchor number of MFMA (kind, s or t) of the k-th row tile of chunk ci; f16 kinds: 'm16' hi(W) hi(e), 'mhl' hi(W) lo(e),
+    'mlh' lo(W) hi(e) of k-step sj, back to back"""
+    if FMT == 'f16':
+        return ci * ANCH_PER_CHUNK + k * ANCH_PER_RT + 3 * sj + ('m16', 'mhl', 'mlh').index(kind)
     return ci * ANCH_PER_CHUNK + k * 6 + (sj if kind == 'm16' else 4 + sj)
 
 
@@ -301,6 +336,7 @@ class Opts:
         self.cap = 7
         self.dma_gap = 1
         self.pair_waits = True    # one lgkmcnt wait for two consecutive fp16 fragments when both reads are out
+        self.fmt = 'bf6'
         self.__dict__.update(kw)
 
 
@@ -309,6 +345,7 @@ def build_fillers(opts):
     # fp16 fragments: one per m16 anchor, NHI rotating buffers
     n16, n6 = 0, 0
     last16, last6 = {}, {}
+    HALF = ANCH_PER_CHUNK // 2
     for ci in range(NCH):
         for k in range(4):
             for s in range(4):
@@ -316,15 +353,21 @@ def build_fillers(opts):
                 prev = last16.get(n16 - NHI, -1)
                 pc = piece_hi(k, s)
                 bv, off = lds_addr(ci % NSLOT, pc * 1024, 16)
-                cert = -1 if ci < 3 else (ci - 1) * ANCH_PER_CHUNK + 12 + 1
+                cert = -1 if ci < 3 else (ci - 1) * ANCH_PER_CHUNK + HALF + 1
                 F.append(Filler(ds_read_b128(V_HI + (n16 % NHI) * 4, bv, off, tag=('hi', ci, k, s)),
                                 max(prev, a - opts.rd_lead, cert), a, ('rd',)))
-                last16[n16] = a
+                last16[n16] = anchor(ci, k, 'mhl', s) if FMT == 'f16' else a
+                if FMT == 'f16':      # lo(W) of the same k-step, second ring
+                    al = anchor(ci, k, 'mlh', s)
+                    bv, off = lds_addr(ci % NSLOT, (16 + pc) * 1024, 16)
+                    F.append(Filler(ds_read_b128(V_HL + (n16 % NHL) * 4, bv, off, tag=('hl', ci, k, s)),
+                                    max(last6.get(n16 - NHL, -1), al - opts.rd_lead, cert), al, ('rdl',)))
+                    last6[n16] = al
                 n16 += 1
-            for t in range(2):
+            for t in range(2 if FMT != 'f16' else 0):
                 a = anchor(ci, k, 'm6', t)
                 prev = last6.get(n6 - 2, -1)
-                cert = -1 if ci < 3 else (ci - 1) * ANCH_PER_CHUNK + 12 + 1
+                cert = -1 if ci < 3 else (ci - 1) * ANCH_PER_CHUNK + HALF + 1
                 e = max(prev, a - opts.rd_lead6, cert)
                 bv, off = lds_addr(ci % NSLOT, piece_a6(k, t) * 1024, 16)
                 F.append(Filler(ds_read_b128(V_A6 + (n6 & 1) * 6, bv, off, tag=('a6', ci, k, t, 0)), e, a, ('rd6',)))
@@ -341,7 +384,7 @@ def build_fillers(opts):
             F.append(Filler(ins, a0 + (i * (a1 - a0 - 6)) // len(ops), a1 - 3, ('emb',)))
     # rendezvous + refill at the middle of every chunk
     for ci in range(NCH):
-        ar = ci * ANCH_PER_CHUNK + 12
+        ar = ci * ANCH_PER_CHUNK + HALF
         ch = ('dma',)
         F.append(Filler(waitcnt_vm(PW if ci >= 1 else 0), ar - 1, ar + 1, ch))
         F.append(Filler(barrier(), ar - 1, ar + 1, ch))
@@ -420,10 +463,21 @@ def schedule(opts):
                 break
             issue(r[0])
         ci, rem = divmod(a, ANCH_PER_CHUNK)
-        k, j = divmod(rem, 6)
+        k, j = divmod(rem, ANCH_PER_RT)
         p, u = ci >> 1, 4 * (ci & 1) + k
         b = p & 1
-        if j < 4:
+        if FMT == 'f16':
+            sj, which = divmod(j, 3)
+            if which == 0:
+                sch.need(('hi', ci, k, sj))
+                ins = mfma32_16('a', X(u), V_HI + (n16 % NHI) * 4, EH(b, sj), 'a', X(u), tag=('m16', ci, k, sj))
+            elif which == 1:
+                ins = mfma32_16('a', X(u), V_HI + (n16 % NHI) * 4, EL(b, sj), 'a', X(u), tag=('mhl', ci, k, sj))
+            else:
+                sch.need(('hl', ci, k, sj))
+                ins = mfma32_16('a', X(u), V_HL + (n16 % NHL) * 4, EH(b, sj), 'a', X(u), tag=('mlh', ci, k, sj))
+                n16 += 1
+        elif j < 4:
             nxt = [('hi', ci, k, j + 1)] if j < 3 and opts.pair_waits else []
             sch.need(('hi', ci, k, j), nxt)
             ins = mfma32_16('a', X(u), V_HI + (n16 % NHI) * 4, EH(b, j), 'a', X(u), tag=('m16', ci, k, j))
@@ -518,7 +572,8 @@ def head_ops():
     for u in range(8):
         for g in range(4):
             ops.append(ds_read_b128(X(u) + 4 * g, V_AUX, 128 * u + 32 * g, tag=('bias', u, g), dfile='a'))
-    ops.append(ds_read_b64(V_SC, V_AUX, AUX_SCALES, tag=('scale',)))
+    if FMT != 'f16':
+        ops.append(ds_read_b64(V_SC, V_AUX, AUX_SCALES, tag=('scale',)))
     ops += embed_ops(0)
     ops.append(waitcnt_lgkm(0))
     return ops
@@ -551,21 +606,23 @@ def prologue_ops():
 
 
 def block_stream(opts):
+    configure(opts.fmt)
     return head_ops() + schedule(opts) + tail_ops()
 
 
 def emit(dirname, opts):
+    configure(opts.fmt)
     setup, _ = setup_ops()
     body = block_stream(opts)
     n = {}
     for ins in body:
         n[ins.kind] = n.get(ins.kind, 0) + 1
-    with open(os.path.join(dirname, 'r2l_head_asm.inc'), 'w') as f:
+    with open(os.path.join(dirname, NAME + '_asm.inc'), 'w') as f:
         f.write('// GENERATED by gen/head_gen.py -- do not edit.  Head layer of one 128-ray tile: %s\n' %
                 ', '.join('%s %d' % kv for kv in sorted(n.items())))
         for line in setup + [i.text for i in body] + ['s_mov_b32 m0, %s' % sreg(S_M0SAVE)]:
             f.write('"%s\\n\\t"\n' % line)
-    with open(os.path.join(dirname, 'r2l_head_pro_asm.inc'), 'w') as f:
+    with open(os.path.join(dirname, NAME + '_pro_asm.inc'), 'w') as f:
         f.write('// GENERATED by gen/head_gen.py -- do not edit.  Ring prologue: chunks 0..2 of the stream\n')
         pro = ['s_mov_b32 %s, m0' % sreg(S_M0SAVE), 's_mov_b64 %s, %%[wimg]' % sreg(S_W, 2),
                's_mov_b32 %s, %%[wave]' % sreg(S_WAVE), 's_mul_i32 %s, %s, 0x%x' % (sreg(S_WPW), sreg(S_WAVE), PW * 1024),
@@ -579,15 +636,16 @@ def emit(dirname, opts):
         regs += ['s%d' % i for i in range(N_SGPR_LO, N_SGPR_HI)] + ['vcc', 'scc', 'memory']
         return ', '.join('"%s"' % r for r in regs) + '\n'
 
-    with open(os.path.join(dirname, 'r2l_head_clobbers.inc'), 'w') as f:
+    with open(os.path.join(dirname, NAME + '_clobbers.inc'), 'w') as f:
         f.write('// GENERATED by gen/head_gen.py: registers the tile block owns\n' + clob(range(N_VGPR_CLOBBER), N_AGPR_CLOBBER))
-    with open(os.path.join(dirname, 'r2l_head_pro_clobbers.inc'), 'w') as f:
+    with open(os.path.join(dirname, NAME + '_pro_clobbers.inc'), 'w') as f:
         f.write('// GENERATED by gen/head_gen.py: registers the ring prologue owns\n' + clob([V_L0, V_LOFF, V_LANE], 0))
     return n, body
 
 
 def emulate_tile(opts, img, aux, o, d, z, wave=0, n_tiles=1, check_hazards=True, body=None):
     """o, d: [3][64] f32 per lane (lane = 32 h + ray), z [16].  Returns (x image uint32 [32, 4, 64] as f32, errors)."""
+    configure(opts.fmt)
     body = body or block_stream(opts)
     st = HState(wave, img, aux, z)
     _, setup = setup_ops()
@@ -614,8 +672,9 @@ def main():
     ap.add_argument('--cap', type=int, default=7)
     ap.add_argument('--dma-gap', type=int, default=1)
     ap.add_argument('--no-pair-waits', action='store_true')
+    ap.add_argument('--fmt', default='bf6', choices=['bf6', 'f16'], help='f16: three fp16 passes (r2l_headx_*.inc, R2L_PREC_FP16X3_ASM)')
     a = ap.parse_args()
-    opts = Opts(rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap=a.cap, dma_gap=a.dma_gap, pair_waits=not a.no_pair_waits)
+    opts = Opts(rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap=a.cap, dma_gap=a.dma_gap, pair_waits=not a.no_pair_waits, fmt=a.fmt)
     if a.emit:
         n, body = emit(a.emit, opts)
         print('wrote', a.emit, n, 'model cycles per tile', model_cycles(body))

@@ -287,13 +287,13 @@ static void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
 static void pack_image_host(const r2l_ctx* c, int mode, std::vector<char>& img);
 static int ensure_x(r2l_ctx* c, int tiles, bool need_xb);
 static int pack_body_v3(const r2l_ctx* c, int e4m3, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
-static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out);
+static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out, int f16 = 0);
 
 static int build_image(r2l_ctx* c, int mode) {
     std::vector<char> img;
     if (split_mode(mode)) {
         // head launch: the stream of r2l_head_kernel (bf6 terms in both modes); body + tail: the v3 stream of the mode
-        int rc = pack_head_v1(c, img);
+        int rc = pack_head_v1(c, img, mode == R2L_PREC_FP16X3_ASM);
         if (rc) return rc;
         std::vector<char> body;
         rc = pack_body_v3(c, stream_of(mode), body, &c->aux_off, &c->tail_off);
@@ -488,8 +488,9 @@ unsigned r2l_f_to_bf6(double v) {
 }
 
 // FP16_FP8 head stream of r2l_head_kernel (layout: r2l_common.h r2l_head_col32; restated in gen/head_gen.py pack_head)
-static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
-    out.assign((size_t)R2L_HEAD_STREAM_BYTES + R2L_HEAD_AUX_BYTES, 0);
+static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out, int f16) {
+    const size_t CH = f16 ? R2L_HEADX_CHUNK : 28672, stream_bytes = 32 * CH;
+    out.assign(stream_bytes + R2L_HEAD_AUX_BYTES, 0);
     const float* Wh = c->host_w[0].data();   // [256, 1008]
     const float* bh = c->host_w[1].data();
     const float Sa = c->act_scale;
@@ -500,7 +501,7 @@ static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
         return r2l_set_error(R2L_EINVAL, "head layer: max|w| x act_scale = 2^%d is outside the range the fp16 + bf6 weight "
                              "split covers (2^-12 .. 2^6); use R2L_PREC_FP16X3", e);
     const int el = e - 16, ew = e - 4;
-    uint32_t* aux = reinterpret_cast<uint32_t*>(out.data() + R2L_HEAD_STREAM_BYTES);
+    uint32_t* aux = reinterpret_cast<uint32_t*>(out.data() + stream_bytes);
     for (int n = 0; n < 256; ++n) {
         const float v = (float)((double)bh[n] * Sa);
         memcpy(&aux[n], &v, 4);
@@ -511,7 +512,7 @@ static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
     }
     for (int p = 0; p < 16; ++p)
         for (int u = 0; u < 8; ++u) {
-            char* chunk = out.data() + (size_t)(2 * p + (u >> 2)) * 28672;
+            char* chunk = out.data() + (size_t)(2 * p + (u >> 2)) * CH;
             const int k = u & 3;
             for (int lane = 0; lane < 64; ++lane) {
                 const int h = lane >> 5;
@@ -524,6 +525,11 @@ static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
                         const float w = col < 0 ? 0.f : row[col];
                         const _Float16 hi = (_Float16)w;
                         ph[j] = hi;
+                        if (f16) {      // FP16X3_ASM: the residual as a second fp16 fragment
+                            reinterpret_cast<_Float16*>(chunk + (size_t)(16 + 4 * k + s) * 1024 + lane * 16)[j] =
+                                (_Float16)((double)w - (double)(float)hi);
+                            continue;
+                        }
                         const int i = 8 * s + j, bit = 6 * i, wd = bit >> 6, sh = bit & 63;
                         const uint64_t code[2] = {r2l_f_to_bf6(ldexp((double)w - (double)(float)hi, -el)),
                                                   r2l_f_to_bf6(ldexp((double)w, -ew))};
@@ -533,7 +539,7 @@ static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out) {
                         }
                     }
                 }
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < 2 && !f16; ++t) {
                     memcpy(chunk + (size_t)(16 + 2 * k + t) * 1024 + lane * 16, bits[t], 16);
                     memcpy(chunk + (size_t)(24 + k) * 1024 + t * 512 + lane * 8, &bits[t][2], 8);
                 }
@@ -835,7 +841,7 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
     }
     std::vector<char> img;
     if (split_mode(precision_mode)) {   // the image of this mode's head launch (r2l_head_kernel)
-        int rc = pack_head_v1(&c, img);
+        int rc = pack_head_v1(&c, img, precision_mode == R2L_PREC_FP16X3_ASM);
         if (rc) return rc;
     } else {
         pack_image_host(&c, precision_mode, img);
@@ -1006,7 +1012,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         ph.tile_begin = t0;
         ph.n_tiles = nt;
         ph.range = c->d_range;     // every ray's h0 enters the running maximum (r2l_get_range_status)
-        hipError_t e = r2l_launch_head(ph, grid, s);
+        hipError_t e = r2l_launch_head(ph, grid, s, c->mode == R2L_PREC_FP16X3_ASM);
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
         const float* body_out = c->d_xa;
         bool fused = false;

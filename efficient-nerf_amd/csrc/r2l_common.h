@@ -96,6 +96,11 @@ R2L_HD int r2l_head_col32(int p, int s, int h, int j) {
 #define R2L_HEAD_STREAM_BYTES (32 * 28672)
 #define R2L_HEAD_AUX_BYTES 2048
 #define R2L_HEAD_LDS (4 * 28672 + R2L_HEAD_AUX_BYTES)
+// R2L_PREC_FP16X3_ASM head stream (gen/head_gen.py --fmt f16): 32 chunks of 32 KiB = 16 hi(W) fragments + 16 fragments
+// fp16(w - hi(w)) at pieces 16 + 4 k + s; same aux block (the scale words are unused)
+#define R2L_HEADX_CHUNK 32768
+#define R2L_HEADX_STREAM_BYTES (32 * R2L_HEADX_CHUNK)
+#define R2L_HEADX_LDS (4 * R2L_HEADX_CHUNK + R2L_HEAD_AUX_BYTES)
 // aux block of the body stream (4 KiB per ResMLP block): 256 f32 bias | at 1024: 4 x (swl1, sw1, swl2, sw2) E8M0 |
 // at 1088: the biased activation exponents (127 + E_in, 127 + E_h, 127 + E_out, 0) as dwords, twice
 #define R2L_BODY_AUX_BYTES 4096

@@ -21,7 +21,8 @@ struct R2LParams {
 };
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*
-hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream);      // head layer -> p.xbuf
+// head layer -> p.xbuf; x3: the three-fp16-pass build (R2L_PREC_FP16X3_ASM, stream of pack_head_v1(f16))
+hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream, int x3 = 0);
 
 // hand-scheduled body (r2l_body.hip): x <- ResMLP blocks(x) on the register image written by the head launch
 struct R2LBodyParams {

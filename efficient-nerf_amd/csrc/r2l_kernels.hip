@@ -461,23 +461,35 @@ static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream
 // bias.  The block owns v0-v209, a0-a127, s40-s59, vcc.  The generator's emulator checks the stream against a float64
 // evaluation of the layer (tests/test_head_gen_cpu.py).
 // ------------------------------------------------------------------------------------
+// X3: gen/head_gen.py --fmt f16 (r2l_headx_asm.inc): three fp16 passes per k-step, no bf6 terms (R2L_PREC_FP16X3_ASM).
+template <bool X3>
 __global__ __launch_bounds__(256, 1) void r2l_head_kernel(R2LParams p) {
     extern __shared__ __attribute__((aligned(16))) char r2l_head_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     {   // resident table: bias x act_scale | E8M0 weight scales
-        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + R2L_HEAD_STREAM_BYTES);
-        uint4* dst = reinterpret_cast<uint4*>(r2l_head_lds + 4 * 28672);
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (X3 ? R2L_HEADX_STREAM_BYTES : R2L_HEAD_STREAM_BYTES));
+        uint4* dst = reinterpret_cast<uint4*>(r2l_head_lds + 4 * (X3 ? R2L_HEADX_CHUNK : 28672));
         if (threadIdx.x < R2L_HEAD_AUX_BYTES / 16) dst[threadIdx.x] = src[threadIdx.x];
     }
     __syncthreads();
-    asm volatile(
+    if constexpr (X3) {
+        asm volatile(
+#include "r2l_headx_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "r2l_headx_pro_clobbers.inc"
+        );
+    } else {
+        asm volatile(
 #include "r2l_head_pro_asm.inc"
-        :
-        : [wimg] "s"(p.wimg), [wave] "s"(wave)
-        :
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
 #include "r2l_head_pro_clobbers.inc"
-    );
+        );
+    }
     // read-only, wave-uniform: constant address space => scalar loads
     const __attribute__((address_space(4))) float* zc = (const __attribute__((address_space(4))) float*)p.z;
     const float z0 = zc[0], z1 = zc[1], z2 = zc[2], z3 = zc[3], z4 = zc[4], z5 = zc[5], z6 = zc[6], z7 = zc[7], z8 = zc[8],
@@ -490,16 +502,28 @@ __global__ __launch_bounds__(256, 1) void r2l_head_kernel(R2LParams p) {
         const int ray_raw = (p.tile_begin + tile) * R2L_TILE_RAYS + wave * R2L_RAYS_PER_WAVE + (lane & 31);
         const Ray6 r = make_ray(p, ray_raw < p.n_rays ? ray_raw : p.n_rays - 1);
         float* xout = p.xbuf + ((size_t)(tile * R2L_WAVES + wave) * 32) * 256;
-        asm volatile(
-#include "r2l_head_asm.inc"
-            : [hmax] "+v"(hmax)
-            : [wimg] "s"(p.wimg), [wave] "s"(wave), [xout] "s"(xout), [o0] "v"(r.ox), [o1] "v"(r.oy), [o2] "v"(r.oz),
-              [d0] "v"(r.dx), [d1] "v"(r.dy), [d2] "v"(r.dz), [z0] "s"(z0), [z1] "s"(z1), [z2] "s"(z2), [z3] "s"(z3),
-              [z4] "s"(z4), [z5] "s"(z5), [z6] "s"(z6), [z7] "s"(z7), [z8] "s"(z8), [z9] "s"(z9), [z10] "s"(z10),
+#define R2L_HEAD_BLOCK_OPERANDS                                                                                          \
+            : [hmax] "+v"(hmax)                                                                                          \
+            : [wimg] "s"(p.wimg), [wave] "s"(wave), [xout] "s"(xout), [o0] "v"(r.ox), [o1] "v"(r.oy), [o2] "v"(r.oz),     \
+              [d0] "v"(r.dx), [d1] "v"(r.dy), [d2] "v"(r.dz), [z0] "s"(z0), [z1] "s"(z1), [z2] "s"(z2), [z3] "s"(z3),    \
+              [z4] "s"(z4), [z5] "s"(z5), [z6] "s"(z6), [z7] "s"(z7), [z8] "s"(z8), [z9] "s"(z9), [z10] "s"(z10),        \
               [z11] "s"(z11), [z12] "s"(z12), [z13] "s"(z13), [z14] "s"(z14), [z15] "s"(z15)
-            :
+        if constexpr (X3) {
+            asm volatile(
+#include "r2l_headx_asm.inc"
+                R2L_HEAD_BLOCK_OPERANDS
+                :
+#include "r2l_headx_clobbers.inc"
+            );
+        } else {
+            asm volatile(
+#include "r2l_head_asm.inc"
+                R2L_HEAD_BLOCK_OPERANDS
+                :
 #include "r2l_head_clobbers.inc"
-        );
+            );
+        }
+#undef R2L_HEAD_BLOCK_OPERANDS
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's refill of the ring and its stores
     if (p.range != nullptr) {   // every ray of the launch: rays past the end repeat the last one, so they add nothing foreign
@@ -510,18 +534,22 @@ __global__ __launch_bounds__(256, 1) void r2l_head_kernel(R2LParams p) {
     }
 }
 
-hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream) {
+hipError_t r2l_launch_head(const R2LParams& p, int grid, hipStream_t stream, int x3) {
     static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_head_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 R2L_HEAD_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_head_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    R2L_HEADX_LDS);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(r2l_head_kernel, dim3(grid), dim3(256), R2L_HEAD_LDS, stream, p);
+    if (x3) hipLaunchKernelGGL(r2l_head_kernel<true>, dim3(grid), dim3(256), R2L_HEADX_LDS, stream, p);
+    else hipLaunchKernelGGL(r2l_head_kernel<false>, dim3(grid), dim3(256), R2L_HEAD_LDS, stream, p);
     return hipGetLastError();
 }
 

@@ -72,8 +72,8 @@ FLAGS = [
     # this front-end's own knobs
     # auto (default): fp16_fp8 (fp16 MFMA pass + bf6 correction terms, 1.7x the speed) when the checkpoint's own activation
     # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
-    # contract, fp16x3 otherwise (R2LEngine.choose_precision / check_ranges); the teacher takes fp16_fp8
-    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'auto'])),
+    # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher takes fp16_fp8
+    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
 ]
@@ -349,8 +349,8 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
         eng = NeRFEngine(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance,
                          multires=args.multires, multires_views=args.multires_views, white_bkgd=args.white_bkgd,
                          precision=prec, ndc=llff_ndc, lindisp=args.lindisp)  # main.py:160-162, 525-528, 679-680
-        if args.precision == 'fp16_e4m3':
-            raise R2LError('--precision fp16_e4m3 is a mode of the R2L student (the teacher has fp16x3, fp16_fp8, fp16x1)')
+        if args.precision in ('fp16_e4m3', 'fp16x3_asm'):
+            raise R2LError(f'--precision {args.precision} is a mode of the R2L student (the teacher has fp16x3, fp16_fp8, fp16x1)')
         eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
         if auto:
             # the chain's bf6 terms run under fixed activation exponents: measured against fp16x3 on the first frame's own rays
@@ -406,7 +406,7 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
         local = render_local(i)
         if kind == 'R2L':
             # fp16_fp8: did this frame's rays stay inside the range the bf6 exponents were measured for?  If not, the
-            # exponents are raised (`auto`: or the context falls back to fp16x3) and the frame is rendered again
+            # exponents are raised (`auto`: or the context falls back to fp16x3_asm) and the frame is rendered again
             again = D.check_ranges(eng, log=log if rank == 0 else None)
             if again is not None:
                 local = render_local(i)

@@ -236,7 +236,8 @@ class R2LEngine:
     #: `--precision auto`'s ladder: the largest activation exponent (|a| <= 2^E over all operand sets) up to which a mode
     #: stays inside the 1e-4 rgb contract with margin.  W256D88 networks with every body weight x gain (tools/range_sweep.py,
     #: profiles/r03_range_sweep.txt), L_inf against fp16x3: bf6 terms 3-6e-5 at E = 3, 6e-5-1.4e-4 at 4; e4m3 terms half of
-    #: that; fp16x3 (6e-7) above.
+    #: that; above: fp16x3_asm, three fp16 passes on the same generated kernels (no low-precision term, no scales, nothing
+    #: to watch: 5-7e-7 against the reference golden, as the compiler-scheduled fp16x3 it is 7 % faster than).
     AUTO_MAX_EXP = 3          # fp16_fp8 (bf6 x bf6 terms, 1.5 pass-equivalents)
     AUTO_MAX_EXP_E4M3 = 4     # fp16_e4m3 (e4m3 x e4m3 terms, 2.0 pass-equivalents)
 
@@ -246,11 +247,11 @@ class R2LEngine:
             return PREC_FP16_FP8
         if max_exp is None and top <= self.AUTO_MAX_EXP_E4M3:
             return PREC_FP16_E4M3
-        return PREC_FP16X3
+        return PREC_FP16X3_ASM
 
     def choose_precision(self, c2w=None, rays=None, max_exp=None):
         """`--precision auto`: the fastest mode the network's own activation ranges allow: fp16_fp8 (bf6 correction terms)
-        up to exponent 3, fp16_e4m3 at 4, fp16x3 above.  The error of the low-precision terms is relative to the residual
+        up to exponent 3, fp16_e4m3 at 4, fp16x3_asm above.  The error of the low-precision terms is relative to the residual
         stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so the choice needs the ranges of THESE weights:
         `calibrate_on` measures them on every ray of the frame of pose `c2w` (or of the given `rays` = (rays_o, rays_d)).
         `max_exp` overrides fp16_fp8's limit and disables the middle step (tests).  What is rendered afterwards stays
@@ -278,7 +279,7 @@ class R2LEngine:
         """After a render in fp16_fp8: did the values stay inside the bf6 scales in use?  Returns None when the frame is
         good: every fill below 1 (nothing was clamped).  Fills beyond FILL_LIMIT raise the exponents for what follows
         (recalibrate); when values WERE clamped, or when raising the exponents takes them past `choose_precision`'s
-        limit (the context then switches to fp16x3), the name of the precision to render the frame AGAIN with is
+        limit (the context then switches to fp16x3_asm), the name of the precision to render the frame AGAIN with is
         returned.  An explicit fp16_fp8 context keeps its mode and says so.  Synchronises.
         Row-sharded runs (dist.check_ranges) pass `any_rank` (bool -> True when any rank says so) and `agree` (makes the
         exponents the element-wise maximum over the ranks), so that every rank takes the same decision."""
@@ -307,7 +308,7 @@ class R2LEngine:
                 ': values were clamped' if clamped else ''))
         if auto is not None:
             mode = self._mode_for(top, auto[0])
-            if mode != self.precision and (mode == PREC_FP16X3 or self.precision == PREC_FP16_FP8):   # never back up the ladder
+            if mode != self.precision and (mode == PREC_FP16X3_ASM or self.precision == PREC_FP16_FP8):   # never back up the ladder
                 self.set_precision(mode)
                 if log:
                     log(msg + f'; exponents now up to {top} -> {PREC_NAMES[mode]}, frame rendered again')

@@ -54,5 +54,5 @@ def test_bench_line_schema():
     assert em['auto_precision'] == 'fp16_e4m3' and em['max_act_exponent'] == 4 and em['linf_vs_cpu_oracle'] <= 1e-4
     # the stress weights of SURVEY 8(d) must not be rendered with the bf6 terms: the library's own range check decides
     sw = d['stress_weights']
-    assert sw['auto_precision'] == 'fp16x3' and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
+    assert sw['auto_precision'] == 'fp16x3_asm' and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
     assert d['calibration']['max'] <= d['calibration']['auto_precision_limit']     # ... and would keep fp16_fp8 for the standard set

@@ -198,12 +198,12 @@ def test_cli_rejects_unsupported(pkg, tmp_path):
 def test_cli_precision_auto(pkg, tmp_path):
     """--precision auto measures the checkpoint's activation ranges on a probe render and says what it chose; the same
     checkpoint through the poses path and the given-rays path, a stress checkpoint (body weights x 1.3, 43 blocks)
-    falls back to fp16x3; every render stays within 1e-4 of the oracle"""
+    falls back to fp16x3_asm; every render stays within 1e-4 of the oracle"""
     from efficient_nerf_amd import frontend as fe
     H = 32
     focal = O.focal_from_angle(64) / 2.
     poses = O.novel_poses(1)
-    for tag, gain, want in (('std', 1.0, 'fp16_fp8'), ('stress', 1.3, 'fp16x3')):
+    for tag, gain, want in (('std', 1.0, 'fp16_fp8'), ('stress', 1.3, 'fp16x3_asm')):
         sd = O.make_r2l_state(seed=0)
         for k in sd:
             if k.startswith('body.') and k.endswith('weight'):

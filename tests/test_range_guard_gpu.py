@@ -129,17 +129,17 @@ def test_edge_rays_beyond_the_centre_probe_are_caught(pkg):
     assert full == raised, (full, raised)
     # what `--precision auto` makes of it: the border rays put the exponents past fp16_fp8's limit
     name, top = eng.choose_precision(c2w=c2w)
-    assert name == 'fp16x3' and top == max(full) > eng.AUTO_MAX_EXP
+    assert name == 'fp16x3_asm' and top == max(full) > eng.AUTO_MAX_EXP
     ref = O.r2l_render(sd, H, H, focal, c2w, rows=(0, 8))
     assert (eng.render(c2w, rows=(0, 8)).cpu() - ref).abs().max().item() <= 1e-4
     eng.close()
 
 
-@pytest.mark.parametrize('gain,want', [(1.12, 'fp16_e4m3'), (1.3, 'fp16x3')])
+@pytest.mark.parametrize('gain,want', [(1.12, 'fp16_e4m3'), (1.3, 'fp16x3_asm')])
 def test_auto_falls_back_when_a_later_pose_leaves_the_range(pkg, gain, want):
     """`--precision auto` = choose_precision + check_ranges after every frame: exponents forced low (as if the first frame
     had been a tame one) -> the next frame trips the watch, the context moves down the ladder (fp16_fp8 -> fp16_e4m3 at
-    exponent 4 -> fp16x3 above), and the re-rendered frame meets the contract."""
+    exponent 4 -> fp16x3_asm above), and the re-rendered frame meets the contract."""
     from efficient_nerf_amd import PRECISIONS, R2LEngine
     H = 96
     focal = O.focal_from_angle(H)
@@ -161,7 +161,7 @@ def test_auto_falls_back_when_a_later_pose_leaves_the_range(pkg, gain, want):
     assert eng.precision == PRECISIONS[want] and want in logs[0]
     ref = O.r2l_render(sd, H, H, focal, c2w)
     assert (eng.render(c2w).cpu() - ref).abs().max().item() <= 1e-4
-    assert eng.check_ranges() is None            # inside the scales now (fp16x3 has none to watch)
+    assert eng.check_ranges() is None            # inside the scales now (fp16x3_asm has none to watch)
     # straight through choose_precision: the same rung
     eng2 = R2LEngine(H, H, focal).load_state_dict(sd)
     assert eng2.choose_precision(c2w=c2w)[0] == want
