@@ -8,13 +8,13 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('prec', ['fp16_fp8', 'fp16x3'])
+@pytest.mark.parametrize('prec', ['fp16_fp8', 'fp16x3', 'fp16_e4m3', 'fp16x3_asm'])
 def test_r2l_render_in_a_hip_graph(pkg, prec):
-    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3, R2LEngine
+    from efficient_nerf_amd import PRECISIONS, R2LEngine
     H, nb = 64, 4
     focal = O.focal_from_angle(H)
     sd = O.make_r2l_state(seed=2, netdepth=2 + 2 * nb)
-    eng = R2LEngine(H, H, focal, n_block=nb, precision={'fp16_fp8': PREC_FP16_FP8, 'fp16x3': PREC_FP16X3}[prec]).load_state_dict(sd)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PRECISIONS[prec]).load_state_dict(sd)
     poses = [torch.as_tensor(O.pose_spherical(t, -30., 4.))[:3, :4].float().contiguous() for t in (0., 90., 215.)]
     static_pose = poses[0].cuda().clone().reshape(1, 3, 4)
     out = torch.empty((1, H * H, 3), device='cuda')

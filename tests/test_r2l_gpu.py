@@ -187,7 +187,7 @@ def test_precision_modes_on_other_weight_distributions(pkg, kind):
     """The contract-meeting modes on weights that do not look like nn.Linear's uniform init (heavy
     Laplace tails; half the weights zero; 0.05 % of them 12x larger), full depth: the error budget
     of fp16_fp8 (e4m3 weight residuals, e5m2 activations) must not depend on the distribution."""
-    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3_ASM, R2LEngine
     H = 32
     focal = O.focal_from_angle(H)
     sd = O.make_r2l_state(seed=21, netdepth=88)
@@ -210,9 +210,11 @@ def test_precision_modes_on_other_weight_distributions(pkg, kind):
     e3 = (eng.render(c2w).cpu() - ref).abs().max().item()
     eng.set_precision(PREC_FP16_FP8)
     e8 = (eng.render(c2w).cpu() - ref).abs().max().item()
+    eng.set_precision(PREC_FP16X3_ASM)
+    ea = (eng.render(c2w).cpu() - ref).abs().max().item()
     eng.close()
-    print(f'{kind}: fp16x3 {e3:.2e}, fp16_fp8 {e8:.2e}')
-    assert e3 <= 5e-6 and e8 <= TOL_X3
+    print(f'{kind}: fp16x3 {e3:.2e}, fp16_fp8 {e8:.2e}, fp16x3_asm {ea:.2e}')
+    assert e3 <= 5e-6 and e8 <= TOL_X3 and ea <= 5e-6
 
 
 def test_row_ranges_batches_and_given_rays_agree(g, engines):
@@ -238,23 +240,25 @@ def test_row_ranges_batches_and_given_rays_agree(g, engines):
     assert torch.equal(got, full[sel])
 
 
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16x3_asm'])
 @pytest.mark.parametrize('n_block,use_residual,gain', [(0, True, 1.0), (1, False, 1.0), (5, True, 1.3)])
-def test_small_networks_vs_oracle(pkg, n_block, use_residual, gain):
-    """Depth variants (n_block = 0 exercises head+tail only), --use_residual off, and a
-    stress weight set (body weights x1.3) against the CPU oracle."""
-    from efficient_nerf_amd import R2LEngine
+def test_small_networks_vs_oracle(pkg, n_block, use_residual, gain, prec):
+    """Depth variants (n_block = 0 exercises head+tail only), --use_residual off (fp16x3_asm: the body kernel stores the x
+    image and r2l_tail_kernel finishes the rays), and a stress weight set (body weights x1.3) against the CPU
+    oracle, in both fp32-grade modes."""
+    from efficient_nerf_amd import PRECISIONS, R2LEngine
     H = 40
     focal = O.focal_from_angle(H)
     sd = O.make_r2l_state(seed=5, netdepth=2 + 2 * n_block, body_gain=gain)
-    eng = R2LEngine(H, H, focal, n_block=n_block, use_residual=use_residual).load_state_dict(sd)
+    eng = R2LEngine(H, H, focal, n_block=n_block, use_residual=use_residual, precision=PRECISIONS[prec]).load_state_dict(sd)
     c2w = O.rand_poses(2, seed=11)[1]
     rgb = eng.render(c2w).cpu()
     dirs = O.camera_dirs(H, H, focal)
     pts = O.sample_test(dirs, O.sampler_z_vals(16, 2., 6.), c2w[:3, :4])
     ref = O.r2l_forward(sd, O.positional_embed(pts, 10), use_residual=use_residual)
     err = (rgb - ref).abs().max().item()
-    print(f'n_block={n_block} residual={use_residual} gain={gain}: L_inf {err:.3e}')
-    assert err <= TOL_X3
+    print(f'{prec} n_block={n_block} residual={use_residual} gain={gain}: L_inf {err:.3e}')
+    assert err <= 5e-6
     eng.close()
 
 
@@ -263,7 +267,7 @@ def test_linearity_free_properties_full_size(engines, g):
     north_star's second tolerance: on a strided subset of the frame, PSNR against a stand-in ground truth (the oracle's
     render under weights perturbed by a fixed seed, ~33 dB away: utils/run_nerf_raybased_helpers.py:19-20 applied to
     it) within 0.01 dB of the fp32 reference's own PSNR, in every mode that claims the contract."""
-    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3, PREC_FP16X3_ASM
     eng = engines[800]
     c2w = T(g['poses'][3])
     a = eng.render(c2w)
@@ -278,7 +282,7 @@ def test_linearity_free_properties_full_size(engines, g):
     gt = O.r2l_forward(O.perturbed_state(sd), emb)
     p_ref = O.psnr(ref, gt)
     assert 25 < p_ref < 45, p_ref
-    for prec in (PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3):
+    for prec in (PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM):
         eng.set_precision(prec)
         delta = abs(O.psnr(eng.render(c2w).cpu()[idx], gt) - p_ref)
         print(f'precision {prec}: PSNR vs gt* {p_ref:.3f} dB (reference), delta {delta:.2e} dB')
@@ -286,15 +290,16 @@ def test_linearity_free_properties_full_size(engines, g):
     eng.set_precision(PREC_FP16X3)
     # the bench's default mode at the bench's size: deterministic, finite, and within the contract of
     # the fp16x3 frame everywhere (640,000 rays), row ranges and pose batches agree bit for bit
-    eng.set_precision(PREC_FP16_FP8)
     try:
-        m = eng.render(c2w)
-        assert torch.equal(m, eng.render(c2w)) and torch.isfinite(m).all()
-        assert (m - a).abs().max().item() <= 1e-4
-        part = eng.render(c2w, rows=(311, 517))
-        assert torch.equal(part, m.view(800, 800, 3)[311:517].reshape(-1, 3))
-        two = eng.render_batch(torch.stack([c2w, T(g['poses'][1])])[:, :3, :4].contiguous().cuda(), rows=(100, 200))
-        assert torch.equal(two[0], m.view(800, 800, 3)[100:200].reshape(-1, 3))
+        for prec, tol in ((PREC_FP16_FP8, 1e-4), (PREC_FP16X3_ASM, 5e-6)):
+            eng.set_precision(prec)
+            m = eng.render(c2w)
+            assert torch.equal(m, eng.render(c2w)) and torch.isfinite(m).all()
+            assert (m - a).abs().max().item() <= tol, prec
+            part = eng.render(c2w, rows=(311, 517))
+            assert torch.equal(part, m.view(800, 800, 3)[311:517].reshape(-1, 3))
+            two = eng.render_batch(torch.stack([c2w, T(g['poses'][1])])[:, :3, :4].contiguous().cuda(), rows=(100, 200))
+            assert torch.equal(two[0], m.view(800, 800, 3)[100:200].reshape(-1, 3))
     finally:
         eng.set_precision(PREC_FP16X3)
 

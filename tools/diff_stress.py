@@ -1,5 +1,5 @@
-"""Randomised differential check on the GPU box: fp16_fp8 (generated kernels) against fp16x3 (compiler-scheduled kernels)
-on random networks, frame sizes, poses and weight gains; prints the worst difference per family."""
+"""Randomised differential check on the GPU box: the generated kernels' modes (fp16_fp8, fp16_e4m3, fp16x3_asm) against fp16x3
+(compiler-scheduled kernels) on random networks, frame sizes, poses and weight gains; prints the worst difference per mode."""
 import os
 import sys
 
@@ -9,11 +9,12 @@ import numpy as np
 import torch
 import _pkg
 _pkg.load()
-from efficient_nerf_amd import NeRFEngine, R2LEngine, PREC_FP16X3, PREC_FP16_FP8
+from efficient_nerf_amd import NeRFEngine, R2LEngine, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM
 from oracle import r2l_oracle as O
 
 rng = np.random.default_rng(int(os.environ.get('SEED', 1)))
-worst = 0.0
+MODES = (('fp16_fp8', PREC_FP16_FP8, 2e-4), ('fp16_e4m3', PREC_FP16_E4M3, 1e-4), ('fp16x3_asm', PREC_FP16X3_ASM, 1e-5))
+worst = {m[0]: 0.0 for m in MODES}
 for it in range(int(os.environ.get('N_R2L', 12))):
     H, W = int(rng.integers(3, 70)), int(rng.integers(3, 70))
     nb = int(rng.integers(1, 44))
@@ -26,13 +27,16 @@ for it in range(int(os.environ.get('N_R2L', 12))):
     c2w = O.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-80, -5)), float(rng.uniform(3, 5)))
     focal = O.focal_from_angle(W)
     e3 = R2LEngine(H, W, focal, n_block=nb, precision=PREC_FP16X3).load_state_dict(sd)
-    e8 = R2LEngine(H, W, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
-    a, b = e3.render(c2w).cpu(), e8.render(c2w).cpu()
-    d = (a - b).abs().max().item()
-    assert torch.isfinite(b).all() and d < 2e-4, (H, W, nb, gain, d)
-    worst = max(worst, d)
-    e3.close(); e8.close()
-print('R2L: worst |fp16_fp8 - fp16x3| = %.3e' % worst)
+    a = e3.render(c2w).cpu()
+    e3.close()
+    for name, prec, tol in MODES:
+        e8 = R2LEngine(H, W, focal, n_block=nb, precision=prec).load_state_dict(sd)
+        b = e8.render(c2w).cpu()
+        d = (a - b).abs().max().item()
+        assert torch.isfinite(b).all() and d < tol, (name, H, W, nb, gain, d)
+        worst[name] = max(worst[name], d)
+        e8.close()
+print('R2L: worst difference to fp16x3: ' + ', '.join('%s %.3e' % kv for kv in worst.items()), flush=True)
 worst = 0.0
 for it in range(int(os.environ.get('N_T', 8))):
     H, W = int(rng.integers(3, 30)), int(rng.integers(3, 30))
