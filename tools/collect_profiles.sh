@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_n1_fp16_fp8.json 2> $O/bench.err || exit 1
 python $R/bench.py --precision fp16x3 --no-cpu-baseline --no-teacher > $O/bench_n1_fp16x3.json 2>> $O/bench.err || exit 1
 python $R/bench.py --precision fp16_e4m3 --no-teacher > $O/bench_n1_fp16_e4m3.json 2>> $O/bench.err || exit 1
+python $R/bench.py --precision fp16x3_asm --no-teacher > $O/bench_n1_fp16x3_asm.json 2>> $O/bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --no-cpu-baseline --no-teacher > $O/trace.log 2>&1 || exit 1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" \
            "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16" \
@@ -26,6 +27,13 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   name=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --output-format csv -d $O/pmc8_$name -- python $R/bench.py --precision fp16_e4m3 --steps 4 --warmup 1 --no-cpu-baseline --no-teacher > $O/pmc8_$name.log 2>&1 || exit 1
   python $R/tools/pmc_summary.py $O/pmc8_$name/*/*counter_collection.csv r2l_body8_kernel > $O/pmc8_$name.txt 2>&1
+done
+# the three-fp16-pass body (fp16x3_asm)
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  name=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --output-format csv -d $O/pmcx_$name -- python $R/bench.py --precision fp16x3_asm --steps 4 --warmup 1 --no-cpu-baseline --no-teacher > $O/pmcx_$name.log 2>&1 || exit 1
+  python $R/tools/pmc_summary.py $O/pmcx_$name/*/*counter_collection.csv r2l_bodyx_kernel > $O/pmcx_$name.txt 2>&1
 done
 S_PREC=mix S_REPS=20 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VMEM --output-format csv -d $O/pmc_stress -- python $R/tools/stress.py > $O/pmc_stress.log 2>&1
 grep -h "stress\|MISMATCH" $O/pmc_stress.log > $O/pmc_stress.txt

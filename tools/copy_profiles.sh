@@ -4,6 +4,8 @@ O=gpurun_out/prof_$TAG
 cp $O/bench_n1_fp16_fp8.json profiles/${TAG}_bench_n1_fp16_fp8.json
 cp $O/bench_n1_fp16x3.json profiles/${TAG}_bench_n1_fp16x3.json
 [ -f $O/bench_n1_fp16_e4m3.json ] && cp $O/bench_n1_fp16_e4m3.json profiles/${TAG}_bench_n1_fp16_e4m3.json
+[ -f $O/bench_n1_fp16x3_asm.json ] && cp $O/bench_n1_fp16x3_asm.json profiles/${TAG}_bench_n1_fp16x3_asm.json
+for n in SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; do [ -f $O/pmcx_$n.txt ] && cp $O/pmcx_$n.txt profiles/${TAG}_pmcx_$n.txt; done
 for n in SQ_LDS_IDX_ACTIVE; do [ -f $O/pmc_$n.txt ] && cp $O/pmc_$n.txt profiles/${TAG}_pmc_$n.txt; done
 for n in SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; do [ -f $O/pmc8_$n.txt ] && cp $O/pmc8_$n.txt profiles/${TAG}_pmc8_$n.txt; done
 cp $O/trace/*/*kernel_stats.csv profiles/${TAG}_kernel_stats.csv
