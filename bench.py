@@ -218,7 +218,10 @@ def main():
                               'meaning': 'per operand set: activations * 2^-E fit OCP bf6 (|v| <= 28)'}
         # what the timed steps' own rays did to those scales: h0 of EVERY ray (head launch), all 2 n_block operand sets of
         # every ray of the guarded launches (r2l_body_guard_kernel); fill 1.0 = bf6's +-28, the calibration aims at 0.571
-        out['range_watch'] = dict(st, guard_period=eng._guard_period, within_calibration=not st['beyond_calibration'])
+        out['range_watch'] = dict(st, guard_period=eng._guard_period, calibration_fill_target=16 / 28, fill_limit=eng.FILL_LIMIT,
+                                  # beyond_calibration: some fill passed the 0.571 the calibration pose was scaled to (other poses use
+                                  # part of the 1.75x headroom at no loss); within_limit: no fill passed check_ranges' 0.9, nothing clamped
+                                  within_limit=bool(not st['saturated'] and max(st['h0_fill'], st['worst_fill']) <= eng.FILL_LIMIT))
 
     if world > 1:
         # the assembled frames of the last step against this rank's own render of all rows of the step's first frame: a
