@@ -929,8 +929,13 @@ int r2l_set_precision(r2l_ctx* c, int mode) {
         if (rc) return rc;
         c->act = ex;
     }
+    const int prev = c->mode;
     c->mode = mode;
-    if (c->loaded && (!c->d_img[mode] || (split_mode(mode) && c->body_mode != mode))) return build_image(c, mode);
+    if (c->loaded && (!c->d_img[mode] || (split_mode(mode) && c->body_mode != mode))) {
+        const int rc = build_image(c, mode);
+        if (rc) c->mode = prev;      // weights this mode cannot pack: the context keeps rendering in the mode it had
+        return rc;
+    }
     return R2L_OK;
 }
 

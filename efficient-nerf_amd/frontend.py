@@ -333,7 +333,9 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
             if probe_pose is None and probe_rays is None:
                 raise R2LError('--precision auto needs a pose or rays to measure the activation ranges with')
             name, top = eng.choose_precision(c2w=probe_pose, rays=probe_rays)
-            if log:
+            if log and top is None:
+                log(f'[precision] auto: {eng.auto_note} -> {name}')
+            elif log:
                 log(f'[precision] auto: activation exponents of every ray of the first frame up to {top} '
                     f'(fp16_fp8 up to {eng.AUTO_MAX_EXP}, fp16_e4m3 up to {eng.AUTO_MAX_EXP_E4M3}) -> {name}')
         return 'R2L', eng

@@ -256,8 +256,18 @@ class R2LEngine:
         `calibrate_on` measures them on every ray of the frame of pose `c2w` (or of the given `rays` = (rays_o, rays_d)).
         `max_exp` overrides fp16_fp8's limit and disables the middle step (tests).  What is rendered afterwards stays
         watched (range_status / `check_ranges`).  Synchronous, once per weight load.
+        Weights the generated kernels cannot pack (a layer with max|w| outside 2^-12 .. 2^6) get fp16x3, the compiler-scheduled
+        mode with per-layer scales: ('fp16x3', None), the library's message in `auto_note`.
         Returns (name of the chosen precision, largest exponent)."""
-        self.set_precision(PREC_FP16_FP8)
+        try:
+            self.set_precision(PREC_FP16_FP8)
+        except R2LError as e:
+            # a layer whose max|w| is outside 2^-12 .. 2^6: the generated kernels' fp16 + residual split of the weights does not
+            # cover it (r2l_capi.hip pack_body_v3 / pack_head_v1 refuse); the compiler-scheduled mode scales every layer
+            self.set_precision(PREC_FP16X3)
+            self._auto = None
+            self.auto_note = str(e)
+            return 'fp16x3', None
         if self.n_block == 0:
             return 'fp16_fp8', 0
         top = max(self.calibrate_on(c2w=c2w, rays=rays))

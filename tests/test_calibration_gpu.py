@@ -64,3 +64,26 @@ def test_auto_precision_follows_the_measured_ranges(pkg):
         ref = O.r2l_render(sd, H, H, focal, c2w)
         assert (eng.render(c2w).cpu() - ref).abs().max().item() <= 1e-4, gain
         eng.close()
+
+
+def test_auto_precision_on_weights_the_generated_kernels_cannot_pack(pkg):
+    """A layer scaled far outside the range the fp16 + residual weight split covers (max|w| = 2^8; the next layer undoes it):
+    the split modes refuse the weights with a message, `--precision auto` takes the compiler-scheduled fp16x3 (per-layer
+    scales) and says why; the render meets the contract."""
+    from efficient_nerf_amd import PREC_FP16X3, PREC_FP16_FP8, R2LEngine, R2LError
+    H = 24
+    focal = O.focal_from_angle(H)
+    c2w = O.pose_spherical(10., -30., 4.)
+    sd = O.make_r2l_state(seed=3, netdepth=10)
+    sd['body.1.body.0.weight'] = sd['body.1.body.0.weight'] * 4096.
+    sd['body.1.body.0.bias'] = sd['body.1.body.0.bias'] * 4096.
+    sd['body.1.body.2.weight'] = sd['body.1.body.2.weight'] / 4096.
+    eng = R2LEngine(H, H, focal, n_block=4).load_state_dict(sd)
+    with pytest.raises(R2LError, match='outside the range'):
+        eng.set_precision(PREC_FP16_FP8)
+    name, top = eng.choose_precision(c2w=c2w)
+    assert (name, top) == ('fp16x3', None) and eng.precision == PREC_FP16X3 and 'outside the range' in eng.auto_note
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    assert (eng.render(c2w).cpu() - ref).abs().max().item() <= 1e-4
+    assert eng.check_ranges() is None
+    eng.close()
