@@ -144,7 +144,16 @@ GSTAT_ROW = 128
 # fresh accumulator and joins X ONCE per row tile: 48 MFMAs rounding at ulp(X) each are what would dominate its error otherwise.
 F16_WSHIFT = 8
 V_XT = 216        # f16: 8 temporaries of the layer-2 epilogue (X values on their way through the VALU)
+DEEP_RING = True  # bf6: fragment / operand rings extended into the free AGPRs (--shallow-ring: the round-2 rings of 4 / 2 buffers)
+STAGE_ON = False  # set by --stage / Opts.stage users: the staging registers are the same AGPRs
 DMA6 = False      # --dma6 (bf6r): a wave's share as 6 x dwordx4, the sixth overlapping the fifth by 512 B, instead of 5 + 2 x dword
+
+def set_ring(opts):
+    """the deep rings and the staged transfer want the same free AGPRs of the bf6 build"""
+    global DEEP_RING, STAGE_ON
+    STAGE_ON = bool(getattr(opts, 'stage', False))
+    DEEP_RING = not (STAGE_ON or getattr(opts, 'shallow_ring', False))
+
 
 def configure(fmt):
     """Format of the two correction terms and source of the bf6(W) operand:
@@ -162,6 +171,7 @@ def configure(fmt):
     are run once per variant)."""
     global FMT, WREG, NA6, NHI, PIECES, CHUNK, SLOT, WAVE_BYTES, PW, LDS_AUX, LDS_TAIL, LDS_BYTES, LDS_GSTAT
     global V_HI, V_HL, V_A6, A_A6, V_LO, V_CV, V_WCV, V_WSC, V_DMAOFF4, A_H6, N_AGPR_USED, ORDER, ANCH_PER_TILE, A_INL, A_HLO
+    global NHI_V, NA6B, A_FRX, A_A6X
     WREG = fmt == 'bf6r'
     FMT = 'bf6' if WREG else fmt
     ANCH_PER_TILE = 48 if FMT == 'f16' else 24      # MFMAs of a row tile
@@ -199,6 +209,14 @@ def configure(fmt):
         assert V_CV + (6 if FMT == 'bf6' else 8) <= V_L0
         ORDER = ORDER_BASE
     A_H6 = A_IN6 + 8 * NA6
+    NHI_V, NA6B = NHI, 2                            # fragment buffers in VGPRs; buffers of the streamed K=64 operands
+    if FMT == 'bf6' and not WREG and DEEP_RING:
+        # a[224:255] are free in this build: 4 more fragment buffers and 2 more K=64 operand buffers.  Without them a read can be
+        # issued at most 3 MFMAs (96 cycles) ahead of its use -- less than the LDS latency under the LDS-DMA writes: the counted
+        # lgkmcnt waits were 14 % of the kernel (knock-out without them: 8.43 against 9.79 ms)
+        NHI, NA6B = 8, 4
+        A_FRX, A_A6X = A_H6 + 8 * NA6, A_H6 + 8 * NA6 + 16
+        assert A_A6X + 2 * NA6 <= 256
     N_AGPR_USED = 256 if FMT == 'f16' else A_H6 + 8 * NA6 + (12 if WREG else 0)
     assert N_AGPR_USED <= 256
 
@@ -223,9 +241,17 @@ def HI(b):
     return V_HI + b * 4
 
 
+def HIF(b):
+    """buffer b of the fp16 fragment ring: (file, first register).  The bf6 build has 32 AGPRs left: buffers 4.. live there
+    (ds_read and the MFMA's A operand take AGPRs), so that a fragment read can run up to NHI - 1 MFMAs ahead of its use"""
+    return ('v', V_HI + b * 4) if b < NHI_V else ('a', A_FRX + (b - NHI_V) * 4)
+
+
 def A6(b):
     """buffer b of the streamed K=64 weight operands: (file, first register)"""
-    return ('a', A_A6 + b * NA6) if WREG else ('v', V_A6 + b * NA6)
+    if WREG:
+        return ('a', A_A6 + b * NA6)
+    return ('v', V_A6 + b * NA6) if b < 2 else ('a', A_A6X + (b - 2) * NA6)
 
 
 def X(u):
@@ -617,13 +643,17 @@ class Sched:
         if ins.kind == 'ds':
             self.ds_issued += 1
 
-    def need(self, it, key):
-        """make sure the LDS read registered under `key` has landed"""
+    def need(self, it, key, also=()):
+        """make sure the LDS read registered under `key` has landed; reads in `also` that have been issued by now ride along
+        (one s_waitcnt for a run of MFMAs: the instruction itself holds the wave's issue for some cycles, needed or not)"""
         if key not in self.ds_index and it == 0:
             return  # issued by the iteration before the schedule starts (iteration 0 is never the extracted one)
         idx = self.ds_index[key]
         if idx < self.ds_done:
             return
+        for k2 in also:
+            if k2 in self.ds_index:
+                idx = max(idx, self.ds_index[k2])
         n = min(15, self.ds_issued - idx - 1)         # the counter has 4 bits; waiting for more is always right
         self.emit(it, waitcnt_lgkm(n))
         self.ds_done = self.ds_issued - n
@@ -677,22 +707,23 @@ def build_fillers(it, opts):
                 earliest = max(A(TP, 'm16', prev % 16), cvt_window(TP, tp)[1], A(T, 'm16', s_) - opts.rd_lead - 4)
                 deadline = min(deadline, cvt_window(T, s_ >> 2)[0])
             bv, off = lds_addr(slot, off_hi(s_), 16)
-            F.append(Filler(ds_read_b128(HI(n % NHI), bv, off, tag=('hi', it, T, s_)), earliest, deadline, ('rd',)))
+            fl, rg = HIF(n % NHI)
+            F.append(Filler(ds_read_b128(rg, bv, off, tag=('hi', it, T, s_), dfile=fl), earliest, deadline, ('rd',)))
         for j in range(8):
             if not in_stream(j) or FMT == 'f16':
                 continue
             n = T * 4 + (j >> 1) if WREG else T * 8 + j
             prevj = [jj for jj in range(8) if in_stream(jj)]
             k = prevj.index(j)
-            # the buffer's last user: the operand two before this one in stream order
-            if k >= 2:
-                pa = A(T, 'm6', prevj[k - 2])
+            # the buffer's last user: the operand NA6B before this one in stream order
+            if k >= NA6B:
+                pa = A(T, 'm6', prevj[k - NA6B])
             else:
-                pa = A(T - 1, 'm6', prevj[len(prevj) - 2 + k])
+                pa = A(T - 1, 'm6', prevj[len(prevj) - NA6B + k])
             earliest = max(pa, A(T, 'm6', j) - opts.rd_lead6)
             deadline = A(T, 'm6', j)
             o1, o2 = off_a6(j)
-            fl, reg = A6(n & 1)
+            fl, reg = A6(n % NA6B)
             bv, off = lds_addr(slot, o1, 16)
             F.append(Filler(ds_read_b128(reg, bv, off, tag=('a6', it, T, j, 0), dfile=fl), earliest, deadline, ('rd6',)))
             if FMT == 'bf6':
@@ -812,6 +843,7 @@ def build_fillers(it, opts):
 def schedule(opts, n_iter=3):
     """list-schedule n_iter block iterations; returns [(iteration_of_position, Ins)] where the
     position's iteration is that of the surrounding anchors"""
+    set_ring(opts)
     configure(opts.fmt)
     sch = Sched(opts)
     fillers = []
@@ -827,6 +859,10 @@ def schedule(opts, n_iter=3):
         for i in range(len(ch) - 2, -1, -1):   # a filler must not hold up a successor with an earlier deadline
             ch[i].deadline = min(ch[i].deadline, ch[i + 1].deadline)
     heads = {ch: 0 for ch in chains}
+    deep = FMT == 'bf6' and not WREG and DEEP_RING
+    # with the deep rings the reads run far enough ahead for one wait to cover a short run of MFMAs (-1 % on top of the rings' -1 %)
+    wg16 = opts.wait_group if opts.wait_group is not None else (3 if deep else 1)
+    wg6 = opts.wait_group6 if opts.wait_group6 is not None else (2 if deep else 1)
     per_block = TILES * ANCH_PER_TILE
     total_anchors = n_iter * per_block
     anchors = tile_anchors()
@@ -900,31 +936,33 @@ def schedule(opts, n_iter=3):
                 ins = mfma32_16(dfile, d, V_HL + 4 * (n % NHI), hset(sj), dfile, d, tag=(kind, it, T, sj))
             cap = opts.cap16
         elif kind == 'm16':
-            sch.need(it, ('hi', it, T, sj))
+            sch.need(it, ('hi', it, T, sj), [('hi', it, T, sj + g) for g in range(1, wg16) if sj + g < 16])
             n = T * 16 + sj
             if layer == 0 and sj == 0:
                 sch.need(it, ('bias', it, T, 3))
-                ins = mfma32_16('v', d, HI(n % NHI), hset(sj), 'v', d if WREG else V_BIAS, tag=('m16', it, T, sj))
+                fl, rg = HIF(n % NHI)
+                ins = mfma32_16('v', d, rg, hset(sj), 'v', d if WREG else V_BIAS, tag=('m16', it, T, sj), afile=fl)
             elif FMT == 'f16' and sj == 0:      # layer 2: a fresh accumulator (its bias is folded into later layer-1 biases)
                 ins = mfma32_16('v', d, HI(n % NHI), hset(sj), '0', 0, tag=('m16', it, T, sj))
             else:
-                ins = mfma32_16(dfile, d, HI(n % NHI), hset(sj), dfile, d, tag=('m16', it, T, sj))
+                fl, rg = HIF(n % NHI)
+                ins = mfma32_16(dfile, d, rg, hset(sj), dfile, d, tag=('m16', it, T, sj), afile=fl)
             cap = opts.cap16
         else:
             term, t = J_ORDER[sj]
             n = T * 4 + t if WREG else T * 8 + sj
             if in_stream(sj):
-                sch.need(it, ('a6', it, T, sj, 1))
+                sch.need(it, ('a6', it, T, sj, 1), [('a6', it, T, sj + g, 1) for g in range(1, wg6) if sj + g < 8])
             if u == 0 and (kind, sj) == [x for x in anchors if x[0] == 'm6'][0]:
                 sch.need(it, ('scale', it, layer))
             if sj == 0 and ORDER == 'tail' and opts.chain_nop >= 0:
                 sch.emit(it, s_nop(opts.chain_nop))      # fp16 -> scaled MFMA on one accumulator: keep them apart
             b6 = A_IN6 if layer == 0 else A_H6
             if FMT == 'fp8':
-                ins = mfma32_8(dfile, d, A6(n & 1)[1], B6(b6, term, t), V_SC + 2 * layer + term, V_SB + 2 * layer + term,
+                ins = mfma32_8(dfile, d, A6(n % NA6B)[1], B6(b6, term, t), V_SC + 2 * layer + term, V_SB + 2 * layer + term,
                                tag=('m6', it, T, sj))
             else:
-                fl, reg = ('v', V_WCV) if not in_stream(sj) else A6(n & 1)     # bf6r term 1: the operand just converted
+                fl, reg = ('v', V_WCV) if not in_stream(sj) else A6(n % NA6B)     # bf6r term 1: the operand just converted
                 ins = mfma32_6(dfile, d, reg, B6(b6, term, t), V_SC + 2 * layer + term, V_SB + 2 * layer + term,
                                tag=('m6', it, T, sj), afile=fl)
             cap = opts.cap6 * (1 if FMT == 'bf6' else 2)    # a 64-cycle MFMA shadows twice the issue slots
@@ -953,6 +991,9 @@ class Opts:
         self.guard = False        # the range-guard build: per operand set the maximum |a| over every ray of the launch
         self.fmt = 'bf6'          # correction terms: 'bf6' (e3m2 x e3m2) | 'fp8' (e4m3 x e4m3): configure()
         self.stage = False        # weight stream through staging AGPRs + ds_write_b128 instead of LDS-DMA (bf6 only)
+        self.wait_group = None    # fp16 fragments one s_waitcnt may cover (those already issued); None: 3 with the deep rings, else 1
+        self.wait_group6 = None   # ... K=64 operands; None: 2 with the deep rings, else 1
+        self.shallow_ring = False # bf6: fragment / operand rings of 4 / 2 buffers in VGPRs only (the round-2 kernel)
         self.__dict__.update(kw)
 
 
@@ -1079,6 +1120,7 @@ def kernel_text(opts):
     %0 wimg (s64)  %1 aux (s64)  %2 xin (s64)  %3 xout (s64)  %4 n_tiles  %5 n_block  %6 wave  %7 blockIdx.x
     %8 gridDim.x  %9 rgb (s64; 0: store the x image to xout, else the fused tail writes rgb and xout is unused)
     %10 tail table (s64)  %11 n_rays  %12 number of the launch's first tile"""
+    set_ring(opts)
     configure(opts.fmt)
     pro, body = steady_block(opts)
     L = []
@@ -1275,6 +1317,7 @@ def emit_inc(path, opts):
 # ---------------------------------------------------------------------------------------------
 def emulate_tile(opts, img, aux, x_tile_regs, n_block, wave=0, check_hazards=True):
     """x_tile_regs: float32 [128, 64] register image of one wave's X.  Returns (X out [128, 64], errors)."""
+    set_ring(opts)
     configure(opts.fmt)
     pro, body = steady_block(opts)
     st = State(wave, img, aux, n_block, LDS_BYTES + (2 * n_block * GSTAT_ROW if opts.guard else 0))
@@ -1362,6 +1405,9 @@ def main():
     ap.add_argument('--fmt', default='bf6', choices=['bf6', 'bf6r', 'fp8', 'f16'],
                     help='correction terms: bf6 (e3m2, all operands streamed) | bf6r (bf6(W) converted from the fp16 fragments in registers) | fp8 (e4m3) | '
                          'f16 (three fp16 passes: R2L_PREC_FP16X3 on this machine)')
+    ap.add_argument('--wait-group', type=int, default=None)
+    ap.add_argument('--wait-group6', type=int, default=None)
+    ap.add_argument('--shallow-ring', action='store_true', help='bf6: the round-2 rings (4 fragment / 2 operand buffers, VGPRs only)')
     ap.add_argument('--stage', action='store_true', help='bf6: the weight stream through 28 staging AGPRs + ds_write_b128 instead of LDS-DMA')
     ap.add_argument('--dma6', action='store_true', help='bf6r: 6 x dwordx4 per wave and chunk (512 B moved twice) instead of 5 x dwordx4 + 2 x dword')
     ap.add_argument('--dump', help='write the loop body as plain text')
@@ -1376,7 +1422,7 @@ def main():
         global DMA6
         DMA6 = True
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap16=a.cap16, cap6=a.cap6, dma_gap=a.dma_gap,
-                chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, stage=a.stage, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
+                chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, stage=a.stage, shallow_ring=a.shallow_ring, wait_group=a.wait_group, wait_group6=a.wait_group6, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
                 drop=tuple(x for x in a.drop.split(',') if x))
     if a.emit:
         n = emit_inc(a.emit, opts)

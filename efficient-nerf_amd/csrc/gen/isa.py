@@ -629,14 +629,14 @@ def _d32_rows():
 _D32_ROWS = _d32_rows()
 
 
-def mfma32_16(dfile, d, a, b, cfile, c, tag='', bfile='v'):
-    """D[dfile d:d+15] = A(v[a:a+3], 32 x 16) x B([bfile] b:b+3, 16 x 32) + C[cfile c:c+15]: v_mfma_f32_32x32x16_f16"""
+def mfma32_16(dfile, d, a, b, cfile, c, tag='', bfile='v', afile='v'):
+    """D[dfile d:d+15] = A([afile] a:a+3, 32 x 16) x B([bfile] b:b+3, 16 x 32) + C[cfile c:c+15]: v_mfma_f32_32x32x16_f16"""
     rf = {'v': vreg, 'a': areg, '0': lambda c_, n_: '0'}      # cfile '0': the inline constant 0 (a fresh accumulator)
-    text = 'v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (rf[dfile](d, 16), vreg(a, 4), rf[bfile](b, 4), rf[cfile](c, 16))
+    text = 'v_mfma_f32_32x32x16_f16 %s, %s, %s, %s' % (rf[dfile](d, 16), rf[afile](a, 4), rf[bfile](b, 4), rf[cfile](c, 16))
 
     def emu(st):
         lanes = np.arange(64)
-        Ah = _halves(st.V[a:a + 4])         # [64, 8]
+        Ah = _halves(st.regs(afile)[a:a + 4])         # [64, 8]
         Bh = _halves(st.regs(bfile)[b:b + 4])
         Am = np.zeros((32, 16))
         Bm = np.zeros((16, 32))
@@ -653,7 +653,8 @@ def mfma32_16(dfile, d, a, b, cfile, c, tag='', bfile='v'):
     rc = [] if cfile == '0' else vr(c, 16) if cfile == 'v' else ar(c, 16)
     wd = vr(d, 16) if dfile == 'v' else ar(d, 16)
     rb = vr(b, 4) if bfile == 'v' else ar(b, 4)
-    return Ins(text, 'mfma16', rd=vr(a, 4) + rb + rc, wr=wd, emu=emu, tag=tag, cost=1)
+    ra = vr(a, 4) if afile == 'v' else ar(a, 4)
+    return Ins(text, 'mfma16', rd=ra + rb + rc, wr=wd, emu=emu, tag=tag, cost=1)
 
 
 def mfma32_6(dfile, d, a, b_agpr, scale_a, scale_b, tag='', bfile='a', afile='v'):
