@@ -827,8 +827,9 @@ def build_fillers(it, opts):
         else:
             # SALU prelude right behind the barrier, then the pieces spread over the following MFMAs
             # 4 waves x 7 pieces of 1 KiB right behind the barrier ask the 64 B/clk path into the CU for 128 B/clk; at one piece
-            # per three MFMAs the waves wait less (bf6: -0.7 % kernel time, profiles/r03_dma_experiments.txt item 6)
-            gap = opts.dma_gap if opts.dma_gap is not None else (3 if FMT == 'bf6' and not WREG and not opts.stage else 1)
+            # per two to four MFMAs the waves wait less (bf6 -0.7 %, e4m3 -1.2 %, f16 -2.0 % kernel time:
+            # profiles/r03_dma_experiments.txt item 6)
+            gap = opts.dma_gap if opts.dma_gap is not None else (1 if WREG or opts.stage else {'bf6': 3, 'fp8': 2, 'f16': 4}[FMT])
             first_piece = next(i for i, x in enumerate(seq) if x.kind in ('dma', 'vload', 'ds') and x.tag)
             for ins in seq[:first_piece]:
                 F.append(Filler(ins, a0 - 1, a0 + 3, ch))
@@ -861,7 +862,7 @@ def schedule(opts, n_iter=3):
     heads = {ch: 0 for ch in chains}
     deep = FMT == 'bf6' and not WREG and DEEP_RING
     # with the deep rings the reads run far enough ahead for one wait to cover a short run of MFMAs (-1 % on top of the rings' -1 %)
-    wg16 = opts.wait_group if opts.wait_group is not None else (3 if deep else 1)
+    wg16 = opts.wait_group if opts.wait_group is not None else (3 if deep else 2 if FMT in ('fp8', 'f16') else 1)
     wg6 = opts.wait_group6 if opts.wait_group6 is not None else (2 if deep else 1)
     per_block = TILES * ANCH_PER_TILE
     total_anchors = n_iter * per_block

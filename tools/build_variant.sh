@@ -7,15 +7,20 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 d=$root/build_variants/$name
 mkdir -p $d
 cp $root/efficient-nerf_amd/csrc/*.hip $root/efficient-nerf_amd/csrc/*.h $root/efficient-nerf_amd/csrc/*.inc $d/
-python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --emit $d/r2l_body_asm.inc "$@" > /dev/null || exit 1
-python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --guard --emit $d/r2l_body_guard_asm.inc "$@" > /dev/null || exit 1
+# `--fmt fp8` / `--fmt f16` variants replace the includes of r2l_body8_kernel / r2l_bodyx_kernel (time them with BT_PREC)
+stem=r2l_body
+case " $* " in *" --fmt fp8 "*) stem=r2l_body8;; *" --fmt f16 "*) stem=r2l_bodyx;; esac
+python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --emit $d/${stem}_asm.inc "$@" > /dev/null || exit 1
+[ $stem = r2l_bodyx ] || python3 $root/efficient-nerf_amd/csrc/gen/body_gen.py --guard --emit $d/${stem}_guard_asm.inc "$@" > /dev/null || exit 1
+# HEAD_OPTS="--dma-gap 2 ...": a differently generated head layer as well (gen/head_gen.py options)
+if [ -n "$HEAD_OPTS" ]; then python3 $root/efficient-nerf_amd/csrc/gen/head_gen.py --emit $d $HEAD_OPTS > /dev/null || exit 1; fi
 sed -i 's#"../../include/r2l_hip.h"#"'$root'/include/r2l_hip.h"#' $d/*.hip
 cd $d
 # a variant generated with `--fmt bf6r` streams 22 KiB chunks: its packer and LDS size are selected at compile time
 DEF=""
 case " $* " in *" --fmt bf6r "*) DEF="-DR2L_BF6R_STREAM";; esac
 for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_kernels nerf_capi; do
-  if [ $f = r2l_body ] || [ $f = r2l_capi -a -n "$DEF" ] || [ ! -f $root/efficient-nerf_amd/csrc/$f.o ]; then
+  if [ $f = r2l_body ] || [ $f = r2l_kernels -a -n "$HEAD_OPTS" ] || [ $f = r2l_capi -a -n "$DEF" ] || [ ! -f $root/efficient-nerf_amd/csrc/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $DEF -c $f.hip -o $f.o
   else cp $root/efficient-nerf_amd/csrc/$f.o $f.o; fi
 done
