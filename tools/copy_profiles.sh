@@ -8,11 +8,11 @@ cp $O/bench_n1_fp16x3.json profiles/${TAG}_bench_n1_fp16x3.json
 for n in SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; do [ -f $O/pmcx_$n.txt ] && cp $O/pmcx_$n.txt profiles/${TAG}_pmcx_$n.txt; done
 for n in SQ_LDS_IDX_ACTIVE; do [ -f $O/pmc_$n.txt ] && cp $O/pmc_$n.txt profiles/${TAG}_pmc_$n.txt; done
 for n in SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; do [ -f $O/pmc8_$n.txt ] && cp $O/pmc8_$n.txt profiles/${TAG}_pmc8_$n.txt; done
-cp $O/trace/*/*kernel_stats.csv profiles/${TAG}_kernel_stats.csv
+cp $(ls -t $O/trace/*/*kernel_stats.csv | head -1) profiles/${TAG}_kernel_stats.csv      # the newest: gpurun merges runs into one directory
 for n in FETCH_SIZE GRBM_GUI_ACTIVE SQ_WAVE_CYCLES TCC_HIT_sum WRITE_SIZE; do cp $O/pmc_$n.txt profiles/${TAG}_pmc_$n.txt; done
 cp $O/traffic.json profiles/${TAG}_traffic.json
 grep -h "^stress\|MISMATCH" $O/pmc_stress.log > profiles/${TAG}_pmc_stress.txt
-cp $O/teacher_trace/*/*kernel_stats.csv profiles/${TAG}_teacher_kernel_stats.csv
+cp $(ls -t $O/teacher_trace/*/*kernel_stats.csv | head -1) profiles/${TAG}_teacher_kernel_stats.csv
 grep teacher $O/teacher_time.txt > profiles/${TAG}_teacher_time.txt
 cp $O/teacher_pmc_SQ_WAVE_CYCLES.txt profiles/${TAG}_teacher_pmc_SQ_WAVE_CYCLES.txt
 cp $O/teacher_pmc_GRBM_GUI_ACTIVE.txt profiles/${TAG}_teacher_pmc_GRBM_GUI_ACTIVE.txt
