@@ -777,7 +777,7 @@ def build_fillers(it, opts):
                 dl = min(dl, first - 2)
             F.append(Filler(ins, e0, dl, ('epi',)))
         # --- rendezvous + refill at the middle of each chunk (= row tile) ------------------------
-        a0 = base_anchor + T * ANCH_PER_TILE + ANCH_PER_TILE // 3
+        a0 = base_anchor + T * ANCH_PER_TILE + (opts.rdv_at if opts.rdv_at is not None else ANCH_PER_TILE // 3)
         ch = ('dma',)
         F.append(Filler(waitcnt_vm(0 if opts.stage else PW), a0 - 1, a0 + 1, ch))
         F.append(Filler(barrier(), a0 - 1, a0 + 1, ch))
@@ -820,7 +820,7 @@ def build_fillers(it, opts):
                     seq.append(salu('s_add_u32 m0, m0, 0x1000', lambda st: setattr(st, 'm0', st.m0 + 4096)))
                     seq.append(s_nop(0))
                 seq.append(dma_piece(i, tag=('dma', it, T, i)))
-        end = base_anchor + (T + 1) * ANCH_PER_TILE + ANCH_PER_TILE // 4      # well before the next rendezvous
+        end = a0 + ANCH_PER_TILE - ANCH_PER_TILE // 12      # well before the next rendezvous
         if opts.dma_burst:
             for ins in seq:
                 F.append(Filler(ins, a0 - 1, a0 + 1, ch))
@@ -994,6 +994,7 @@ class Opts:
         self.stage = False        # weight stream through staging AGPRs + ds_write_b128 instead of LDS-DMA (bf6 only)
         self.wait_group = None    # fp16 fragments one s_waitcnt may cover (those already issued); None: 3 with the deep rings, else 1
         self.wait_group6 = None   # ... K=64 operands; None: 2 with the deep rings, else 1
+        self.rdv_at = None        # anchor of a row tile in front of which its rendezvous sits (None: a third into the tile)
         self.shallow_ring = False # bf6: fragment / operand rings of 4 / 2 buffers in VGPRs only (the round-2 kernel)
         self.__dict__.update(kw)
 
@@ -1408,6 +1409,7 @@ def main():
                          'f16 (three fp16 passes: R2L_PREC_FP16X3 on this machine)')
     ap.add_argument('--wait-group', type=int, default=None)
     ap.add_argument('--wait-group6', type=int, default=None)
+    ap.add_argument('--rdv-at', type=int, default=None)
     ap.add_argument('--shallow-ring', action='store_true', help='bf6: the round-2 rings (4 fragment / 2 operand buffers, VGPRs only)')
     ap.add_argument('--stage', action='store_true', help='bf6: the weight stream through 28 staging AGPRs + ds_write_b128 instead of LDS-DMA')
     ap.add_argument('--dma6', action='store_true', help='bf6r: 6 x dwordx4 per wave and chunk (512 B moved twice) instead of 5 x dwordx4 + 2 x dword')
@@ -1423,7 +1425,7 @@ def main():
         global DMA6
         DMA6 = True
     opts = Opts(dma_burst=a.dma_burst, rd_lead=a.rd_lead, rd_lead6=a.rd_lead6, cap16=a.cap16, cap6=a.cap6, dma_gap=a.dma_gap,
-                chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, stage=a.stage, shallow_ring=a.shallow_ring, wait_group=a.wait_group, wait_group6=a.wait_group6, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
+                chain_nop=a.chain_nop, guard=a.guard, fmt=a.fmt, stage=a.stage, shallow_ring=a.shallow_ring, rdv_at=a.rdv_at, wait_group=a.wait_group, wait_group6=a.wait_group6, skip_terms=tuple(int(t) for t in a.skip_terms.split(',') if t),
                 drop=tuple(x for x in a.drop.split(',') if x))
     if a.emit:
         n = emit_inc(a.emit, opts)
