@@ -39,13 +39,14 @@ def cpu_threads():
 
 
 def kernel_sources_digest():
-    """sha256 over the kernel sources (csrc/*.hip, *.h, the body generator): identifies the build a PMC pass measured"""
+    """sha256 over what is compiled (csrc/*.hip, *.h and the generated *.inc, which are committed and byte-reproducible from
+    the generators): identifies the build a PMC pass measured"""
     import glob
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc')
     for f in sorted(glob.glob(os.path.join(base, '*.hip')) + glob.glob(os.path.join(base, '*.h')) +
-                    glob.glob(os.path.join(base, 'gen', '*.py'))):
+                    glob.glob(os.path.join(base, '*.inc'))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
