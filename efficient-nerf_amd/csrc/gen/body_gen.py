@@ -1303,6 +1303,9 @@ def emit_inc(path, opts):
         first = L.index('L_block_%=:')
         last = len(L) - 1 - L[::-1].index('s_sub_u32 %s, %s, 1' % (sreg(S_BLK), sreg(S_BLK)))
         L = L[:first + 1] + [t for t in L[first + 1:last] if not (t in texts and not t.startswith(keep_always))] + L[last:]
+    if 'lgkmnop' in drop:      # every counted LDS wait replaced by an s_nop 0: same instruction count, no waiting (wrong results)
+        first = L.index('L_block_%=:')
+        L = L[:first + 1] + ['s_nop 0' if t.startswith('s_waitcnt lgkmcnt') else t for t in L[first + 1:]]
     n = {}
     for ins in body:
         n[ins.kind] = n.get(ins.kind, 0) + 1
