@@ -146,6 +146,7 @@ F16_WSHIFT = 8
 V_XT = 216        # f16: 8 temporaries of the layer-2 epilogue (X values on their way through the VALU)
 DEEP_RING = True  # bf6: fragment / operand rings extended into the free AGPRs (--shallow-ring: the round-2 rings of 4 / 2 buffers)
 STAGE_ON = False  # set by --stage / Opts.stage users: the staging registers are the same AGPRs
+DMA_POLICY = ''   # --dma-policy: cache-policy suffix of the stream's LDS-DMA instructions (' nt', ' sc1', ' sc0 sc1'); experiment
 DMA6 = False      # --dma6 (bf6r): a wave's share as 6 x dwordx4, the sixth overlapping the fifth by 512 B, instead of 5 + 2 x dword
 
 def set_ring(opts):
@@ -392,7 +393,7 @@ def dma_piece(i, tag=''):
         voffr, width, imm = V_DMAOFF4, 4, 1024 + 256 * (i - 5)        # relative to M0 + 4096 / the + 4096 offset register
     else:
         voffr, width, imm = (V_DMAOFF if i < 4 else V_DMAOFF2), 16, 1024 * (i & 3)
-    text = 'global_load_lds_dword%s %s, %s offset:%d' % ('x4' if width == 16 else '', vreg(voffr), sreg(S_G, 2), imm)
+    text = 'global_load_lds_dword%s %s, %s offset:%d%s' % ('x4' if width == 16 else '', vreg(voffr), sreg(S_G, 2), imm, DMA_POLICY)
 
     def emu(st):
         copies = []
@@ -1413,6 +1414,7 @@ def main():
     ap.add_argument('--wait-group', type=int, default=None)
     ap.add_argument('--wait-group6', type=int, default=None)
     ap.add_argument('--rdv-at', type=int, default=None)
+    ap.add_argument('--dma-policy', default='')
     ap.add_argument('--shallow-ring', action='store_true', help='bf6: the round-2 rings (4 fragment / 2 operand buffers, VGPRs only)')
     ap.add_argument('--stage', action='store_true', help='bf6: the weight stream through 28 staging AGPRs + ds_write_b128 instead of LDS-DMA')
     ap.add_argument('--dma6', action='store_true', help='bf6r: 6 x dwordx4 per wave and chunk (512 B moved twice) instead of 5 x dwordx4 + 2 x dword')
@@ -1424,6 +1426,9 @@ def main():
     if a.order:
         global ORDER_BASE
         ORDER_BASE = a.order
+    if a.dma_policy:
+        global DMA_POLICY
+        DMA_POLICY = ' ' + a.dma_policy.replace('+', ' ')
     if a.dma6:
         global DMA6
         DMA6 = True
