@@ -96,8 +96,9 @@ def middle_rung(torch, O, R2LEngine, sd, poses, focal):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # warm-up 10, >= 100 timed frames (the reference's --benchmark is timeit(100), main.py:1124-1133): 1.1 s of rendering
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--precision', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm'], default='fp16_fp8',
                     help='fp16_fp8 (default: fp16 main pass + bf6 correction terms) and fp16x3 meet the <=1e-4 L_inf '
                          'contract (measured 3e-5 / 6e-7, checked in this run against the CPU oracle); fp16x1 (3.5e-4) does not')
