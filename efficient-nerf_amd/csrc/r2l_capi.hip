@@ -196,7 +196,9 @@ static int stream_of(int mode) {
            (R2L_BF6_CHUNK == 28672 ? R2L_STREAM_BF6 : R2L_STREAM_BF6R);
 }
 #define R2L_N_MODES 5
+#ifndef R2L_SLICE_TILES
 #define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head / body launch pair (1 KiB of h0 per ray)
+#endif
 
 
 int r2l_create(r2l_ctx** out, int H, int W, double focal, float near_, float far_, int n_sample, int L,
