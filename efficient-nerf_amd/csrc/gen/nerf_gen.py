@@ -478,8 +478,9 @@ class Opts:
         self.lead = 8          # anchors a fragment read is issued ahead of its first MFMA
         self.lead6 = 5
         self.cap = 3           # issue slots for fillers behind each MFMA
-        self.dma_gap = 3       # anchors between two LDS-DMA pieces
+        self.dma_gap = 4       # anchors (16-cycle MFMAs) between two LDS-DMA pieces: 4 .. 6 are 1.7 % faster than 3, 2 is slower
         self.pair = False
+        self.wait_group = 2    # fp16 fragments one s_waitcnt may cover (those already issued)
         self.__dict__.update(kw)
 
 
@@ -621,12 +622,17 @@ class Sched:
             self.ds_index[ins.tag] = self.ds_issued
             self.ds_issued += 1
 
-    def need(self, key):
+    def need(self, key, also=()):
+        """wait for the LDS read `key`; reads in `also` that have been issued ride along (one s_waitcnt for a run of MFMAs)"""
         idx = self.ds_index[key]
         if idx < self.ds_done:
             return
-        self.emit(waitcnt_lgkm(self.ds_issued - idx - 1))
-        self.ds_done = idx + 1
+        for k2 in also:
+            if k2 in self.ds_index:
+                idx = max(idx, self.ds_index[k2])
+        n = min(15, self.ds_issued - idx - 1)
+        self.emit(waitcnt_lgkm(n))
+        self.ds_done = self.ds_issued - n
 
 
 def schedule(opts):
@@ -684,7 +690,7 @@ def schedule(opts):
             ek, e = L.extra[k]
             ins = mfma16(d, bufmap[key], 'a', E_reg(ek, e, c, p == 1), csrc, tag=('x', T, k, c, p), btext=E_name(ek, e, c, p == 1))
         elif kind == 'm16':
-            sch.need(key)
+            sch.need(key, [('hi', T, k + g) for g in range(1, opts.wait_group)])
             ins = mfma16(d, bufmap[key], 'v', hset(L.src, k, c), csrc, tag=('m16', T, k, c))
         else:
             sch.need(key + (1,))
@@ -843,12 +849,13 @@ def main():
     ap.add_argument('--lead', type=int, default=8)
     ap.add_argument('--lead6', type=int, default=5)
     ap.add_argument('--cap', type=int, default=3)
-    ap.add_argument('--dma-gap', type=int, default=3)
+    ap.add_argument('--dma-gap', type=int, default=4)
+    ap.add_argument('--wait-group', type=int, default=2)
     ap.add_argument('--pair', action='store_true', help='fillers only behind the second MFMA of a column-tile pair')
     ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the emitted '
                     'text (lgkm, dma, valu, ds, mfma6, mfma16, salu, nop): timing knock-outs, wrong results')
     a = ap.parse_args()
-    opts = Opts(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap, pair=a.pair, drop=tuple(x for x in a.drop.split(',') if x))
+    opts = Opts(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap, pair=a.pair, wait_group=a.wait_group, drop=tuple(x for x in a.drop.split(',') if x))
     print('tiles', NT, 'chunks', NCH, 'MFMAs', N_ANCH, 'stream bytes', STREAM_BYTES)
     if a.emit:
         n, body = emit(a.emit, opts)
