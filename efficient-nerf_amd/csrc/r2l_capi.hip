@@ -196,6 +196,21 @@ static int stream_of(int mode) {
            (R2L_BF6_CHUNK == 28672 ? R2L_STREAM_BF6 : R2L_STREAM_BF6R);
 }
 #define R2L_N_MODES 5
+
+// Persistent workgroups take ray tiles b, b + grid, ...: with one workgroup per CU the launch lasts ceil(n_tiles / n_cu) tile
+// times and the last round is partly empty (5,000 tiles on 256 CUs: 19.5 rounds).  The smallest grid with the same number of
+// rounds gives every workgroup the same work and leaves the idle CUs' share of the package power to the others: 250 workgroups
+// for 5,000 tiles, -1.3 % kernel time (256 -> 250 same-call A/B; 228 = 22 rounds +0.9 %, 200 = 25 rounds +3.9 %).
+#ifdef R2L_GRID_OVERRIDE      // experiment (tools/build_variant.sh CAPI_DEF=-DR2L_GRID_OVERRIDE=250)
+static int balanced_grid(int n_tiles, int) { return n_tiles < R2L_GRID_OVERRIDE ? n_tiles : R2L_GRID_OVERRIDE; }
+#else
+static int balanced_grid(int n_tiles, int n_cu) {
+    if (n_tiles <= n_cu) return n_tiles;
+    const int rounds = (n_tiles + n_cu - 1) / n_cu;
+    return (n_tiles + rounds - 1) / rounds;
+}
+#endif
+
 #ifndef R2L_SLICE_TILES
 #define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head / body launch pair (1 KiB of h0 per ray)
 #endif
@@ -914,7 +929,7 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3 ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
     pb.gstats = c->guard_period == 1 && scaled_mode(c->mode) && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) ? c->d_gstats : nullptr;
     c->last_stream = (hipStream_t)stream;
-    hipError_t e = r2l_launch_body(pb, n_tiles < c->n_cu ? n_tiles : c->n_cu, (hipStream_t)stream);
+    hipError_t e = r2l_launch_body(pb, balanced_grid(n_tiles, c->n_cu), (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
     return R2L_OK;
 }
@@ -1012,7 +1027,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
     c->last_stream = s;
     for (int t0 = 0; t0 < p.n_tiles; t0 += R2L_SLICE_TILES) {
         const int nt = p.n_tiles - t0 < R2L_SLICE_TILES ? p.n_tiles - t0 : R2L_SLICE_TILES;
-        const int grid = nt < c->n_cu ? nt : c->n_cu;
+        const int grid = balanced_grid(nt, c->n_cu);
         R2LParams ph = p;
         ph.wimg = c->d_img[c->mode];
         ph.xbuf = c->d_xa;
@@ -1083,7 +1098,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
 
 static int timed_launch(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
     if (split_mode(c->mode)) return launch_split(c, p, s);
-    const int grid = p.n_tiles < c->n_cu ? p.n_tiles : c->n_cu;
+    const int grid = balanced_grid(p.n_tiles, c->n_cu);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         int rc = timing_events(c, &e0, &e1);
