@@ -452,7 +452,7 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     p.act_scale = c->act_scale;
     p.neg1 = -1.0f;
     memcpy(p.inv_scale, c->net[which].inv_scale[c->mode], sizeof p.inv_scale);
-    const int grid = p.n_tiles < c->n_cu ? p.n_tiles : c->n_cu;
+    const int grid = balanced_grid(p.n_tiles, c->n_cu);
     hipError_t e = nerf_launch_mlp(p, c->mode, grid, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
     return R2L_OK;

@@ -197,19 +197,6 @@ static int stream_of(int mode) {
 }
 #define R2L_N_MODES 5
 
-// Persistent workgroups take ray tiles b, b + grid, ...: with one workgroup per CU the launch lasts ceil(n_tiles / n_cu) tile
-// times and the last round is partly empty (5,000 tiles on 256 CUs: 19.5 rounds).  The smallest grid with the same number of
-// rounds gives every workgroup the same work and leaves the idle CUs' share of the package power to the others: 250 workgroups
-// for 5,000 tiles, -1.3 % kernel time (256 -> 250 same-call A/B; 228 = 22 rounds +0.9 %, 200 = 25 rounds +3.9 %).
-#ifdef R2L_GRID_OVERRIDE      // experiment (tools/build_variant.sh CAPI_DEF=-DR2L_GRID_OVERRIDE=250)
-static int balanced_grid(int n_tiles, int) { return n_tiles < R2L_GRID_OVERRIDE ? n_tiles : R2L_GRID_OVERRIDE; }
-#else
-static int balanced_grid(int n_tiles, int n_cu) {
-    if (n_tiles <= n_cu) return n_tiles;
-    const int rounds = (n_tiles + n_cu - 1) / n_cu;
-    return (n_tiles + rounds - 1) / rounds;
-}
-#endif
 
 #ifndef R2L_SLICE_TILES
 #define R2L_SLICE_TILES 8192   // FP16_FP8: ray tiles per head / body launch pair (1 KiB of h0 per ray)
