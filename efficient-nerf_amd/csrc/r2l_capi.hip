@@ -856,7 +856,7 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
 
 static thread_local int g_debug_pack_e4m3 = 0;
 int r2l_debug_pack_body_format(int fmt) {   // which stream r2l_debug_pack_body_host packs: R2L_STREAM_*
-    if (fmt < 0 || fmt > 2) return r2l_set_error(R2L_EINVAL, "stream format %d", fmt);
+    if (fmt < 0 || fmt > R2L_STREAM_F16) return r2l_set_error(R2L_EINVAL, "stream format %d", fmt);
     g_debug_pack_e4m3 = fmt;
     return R2L_OK;
 }

@@ -273,6 +273,22 @@ def test_bf6r_stream_converts_the_weight_operands_from_registers(nb, wave, guard
     assert err < 2.5e-5 * nb and err < 1.15 * err0 + 1e-6
 
 
+def test_cxx_packer_matches_python_restatement_f16():
+    """R2L_PREC_FP16X3_ASM's stream (r2l_capi.hip pack_body_v3, format 3): 32 KiB chunks of 16 hi + 16 residual fragments of
+    256 w, the layer-1 bias carrying the same factor"""
+    W = make_weights(2, seed=9, gain=0.5)
+    buf, aux_off, tail_off, _ = cxx_pack(*W, e4m3=3)
+    img, aux, _ = G.pack_body_image(*W, fmt='f16')
+    G.configure('bf6')
+    assert aux_off == img.size == 2 * 16 * 32768 and tail_off == aux_off + 2 * G.AUX_BYTES
+    assert np.array_equal(buf[:aux_off], img)
+    got = buf[aux_off:tail_off].view(np.uint32).reshape(2, -1)
+    assert np.array_equal(got[:, :256], aux[:, :256])          # the biases; the scale words are not read by this build
+    lo = img.reshape(2, 16, 32, 1024)[:, :, 16:].view(np.float16)
+    # a residual is uniform in +-ulp/2 of 256 w: all but the few closest to zero are normal fp16 numbers (unscaled: almost none)
+    assert np.abs(lo).max() > 0 and (np.abs(lo[lo != 0]) >= 2.0 ** -14).mean() > 0.9
+
+
 @pytest.mark.parametrize('nb,wave', [(2, 0), (3, 3)])
 def test_f16_stream_three_fp16_passes(nb, wave):
     """R2L_PREC_FP16X3 on the body's machine ('f16'): hi(W) hi(a) + hi(W) lo(a) + lo(W) hi(a) as three fp16 MFMAs per
