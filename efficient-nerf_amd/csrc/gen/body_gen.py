@@ -1232,11 +1232,22 @@ def kernel_text(opts):
     a('s_add_u32 %s, %s, %s' % (sreg(S_T0 + 4), sreg(S_XIN), sreg(S_TILEOFF)))
     a('s_addc_u32 %s, %s, %s' % (sreg(S_T0 + 5), sreg(S_XIN + 1), sreg(S_TILEOFF + 1)))
     for i in range(32):
+        if 'xload' in getattr(opts, 'drop', ()):      # diagnostics (wrong results): what the exposed x load of a ray tile costs
+            continue
         a('global_load_dwordx4 %s, %s, %s offset:%d' % (areg(A_X + 4 * i, 4), vreg(V_L0), sreg(S_T0 + 4, 2), (i % 4) * 1024))
         if i % 4 == 3:
             a('s_add_u32 %s, %s, 0x1000' % (sreg(S_T0 + 4), sreg(S_T0 + 4)))
             a('s_addc_u32 %s, %s, 0' % (sreg(S_T0 + 5), sreg(S_T0 + 5)))
     a('s_waitcnt vmcnt(0)')
+    if 'xload2' in getattr(opts, 'drop', ()):      # diagnostics (same results): the x load a second time, exposed like the first
+        a('s_add_u32 %s, %s, %s' % (sreg(S_T0 + 4), sreg(S_XIN), sreg(S_TILEOFF)))
+        a('s_addc_u32 %s, %s, %s' % (sreg(S_T0 + 5), sreg(S_XIN + 1), sreg(S_TILEOFF + 1)))
+        for i in range(32):
+            a('global_load_dwordx4 %s, %s, %s offset:%d sc1' % (areg(A_X + 4 * i, 4), vreg(V_L0), sreg(S_T0 + 4, 2), (i % 4) * 1024))
+            if i % 4 == 3:
+                a('s_add_u32 %s, %s, 0x1000' % (sreg(S_T0 + 4), sreg(S_T0 + 4)))
+                a('s_addc_u32 %s, %s, 0' % (sreg(S_T0 + 5), sreg(S_T0 + 5)))
+        a('s_waitcnt vmcnt(0)')
     # initial split of row tiles 0..6 (tile 7's runs at the head of the loop body)
     if opts.guard:
         a('v_mov_b32 %s, 0' % vreg(V_GMAX))
