@@ -37,6 +37,7 @@ class RangeStatus(C.Structure):
 SIGNATURES = {
     'r2l_last_error': (C.c_char_p, []),
     'r2l_device_count': (C.c_int, []),
+    'r2l_comm_available': (C.c_int, []),
     'r2l_comm_unique_id': (C.c_int, [_vp]),
     'r2l_comm_create': (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
     'r2l_comm_destroy': (None, [_vp]),
@@ -90,6 +91,9 @@ SIGNATURES = {
     'nerf_raw2outputs_noise': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nerf_copy_extras0': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     'nerf_render_rays_ex': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'nerf_timing_enable': (C.c_int, [_vp, C.c_int]),
+    'nerf_kernel_time_ms': (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
+    'r2l_np_legacy_permutation': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_longlong, _vp]),
     'nerf_merge_sorted': (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
 }
 

@@ -4,10 +4,24 @@ reference): random pose + random focal -> teacher render -> [H*W, 9] = (rays_o, 
 shards of `split_size` rays (remainder dropped) -- the on-disk format `BlenderDataset_v2`
 (dataset/load_blender.py:257-324) consumes.
 
-The teacher render is the hot part and runs on the HIP kernels (NeRFEngine).  With several
-ranks the poses of a group are rendered round-robin by rank (by their index inside the group) and
-gathered once per group (one all-gather); every rank then writes the shards k = rank (mod world), so
-the directory is byte-identical for any world size (tests/test_create_data_cpu.py).
+The teacher render is the hot part and runs on the HIP kernels (NeRFEngine); everything else is kept off its
+critical path (round 4; reference loop utils/create_data.py:812-872, which does all of it serially per group):
+
+* the numpy stream is independent of what is rendered, so a PLANNER thread walks it ahead of the GPU: the poses and
+  focal factors of the next groups, and the two 16,000,000-element permutations of each group through the library's
+  restatement of numpy's legacy shuffle (`r2l_np_legacy_permutation`: bit-identical, 0.1-0.2 s instead of 0.5-2.4 s; it
+  releases the GIL);
+* a pose's [H*W, 9] rows are written straight into the group's device slab; at the end of a group ONE device gather
+  applies `data[ix1][ix2] == data[ix1[ix2]]`, ONE device-to-host copy (pinned, on a side stream) brings the rows a rank
+  writes to the host -- the round-3 code did one small gather + copy per shard, 3,906 per group;
+* WRITER threads cut the host buffer into `data_{k}.npy` files while the next group renders.
+
+With several ranks the poses of a group are rendered round-robin by rank (by their index inside the group: balanced for
+any number of groups, also one) and every rank writes the shards k = rank (mod world).  A shard's rows come from all
+poses of the group, so this is the path's one real exchange: ONE all-to-all per group in which a rank receives exactly
+the rows of the shards it writes (576 MB / world at the reference's sizes; round 3 all-gathered the whole 576 MB to
+every rank), sized from the permutation every rank knows.  The directory is byte-identical for any world size
+(tests/test_create_data_cpu.py).
 
 RNG: the reference draws everything from one `np.random.seed(0)` stream
 (create_data.py:18): 2 draws per `get_rand_pose()` (load_blender.py:359-368), 1 per random
@@ -15,11 +29,16 @@ focal (create_data.py:816-818), two `permutation(n)` per saved group (:858-859),
 `load_blender_data` has consumed 200 `get_rand_pose()` calls (load_blender.py:89-90).
 `RandStream` restates that consumption so the generated poses match the reference's.
 """
+import ctypes as C
 import os
+import queue
+import threading
+import time
 
 import numpy as np
 import torch
 
+from . import _lib
 from . import dist as D
 from .frontend import pose_spherical, to8b, write_png
 from .teacher import get_rays
@@ -43,17 +62,193 @@ class RandStream:
         return self.rs.rand() + 1  # focal * (np.random.rand() + 1): [1, 2)
 
     def permutation(self, n):
-        return self.rs.permutation(n)
+        """np.random.permutation(n) of the stream (create_data.py:858-859) as int32 indices: the library's restatement of
+        numpy's legacy shuffle on the stream's own MT19937 state (csrc/np_shuffle.hip), bit-identical to numpy's"""
+        name, key, pos, has_gauss, cached = self.rs.get_state()
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        p = C.c_int(int(pos))
+        out = np.empty(int(n), dtype=np.int32)
+        _lib.check(_lib.lib().r2l_np_legacy_permutation(key.ctypes.data_as(C.c_void_p), C.byref(p), int(n),
+                                                        out.ctypes.data_as(C.c_void_p)))
+        self.rs.set_state((name, key, p.value, has_gauss, cached))
+        return out
+
+
+def _npy_header(shape, dtype=np.float32):
+    """the bytes np.save puts in front of a C-contiguous array of this shape (format 1.0), made by numpy itself"""
+    import io
+    buf = io.BytesIO()
+    np.lib.format.write_array_header_1_0(buf, {'descr': np.lib.format.dtype_to_descr(np.dtype(dtype)), 'fortran_order': False,
+                                               'shape': tuple(int(x) for x in shape)})
+    return buf.getvalue()
+
+
+class _Planner(threading.Thread):
+    """Walks the numpy stream ahead of the renders (it does not depend on them): per group the poses, then the two
+    permutations.  Items arrive in stream order: ('poses', [(i, pose, focal_)...]) for every group incl. the unsaved
+    remainder, ('perm', ix1, ix2) behind every full group."""
+
+    def __init__(self, stream, n_pose_kd, i_save, n_rays, focal, use_rand_focal, depth=2):
+        super().__init__(daemon=True)
+        self.q = queue.Queue(maxsize=2 * depth)
+        self.args = (stream, n_pose_kd, i_save, n_rays, focal, use_rand_focal)
+        self.busy_s = 0.0
+        self.perm_s = 0.0
+
+    def run(self):
+        stream, n_pose_kd, i_save, n_rays, focal, use_rand_focal = self.args
+        try:
+            i = 0
+            while i < n_pose_kd:
+                t0 = time.perf_counter()
+                grp = []
+                for _ in range(min(i_save, n_pose_kd - i)):
+                    i += 1
+                    pose = stream.rand_pose()
+                    grp.append((i, pose, focal * stream.rand_focal_scale() if use_rand_focal else focal))
+                self.busy_s += time.perf_counter() - t0
+                self.q.put(('poses', grp))
+                if len(grp) == i_save:
+                    t0 = time.perf_counter()
+                    n = i_save * n_rays
+                    ix1 = stream.permutation(n)
+                    ix2 = stream.permutation(n)
+                    dt = time.perf_counter() - t0
+                    self.busy_s += dt
+                    self.perm_s += dt
+                    self.q.put(('perm', ix1, ix2))
+            self.q.put(('end',))
+        except BaseException as e:   # the consumer re-raises it
+            self.q.put(('error', e))
+
+    def get(self, kind):
+        item = self.q.get()
+        if item[0] == 'error':
+            raise item[1]
+        assert item[0] == kind, (item[0], kind)
+        return item[1:]
+
+
+class _ShardWriter:
+    """Host threads that cut a group's host buffer into `data_{k}.npy` files while the next group renders.  Files are
+    written as np.save writes them (numpy's own header bytes + the rows)."""
+
+    def __init__(self, datadir, split_size, n_threads=2):
+        self.datadir, self.split_size = datadir, split_size
+        self.header = _npy_header((split_size, 9))
+        self.q = queue.Queue()
+        self.err = []
+        self.busy_s = 0.0
+        self.lock = threading.Lock()
+        self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(n_threads)]
+        for t in self.threads:
+            t.start()
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            try:
+                t0 = time.perf_counter()
+                item()
+                with self.lock:
+                    self.busy_s += time.perf_counter() - t0
+            except BaseException as e:
+                self.err.append(e)
+
+    def put_group(self, host, shard_ids, ready=None, release=None):
+        """host [len(shard_ids) * split_size, 9] f32 (pinned when it comes from the device; `ready`: the event behind its
+        copy); shard k of the list goes to data_{shard_ids[k]}.npy; `release()` when the buffer is free again"""
+        n = len(shard_ids)
+        parts = max(1, min(len(self.threads), n))
+        pending = [parts]
+
+        def job(lo, hi):
+            def run():
+                if ready is not None:
+                    ready.synchronize()
+                rows = host.numpy()
+                for k in range(lo, hi):
+                    with open(os.path.join(self.datadir, f'data_{shard_ids[k]}.npy'), 'wb') as f:
+                        f.write(self.header)
+                        f.write(memoryview(rows[k * self.split_size:(k + 1) * self.split_size]).cast('B'))
+                with self.lock:
+                    pending[0] -= 1
+                    last = pending[0] == 0
+                if last and release is not None:
+                    release()
+            return run
+
+        for t in range(parts):
+            self.q.put(job(n * t // parts, n * (t + 1) // parts))
+
+    def put(self, fn):
+        self.q.put(fn)
+
+    def close(self):
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join()
+        if self.err:
+            raise self.err[0]
+
+
+def _exchange_plan(comb, n_rays, world, rank, shard0, split_size):
+    """Who sends which rows to whom for one save group (every rank computes its own part from the permutation all ranks
+    know).  comb [num] int64 on the compute device: output position p takes global row comb[p] (pose-major: pose j of the
+    group holds rows [j n_rays, (j + 1) n_rays)); position p belongs to shard shard0 + 1 + p // split_size, written by rank
+    (shard id) % world; pose j was rendered by rank j % world into slot j // world of its slab.
+    Returns (send_rows, send_counts, recv_counts, place, shard_ids): rows of the local slab in the order they are sent,
+    how many go to / come from each rank, where the received rows go in this rank's [n_my_shards * split_size, 9] buffer,
+    and the ids of the shards that buffer holds (ascending)."""
+    dev = comb.device
+    num = comb.numel()
+    p = torch.arange(num, device=dev)
+    p_owner = (shard0 + 1 + p // split_size) % world
+    src_pose = comb // n_rays
+    src_owner = src_pose % world
+    local_row = (src_pose // world) * n_rays + comb % n_rays
+    # what this rank sends: its rows, grouped by destination, ascending p inside a destination
+    sel = torch.nonzero(src_owner == rank).squeeze(1)
+    dest = p_owner[sel]
+    order = torch.argsort(dest, stable=True)
+    send_rows = local_row[sel][order]
+    send_counts = torch.bincount(dest, minlength=world).tolist()
+    # what it receives: the positions of its shards, arriving grouped by source, ascending p inside a source
+    mine = torch.nonzero(p_owner == rank).squeeze(1)
+    src = src_owner[mine]
+    place = torch.argsort(src, stable=True)      # received row k belongs at local position place[k]
+    recv_counts = torch.bincount(src, minlength=world).tolist()
+    n_shards = num // split_size
+    shard_ids = [k for k in range(shard0 + 1, shard0 + n_shards + 1) if k % world == rank]
+    assert mine.numel() == len(shard_ids) * split_size
+    return send_rows, send_counts, recv_counts, place, shard_ids
+
+
+def _all_to_all_rows(send, send_counts, recv_counts, group=None):
+    """ONE all-to-all of [n, 9] f32 rows (RCCL over xGMI under the nccl backend; a gloo rehearsal with device tensors goes
+    through the host)"""
+    import torch.distributed as tdist
+    out = torch.empty((sum(recv_counts), send.shape[1]), dtype=send.dtype, device=send.device)
+    if send.is_cuda and tdist.get_backend(group) == 'gloo':
+        host = torch.empty(out.shape, dtype=out.dtype)
+        tdist.all_to_all_single(host, send.cpu(), recv_counts, send_counts, group=group)
+        out.copy_(host)
+    else:
+        tdist.all_to_all_single(out, send.contiguous(), recv_counts, send_counts, group=group)
+    return out
 
 
 def create_rand(engine, H, W, focal, n_pose_kd, datadir_new, use_rand_focal=True, i_save=100, split_size=4096,
-                stream=None, rm_existing_data=False, log=print, save_png=5, get_rays_fn=None):
+                stream=None, rm_existing_data=False, log=print, save_png=5, get_rays_fn=None, timings=None, writer_threads=2):
     """Returns the number of `.npy` shards of this call (the same on every rank).
 
     Multi-rank (torch.distributed initialised): pose j of a save group (j = index INSIDE the group) is rendered
-    by rank j % world; one all-gather per group puts the whole group on every rank; every rank applies the two
-    permutations (all ranks draw the same numpy stream) and writes the shards k with k % world == rank, so the
-    directory is byte-identical for any world size."""
+    by rank j % world; ONE all-to-all per group hands every rank the rows of the shards it writes (k % world == rank)
+    under the group's two permutations (all ranks draw the same numpy stream), so the directory is byte-identical for
+    any world size.  `timings` (dict, optional) receives the wall-clock split of the call."""
     import torch.distributed as tdist
     world = tdist.get_world_size() if tdist.is_initialized() else 1
     rank = tdist.get_rank() if tdist.is_initialized() else 0
@@ -70,96 +265,162 @@ def create_rand(engine, H, W, focal, n_pose_kd, datadir_new, use_rand_focal=True
     if world > 1:
         tdist.barrier()  # everybody has counted before anybody writes
     first_split = split
-    dev = engine.device
-    group = []  # (index in group, [H*W, 9]) rendered by this rank
-    for i in range(1, n_pose_kd + 1):
-        pose = stream.rand_pose()                       # every rank advances the same stream
-        focal_ = focal * stream.rand_focal_scale() if use_rand_focal else focal
-        j = (i - 1) % i_save                            # index inside the save group
-        if j % world == rank:
-            rays_o, rays_d = get_rays_fn(H, W, focal_, pose[:3, :4], device=dev)  # get_rays1 (:819)
-            out = engine.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3))
-            data_ = torch.cat([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), out['rgb_map']], dim=-1)  # [H*W, 9]
-            group.append((j, data_))
-            if i <= save_png:
-                write_png(os.path.join(datadir_new, f'pseudo_sample_{i}.png'),
-                          to8b(out['rgb_map'].view(H, W, 3).cpu().numpy()))
-        if i % i_save == 0:
-            data = _assemble_group(group, i_save, H * W, world, dev)
-            group = []
-            # shuffle rays: data[rand_ix1][rand_ix2] == data[rand_ix1[rand_ix2]]  (:858-860)
-            ix1 = stream.permutation(data.shape[0])
-            ix2 = stream.permutation(data.shape[0])
-            comb = torch.from_numpy(ix1[ix2])
-            num = data.shape[0] // split_size * split_size
-            for ix in range(0, num, split_size):
-                split += 1
-                if split % world == rank:
-                    rows = data[comb[ix:ix + split_size].to(dev)].cpu().numpy()
-                    np.save(os.path.join(datadir_new, f'data_{split}.npy'), rows)
-            log(f'[{i}/{n_pose_kd}] Saved data at "{datadir_new}"')
+    dev = torch.device(engine.device)
+    on_gpu = dev.type == 'cuda'
+    n_rays = H * W
+    per_rank = (i_save + world - 1) // world
+    num = i_save * n_rays // split_size * split_size          # rows of a group that reach a shard (remainder dropped, :864)
+    t_wall = time.perf_counter()
+    planner = _Planner(stream, n_pose_kd, i_save, n_rays, focal, use_rand_focal)
+    planner.start()
+    writer = _ShardWriter(datadir_new, split_size, writer_threads)
+    slab = torch.empty((per_rank, n_rays, 9), dtype=torch.float32, device=dev)     # this rank's poses of the current group
+    copy_stream = torch.cuda.Stream(device=dev) if on_gpu else None
+    free_host = queue.Queue()     # pinned host buffers coming back from the writer (two in flight at most)
+    n_host = 0
+    shard_buf = [None, None]      # device rows of the group being copied out / of the one before
+    d2h_done = [None, None]
+    ev_pairs = []                 # (assemble start, assemble end, d2h end) per group
+    timing = on_gpu and hasattr(engine, 'kernel_time_ms')
+    if timing:
+        engine.timing(True)
+        engine.kernel_time_ms(reset=True)
+    t_render_done = None
+    g = 0
+    i_done = 0
+    while i_done < n_pose_kd:
+        (grp,) = planner.get('poses')
+        for i, pose, focal_ in grp:
+            j = (i - 1) % i_save                            # index inside the save group
+            if j % world == rank:
+                rays_o, rays_d = get_rays_fn(H, W, focal_, pose[:3, :4], device=dev)  # get_rays1 (:819)
+                out = engine.render_rays(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3))
+                torch.cat([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), out['rgb_map']], dim=-1, out=slab[j // world])  # [H*W, 9]
+                if i <= save_png:
+                    img = out['rgb_map'].view(H, W, 3).cpu().numpy()
+                    path = os.path.join(datadir_new, f'pseudo_sample_{i}.png')
+                    writer.put(lambda img=img, path=path: write_png(path, to8b(img)))
+        i_done = grp[-1][0]
+        if len(grp) < i_save:
+            break        # the remainder of the last group is rendered and never flushed, as in the reference (:855)
+        if on_gpu:
+            t_render_done = torch.cuda.Event(enable_timing=True)
+            t_render_done.record()
+        ix1, ix2 = planner.get('perm')
+        # shuffle rays: data[rand_ix1][rand_ix2] == data[rand_ix1[rand_ix2]]  (:858-860); only the first `num` rows are kept
+        ix1_d = torch.from_numpy(ix1).to(dev)
+        ix2_d = torch.from_numpy(ix2[:num]).to(dev)
+        e0 = e1 = e2 = None
+        if on_gpu:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            if d2h_done[g % 2] is not None:
+                torch.cuda.current_stream().wait_event(d2h_done[g % 2])    # the copy that read this device buffer last
+        comb = ix1_d[ix2_d.long()].long()
+        flat = slab.view(-1, 9)
+        if world == 1:
+            rows = flat.index_select(0, comb)
+            shard_ids = list(range(split + 1, split + num // split_size + 1))
+        else:
+            send_rows, send_counts, recv_counts, place, shard_ids = _exchange_plan(comb, n_rays, world, rank, split, split_size)
+            got = _all_to_all_rows(flat.index_select(0, send_rows), send_counts, recv_counts)
+            rows = torch.empty_like(got)
+            rows[place] = got
+        del comb, ix1_d, ix2_d
+        split += num // split_size
+        if on_gpu:
+            shard_buf[g % 2] = rows
+            e1.record()
+            try:
+                host = free_host.get_nowait()
+            except queue.Empty:
+                if n_host < 2:
+                    host = torch.empty((rows.shape[0], 9), dtype=torch.float32, pin_memory=True)
+                    n_host += 1
+                else:
+                    host = free_host.get()        # both buffers still being written: the writer is the bottleneck
+            copy_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(copy_stream):
+                host[:rows.shape[0]].copy_(rows, non_blocking=True)
+                e2.record(copy_stream)
+            d2h_done[g % 2] = e2
+            ev_pairs.append((e0, e1, e2))
+            writer.put_group(host[:rows.shape[0]], shard_ids, ready=e2, release=lambda host=host: free_host.put(host))
+        else:
+            writer.put_group(rows, shard_ids)
+        g += 1
+        log(f'[{i_done}/{n_pose_kd}] Saved data at "{datadir_new}"')
+    t_loop_end = time.perf_counter()
+    tail_from = None
+    if on_gpu and t_render_done is not None:
+        t_render_done.synchronize()
+        tail_from = time.perf_counter()
+    writer.close()
+    planner.join()
+    if on_gpu:
+        torch.cuda.synchronize(dev)
     if world > 1:
         tdist.barrier()  # all shards are on disk when any rank returns
+    t_end = time.perf_counter()
+    if timings is not None:
+        timings.update(wall_s=t_end - t_wall, loop_s=t_loop_end - t_wall, groups=g, poses=i_done, world=world,
+                       shards=split - first_split, planner_busy_s=planner.busy_s, permutation_s=planner.perm_s,
+                       writer_busy_s=writer.busy_s, writer_threads=writer_threads)
+        if tail_from is not None:
+            # what follows the last group's last render: its shuffle, exchange, copy and file writes -- the only ones nothing overlaps
+            timings['tail_s'] = t_end - tail_from
+        if ev_pairs:
+            timings['assemble_ms'] = sum(a.elapsed_time(b) for a, b, _ in ev_pairs)
+            timings['d2h_ms'] = sum(b.elapsed_time(c) for _, b, c in ev_pairs)
+        if timing:
+            ms, n = engine.kernel_time_ms(reset=True)
+            engine.timing(False)
+            timings['mlp_kernel_ms'] = ms
+            timings['mlp_launches'] = n
     return split - first_split
 
 
-def _assemble_group(group, n_in_group, n_rays, world, dev):
-    """All poses of a save group in pose order, on every rank: [n_in_group * n_rays, 9].
-    `group`: this rank's (index in group j, data) with j % world == rank."""
-    group = sorted(group, key=lambda x: x[0])
-    if world == 1:
-        assert [j for j, _ in group] == list(range(n_in_group))
-        return torch.cat([d for _, d in group], 0)
-    per_rank = (n_in_group + world - 1) // world
-    slab = torch.zeros((per_rank, n_rays, 9), dtype=torch.float32, device=dev)
-    for j, d in group:
-        slab[j // world] = d   # pose j sits on rank j % world in slot j // world
-    out = D.all_gather_cat(slab).view(world, per_rank, n_rays, 9)
-    return torch.cat([out[j % world, j // world] for j in range(n_in_group)], 0)
-
-
 class BlenderDataset_v2:
-    """Reader of the shard directory `create_rand` writes, with the indexing of the reference's
-    `BlenderDataset_v2` (dataset/load_blender.py:257-324): item k = file k of the listing -> (rays_o [n,3],
-    rays_d [n,dim_dir], rgb [n,dim_rgb]); `train_*.npy` files are the original data, the rest pseudo data;
-    pseudo_ratio / hold_ratio sub-sample the file list with np.random.choice exactly as the reference does."""
+    """Reader of a shard directory: item k -> (rays_o [n,3], rays_d [n,dim_dir], rgb [n,dim_rgb]) of file k.
+
+    Same constructor arguments and selection rule as the reference's class of this name (dataset/load_blender.py:257-324),
+    because a training script that switches libraries must see the same files in the same order with the same numpy draws:
+    `train_*.npy` are original data, everything else pseudo data; pseudo_ratio r keeps int(n_orig / (1 - r)) - n_orig
+    randomly chosen pseudo files (np.random.choice, with replacement) beside all originals, -1 keeps everything;
+    hold_ratio drops a random share of the result; rand_crop_size > 0 cuts a random square out of [H, W, 9] files."""
 
     def __init__(self, datadir, dim_dir=3, dim_rgb=3, rand_crop_size=-1, img_H=0, img_W=0, hold_ratio=0, pseudo_ratio=1.):
-        self.datadir = datadir
-        names = os.listdir(datadir)
-        pseudo = [f'{datadir}/{x}' for x in names if x.endswith('.npy') and not x.startswith('train_')]
-        original = [f'{datadir}/{x}' for x in names if x.endswith('.npy') and x.startswith('train_')]
-        assert 0 <= pseudo_ratio <= 1 or pseudo_ratio == -1
-        if pseudo_ratio == -1 or (pseudo_ratio == 1 and not original):  # use all the data
-            all_splits = pseudo + original
-        else:
+        if not (0 <= pseudo_ratio <= 1 or pseudo_ratio == -1) or not 0 <= hold_ratio < 1:
+            raise ValueError(f'pseudo_ratio={pseudo_ratio} hold_ratio={hold_ratio}')
+        listing = [x for x in os.listdir(datadir) if x.endswith('.npy')]
+        is_orig = [x.startswith('train_') for x in listing]
+        pseudo = [f'{datadir}/{x}' for x, o in zip(listing, is_orig) if not o]
+        original = [f'{datadir}/{x}' for x, o in zip(listing, is_orig) if o]
+        if pseudo_ratio != -1 and not (pseudo_ratio == 1 and not original):
             if pseudo_ratio == 1:
                 raise ValueError('pseudo_ratio = 1 with original data present divides by zero in the reference '
                                  '(load_blender.py:288-289); pass -1 to use everything')
-            num_pseudo = int(len(original) / (1. - pseudo_ratio)) - len(original)
-            pseudo = np.random.choice(pseudo, num_pseudo).tolist()
-            all_splits = pseudo + original
-        assert 0 <= hold_ratio < 1
+            keep = int(len(original) / (1. - pseudo_ratio)) - len(original)
+            pseudo = np.random.choice(pseudo, keep).tolist()
+        files = pseudo + original
         if hold_ratio > 0:
-            all_splits = np.random.choice(all_splits, int(len(all_splits) * (1 - hold_ratio)))
-        self.all_splits = all_splits
+            files = np.random.choice(files, int(len(files) * (1 - hold_ratio)))
+        self.datadir, self.all_splits = datadir, files
+        self.cols = (slice(0, 3), slice(3, 3 + dim_dir), slice(3 + dim_dir, 3 + dim_dir + dim_rgb))
         self.dim_dir, self.dim_rgb = dim_dir, dim_rgb
         self.rand_crop_size, self.img_H, self.img_W = rand_crop_size, img_H, img_W
 
-    def _square_rand_bbox(self):
-        bbx1 = np.random.randint(0, self.img_W - self.rand_crop_size + 1)
-        bby1 = np.random.randint(0, self.img_H - self.rand_crop_size + 1)
-        return bbx1, bby1, bbx1 + self.rand_crop_size, bby1 + self.rand_crop_size
-
-    def __getitem__(self, index):
-        d = torch.from_numpy(np.load(self.all_splits[index])).float()  # [H, W, 9] or [n_ray, 9]
-        if self.rand_crop_size > 0:
-            bbx1, bby1, bbx2, bby2 = self._square_rand_bbox()
-            d = d[bby1:bby2, bbx1:bbx2, :]
-        return d[..., :3], d[..., 3:3 + self.dim_dir], d[..., 3 + self.dim_dir:3 + self.dim_dir + self.dim_rgb]
-
     def __len__(self):
         return len(self.all_splits)
+
+    def __getitem__(self, index):
+        rows = torch.from_numpy(np.load(self.all_splits[index])).float()
+        c = self.rand_crop_size
+        if c > 0:     # x first, then y: the order of the reference's two randint draws
+            x0 = np.random.randint(0, self.img_W - c + 1)
+            y0 = np.random.randint(0, self.img_H - c + 1)
+            rows = rows[y0:y0 + c, x0:x0 + c]
+        return tuple(rows[..., s] for s in self.cols)
 
 
 def main(argv=None):
@@ -187,13 +448,15 @@ def main(argv=None):
     torch.cuda.set_device(D.local_device(local_rank))
     ckpt = fe.load_checkpoint(own.teacher_ckpt)
     _, (H, W, focal) = fe.load_test_poses(args)
-    prec = PRECISIONS[args.precision]
+    prec = PRECISIONS['fp16_fp8' if args.precision == 'auto' else args.precision]
     eng = NeRFEngine(H, W, focal, 2., 6., N_samples=args.N_samples, N_importance=args.N_importance,
                      white_bkgd=args.white_bkgd, precision=prec)
     eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
+    tm = {}
     n = create_rand(eng, H, W, focal, own.n_pose_kd, own.datadir_kd.split(':')[1], not own.no_rand_focal,
                     i_save=own.create_data_chunk, split_size=own.split_size, rm_existing_data=own.rm_existing_data,
-                    log=print if rank == 0 else (lambda *a, **k: None))
+                    log=print if rank == 0 else (lambda *a, **k: None), timings=tm)
     if rank == 0:
-        print(f'wrote {n} shard(s) of {own.split_size} rays')
+        print(f'wrote {n} shard(s) of {own.split_size} rays; {tm["poses"]} poses in {tm["wall_s"]:.2f} s = '
+              f'{tm["poses"] / tm["wall_s"]:.2f} poses/s on {world} GPU(s)')
     return 0

@@ -210,6 +210,10 @@ struct nerf_ctx {
     float *d_rays_o = nullptr, *d_rays_d = nullptr, *d_raw0 = nullptr, *d_w0 = nullptr, *d_zs = nullptr,
           *d_zall = nullptr, *d_raw = nullptr, *d_rgb0 = nullptr, *d_disp0 = nullptr, *d_acc0 = nullptr,
           *d_ndc_o = nullptr, *d_ndc_d = nullptr, *d_vdir = nullptr;
+    // HIP-event timing of the MLP launches (nerf_timing_enable / nerf_kernel_time_ms), on the stream they are launched on
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    int ev_used = 0;
 };
 
 static void free_tmp(nerf_ctx* c) {
@@ -308,6 +312,7 @@ void nerf_destroy(nerf_ctx* c) {
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_zmid) (void)hipFree(c->d_zmid);
     if (c->d_u) (void)hipFree(c->d_u);
+    for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -453,8 +458,45 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     p.neg1 = -1.0f;
     memcpy(p.inv_scale, c->net[which].inv_scale[c->mode], sizeof p.inv_scale);
     const int grid = balanced_grid(p.n_tiles, c->n_cu);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        if (c->ev_used + 2 > (int)c->ev.size())
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t ev;
+                hipError_t er = hipEventCreate(&ev);
+                if (er != hipSuccess) return r2l_set_error(R2L_EHIP, "hipEventCreate: %s", hipGetErrorString(er));
+                c->ev.push_back(ev);
+            }
+        e0 = c->ev[c->ev_used];
+        e1 = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+        (void)hipEventRecord(e0, s);
+    }
     hipError_t e = nerf_launch_mlp(p, c->mode, grid, s);
+    if (c->timing) (void)hipEventRecord(e1, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
+    return R2L_OK;
+}
+
+int nerf_timing_enable(nerf_ctx* c, int on) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    c->timing = on != 0;
+    return R2L_OK;
+}
+
+int nerf_kernel_time_ms(nerf_ctx* c, double* total_ms, int* n_launches, int reset) {
+    if (!c || !total_ms || !n_launches) return r2l_set_error(R2L_EINVAL, "NULL argument");
+    double tot = 0;
+    for (int i = 0; i + 1 < c->ev_used; i += 2) {
+        hipError_t e = hipEventSynchronize(c->ev[i + 1]);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "event timing: %s", hipGetErrorString(e));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *n_launches = c->ev_used / 2;
+    if (reset) c->ev_used = 0;
     return R2L_OK;
 }
 

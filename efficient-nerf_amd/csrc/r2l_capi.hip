@@ -164,10 +164,14 @@ struct r2l_ctx {
     int calib_pending = 0;                    // the next FP16_FP8 render derives them from its own head output (device side)
     int calib_started = 0;                    // maxima of earlier, smaller calls are in d_stats: the next measurement adds to them
     int calib_calls = 0;                      // thin calls the open measurement has seen (closed after R2L_CALIB_MAX_CALLS)
-    // range tracking (r2l_get_range_status): d_range[0] = max h0 of EVERY ray since the last reset (head launch);
-    // d_gstats[2 n_block] = maxima of every operand set over every ray of the guarded body launches since the last reset
+    // range tracking (r2l_get_range_status), ONE allocation so that the host reads it with one copy:
+    // d_range[0] = max h0 of EVERY ray since the last reset (head launch), [1..3] spare;
+    // d_gstats = d_range + 4: [2 n_block + 1] maxima of every operand set over every ray of the guarded body launches since
+    // the last reset; d_exps = d_gstats + 2 n_block + 1: [2 n_block + 1] the activation exponents in use (what the aux blocks
+    // hold, written beside them by the calibration kernels and by r2l_set_act_exponents)
     unsigned* d_range = nullptr;
     unsigned* d_gstats = nullptr;
+    int* d_exps = nullptr;
     int guard_period = R2L_GUARD_PERIOD_DEFAULT;
     long long n_body = 0, n_guarded = 0;      // FP16_FP8 body launches since the last reset / of them guarded
     long long n_since_load = 0;               // ... since r2l_load_weights (the guard's phase)
@@ -268,8 +272,7 @@ void r2l_destroy(r2l_ctx* c) {
     if (c->d_xb) (void)hipFree(c->d_xb);
     if (c->d_wcal) (void)hipFree(c->d_wcal);
     if (c->d_stats) (void)hipFree(c->d_stats);
-    if (c->d_range) (void)hipFree(c->d_range);
-    if (c->d_gstats) (void)hipFree(c->d_gstats);
+    if (c->d_range) (void)hipFree(c->d_range);   // d_gstats, d_exps: the same allocation
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_z) (void)hipFree(c->d_z);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -338,14 +341,21 @@ static int build_image(r2l_ctx* c, int mode) {
             if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "calibration operands: %s", hipGetErrorString(eb));
         }
         // range tracking words; the h0 buffer of the context's own frame: nothing is allocated inside a render of <= H x W rays
-        if (!c->d_range) eb = hipMalloc((void**)&c->d_range, 4 * sizeof(unsigned));
-        if (eb == hipSuccess && c->d_gstats) {
-            (void)hipFree(c->d_gstats);
-            c->d_gstats = nullptr;
+        const size_t nset1 = (size_t)2 * c->n_block + 1;
+        if (!c->d_range) {
+            eb = hipMalloc((void**)&c->d_range, (4 + 2 * nset1) * sizeof(unsigned));
+            if (eb == hipSuccess) {
+                c->d_gstats = c->d_range + 4;
+                c->d_exps = reinterpret_cast<int*>(c->d_gstats + nset1);
+            }
         }
-        if (eb == hipSuccess) eb = hipMalloc((void**)&c->d_gstats, (size_t)(2 * c->n_block + 1) * sizeof(unsigned));
-        if (eb == hipSuccess) eb = hipMemset(c->d_range, 0, 4 * sizeof(unsigned));
-        if (eb == hipSuccess) eb = hipMemset(c->d_gstats, 0, (size_t)(2 * c->n_block + 1) * sizeof(unsigned));
+        if (eb == hipSuccess) eb = hipMemset(c->d_range, 0, (4 + nset1) * sizeof(unsigned));
+        if (eb == hipSuccess) {      // the exponents pack_body_v3 has just put into the aux blocks
+            std::vector<int> ex(nset1);
+            for (size_t j = 0; j < nset1; ++j) ex[j] = j < c->act.size() ? c->act[j] : R2L_ACT_EXP;
+            if (c->n_block > 0) ex[nset1 - 1] = ex[0];
+            eb = hipMemcpy(c->d_exps, ex.data(), nset1 * sizeof(int), hipMemcpyHostToDevice);
+        }
         if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "range tracking words: %s", hipGetErrorString(eb));
         c->n_body = c->n_guarded = c->n_since_load = 0;
         {
@@ -710,17 +720,13 @@ int r2l_set_act_exponents(r2l_ctx* c, const int* exps, int n) {
             return r2l_set_error(R2L_EINVAL, "exponent %d = %d outside [%d, %d]", i, exps[i], R2L_ACT_EXP_MIN, R2L_ACT_EXP_MAX);
     c->act.assign(exps, exps + n);
     c->calib_pending = 0;
-    if (c->d_body) {        // patch the aux blocks of the uploaded stream
-        for (int b = 0; b < c->n_block; ++b) {
-            uint32_t v[8];
-            for (int half = 0; half < 2; ++half) {
-                for (int i = 0; i < 3; ++i) v[4 * half + i] = (uint32_t)(127 + c->act[(b == c->n_block - 1 && i == 2) ? 0 : 2 * b + i]);
-                v[4 * half + 3] = 0;
-            }
-            hipError_t e = hipMemcpy(c->d_body + c->aux_off + (size_t)b * R2L_BODY_AUX_BYTES + R2L_BODY_AUX_ACT, v, sizeof v,
-                                     hipMemcpyHostToDevice);
-            if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy exponents: %s", hipGetErrorString(e));
-        }
+    if (c->d_body && c->n_block > 0) {   // one copy into the contiguous array, one launch that spreads it into the aux blocks
+        std::vector<int> ex(c->act);
+        ex[n - 1] = ex[0];
+        hipError_t e = hipMemcpy(c->d_exps, ex.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = r2l_launch_spread_exponents(c->d_exps, c->n_block, c->d_body + c->aux_off, c->last_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->last_stream);
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "exponents to the device: %s", hipGetErrorString(e));
     }
     return R2L_OK;
 }
@@ -732,16 +738,10 @@ int r2l_get_act_exponents(r2l_ctx* c, int* out, int n) {
         for (int i = 0; i < n; ++i) out[i] = i < (int)c->act.size() ? c->act[i] : R2L_ACT_EXP;
         return R2L_OK;
     }
-    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);   // a calibration enqueued there writes the aux blocks
-    for (int b = 0; b < c->n_block; ++b) {   // what the kernel reads (after a device-side calibration: only there)
-        uint32_t v[4];
-        hipError_t e = hipMemcpy(v, c->d_body + c->aux_off + (size_t)b * R2L_BODY_AUX_BYTES + R2L_BODY_AUX_ACT, sizeof v,
-                                 hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy exponents: %s", hipGetErrorString(e));
-        out[2 * b] = (int)v[0] - 127;
-        out[2 * b + 1] = (int)v[1] - 127;
-        if (b < c->n_block - 1) out[2 * b + 2] = (int)v[2] - 127;
-    }
+    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);   // a calibration enqueued there writes them
+    // what the kernel reads: after a device-side calibration it exists only there (the aux blocks and this array beside them)
+    hipError_t e = hipMemcpy(out, c->d_exps, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy exponents: %s", hipGetErrorString(e));
     out[2 * c->n_block] = out[0];   // the tail reads x itself; the slot holds the next tile's first input set
     return R2L_OK;
 }
@@ -757,11 +757,6 @@ int r2l_set_guard_period(r2l_ctx* c, int period) {
     return R2L_OK;
 }
 
-static int read_exponents(r2l_ctx* c, std::vector<int>& ex) {
-    ex.assign((size_t)2 * c->n_block + 1, R2L_ACT_EXP);
-    return c->n_block > 0 ? r2l_get_act_exponents(c, ex.data(), (int)ex.size()) : R2L_OK;
-}
-
 int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
     if (!c || !out) return r2l_set_error(R2L_EINVAL, "NULL argument");
     memset(out, 0, sizeof *out);
@@ -769,15 +764,15 @@ int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
     if (!c->loaded || !c->d_range || !c->d_gstats || !scaled_mode(c->mode))
         return r2l_set_error(R2L_ESTATE, "r2l_get_range_status needs loaded weights and R2L_PREC_FP16_FP8 / R2L_PREC_FP16_E4M3 "
                                          "(the other modes have no operand scales to watch)");
-    std::vector<int> ex;
-    int rc = read_exponents(c, ex);      // synchronises the stream of the newest render
-    if (rc) return rc;
+    // ONE copy: range words | maxima of the guarded launches | exponents in use (one allocation, see r2l_ctx)
     const int nset = 2 * c->n_block;
-    std::vector<unsigned> g((size_t)nset + 1);
-    unsigned r[4];
-    hipError_t e = hipMemcpy(r, c->d_range, sizeof r, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(g.data(), c->d_gstats, g.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+    std::vector<unsigned> words((size_t)4 + 2 * (nset + 1));
+    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
+    hipError_t e = hipMemcpy(words.data(), c->d_range, words.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy range words: %s", hipGetErrorString(e));
+    const unsigned* r = words.data();
+    const unsigned* g = r + 4;
+    const int* ex = reinterpret_cast<const int*>(g + nset + 1);
     auto f = [](unsigned u) { float v; memcpy(&v, &u, 4); return v; };
     // largest magnitude of the operand format: bf6 (e3m2) 28, e4m3 448; the calibration aims at <= 16 in both
     const float top = c->mode == R2L_PREC_FP16_E4M3 ? 448.0f : 28.0f;
@@ -799,8 +794,7 @@ int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
     out->launches = c->n_body;
     out->guarded_launches = c->n_guarded;
     if (reset) {
-        e = hipMemset(c->d_range, 0, sizeof r);
-        if (e == hipSuccess) e = hipMemset(c->d_gstats, 0, g.size() * sizeof(unsigned));
+        e = hipMemset(c->d_range, 0, (size_t)(4 + nset + 1) * sizeof(unsigned));
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemset range words: %s", hipGetErrorString(e));
         c->n_body = c->n_guarded = 0;
     }
@@ -812,7 +806,7 @@ int r2l_recalibrate(r2l_ctx* c, void* stream) {
     if (!c->loaded || !c->d_gstats || c->n_block < 1)
         return r2l_set_error(R2L_ESTATE, "r2l_recalibrate needs loaded weights, R2L_PREC_FP16_FP8 and n_block >= 1");
     if (c->n_guarded < 1) return r2l_set_error(R2L_ESTATE, "r2l_recalibrate: no guarded launch since the last reset of the range words");
-    hipError_t e = r2l_launch_recalibrate(c->d_gstats, c->d_range, c->n_block, c->d_body + c->aux_off, (hipStream_t)stream);
+    hipError_t e = r2l_launch_recalibrate(c->d_gstats, c->d_range, c->n_block, c->d_body + c->aux_off, c->d_exps, (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "recalibration launch: %s", hipGetErrorString(e));
     c->calib_pending = 0;
     c->last_stream = (hipStream_t)stream;
@@ -899,7 +893,7 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     if (c->calib_pending && scaled_mode(c->mode)) {   // as a render would: the exponents of these weights on this input
         c->calib_pending = 0;
         hipError_t ec = r2l_launch_calib(x_in_dev, c->d_wcal, c->n_block, n_tiles, c->act_scale, c->d_stats,
-                                         c->d_body + c->aux_off, 0, (hipStream_t)stream);
+                                         c->d_body + c->aux_off, c->d_exps, 0, (hipStream_t)stream);
         if (ec != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l calibration launch: %s", hipGetErrorString(ec));
     }
     R2LBodyParams pb;
@@ -1030,7 +1024,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             // a call of fewer than R2L_CALIB_TILES ray tiles is a thin sample: its maxima count, but the measurement stays open
             // and the next call adds its own (exponents only grow), until one call has filled the sample
             e = r2l_launch_calib(c->d_xa, c->d_wcal, c->n_block, nt, c->act_scale, c->d_stats, c->d_body + c->aux_off,
-                                 c->calib_started, s);
+                                 c->d_exps, c->calib_started, s);
             c->calib_started = 1;
             if (nt >= R2L_CALIB_TILES || ++c->calib_calls >= R2L_CALIB_MAX_CALLS) c->calib_pending = 0;
             if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l calibration launch: %s", hipGetErrorString(e));

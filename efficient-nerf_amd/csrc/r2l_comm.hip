@@ -82,6 +82,8 @@ struct r2l_comm {
         if (r_ != ncclSuccess) return r2l_set_error(R2L_EHIP, what ": %s", g_api.GetErrorString(r_));            \
     } while (0)
 
+int r2l_comm_available(void) { return need_rccl(); }
+
 int r2l_comm_unique_id(char* id_out128) {
     if (!id_out128) return r2l_set_error(R2L_EINVAL, "NULL id");
     int rc = need_rccl();

@@ -54,10 +54,13 @@ hipError_t r2l_launch_tail(const R2LTailParams& p, hipStream_t stream);
 // results land in the aux blocks at `aux` (n_block x R2L_BODY_AUX_BYTES); wcal: per block W1^T | b1' | W2^T in fp32
 #define R2L_CALIB_TILES 8   // ray tiles (1,024 rays) the activation-range measurement samples from one call
 // accumulate != 0: keep the maxima already in stats (earlier calls with fewer tiles than the sample)
+// exps: the same 2 n_block + 1 exponents as one contiguous int array (what the host reads back, one copy)
 hipError_t r2l_launch_calib(const float* xa, const float* wcal, int n_block, int n_tiles, float act_scale, unsigned* stats,
-                            char* aux, int accumulate, hipStream_t stream);
+                            char* aux, int* exps, int accumulate, hipStream_t stream);
 // exponents from the range guard's maxima (gstats: 2 n_block sets, act_scale domain) and the head's h0 maximum (range[0])
-hipError_t r2l_launch_recalibrate(const unsigned* gstats, const unsigned* range, int n_block, char* aux, hipStream_t stream);
+hipError_t r2l_launch_recalibrate(const unsigned* gstats, const unsigned* range, int n_block, char* aux, int* exps, hipStream_t stream);
+// r2l_set_act_exponents: exps (device, contiguous) -> the aux blocks
+hipError_t r2l_launch_spread_exponents(const int* exps, int n_block, char* aux, hipStream_t stream);
 int r2l_body_lds_bytes();
 int r2l_body_guard_max_blocks(int e4m3);   // largest n_block whose 2 n_block maxima rows fit the LDS beside the ring
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,

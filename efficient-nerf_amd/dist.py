@@ -62,10 +62,14 @@ class RowGather:
         idbuf = (C.c_char * 128)()
         # every step below is agreed on by all ranks before anyone acts on it: a rank that failed alone would otherwise
         # fall back to torch.distributed while its peers wait inside the RCCL bootstrap.  Pre-flight: can every rank bind
-        # RCCL at all (r2l_comm_unique_id binds it; only rank 0's id is used)?
+        # RCCL at all?  Rank 0 makes the id (ncclGetUniqueId opens the bootstrap socket and its root thread: once, where it
+        # is used); the others only bind the library (r2l_comm_available)
         err = ''
         try:
-            _lib.check(_lib.lib().r2l_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+            if rank == 0:
+                _lib.check(_lib.lib().r2l_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+            else:
+                _lib.check(_lib.lib().r2l_comm_available())
         except Exception as e:
             err = str(e) or repr(e)
         if world > 1:
@@ -225,21 +229,22 @@ def agree_act_exponents(eng, group=None):
 
 
 def check_ranges(eng, log=None, group=None):
-    """R2LEngine.check_ranges for row-sharded runs: a rank whose rows left the calibrated bf6 range makes EVERY rank raise
-    its exponents to the common maximum (and fall back together when `--precision auto`'s limit is exceeded), so the rows
-    of one assembled frame never come from different arithmetic.  Returns None or the precision to render the frame
-    again with.  One small all-reduce per call; plain eng.check_ranges for one rank."""
+    """R2LEngine.check_ranges for row-sharded runs: a rank whose rows left the calibrated range makes EVERY rank act
+    -- render range-guarded ('measure'), raise its exponents to the common maximum, fall back together when `--precision
+    auto`'s limit is exceeded --, so the rows of one assembled frame never come from different arithmetic.  Returns None or
+    the reason to render the batch again (R2LEngine.check_ranges).  ONE small all-reduce per call when nothing trips (the
+    three flags travel together); plain eng.check_ranges for one rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return eng.check_ranges(log=log)
 
-    def any_rank(flag):
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    def rank_max(vals):      # list of ints -> their element-wise maximum over the ranks
+        t = torch.tensor([int(v) for v in vals], dtype=torch.int32)
         if dist.get_backend(group) == 'nccl':
             t = t.to(eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        return bool(t.item())
+        return [int(x) for x in t.cpu()]
 
-    return eng.check_ranges(log=log, any_rank=any_rank, agree=lambda e: agree_act_exponents(e, group))
+    return eng.check_ranges(log=log, rank_max=rank_max, agree=lambda e: agree_act_exponents(e, group))
 
 
 def barrier_sync():

@@ -273,7 +273,9 @@ def write_png(path, rgb8):
     """Minimal 8-bit RGB / RGBA PNG writer (imageio is not a dependency here)."""
     h, w, ch = rgb8.shape
     assert ch in (3, 4) and rgb8.dtype == np.uint8
-    raw = b''.join(b'\x00' + rgb8[y].tobytes() for y in range(h))
+    rows = np.zeros((h, 1 + w * ch), dtype=np.uint8)      # filter byte 0 in front of every scanline
+    rows[:, 1:] = rgb8.reshape(h, w * ch)
+    raw = rows.tobytes()
 
     def chunk(tag, data):
         c = struct.pack('>I', len(data)) + tag + data
@@ -298,7 +300,10 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     from . import NeRFEngine, PRECISIONS, R2LEngine, R2LError
     H, W, focal = hwf
     auto = args.precision == 'auto'
-    prec = PRECISIONS['fp16_fp8' if auto else args.precision]
+    # auto: the weights are loaded in fp16x3 -- the mode that packs ANY checkpoint (per-layer scales) -- and choose_precision
+    # moves to the generated modes from there; a layer they cannot pack (max|w| outside 2^-12 .. 2^6) then ends in its
+    # documented fp16x3 fallback instead of failing r2l_load_weights.  The teacher's `auto` starts from fp16_fp8.
+    prec = PRECISIONS[args.precision] if not auto else PRECISIONS['fp16x3' if args.model_name in ('R2L', 'nerf_v3.2') else 'fp16_fp8']
     llff_ndc = args.dataset_type == 'llff' and not args.no_ndc
     if args.dataset_type == 'blender':
         near, far = 2., 6.  # main.py:930-931
@@ -369,66 +374,149 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     raise R2LError(f'model_name={args.model_name} is not a render path of this build')
 
 
-def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=print, given_rays=None):
-    """main.py:189-398 for the R2L and nerf branches: per-pose render, per-frame timing lines,
-    PSNR / SSIM when GT is given.  Rows of each frame are sharded over the ranks of
-    torch.distributed (if initialised) and assembled with one all-gather.  `given_rays` =
-    (all_rays_o, all_rays_d) [N, H*W, 3] replaces the camera rays (--given_render_path_rays,
-    main.py:207-230: the DONERF test path through PointSampler.sample_train)."""
+class _ImageWriter:
+    """PNG encoding off the render loop (the reference writes with imageio inside its loop, main.py:337-341; here rank 0
+    would hold the next collective while it deflates 1.9 MB in Python).  Frames are handed over as device tensors; a worker
+    thread copies them to the host and encodes them (zlib releases the GIL) while the loop goes on rendering."""
+
+    def __init__(self, n_threads=4):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.err = []
+        self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(n_threads)]
+        for t in self.threads:
+            t.start()
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            path, img, ready = item
+            try:
+                if ready is not None:
+                    ready.synchronize()          # the event behind the D2H copy of this frame
+                write_png(path, to8b(img.numpy() if torch.is_tensor(img) else img))
+            except Exception as e:               # surfaced by close()
+                self.err.append(e)
+
+    def put(self, path, img, ready=None):
+        self.q.put((path, img, ready))
+
+    def close(self):
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join()
+        if self.err:
+            raise self.err[0]
+
+
+def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=print, given_rays=None, frames_per_batch=None,
+                stats=None):
+    """main.py:189-398 for the R2L and nerf branches: render, per-frame timing lines, PSNR / SSIM when GT is given.
+
+    The loop is the one bench.py times ("batch >= 8 frames per collective"): frames go in batches of
+    `frames_per_batch` (default: the world size, i.e. one frame at N = 1) -- every rank renders its row shard of ALL frames of
+    the batch in one launch (`render_batch`: world x H/world rows = one frame's worth of ray tiles per rank, the grid bench.py
+    fills), ONE `r2l_gather_image` assembles them straight into the frame stack, the range check (one all-reduce) runs once
+    per batch, and the host synchronises once per batch for the reference's timing line.  PNGs are encoded on worker threads
+    from pinned host copies made on a side stream; PSNR / SSIM stay on the device until the loop is over.
+    `given_rays` = (all_rays_o, all_rays_d) [N, H*W, 3] replaces the camera rays (--given_render_path_rays,
+    main.py:207-230: the DONERF test path through PointSampler.sample_train).
+    `stats` (dict, optional) receives the loop's own numbers: render_loop_s (first launch to last sync, image encoding
+    excluded), batches, collectives, rerenders."""
     from . import dist as D
     import torch.distributed as tdist
     H, W, focal = hwf
     world = tdist.get_world_size() if tdist.is_initialized() else 1
     rank = tdist.get_rank() if tdist.is_initialized() else 0
     r0, r1 = D.row_shard(H, rank, world)
+    n_local = (r1 - r0) * W
     from .metrics import ssim_hwc
-    psnrs, ssims = [], []
     n_frames = len(given_rays[0]) if given_rays is not None else len(render_poses)
-    # the frame stack is allocated once and every frame is gathered straight into its slot: the collective's own buffer is
+    B = max(1, int(frames_per_batch or world))
+    # the frame stack is allocated once and every batch is gathered straight into its slots: the collective's own buffer is
     # reused from call to call (dist.RowGather.gather), so keeping views of it would keep N copies of the LAST frame
     rgbs = torch.empty((n_frames, H, W, 3), dtype=torch.float32, device=eng.device)
+    local = torch.empty((B, n_local, 3), dtype=torch.float32, device=eng.device)
+    pose_dev = None
+    if given_rays is None and kind == 'R2L' and n_frames:
+        pose_dev = torch.stack([torch.as_tensor(p)[:3, :4].float() for p in render_poses], 0).contiguous().to(eng.device)
 
-    def render_local(i):
-        if given_rays is not None:
-            ro = given_rays[0][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
-            rd = given_rays[1][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
-            local = eng.render_rays(ro, rd)
-            return local if kind == 'R2L' else local['rgb_map']
-        if kind == 'R2L':
-            return eng.render(render_poses[i][:3, :4], rows=(r0, r1))
-        return eng.render(render_poses[i][:3, :4], rows=(r0, r1))['rgb_map']
+    def render_local(i0, nb):
+        """row shard of frames i0 .. i0 + nb - 1 into local[:nb]"""
+        if pose_dev is not None:
+            eng.render_batch(pose_dev[i0:i0 + nb], rows=(r0, r1), out=local[:nb])
+            return
+        for f in range(nb):
+            i = i0 + f
+            if given_rays is not None:
+                ro = given_rays[0][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+                rd = given_rays[1][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+                got = eng.render_rays(ro, rd)
+            else:
+                got = eng.render(render_poses[i][:3, :4], rows=(r0, r1))
+            local[f].copy_(got if kind == 'R2L' else got['rgb_map'])
 
     if kind == 'R2L' and world > 1 and n_frames > 0:
-        # fp16_fp8 measures its activation ranges on the first render's own rays: one agreed set for all row shards
-        render_local(0)
+        # an explicit fp16_fp8 measures its activation ranges on the first render's own rays: one agreed set for all row
+        # shards (`auto` has measured every ray of a whole frame on every rank already, the all-reduce then only confirms it)
+        render_local(0, 1)
         D.agree_act_exponents(eng)
-    for i in range(n_frames):
-        torch.cuda.synchronize()
+    writer = _ImageWriter() if (savedir is not None and rank == 0) else None
+    copy_stream = torch.cuda.Stream(device=eng.device) if writer is not None else None
+    mse_dev, ssim_dev = [], []
+    n_coll = n_again = n_batches = 0
+    check = (lambda: D.check_ranges(eng, log=log if rank == 0 else None)) if kind == 'R2L' else (lambda: None)
+    torch.cuda.synchronize()
+    t_loop = time.time()
+    for i0 in range(0, n_frames, B):
+        nb = min(B, n_frames - i0)
         t0 = time.time()
-        local = render_local(i)
         if kind == 'R2L':
-            # fp16_fp8: did this frame's rays stay inside the range the bf6 exponents were measured for?  If not, the
-            # exponents are raised (`auto`: or the context falls back to fp16x3_asm) and the frame is rendered again
-            again = D.check_ranges(eng, log=log if rank == 0 else None)
-            if again is not None:
-                local = render_local(i)
-        rgb = D.gather_rows(local[None], H, W, world, out=rgbs[i])[0].view(H, W, 3)
-        torch.cuda.synchronize()
-        if rank == 0:
-            log(f'[#{i}] frame, rendering done, time for this frame: {time.time() - t0:.4f}s')
+            # did this batch's rays stay inside the range the low-precision scales were measured for?  If not: measured,
+            # raised, or the context falls back (`auto`), and the batch is rendered again -- one check per batch
+            _, again = eng.render_checked(lambda: render_local(i0, nb), check=check)
+            n_again += again
+        else:
+            render_local(i0, nb)
+        D.gather_rows(local[:nb], H, W, world, out=rgbs[i0:i0 + nb])
+        n_coll += 1 if world > 1 else 0
+        n_batches += 1
+        if writer is not None:      # D2H on a side stream behind the gather; the worker waits for the event, the loop does not
+            done = torch.cuda.Event()
+            copy_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(copy_stream):
+                host = torch.empty((nb, H, W, 3), dtype=torch.float32, pin_memory=True)
+                host.copy_(rgbs[i0:i0 + nb], non_blocking=True)
+                done.record(copy_stream)
+            for f in range(nb):
+                writer.put(os.path.join(savedir, f'{i0 + f:03d}.png'), host[f], done)
         if gt_imgs is not None:
-            gt = gt_imgs[i].to(rgb.device)
-            psnrs.append(mse2psnr(torch.mean((rgb - gt) ** 2)))
-            ssims.append(float(ssim_hwc(rgb, gt)))  # main.py:334-335
-        if savedir is not None and rank == 0:
-            write_png(os.path.join(savedir, f'{i:03d}.png'), to8b(rgb.cpu().numpy()))
-            if gt_imgs is not None:  # main.py:340-341
-                write_png(os.path.join(savedir, f'{i:03d}_gt.png'), to8b(gt_imgs[i].cpu().numpy()))
+            for f in range(nb):
+                gt = gt_imgs[i0 + f].to(rgbs.device)
+                mse_dev.append(torch.mean((rgbs[i0 + f] - gt) ** 2))
+                ssim_dev.append(ssim_hwc(rgbs[i0 + f], gt))   # main.py:334-335
+                if writer is not None:  # main.py:340-341
+                    writer.put(os.path.join(savedir, f'{i0 + f:03d}_gt.png'), gt_imgs[i0 + f].cpu().numpy())
+        torch.cuda.synchronize()       # the reference's per-frame bracket (main.py:273-310), once per batch here
+        if rank == 0:
+            dt = (time.time() - t0) / nb
+            for f in range(nb):
+                log(f'[#{i0 + f}] frame, rendering done, time for this frame: {dt:.4f}s')
+    t_loop = time.time() - t_loop
+    if writer is not None:
+        writer.close()
+    if stats is not None:
+        stats.update(render_loop_s=t_loop, frames=n_frames, frames_per_batch=B, batches=n_batches, collectives=n_coll,
+                     rerenders=n_again, world=world, rows_per_rank=r1 - r0)
     misc = {}
     if gt_imgs is not None:
         misc['test_psnr'] = mse2psnr(torch.mean((rgbs - gt_imgs.to(rgbs.device)) ** 2))
-        misc['test_psnr_v2'] = float(np.mean(psnrs))
-        misc['test_ssim'] = float(np.mean(ssims))
+        misc['test_psnr_v2'] = float(np.mean([mse2psnr(m) for m in mse_dev]))
+        misc['test_ssim'] = float(np.mean([float(v) for v in ssim_dev]))
     return rgbs, misc
 
 
@@ -484,12 +572,17 @@ def main(argv=None):
         return 0
     log('RENDER ONLY')
     t_ = time.time()
+    st = {}
     with torch.no_grad():
-        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log, given_rays=given)
+        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log, given_rays=given, stats=st)
     dt = time.time() - t_
     if rank == 0:
         np.save(os.path.join(outdir, 'rgbs.npy'), rgbs.cpu().numpy())
         H, W, _ = hwf
+        # the loop bench.py times (render + range check + gather, synchronised per batch); image encoding runs beside it
+        log(f'Render loop: {len(rgbs)} view(s) {H}x{W} on {world} GPU(s) in {st["render_loop_s"]:.3f}s = '
+            f'{len(rgbs) * H * W / max(st["render_loop_s"], 1e-9):.3e} rays/s ({st["batches"]} batch(es) of {st["frames_per_batch"]} '
+            f'frame(s), {st["collectives"]} collective(s), {st["rerenders"]} re-render(s))')
         log(f'Rendered {len(rgbs)} view(s) {H}x{W} on {world} GPU(s) in {dt:.2f}s '
             f'({len(rgbs) * H * W / dt:.3e} rays/s incl. host I/O)')
         if 'test_psnr' in misc:

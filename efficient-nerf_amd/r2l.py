@@ -279,55 +279,97 @@ class R2LEngine:
                 self.range_status(reset=True)
         return PREC_NAMES[mode], top
 
-    #: fill (fraction of bf6's +-28 the largest value of an operand set reached) beyond which check_ranges raises the
-    #: exponents.  The calibration aims at <= 16/28 = 0.57 on the frame it saw; bf6 represents 16..28 as well as 8..16, so
-    #: other poses may use that headroom (the 200-pose test path of the synthetic weights: up to 0.66) at no loss; at 1.0
-    #: values are clamped and the frame is wrong.
+    #: check_ranges raises the exponents when the largest value of an operand set, in units of its scale (|a| act_scale / 2^E:
+    #: the calibration aims at <= 16 on the frame it saw), passes 0.9 x 28 = 25.2 -- for BOTH operand formats.  bf6 clamps at
+    #: 28 (fill 1.0) and represents 16..28 as well as 8..16, so other poses may use that headroom (the 200-pose test path of
+    #: the synthetic weights: up to 0.75 x 28) at no loss.  e4m3 clamps only at 448, but the error of its terms grows with |a|
+    #: all the same, and the ladder admits it up to exponent 4 only: its limit is the same 1.58 x the calibrated range, not 0.9
+    #: of ITS top (which would let activations grow 25-fold unnoticed).
     FILL_LIMIT = 0.9
+    RAISE_AT = FILL_LIMIT * 28.0
+    #: frontend.render_path / dist: how often a batch is rendered again at most (measure -> raise -> fall back -> good)
+    MAX_RERENDERS = 4
 
-    def check_ranges(self, log=None, any_rank=None, agree=None):
-        """After a render in fp16_fp8: did the values stay inside the bf6 scales in use?  Returns None when the frame is
-        good: every fill below 1 (nothing was clamped).  Fills beyond FILL_LIMIT raise the exponents for what follows
-        (recalibrate); when values WERE clamped, or when raising the exponents takes them past `choose_precision`'s
-        limit (the context then switches to fp16x3_asm), the name of the precision to render the frame AGAIN with is
-        returned.  An explicit fp16_fp8 context keeps its mode and says so.  Synchronises.
-        Row-sharded runs (dist.check_ranges) pass `any_rank` (bool -> True when any rank says so) and `agree` (makes the
+    def fill_limit(self, format_top=None):
+        """FILL_LIMIT in units of the operand format in use: 0.9 (bf6), 0.9 x 28 / 448 (e4m3)"""
+        top = format_top or (448.0 if self.precision == PREC_FP16_E4M3 else 28.0)
+        return self.RAISE_AT / top
+
+    def check_ranges(self, log=None, rank_max=None, agree=None):
+        """After a render in fp16_fp8 / fp16_e4m3: did the values stay inside the scales in use?  Returns None when the frame
+        is good.  Otherwise the frame must be rendered AGAIN and check_ranges called again (until None; MAX_RERENDERS bounds
+        the loop); the return value says why:
+          'measure'   a value passed the limit (or was clamped) but only the head's running maximum exists -- 7 of 8 launches
+                      at the default guard period --, so nothing is known about the other operand sets of these rays: the
+                      next launch is range-guarded and measures all of them;
+          a precision name: the exponents were raised from the maxima of the guarded launches (r2l_recalibrate) and values
+                      WERE clamped in the frame, or the raised exponents leave the current rung of `choose_precision`'s
+                      ladder and the context has switched (fp16_fp8 -> fp16_e4m3 -> fp16x3_asm; never back).
+        Values beyond RAISE_AT that were not clamped raise the exponents for what follows and the frame stands (None).
+        An explicit precision keeps its mode and says so.  Synchronises: one stream sync + one device copy
+        (r2l_get_range_status) per call, more only when it acts.
+        Row-sharded runs (dist.check_ranges) pass `rank_max` (list of ints -> element-wise maximum over the ranks) and `agree` (makes the
         exponents the element-wise maximum over the ranks), so that every rank takes the same decision."""
         if self.precision not in SPLIT_MODES or self.n_block == 0:
             return None
         st = self.range_status()
-        fill = max(st['h0_fill'], st['worst_fill'])
-        act, clamped = fill > self.FILL_LIMIT, bool(st['saturated'])
-        if any_rank is not None:
-            act, clamped = any_rank(act), any_rank(clamped)
-        if not act:
+        top = st['format_top']
+        scaled = max(st['h0_fill'], st['worst_fill']) * top
+        act, clamped = scaled > self.RAISE_AT, bool(st['saturated'])
+        guarded = st['guarded_launches'] > 0
+        if rank_max is not None:    # the ranks launch in step, so `guarded` agrees anyway; it rides along in the one all-reduce
+            act, clamped, guarded = (bool(v) for v in rank_max([act, clamped, guarded]))
+        if not (act or clamped):
             return None
+        fmt = 'bf6' if self.precision == PREC_FP16_FP8 else 'e4m3'
+        msg = ('[precision] activations reach %.1f in units of their %s scale (operand set %d; h0: %.1f; calibrated to <= 16, limit '
+               '%.1f, clamped beyond %g)%s' % (st['worst_fill'] * top, fmt, st['worst_set'], st['h0_fill'] * top, self.RAISE_AT, top,
+                                                 ': values were clamped' if clamped else ''))
+        if not guarded:
+            self.range_status(reset=True)
+            self.set_guard_period(self._guard_period)      # restarts the guard's phase: the next launch is range-guarded
+            if log:
+                log(msg + '; only the head output of these rays was watched: rendered again range-guarded')
+            return 'measure'
         auto = getattr(self, '_auto', None)
         before = self.act_exponents()
-        if st['guarded_launches'] > 0 and fill > self.FILL_LIMIT:
-            self.recalibrate()
-        elif any_rank is None:   # only the head's running maximum exists: the next launch measures every set
-            self.set_guard_period(self._guard_period)
+        self.recalibrate()
         if agree is not None:
             agree(self)
         after = self.act_exponents()
-        top = max(after)
+        top_e = max(after)
         self.range_status(reset=True)
-        msg = ('[precision] activations fill %.2f of the %s scale of operand set %d (h0: %.2f)%s' %
-               (st['worst_fill'], 'bf6' if self.precision == PREC_FP16_FP8 else 'e4m3', st['worst_set'], st['h0_fill'],
-                ': values were clamped' if clamped else ''))
+        if clamped:
+            # the maxima behind the new exponents come from a forward pass with clamped operands: the re-render is
+            # range-guarded as well, so that the next check sees every set of the frame under the new scales
+            self.set_guard_period(self._guard_period)
         if auto is not None:
-            mode = self._mode_for(top, auto[0])
+            mode = self._mode_for(top_e, auto[0])
             if mode != self.precision and (mode == PREC_FP16X3_ASM or self.precision == PREC_FP16_FP8):   # never back up the ladder
                 self.set_precision(mode)
                 if log:
-                    log(msg + f'; exponents now up to {top} -> {PREC_NAMES[mode]}, frame rendered again')
+                    log(msg + f'; exponents now up to {top_e} -> {PREC_NAMES[mode]}, frame rendered again')
                 return PREC_NAMES[mode]
         if log:
-            log(msg + ('; exponents raised (up to %d)' % top if after != before else '; next launch range-guarded') +
+            log(msg + ('; exponents raised (up to %d)' % top_e if after != before else '; exponents unchanged') +
                 (', frame rendered again' if clamped else '') +
                 ('' if auto is not None else ' [explicit precision: no fallback; --precision auto has one]'))
         return PREC_NAMES[self.precision] if clamped else None
+
+    def render_checked(self, render, log=None, check=None):
+        """`render()` (any callable that launches on this context) until check_ranges has nothing left to say: the loop every
+        caller of check_ranges needs (frontend.render_path, tests).  `check` replaces self.check_ranges (dist.check_ranges for
+        row-sharded runs).  Returns (render()'s last result, number of extra renders)."""
+        check = check or (lambda: self.check_ranges(log=log))
+        out = render()
+        again = 0
+        while check() is not None:
+            if again >= self.MAX_RERENDERS:
+                raise R2LError('check_ranges asked for more than %d re-renders of one batch: activation ranges do not settle'
+                               % self.MAX_RERENDERS)
+            again += 1
+            out = render()
+        return out, again
 
     def _set_fused_tail(self, on):
         """parity tests: 0 = the three-launch form (body kernel writes x, r2l_tail_kernel finishes the rays)"""

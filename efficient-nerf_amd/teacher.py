@@ -237,6 +237,16 @@ class NeRFEngine:
             return 'fp16x3', diff
         return 'fp16_fp8', diff
 
+    def timing(self, on=True):
+        """HIP events around every MLP launch (nerf_chain_kernel / nerf_mlp_kernel), on its launch stream"""
+        check(lib().nerf_timing_enable(self._ctx, int(on)))
+
+    def kernel_time_ms(self, reset=True):
+        """(sum of the MLP launches' durations since the last reset in ms, their number); synchronises those events"""
+        tot, n = C.c_double(), C.c_int()
+        check(lib().nerf_kernel_time_ms(self._ctx, C.byref(tot), C.byref(n), int(reset)))
+        return tot.value, n.value
+
     def _outs(self, n):
         dev = self.device
         return (torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),

@@ -71,6 +71,8 @@ int r2l_device_count(void);
  * ONE RCCL collective over xGMI assembles the frames on every rank.  The reference has no counterpart (it
  * renders on one GPU, main.py:473): SURVEY.md 8(b) seam 3 is the contract.  RCCL is bound at run time; a
  * process that never calls these needs no librccl.
+ *   r2l_comm_available   0 when this process can bind RCCL (no id is made, no bootstrap socket opened: the pre-flight
+ *                        of the ranks other than 0), else the code and message r2l_comm_create would fail with
  *   r2l_comm_unique_id   rank 0 obtains the 128-byte id and hands it to the other ranks by any host channel
  *   r2l_comm_create      every rank, after hipSetDevice(its GPU): ncclCommInitRank
  *   r2l_gather_image     local_rows_dev [n_frames, rows_of_this_rank * row_floats] -> full_image_dev
@@ -78,6 +80,7 @@ int r2l_device_count(void);
  *                        one grouped launch: ncclAllGather per frame (equal shards) or ncclBroadcast per shard
  * --------------------------------------------------------------------------------- */
 typedef struct r2l_comm r2l_comm;
+int r2l_comm_available(void);
 int r2l_comm_unique_id(char* id_out128);
 int r2l_comm_create(r2l_comm** out, int rank, int world, const char* id128);
 void r2l_comm_destroy(r2l_comm* comm);
@@ -190,6 +193,13 @@ int r2l_get_act_exponents(r2l_ctx* ctx, int* out, int n);
  * r2l_get_range_status reads the words (synchronises the stream of the newest render) and relates them to the exponents
  * in use: fill = max * 16 / 2^E / 28 is the fraction of bf6's +-28 the largest value of a set reached; the calibration
  * aims at <= 16/28 = 0.571, values beyond 1 were clamped.  reset != 0 clears the words and the launch counters.
+ * Cost: one stream synchronisation and ONE device-to-host copy (range word, the 2 n_block maxima and the 2 n_block + 1
+ * exponents live in one allocation); r2l_get_act_exponents likewise one copy, r2l_set_act_exponents one copy + one launch.
+ * Under HIP-graph capture the choice "range-guarded or not" is host state evaluated when the launch is ENQUEUED: a
+ * captured graph replays the build it captured (every replay guarded, or none), and the launch counters of
+ * r2l_range_status count enqueues, not replays (the maxima themselves are device words and do keep accumulating when the
+ * captured build is the guarded one).  Capture with guard_period 0 and run one eager range-guarded render every so many
+ * replays, or capture the guarded build (+1.2 %).
  * r2l_recalibrate (stream-ordered device work) replaces the exponents by those the collected maxima ask for: what the
  * first call would have measured had it seen every ray of the guarded launches; frames rendered before it with
  * saturated sets should be rendered again. */
@@ -273,6 +283,20 @@ int nerf_render_rays_ex(nerf_ctx* ctx, const float* rays_o_dev, const float* ray
                         const float* z_coarse_dev, const float* u_dev, const float* noise0_dev,
                         const float* noise1_dev, float* rgb_dev, float* disp_dev, float* acc_dev,
                         float* depth_dev, void* stream);
+
+/* HIP-event timing of the teacher's MLP launches (nerf_chain_kernel / nerf_mlp_kernel: 99 % of a frame) on the stream they
+ * are launched on, as r2l_timing_enable / r2l_kernel_time_ms: sum and count since the last reset (bench.py's create_data
+ * and teacher legs). */
+int nerf_timing_enable(nerf_ctx* ctx, int on);
+int nerf_kernel_time_ms(nerf_ctx* ctx, double* total_ms, int* n_launches, int reset);
+
+/* Host-only (no device call): the shuffle of `create_data rand` -- utils/create_data.py:858-859 draws two
+ * np.random.permutation(n) per save group from the one global numpy stream (create_data.py:18), n = 16,000,000 rays at
+ * the reference's sizes; every rank has to walk that stream, so it is the serial piece of config 5.  numpy's legacy
+ * RandomState.permutation restated (arange + Fisher-Yates with random_interval's masked rejection on MT19937 words):
+ * mt_key624 / mt_pos are the state of RandomState.get_state() and are advanced in place (set_state them back), out[n]
+ * receives the permutation as 32-bit indices.  Bit-identical to numpy, 5-20x faster (csrc/np_shuffle.hip). */
+int r2l_np_legacy_permutation(unsigned* mt_key624, int* mt_pos, long long n, int* out);
 
 /* Forward-facing scenes (render(..., ndc=True), main.py:148-162): when on, nerf_render and
  * nerf_render_rays take the view directions from the given (world-space) rays, project the rays

@@ -101,3 +101,85 @@ def test_shard_reader_round_trip(tmp_path):
     np.random.seed(0)
     ds2 = BlenderDataset_v2(d, pseudo_ratio=0.5)
     assert len(ds2) == 2 and sum(os.path.basename(p).startswith('train_') for p in ds2.all_splits) == 1
+
+
+def _load_pkg():
+    sys.path.insert(0, ROOT)
+    import _pkg
+    _pkg.load()
+
+
+@pytest.mark.parametrize('n', [0, 1, 2, 3, 17, 63, 64, 65, 129, 1000, 65536, 65537, 1 << 20])
+def test_library_permutation_is_numpys_legacy_permutation(n):
+    """RandStream.permutation = r2l_np_legacy_permutation (csrc/np_shuffle.hip) on the stream's own MT19937 state: the same
+    indices as np.random.RandomState.permutation AND the same state afterwards (the next rand() / permutation agree), from a
+    state in the middle of a block of 624 words"""
+    _load_pkg()
+    from efficient_nerf_amd.create_data import RandStream
+    ours, ref = RandStream(seed=3, n_loader_poses=7), np.random.RandomState(3)
+    for _ in range(7):
+        ref.rand(), ref.rand()
+    for _ in range(2):
+        a, b = ours.permutation(n), ref.permutation(n)
+        assert a.dtype == np.int32 and np.array_equal(a, b)
+        assert ours.rs.rand() == ref.rand()
+    assert torch.equal(ours.rand_pose(), RandStreamRef(ref).rand_pose())
+
+
+class RandStreamRef:
+    def __init__(self, rs):
+        self.rs = rs
+
+    def rand_pose(self):
+        from oracle import r2l_oracle as O
+        theta = -180 + self.rs.rand() * 360
+        phi = -90 + self.rs.rand() * 90
+        return O.pose_spherical(theta, phi, 4)
+
+
+def test_permutation_rejects_bad_arguments():
+    _load_pkg()
+    import ctypes as C
+    from efficient_nerf_amd import _lib
+    L = _lib.lib()
+    key = (C.c_uint * 624)()
+    out = (C.c_int * 4)()
+    pos = C.c_int(625)
+    assert L.r2l_np_legacy_permutation(key, C.byref(pos), 4, out) != 0 and b'position' in L.r2l_last_error()
+    pos = C.c_int(0)
+    assert L.r2l_np_legacy_permutation(key, C.byref(pos), -1, out) != 0
+    assert L.r2l_np_legacy_permutation(None, C.byref(pos), 4, out) != 0 and b'NULL' in L.r2l_last_error()
+
+
+def test_shards_are_the_reference_loops_bytes(tmp_path):
+    """The directory against a literal restatement of the reference's loop (utils/create_data.py:812-872) with numpy's OWN
+    permutation and np.save: pose + focal draws, cat, data[ix1][ix2], split_size slices, remainder dropped, the poses behind
+    the last full group never flushed -- every file byte for byte."""
+    _load_pkg()
+    import io
+    from efficient_nerf_amd.create_data import RandStream
+    from oracle import r2l_oracle as O
+    H, W, n_pose, i_save, split_size = 6, 8, 7, 3, 64
+    d = str(tmp_path / 'ours')
+    _run(0, 1, 0, d, n_pose, i_save, H, W)
+    rs = RandStream()          # only its pose / focal draws are used below; the permutations are numpy's
+    teacher, focal = FakeTeacher(), O.focal_from_angle(W)
+    data, split = [], 0
+    for i in range(1, n_pose + 1):
+        pose = rs.rand_pose()
+        focal_ = focal * rs.rand_focal_scale()
+        ro, rd = O.get_rays(H, W, focal_, pose[:3, :4])
+        rgb = teacher.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3))['rgb_map']
+        data.append(torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), rgb], -1))
+        if i % i_save == 0:
+            dd = torch.cat(data, 0)
+            ix1, ix2 = rs.rs.permutation(dd.shape[0]), rs.rs.permutation(dd.shape[0])
+            dd = dd[ix1][ix2].numpy()
+            for ix in range(0, dd.shape[0] // split_size * split_size, split_size):
+                split += 1
+                buf = io.BytesIO()
+                np.save(buf, dd[ix:ix + split_size])
+                assert open(os.path.join(d, f'data_{split}.npy'), 'rb').read() == buf.getvalue(), split
+            data = []
+    assert split == len([x for x in os.listdir(d) if x.endswith('.npy')]) == 2 * (3 * 48 // 64)
+    assert os.path.exists(os.path.join(d, 'pseudo_sample_5.png'))

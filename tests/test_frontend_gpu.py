@@ -257,3 +257,62 @@ def test_r2l_render_only_cli_two_ranks(pkg, tmp_path):
     for i, c2w in enumerate(O.novel_poses(3)):
         ref = O.r2l_render(sd, H, H, focal, c2w).view(H, H, 3).numpy()
         assert np.abs(rgbs[i] - ref).max() <= 1e-4, i
+
+
+def test_cli_auto_with_a_layer_the_generated_kernels_cannot_pack(pkg, tmp_path):
+    """`--precision auto` (the CLI default) on a checkpoint with a layer of max|w| = 2^8: the weights load in
+    fp16x3, choose_precision finds the generated modes refuse them and stays there, saying why -- the checkpoint renders,
+    inside the contract, instead of failing in r2l_load_weights"""
+    from efficient_nerf_amd import frontend as fe
+    sd = O.make_r2l_state(seed=3, netdepth=10)
+    sd['body.1.body.0.weight'] = sd['body.1.body.0.weight'] * 4096.
+    sd['body.1.body.0.bias'] = sd['body.1.body.0.bias'] * 4096.
+    sd['body.1.body.2.weight'] = sd['body.1.body.2.weight'] / 4096.
+    ck = str(tmp_path / 'odd.tar')
+    fe.save_checkpoint(ck, sd)
+    out = str(tmp_path / 'out')
+    log = run_main(['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256',
+                    '--netdepth', '10', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck,
+                    '--render_only', '--synthetic_poses', '1', '--H', '48', '--outdir', out])
+    assert '[precision] auto' in log and 'outside the range' in log and '-> fp16x3' in log, log
+    H = 24
+    ref = O.r2l_render(sd, H, H, O.focal_from_angle(48) / 2., O.novel_poses(1)[0]).view(H, H, 3).numpy()
+    assert np.abs(np.load(os.path.join(out, 'rgbs.npy'))[0] - ref).max() <= 1e-4
+
+
+def test_render_path_batches_frames_per_collective_two_ranks(pkg, tmp_path):
+    """`torchrun main.py` runs the loop bench.py times.  Two ranks (gloo between them, both on this GPU),
+    H = 33 (ragged 17 / 16 rows), 5 frames, `--precision auto`: every rank renders its row shard of BOTH frames of a batch in
+    one launch, one collective and one range check per batch (3 batches for 5 frames: the CLI prints the counts), PNGs
+    come from the writer threads, every frame within 1e-4 of the oracle."""
+    import re
+    import socket
+    from efficient_nerf_amd import frontend as fe
+    sd = O.make_r2l_state(seed=12, netdepth=14)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    out = str(tmp_path / 'out')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, R2L_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'main.py'),
+                        '--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256',
+                        '--netdepth', '14', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck,
+                        '--render_only', '--synthetic_poses', '5', '--H', '66', '--outdir', out],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r'Render loop: 5 view\(s\) 33x33 on 2 GPU\(s\) .* \((\d+) batch\(es\) of (\d+) frame\(s\), (\d+) collective\(s\), (\d+) re-render',
+                  r.stdout)
+    assert m, r.stdout[-2000:]
+    assert (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (3, 2, 3), m.group(0)
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    H = 33
+    assert rgbs.shape == (5, H, H, 3)
+    focal = O.focal_from_angle(66) / 2.
+    for i, c2w in enumerate(O.novel_poses(5)):
+        ref = O.r2l_render(sd, H, H, focal, c2w).view(H, H, 3).numpy()
+        assert np.abs(rgbs[i] - ref).max() <= 1e-4, i
+        assert os.path.getsize(os.path.join(out, f'{i:03d}.png')) > 100

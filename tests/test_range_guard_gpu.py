@@ -194,3 +194,98 @@ def test_calibrate_on_one_pose_holds_the_contract_on_the_whole_test_path(pkg):
     print('8 poses of the test path under pose-0 exponents: L_inf %.2e, largest fill %.3f (calibration aims at 0.571)' % (worst, fill))
     assert worst <= 1e-4, worst
     eng.close()
+
+
+def test_unguarded_frame_that_clamps_is_measured_then_raised(pkg):
+    """at the default guard period 7 of 8 launches track only the head output.  A frame whose h0 was clamped on
+    such a launch must not be emitted: check_ranges asks for a range-guarded render of the frame ('measure'), raises the
+    exponents from what that render saw, asks for the frame once more (values had been clamped) and only then lets it
+    stand.  `render_checked` is the loop frontend.render_path runs."""
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H, nb = 96, 6
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=5, netdepth=2 + 2 * nb)
+    c2w = O.pose_spherical(20., -40., 4.)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    good = eng.calibrate_on(c2w=c2w)
+    assert eng._guard_period == 8
+    eng.render(c2w)                                   # launch 0 of the guard's phase: guarded; the next seven are not
+    eng.set_act_exponents([e - 2 for e in good])      # as if the calibration frame had been a tame one
+    eng.range_status(reset=True)
+    logs = []
+    seq = []
+
+    def check():
+        r = eng.check_ranges(log=logs.append)
+        seq.append(r)
+        return r
+
+    rgb, again = eng.render_checked(lambda: eng.render(c2w), check=check)
+    assert seq[0] == 'measure' and seq[1] == 'fp16_fp8' and seq[-1] is None and again == len(seq) - 1 <= 3, (seq, logs)
+    assert 'only the head output' in logs[0] and 'values were clamped' in logs[0] and 'exponents raised' in logs[1], logs
+    assert eng.range_status()['guarded_launches'] == 1      # the frame that stands was watched in every operand set
+    # the maxima came from a pass with clamped correction terms: within one of the clean calibration, never clamping
+    assert all(abs(a - b) <= 1 for a, b in zip(eng.act_exponents(), good)), (eng.act_exponents(), good)
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    assert (rgb.cpu() - ref).abs().max().item() <= 1e-4
+    eng.close()
+
+
+def test_e4m3_limit_is_relative_to_the_calibrated_range(pkg):
+    """e4m3 clamps at 448, 28 x the value the calibration aims at, so a limit of 0.9 x the format's top would let
+    activations grow 25-fold -- far past exponent 4, the last one the ladder admits e4m3 at -- before anything acted.  The
+    limit is the bf6 one in units of the scale (25.2 against the calibrated 16): exponents two too small (values up to 64,
+    nothing clamped) must trip it, and `auto` must move on to fp16x3_asm when the raised exponents pass 4."""
+    from efficient_nerf_amd import PREC_FP16_E4M3, PRECISIONS, R2LEngine
+    H = 96
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=0)
+    for k in sd:
+        if k.startswith('body.') and k.endswith('weight'):
+            sd[k] = sd[k] * 1.3                   # exponents 5-6
+    c2w = O.pose_spherical(40., -30., 4.)
+    eng = R2LEngine(H, H, focal).load_state_dict(sd)
+    eng.set_precision(PREC_FP16_E4M3)
+    true_ex = eng.calibrate_on(c2w=c2w)
+    assert max(true_ex) > eng.AUTO_MAX_EXP_E4M3
+    eng._auto = (None,)                           # the real ladder, with exponents two too small
+    eng.set_act_exponents([e - 2 for e in true_ex])
+    eng.set_guard_period(1)
+    eng.range_status(reset=True)
+    eng.render(c2w)
+    st = eng.range_status()
+    assert not st['saturated'] and 25.2 < st['worst_fill'] * st['format_top'] <= 64 * 1.01, st
+    assert abs(eng.fill_limit(st['format_top']) - 25.2 / 448) < 1e-9
+    logs = []
+    assert eng.check_ranges(log=logs.append) == 'fp16x3_asm', logs
+    assert eng.precision == PRECISIONS['fp16x3_asm']
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    assert (eng.render(c2w).cpu() - ref).abs().max().item() <= 1e-4
+    eng.close()
+
+
+def test_range_status_is_one_copy(pkg):
+    """range word, maxima and exponents live in one allocation; what r2l_get_range_status and
+    r2l_get_act_exponents report must agree with r2l_set_act_exponents and with a device-side calibration"""
+    from efficient_nerf_amd import PREC_FP16_FP8, R2LEngine
+    H, nb = 48, 5
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=8, netdepth=2 + 2 * nb)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    want = [3, 1, 2, 0, 4, -1, 2, 2, 1, 0, 3]
+    eng.set_act_exponents(want)
+    assert eng.act_exponents() == want
+    c2w = O.pose_spherical(0., -30., 4.)
+    a = eng.render(c2w).cpu()
+    assert eng.act_exponents() == want                      # a render under fixed exponents leaves them alone
+    eng.set_act_exponents(None)                             # measure again: the calibration kernels write both places
+    eng.render(c2w)
+    ex = eng.act_exponents()
+    assert ex != want and ex[-1] == ex[0]
+    eng.set_act_exponents(ex)                               # spread kernel writes what the calibration wrote
+    b = eng.render(c2w).cpu()
+    eng.set_act_exponents(None)
+    eng.render(c2w)
+    assert eng.act_exponents() == ex and torch.equal(eng.render(c2w).cpu(), b)
+    assert (a - b).abs().max().item() < 1e-3
+    eng.close()
