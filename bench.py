@@ -54,19 +54,64 @@ def kernel_sources_digest():
 
 def measured_traffic(precision):
     """HBM-side bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/rNN_traffic.json,
-    written by tools/traffic_json.py; counters cannot be collected from inside the timed process).  None when no pass
-    exists for this precision or when the pass measured other kernel sources than the ones in the tree."""
+    written by tools/traffic_json.py; counters cannot be collected from inside the timed process) and the file it came from:
+    a CARRIED-OVER number, which the JSON line says (`traffic_source`).  (None, reason) when no pass exists for this precision
+    or when the pass measured other kernel sources than the ones in the tree."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
     if not files:
-        return None
+        return None, 'no profiles/r*_traffic.json'
+    rel = os.path.relpath(files[-1], ROOT)
     try:
         e = json.load(open(files[-1])).get(precision, {})
     except (OSError, ValueError):
-        return None
+        return None, rel + ' unreadable'
+    if not e:
+        return None, rel + ' has no pass for ' + precision
     if e.get('sources') != kernel_sources_digest():
-        return None
-    return e.get('bytes_per_launch')
+        return None, rel + ' measured other kernel sources (digest %s, tree %s)' % (e.get('sources'), kernel_sources_digest())
+    return e.get('bytes_per_launch'), rel + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources; not measured in this run)'
+
+
+def create_data_leg(torch, O, precision):
+    """secondary, outside the timed region: BASELINE config 5's unit of work at the reference's own size -- ONE save group of
+    `utils/create_data.py --create_data rand` (:812-872): 100 random poses (random focal) at 400x400 through the teacher,
+    i_save = 100, split_size = 4096 -> 3,906 shards of 147 KB -- with the wall-clock split and the extrapolation to
+    --n_pose_kd 10000, for which the reference quotes "around 24 hrs" (README.md:87)."""
+    import shutil
+    import tempfile
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    from efficient_nerf_amd import create_data as CD
+    th, n_pose = 400, 100
+    focal = O.focal_from_angle(th)
+    eng = NeRFEngine(th, th, focal, precision=PRECISIONS[precision]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    eng.render(O.novel_poses(1)[0][:3, :4])          # buffers allocated, kernels loaded
+    torch.cuda.synchronize()
+    out = tempfile.mkdtemp(prefix='r2l_pseudo_')
+    tm = {}
+    try:
+        t0 = time.perf_counter()
+        n = CD.create_rand(eng, th, th, focal, n_pose, out, i_save=100, split_size=4096, stream=CD.RandStream(),
+                           log=lambda *a, **k: None, timings=tm)
+        wall = time.perf_counter() - t0
+        nbytes = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if f.endswith('.npy'))
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    eng.close()
+    mlp_s = tm.get('mlp_kernel_ms', 0.0) / 1e3
+    return {'workload': 'create_data rand: 100 random poses (random focal) 400x400, NeRF teacher 64 + 128 samples, i_save 100, '
+                        'split_size 4096 (utils/create_data.py:812-872)', 'precision': precision,
+            'poses': n_pose, 'shards': n, 'shard_bytes_total': nbytes, 'wall_s': wall, 'poses_per_s': n_pose / wall,
+            'rays_per_s': n_pose * th * th / wall,
+            # where the wall clock goes: the teacher's MLP launches (HIP events on their stream) ...
+            'mlp_kernel_s': mlp_s, 'mlp_kernel_share_of_wall': mlp_s / wall, 'mlp_launches': tm.get('mlp_launches'),
+            # ... what follows the last render of the (only) group and nothing can overlap: shuffle gather, copy, 3,906 file writes
+            'tail_s': tm.get('tail_s'), 'assemble_ms': tm.get('assemble_ms'), 'd2h_ms': tm.get('d2h_ms'),
+            # ... and what runs beside the renders on host threads
+            'permutation_s_on_planner_thread': tm.get('permutation_s'), 'writer_busy_s': tm.get('writer_busy_s'),
+            'writer_threads': tm.get('writer_threads'),
+            'extrapolated_n_pose_kd_10000_hours_one_gpu': 1e4 / n_pose * wall / 3600,
+            'reference_quotes_hours': 24, 'reference_quote': 'README.md:87 "around 24 hrs" for --n_pose_kd 10000 (hardware unstated)'}
 
 
 def middle_rung(torch, O, R2LEngine, sd, poses, focal):
@@ -106,6 +151,10 @@ def main():
                     help='fp16_fp8: every k-th body launch runs the range-guard build (library default 8; 1 every launch, 0 never)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-teacher', action='store_true', help='skip the secondary teacher measurement')
+    ap.add_argument('--no-create-data', action='store_true', help='skip the secondary create_data (config 5) measurement')
+    ap.add_argument('--allow-fallback', action='store_true',
+                    help='N > 1: accept torch.distributed as the assembling collective when the library cannot run r2l_gather_image '
+                         '(default: exit non-zero -- a scaling record must time the collective it names)')
     ap.add_argument('--cpu-rays', type=int, default=H * W,
                     help='rays of one frame the CPU oracle renders for the baseline / parity check')
     args = ap.parse_args()
@@ -138,6 +187,19 @@ def main():
     def step(s):
         eng.render_batch(pose_dev[s], rows=(r0, r1), out=local)
         return D.gather_rows(local, H, W, world)
+
+    if world > 1 and not args.allow_fallback:
+        # a scaling run times the library's own collective or nothing: no silent stand-in (dist.gather_rows raises on every
+        # rank together: the binding pre-flight is agreed between them)
+        os.environ['R2L_REQUIRE_RCCL'] = '1'
+        try:
+            step(0)
+        except Exception as e:
+            if rank == 0:
+                print('bench.py --gpus %d: r2l_gather_image (RCCL, C-ABI) cannot assemble the frames: %s\n'
+                      'pass --allow-fallback to time the torch.distributed stand-in instead (config.gather will say so)'
+                      % (world, e), file=sys.stderr, flush=True)
+            sys.exit(3)
 
     split = args.precision in ('fp16_fp8', 'fp16_e4m3')
     if split:
@@ -182,6 +244,7 @@ def main():
     passes = {'fp16x3': 3, 'fp16x1': 1, 'fp16_fp8': 1.5, 'fp16_e4m3': 2.0, 'fp16x3_asm': 3}[args.precision]
     path_tflops = flops_per_ray * rays_per_step * args.steps / dt / world / 1e12   # per GPU, everything in the step
 
+    traffic, traffic_source = measured_traffic(args.precision)
     out = {
         'metric': 'rays/sec at 800x800 (R2L W256D88)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -200,7 +263,7 @@ def main():
                    'precision': args.precision, 'parallelism': 'ray-shard x%d' % world,
                    'gather': D.gather_backend(dev.index, world)},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP16_TFLOPS, 'traffic': measured_traffic(args.precision),
+                     'frac': achieved / PEAK_FP16_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                      'kernel': {'fp16x3': 'r2l_resmlp_kernel<2, false, false>', 'fp16x1': 'r2l_resmlp_kernel<1, false, false>',
                                 'fp16_fp8': 'r2l_body_kernel', 'fp16_e4m3': 'r2l_body8_kernel', 'fp16x3_asm': 'r2l_bodyx_kernel'}[args.precision],
                      'avg_kernel_ms': avg_kernel_s * 1e3, 'launches': n_launch,
@@ -214,6 +277,11 @@ def main():
         # the exponents the bf6 / e4m3 correction terms were scaled with (measured on the device by the first warm-up render)
         ex = [int(e) for e in eng.act_exponents()]
         st = eng.range_status()
+        # the rate is that of ONE rung of `--precision auto`'s ladder; which rung a checkpoint gets depends on its own activations
+        out['value_valid_for'] = ('activation exponent <= %d (max|a| <= %d over all operand sets: the rung --precision auto gives '
+                                  'these weights; exponent 4 -> fp16_e4m3, above -> fp16x3_asm: e4m3_mode / stress_weights below)'
+                                  % ((eng.AUTO_MAX_EXP, 2 ** eng.AUTO_MAX_EXP) if args.precision == 'fp16_fp8' else
+                                     (eng.AUTO_MAX_EXP_E4M3, 2 ** eng.AUTO_MAX_EXP_E4M3)))
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
                               'auto_precision_limit': eng.AUTO_MAX_EXP,   # --precision auto takes fp16_fp8 up to this exponent
                               'measured_on': 'every ray of one 800x800 frame (test pose 0), range-guarded render',
@@ -234,7 +302,8 @@ def main():
         import torch.distributed as dist
         flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        out['gather_check'] = {'assembled_frame_equals_own_render_on_every_rank': bool(flag.item() == 1)}
+        out['gather_check'] = {'assembled_frame_equals_own_render_on_every_rank': bool(flag.item() == 1),
+                               'collective': D.gather_backend(dev.index, world), 'fallback_allowed': bool(args.allow_fallback)}
 
     if rank == 0:
         # parity on the bounded CPU sample + CPU baseline (same box, same run)
@@ -340,6 +409,8 @@ def main():
                 out['teacher']['linf_vs_cpu_oracle'] = (tg - tref['rgb_map']).abs().max().item()
                 out['teacher']['rays_checked'] = int(idx.numel())
             teng.close()
+        if not args.no_create_data and world == 1:
+            out['create_data'] = create_data_leg(torch, O, args.precision if args.precision in ('fp16x3', 'fp16x1', 'fp16_fp8') else 'fp16_fp8')
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -56,3 +56,55 @@ def test_bench_line_schema():
     sw = d['stress_weights']
     assert sw['auto_precision'] == 'fp16x3_asm' and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
     assert d['calibration']['max'] <= d['calibration']['auto_precision_limit']     # ... and would keep fp16_fp8 for the standard set
+
+
+def test_bench_line_round4_fields():
+    """the config-5 leg at the reference's own group size, where the traffic figure comes from,
+    and for which activations the headline rate holds"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-teacher'], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert 'traffic_source' in d['roofline'] and isinstance(d['roofline']['traffic_source'], str)
+    assert (d['roofline']['traffic'] is None) == ('not measured in this run' not in d['roofline']['traffic_source'])
+    assert d['value_valid_for'].startswith('activation exponent <= 3')
+    cd = d['create_data']
+    assert cd['poses'] == 100 and cd['shards'] == 100 * 160000 // 4096 == 3906 and cd['shard_bytes_total'] == 3906 * (128 + 4096 * 36)
+    assert abs(cd['poses_per_s'] - 100 / cd['wall_s']) < 1e-9 and cd['mlp_launches'] == 200
+    # the teacher's MLP launches are the leg: >= 90 % of its wall clock (VERDICT r3's bar), the exposed tail of the one group
+    # (shuffle gather, copy, 3,906 file writes) well under a second
+    assert cd['mlp_kernel_share_of_wall'] >= 0.90, cd
+    assert cd['tail_s'] < 1.0 and cd['extrapolated_n_pose_kd_10000_hours_one_gpu'] < 1.0 < cd['reference_quotes_hours']
+
+
+def _torchrun_bench(extra, port):
+    env = dict(os.environ, R2L_DIST_BACKEND='gloo')
+    return subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                           '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+                           '--warmup', '1', '--no-cpu-baseline', '--no-teacher'] + extra, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=900)
+
+
+def test_scaling_run_refuses_a_silent_collective_fallback():
+    """at --gpus N > 1 the record must time r2l_gather_image or say loudly that it does not.  Two ranks with
+    gloo between them (both on this GPU: the library's RCCL collective cannot run there): without --allow-fallback bench.py
+    exits non-zero and prints no JSON line; with it the line names the stand-in and carries gather_check."""
+    import socket
+
+    def port():
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+
+    r = _torchrun_bench([], port())
+    assert r.returncode != 0 and 'r2l_gather_image (RCCL, C-ABI) cannot assemble' in r.stderr, r.stdout[-800:] + r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    r = _torchrun_bench(['--allow-fallback'], port())
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-1500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and 'torch.distributed all_gather (gloo)' in d['config']['gather']
+    gc = d['gather_check']
+    assert gc['assembled_frame_equals_own_render_on_every_rank'] is True and gc['fallback_allowed'] is True
+    assert gc['collective'] == d['config']['gather']

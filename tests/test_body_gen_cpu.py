@@ -328,3 +328,22 @@ def test_staged_stream_is_bit_identical_to_the_lds_dma_stream(nb, wave, guard):
     assert np.array_equal(r0[0], r1[0])
     if guard:
         assert np.array_equal(r0[2], r1[2])
+
+
+@pytest.mark.parametrize('name,fmt,guard', [('r2l_body_asm.inc', 'bf6', False), ('r2l_body_guard_asm.inc', 'bf6', True),
+                                            ('r2l_body8_asm.inc', 'fp8', False), ('r2l_body8_guard_asm.inc', 'fp8', True),
+                                            ('r2l_bodyx_asm.inc', 'f16', False)])
+def test_committed_asm_is_the_generators_output(tmp_path, name, fmt, guard):
+    """The five body streams hipcc assembles are committed text; the emulator tests above run the generator's stream, not that
+    text -- this pins one to the other (as tests/test_head_gen_cpu.py and tests/test_nerf_gen_cpu.py do for theirs), with the
+    options of csrc/Makefile's rules.  Also what r2l_body.hip's clobber list relies on: the stream saves m0 with its first
+    instruction and restores it with its last."""
+    out = str(tmp_path / name)
+    try:
+        G.emit_inc(out, G.Opts(fmt=fmt, guard=guard))
+    finally:
+        G.configure('bf6')
+    built = open(os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)).read()
+    assert open(out).read() == built, name
+    lines = [ln for ln in built.splitlines() if ln.startswith('"')]
+    assert lines[0].startswith('"s_mov_b32 s76, m0') and lines[-1].startswith('"s_mov_b32 m0, s76'), (lines[0], lines[-1])

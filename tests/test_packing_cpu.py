@@ -185,3 +185,74 @@ def test_fp16_fp8_packers_reject_weights_outside_the_split_range(pkg, built_lib)
     assert b'teacher layer 3' in L.r2l_last_error() and b'outside the range' in L.r2l_last_error()
     keep, arr = _lib.host_ptrs([O.make_teacher_state(1)[n] for n in NeRFEngine.STATE_NAMES])
     assert L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs) > 0
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for c in np.frombuffer(b, dtype=np.uint8).tolist():
+        h = ((h ^ c) * 1099511628211) & 0xffffffffffffffff
+    return '%016x' % h
+
+
+def test_host_packers_under_asan_ubsan(pkg, built_lib, tmp_path):
+    """the host-only packers (pack_image_host / pack_head_v1 / pack_body_v3 / pack_chain) and the numpy
+    shuffle, compiled from the product sources with -fsanitize=address,undefined (`make asan`: host side only, no device
+    code) and run on seeded weights: a clean sanitizer log, and byte-for-byte the streams the product library packs."""
+    import os
+    import subprocess
+    from efficient_nerf_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(['make', '-C', os.path.join(root, 'efficient-nerf_amd', 'csrc'), 'asan'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    n_block = 2
+    sd = O.make_r2l_state(seed=21, netdepth=2 + 2 * n_block)
+    sd['body.1.body.0.weight'] = sd['body.1.body.0.weight'] * 3.7         # layers with different exponents
+    sd['body.0.body.2.weight'] = sd['body.0.body.2.weight'] * 0.11
+    tsd = O.make_teacher_state(5)
+    names = O.r2l_state_names(n_block)
+    tnames = [f'pts_linears.{i}.{k}' for i in range(8) for k in ('weight', 'bias')] + [
+        'views_linears.0.weight', 'views_linears.0.bias', 'feature_linear.weight', 'feature_linear.bias',
+        'alpha_linear.weight', 'alpha_linear.bias', 'rgb_linear.weight', 'rgb_linear.bias']
+    path = str(tmp_path / 'weights.bin')
+    with open(path, 'wb') as f:
+        f.write(np.int32(n_block).tobytes())
+        for n in names:
+            f.write(sd[n].contiguous().numpy().astype(np.float32).tobytes())
+        for n in tnames:
+            f.write(tsd[n].contiguous().numpy().astype(np.float32).tobytes())
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    r = subprocess.run([os.path.join(root, 'tests', '_build', 'pack_asan'), path], capture_output=True, text=True, env=env, timeout=600)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0 and 'AddressSanitizer' not in log and 'runtime error' not in log and 'LeakSanitizer' not in log, log[-3000:]
+    got = {}
+    for ln in r.stdout.splitlines():
+        t = ln.split()
+        got[(t[0], t[1]) if t[0] != 'pack_chain' else (t[0],)] = t[1:] if t[0] == 'pack_chain' else t[2:]
+    # the product library on the same tensors
+    L = _lib.lib()
+    keep, arr = _lib.host_ptrs([sd[n] for n in names])
+    for mode in range(5):
+        size = L.r2l_debug_pack_host(arr, len(keep), n_block, mode, None, 0)
+        buf = (C.c_char * size)()
+        assert L.r2l_debug_pack_host(arr, len(keep), n_block, mode, buf, size) == size
+        assert got[('pack_host', str(mode))] == [str(size), _fnv(bytes(buf))], mode
+    for fmt in (0, 1, 3):
+        assert L.r2l_debug_pack_body_format(fmt) == 0
+        offs = (C.c_longlong * 2)()
+        size = L.r2l_debug_pack_body_host(arr, len(keep), n_block, None, 0, offs)
+        buf = (C.c_char * size)()
+        assert L.r2l_debug_pack_body_host(arr, len(keep), n_block, buf, size, offs) == size
+        assert got[('pack_body', str(fmt))] == [str(size), _fnv(bytes(buf)), str(offs[0]), str(offs[1])], fmt
+    L.r2l_debug_pack_body_format(0)
+    tkeep, tarr = _lib.host_ptrs([tsd[n] for n in tnames])
+    off = (C.c_longlong * 1)()
+    size = L.nerf_debug_pack_chain_host(tarr, 24, None, 0, off)
+    buf = (C.c_char * size)()
+    assert L.nerf_debug_pack_chain_host(tarr, 24, buf, size, off) == size
+    assert got[('pack_chain',)] == [str(size), _fnv(bytes(buf)), str(off[0])]
+    key = (np.uint32(2654435761) * np.arange(1, 625, dtype=np.uint32)).astype(np.uint32)
+    pos = C.c_int(300)
+    for n in (0, 1, 2, 63, 64, 65, 100000):
+        out = np.empty(n, dtype=np.int32)
+        assert L.r2l_np_legacy_permutation(key.ctypes.data_as(C.c_void_p), C.byref(pos), n, out.ctypes.data_as(C.c_void_p)) == 0
+        assert got[('perm', str(n))] == [_fnv(out.tobytes()), str(pos.value)], n
