@@ -452,3 +452,30 @@ def perturbed_state(sd, seed=1234, rel=0.05):
     for k, v in sd.items():
         out[k] = v * (1 + rel * torch.randn(v.shape, generator=g)) if k.endswith('weight') else v.clone()
     return out
+
+
+def redistributed_state(sd, kind, seed=5, body_gain=1.0):
+    """Synthetic weights that do not look like nn.Linear's uniform init (no trained checkpoint exists offline):
+    every weight matrix of `sd` replaced by one of the same scale with another distribution -- 'laplace' (heavy tails, same
+    standard deviation), 'sparse' (half the weights zero, the rest x sqrt 2), 'outlier' (0.05 % of the weights x 12) --,
+    'uniform' keeps it; then every body weight x body_gain (the lever that moves the activation range).  Test / tool
+    infrastructure: tests/test_r2l_gpu.py, tools/range_sweep_dists.py."""
+    gen = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, w in sd.items():
+        if not k.endswith('weight') or kind == 'uniform':
+            out[k] = w.clone()
+        elif kind == 'laplace':
+            u = torch.rand(w.shape, generator=gen) - 0.5
+            out[k] = (-torch.sign(u) * torch.log1p(-2 * u.abs()) * w.std() / np.sqrt(2)).float()
+        elif kind == 'sparse':
+            out[k] = w * (torch.rand(w.shape, generator=gen) < 0.5).float() * float(np.sqrt(2))
+        elif kind == 'outlier':
+            w2 = w.clone()
+            w2.view(-1)[torch.randint(0, w.numel(), (max(1, w.numel() // 2000),), generator=gen)] *= 12.0
+            out[k] = w2
+        else:
+            raise ValueError(kind)
+        if k.startswith('body.') and k.endswith('weight') and body_gain != 1.0:
+            out[k] = out[k] * body_gain
+    return out

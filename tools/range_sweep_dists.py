@@ -1,0 +1,53 @@
+"""the evidence under `--precision auto` beyond one weight family.  W256D88 networks at full depth and
+800x800 whose weight matrices are Laplace / 50 %-sparse / outlier-laden / nn.Linear-uniform (oracle.redistributed_state), two
+seeds each, every body weight x gain over a range that lands on activation exponents 2 .. 5.  Per cell: the exponent measured on
+every ray of pose 0 (block inputs x / hidden h), max|a| of any operand set, the rung `--precision auto` picks, and L_inf against the
+compiler-scheduled fp16x3 (itself 6e-7 from the fp32 oracle) over three poses (the calibration pose and two 120 degrees away) of
+fp16_fp8 (bf6 terms), fp16_e4m3 and of what auto picked; the slope L_inf / max|a| of the two low-precision modes.
+The question per cell: does the rung the exponent selects hold 1e-4 with margin, whatever the distribution?
+    python tools/range_sweep_dists.py [H]     (through gpurun; ~4 min at H = 800)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import _pkg
+_pkg.load()
+from efficient_nerf_amd import R2LEngine, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3
+from oracle import r2l_oracle as O
+
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 800
+focal = O.focal_from_angle(H)
+poses = [O.pose_spherical(th, -30., 4.) for th in (0., 120., 240.)]
+GAINS = {'uniform': (0.9, 1.0, 1.05, 1.1, 1.15, 1.2), 'laplace': (0.9, 1.0, 1.05, 1.1, 1.15, 1.2),
+         'sparse': (0.9, 1.0, 1.05, 1.1, 1.15, 1.2), 'outlier': (0.85, 0.95, 1.0, 1.05, 1.1, 1.15)}
+worst_by_rung = {}
+for kind in ('uniform', 'laplace', 'sparse', 'outlier'):
+    for seed in (0, 1):
+        for gain in GAINS[kind]:
+            sd = O.redistributed_state(O.make_r2l_state(seed=seed), kind, seed=5 + seed, body_gain=gain)
+            e3 = R2LEngine(H, H, focal, precision=PREC_FP16X3).load_state_dict(sd)
+            ref = [e3.render(c).clone() for c in poses]
+            e3.close()
+            worst, top = {}, None
+            for name, prec in (('fp16_fp8', PREC_FP16_FP8), ('fp16_e4m3', PREC_FP16_E4M3)):
+                e8 = R2LEngine(H, H, focal, precision=prec).load_state_dict(sd)
+                ex = e8.calibrate_on(c2w=poses[0])
+                top = (max(ex[0::2]), max(ex[1::2]), e8.stream_max)
+                worst[name] = max((e8.render(c) - r).abs().max().item() for c, r in zip(poses, ref))
+                st = e8.range_status()
+                e8.close()
+            ea = R2LEngine(H, H, focal).load_state_dict(sd)
+            pick, ptop = ea.choose_precision(c2w=poses[0])
+            err = max((ea.render(c) - r).abs().max().item() for c, r in zip(poses, ref))
+            ea.close()
+            key = (pick, ptop)
+            worst_by_rung[key] = max(worst_by_rung.get(key, 0.0), err)
+            print('%-8s seed %d gain %.2f: exponent x %2d h %2d  max|a| %6.2f   L_inf vs fp16x3: fp16_fp8 %.2e (%.1e x max|a|)  fp16_e4m3 %.2e '
+                  '(%.1e x max|a|)   auto -> %-10s %.2e  %s'
+                  % (kind, seed, gain, top[0], top[1], top[2], worst['fp16_fp8'], worst['fp16_fp8'] / top[2], worst['fp16_e4m3'],
+                     worst['fp16_e4m3'] / top[2], pick, err, 'OK' if err <= 7e-5 else ('tight' if err <= 1e-4 else 'OVER')), flush=True)
+print()
+for (pick, ptop), e in sorted(worst_by_rung.items(), key=lambda kv: (kv[0][1] or 0, kv[0][0])):
+    print('worst L_inf of the rung auto picked, by exponent: exponent %s -> %-10s %.2e' % (ptop, pick, e))
