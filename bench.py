@@ -278,10 +278,11 @@ def main():
         ex = [int(e) for e in eng.act_exponents()]
         st = eng.range_status()
         # the rate is that of ONE rung of `--precision auto`'s ladder; which rung a checkpoint gets depends on its own activations
-        out['value_valid_for'] = ('activation exponent <= %d (max|a| <= %d over all operand sets: the rung --precision auto gives '
-                                  'these weights; exponent 4 -> fp16_e4m3, above -> fp16x3_asm: e4m3_mode / stress_weights below)'
-                                  % ((eng.AUTO_MAX_EXP, 2 ** eng.AUTO_MAX_EXP) if args.precision == 'fp16_fp8' else
-                                     (eng.AUTO_MAX_EXP_E4M3, 2 ** eng.AUTO_MAX_EXP_E4M3)))
+        out['value_valid_for'] = ('activation exponent <= 3 (max|a| <= %g over all operand sets of every ray: the rung --precision auto '
+                                  'gives these weights; up to %g -> fp16_e4m3, above -> fp16x3_asm: e4m3_mode / stress_weights below; '
+                                  'limits from profiles/r04_range_sweep_dists.txt)' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)
+                                  if args.precision == 'fp16_fp8' else
+                                  'max|a| <= %g over all operand sets of every ray (the middle rung of --precision auto)' % eng.AUTO_MAX_ABS_E4M3)
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
                               'auto_precision_limit': eng.AUTO_MAX_EXP,   # --precision auto takes fp16_fp8 up to this exponent
                               'measured_on': 'every ray of one 800x800 frame (test pose 0), range-guarded render',

@@ -326,13 +326,14 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
         if not args.trial.ON or args.trial.body_arch != 'resmlp':
             raise R2LError('R2L rendering needs --trial.ON --trial.body_arch resmlp (README.md:51)')
         if args.act.lower() != 'relu' or args.trial.inact.lower() != 'relu' or args.trial.outact.lower() != 'none' \
-                or float(args.trial.res_scale) != 1. or int(args.trial.n_learnable) != 2:
+                or int(args.trial.n_learnable) != 2:
             raise R2LError(f'act={args.act} trial.inact={args.trial.inact} trial.outact={args.trial.outact} '
-                           f'trial.res_scale={args.trial.res_scale} trial.n_learnable={args.trial.n_learnable}: the ResMLP '
-                           f'kernels are built for relu / relu / none / 1 / 2 (model/nerf_raybased.py:443-465)')
+                           f'trial.n_learnable={args.trial.n_learnable}: the ResMLP kernels are built for relu / relu / none / 2 '
+                           f'(model/nerf_raybased.py:443-465); --trial.res_scale is honoured (folded into the second layer)')
         n_block = args.trial.n_block if args.trial.n_block > 0 else (args.netdepth - 2) // 2
         eng = R2LEngine(H, W, focal, near, far, n_sample=args.n_sample_per_ray, L=args.multires,
-                        width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec)
+                        width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec,
+                        res_scale=float(args.trial.res_scale))
         eng.load_state_dict(ckpt['network_fn_state_dict'])
         if auto:
             if probe_pose is None and probe_rays is None:
@@ -341,8 +342,8 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
             if log and top is None:
                 log(f'[precision] auto: {eng.auto_note} -> {name}')
             elif log:
-                log(f'[precision] auto: activation exponents of every ray of the first frame up to {top} '
-                    f'(fp16_fp8 up to {eng.AUTO_MAX_EXP}, fp16_e4m3 up to {eng.AUTO_MAX_EXP_E4M3}) -> {name}')
+                log(f'[precision] auto: activations of every ray of the first frame up to {eng.stream_max:.2f} (exponent {top}; '
+                    f'fp16_fp8 up to {eng.AUTO_MAX_ABS:g}, fp16_e4m3 up to {eng.AUTO_MAX_ABS_E4M3:g}) -> {name}')
         return 'R2L', eng
     if args.model_name == 'nerf':
         if not args.use_viewdirs or args.N_importance <= 0:

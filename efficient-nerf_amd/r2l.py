@@ -45,8 +45,12 @@ class R2LEngine:
     """One r2l_ctx: geometry + weights + launches (include/r2l_hip.h)."""
 
     def __init__(self, H, W, focal, near=2., far=6., n_sample=16, L=10, width=256, n_block=43,
-                 use_residual=True, precision=PREC_FP16X3, device=None, z_vals=None):
+                 use_residual=True, precision=PREC_FP16X3, device=None, z_vals=None, res_scale=1.0):
+        """res_scale: ResMLP's `--trial.res_scale` (model/nerf_raybased.py:461: x = body(x).mul(res_scale) + x).  The kernels
+        compute x += W2 h + b2; the factor is folded into W2 and b2 when the weights are loaded (exact for powers of two, one
+        fp32 rounding per weight otherwise: far inside the 1e-4 contract)."""
         self.device = _dev(device)
+        self.res_scale = float(res_scale)
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.n_block = int(n_block)
         self._ctx = C.c_void_p()
@@ -97,6 +101,11 @@ class R2LEngine:
             want = shapes.get(n, (256, 256) if n.endswith('weight') else (256,))
             if tuple(sd[n].shape) != want:
                 raise R2LError(f'{n}: shape {tuple(sd[n].shape)} != {want}')
+        if self.res_scale != 1.0:      # (W2 h + b2) s + x = (s W2) h + s b2 + x
+            sd = dict(sd)
+            for i in range(self.n_block):
+                for k in (f'body.{i}.body.2.weight', f'body.{i}.body.2.bias'):
+                    sd[k] = sd[k].detach().to('cpu', torch.float32) * self.res_scale
         keep, arr = _lib.host_ptrs([sd[n] for n in names])
         with torch.cuda.device(self.device):
             check(lib().r2l_load_weights(self._ctx, arr, len(keep)))
@@ -233,32 +242,37 @@ class R2LEngine:
 
     _guard_period = 8
 
-    #: `--precision auto`'s ladder: the largest activation exponent (|a| <= 2^E over all operand sets) up to which a mode
-    #: stays inside the 1e-4 rgb contract with margin.  W256D88 networks with every body weight x gain (tools/range_sweep.py,
-    #: profiles/r03_range_sweep.txt), L_inf against fp16x3: bf6 terms 3-6e-5 at E = 3, 6e-5-1.4e-4 at 4; e4m3 terms half of
-    #: that; above: fp16x3_asm, three fp16 passes on the same generated kernels (no low-precision term, no scales, nothing
-    #: to watch: 5-7e-7 against the reference golden, as the compiler-scheduled fp16x3 it is 7 % faster than).
-    AUTO_MAX_EXP = 3          # fp16_fp8 (bf6 x bf6 terms, 1.5 pass-equivalents)
-    AUTO_MAX_EXP_E4M3 = 4     # fp16_e4m3 (e4m3 x e4m3 terms, 2.0 pass-equivalents)
+    #: `--precision auto`'s ladder: the largest |activation| over all operand sets (`stream_max`, measured on every ray) up to
+    #: which a mode stays inside the 1e-4 rgb contract with margin.  The error of the low-precision terms is proportional to it.
+    #: Measured slopes, L_inf against fp16x3 / max|a|, W256D88 at 800x800, three poses: nn.Linear-uniform weights x gain (three
+    #: seeds, profiles/r03_range_sweep.txt) AND Laplace / 50 %-sparse / outlier-laden weights (two seeds each,
+    #: profiles/r04_range_sweep_dists.txt): bf6 terms <= 9.7e-6 up to max|a| = 10 (1.1-1.3e-5 beyond), e4m3 terms <= 6.6e-6.
+    #: With a budget of 8e-5: bf6 up to max|a| = 8 (= activation exponent 3: worst cell 6.0e-5), e4m3 up to 12 (worst cell
+    #: 7.0e-5; at 13.7 a Laplace network reads 7.3e-5 and the slope would pass 1e-4 before 16, so the rung does NOT cover all of
+    #: exponent 4 as it did in round 3), above: fp16x3_asm, three fp16 passes on the same generated kernels (no low-precision
+    #: term, no scales, nothing to watch: 5-7e-7 against the reference golden).
+    AUTO_MAX_ABS = 8.0         # fp16_fp8 (bf6 x bf6 terms, 1.5 pass-equivalents)
+    AUTO_MAX_ABS_E4M3 = 12.0   # fp16_e4m3 (e4m3 x e4m3 terms, 2.0 pass-equivalents)
+    AUTO_MAX_EXP = 3           # = log2(AUTO_MAX_ABS): the exponent view of the first limit (messages, bench.py)
+    AUTO_MAX_EXP_E4M3 = 4      # the exponent the middle rung lies in (it covers max|a| in (8, 12] of (8, 16])
+    LADDER = (PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM)
 
-    def _mode_for(self, top, max_exp=None):
-        lim = self.AUTO_MAX_EXP if max_exp is None else int(max_exp)
-        if top <= lim:
-            return PREC_FP16_FP8
-        if max_exp is None and top <= self.AUTO_MAX_EXP_E4M3:
-            return PREC_FP16_E4M3
-        return PREC_FP16X3_ASM
+    def _rung_for(self, amax, max_exp=None):
+        """index into LADDER for a largest |activation| of `amax`; max_exp (tests): fp16_fp8 up to 2^max_exp, no middle rung"""
+        if max_exp is not None:
+            return 0 if amax <= 2.0 ** int(max_exp) else 2
+        return 0 if amax <= self.AUTO_MAX_ABS else 1 if amax <= self.AUTO_MAX_ABS_E4M3 else 2
 
     def choose_precision(self, c2w=None, rays=None, max_exp=None):
         """`--precision auto`: the fastest mode the network's own activation ranges allow: fp16_fp8 (bf6 correction terms)
-        up to exponent 3, fp16_e4m3 at 4, fp16x3_asm above.  The error of the low-precision terms is relative to the residual
+        up to max|a| = 8, fp16_e4m3 up to 12, fp16x3_asm above.  The error of the low-precision terms is relative to the residual
         stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so the choice needs the ranges of THESE weights:
         `calibrate_on` measures them on every ray of the frame of pose `c2w` (or of the given `rays` = (rays_o, rays_d)).
         `max_exp` overrides fp16_fp8's limit and disables the middle step (tests).  What is rendered afterwards stays
-        watched (range_status / `check_ranges`).  Synchronous, once per weight load.
+        watched (range_status / `check_ranges`, which applies the same limits to what it sees).  Synchronous, once per weight load.
         Weights the generated kernels cannot pack (a layer with max|w| outside 2^-12 .. 2^6) get fp16x3, the compiler-scheduled
         mode with per-layer scales: ('fp16x3', None), the library's message in `auto_note`.
-        Returns (name of the chosen precision, largest exponent)."""
+        Returns (name of the chosen precision, largest exponent); `stream_max` holds the largest |activation|."""
         try:
             self.set_precision(PREC_FP16_FP8)
         except R2LError as e:
@@ -272,7 +286,7 @@ class R2LEngine:
             return 'fp16_fp8', 0
         top = max(self.calibrate_on(c2w=c2w, rays=rays))
         self._auto = (max_exp,)
-        mode = self._mode_for(top, max_exp)
+        mode = self.LADDER[self._rung_for(self.stream_max, max_exp)]
         if mode != PREC_FP16_FP8:
             self.set_precision(mode)          # the exponents travel with a switch between the two split modes
             if mode in SPLIT_MODES:
@@ -303,8 +317,9 @@ class R2LEngine:
                       at the default guard period --, so nothing is known about the other operand sets of these rays: the
                       next launch is range-guarded and measures all of them;
           a precision name: the exponents were raised from the maxima of the guarded launches (r2l_recalibrate) and values
-                      WERE clamped in the frame, or the raised exponents leave the current rung of `choose_precision`'s
-                      ladder and the context has switched (fp16_fp8 -> fp16_e4m3 -> fp16x3_asm; never back).
+                      WERE clamped in the frame; or (`--precision auto` only) the largest |activation| these rays produced is
+                      beyond what the current rung of `choose_precision`'s ladder holds to 1e-4 -- the same limits, applied
+                      to every frame -- and the context has switched (fp16_fp8 -> fp16_e4m3 -> fp16x3_asm; never back).
         Values beyond RAISE_AT that were not clamped raise the exponents for what follows and the frame stands (None).
         An explicit precision keeps its mode and says so.  Synchronises: one stream sync + one device copy
         (r2l_get_range_status) per call, more only when it acts.
@@ -317,21 +332,34 @@ class R2LEngine:
         scaled = max(st['h0_fill'], st['worst_fill']) * top
         act, clamped = scaled > self.RAISE_AT, bool(st['saturated'])
         guarded = st['guarded_launches'] > 0
+        auto = getattr(self, '_auto', None)
+        cur = self.LADDER.index(self.precision)
+        # the ladder's own limit applied to what THESE rays did (h0 of every ray; every set on the guarded launches)
+        want = max(cur, self._rung_for(st['stream_max'], auto[0])) if auto is not None else cur
         if rank_max is not None:    # the ranks launch in step, so `guarded` agrees anyway; it rides along in the one all-reduce
-            act, clamped, guarded = (bool(v) for v in rank_max([act, clamped, guarded]))
-        if not (act or clamped):
+            act, clamped, guarded, want = rank_max([act, clamped, guarded, want])
+            act, clamped, guarded = bool(act), bool(clamped), bool(guarded)
+        if not (act or clamped or want > cur):
             return None
         fmt = 'bf6' if self.precision == PREC_FP16_FP8 else 'e4m3'
         msg = ('[precision] activations reach %.1f in units of their %s scale (operand set %d; h0: %.1f; calibrated to <= 16, limit '
                '%.1f, clamped beyond %g)%s' % (st['worst_fill'] * top, fmt, st['worst_set'], st['h0_fill'] * top, self.RAISE_AT, top,
                                                  ': values were clamped' if clamped else ''))
+        if not (act or clamped):
+            # inside the scales, but larger than this rung's correction terms hold to 1e-4: down the ladder, frame rendered again
+            self.range_status(reset=True)
+            self.set_precision(self.LADDER[want])
+            if log:
+                log('[precision] largest |activation| %.2f is beyond what %s holds to 1e-4 (fp16_fp8 up to %g, fp16_e4m3 up to %g) -> %s, '
+                    'frame rendered again' % (st['stream_max'], PREC_NAMES[self.LADDER[cur]], self.AUTO_MAX_ABS, self.AUTO_MAX_ABS_E4M3,
+                                              PREC_NAMES[self.LADDER[want]]))
+            return PREC_NAMES[self.LADDER[want]]
         if not guarded:
             self.range_status(reset=True)
             self.set_guard_period(self._guard_period)      # restarts the guard's phase: the next launch is range-guarded
             if log:
                 log(msg + '; only the head output of these rays was watched: rendered again range-guarded')
             return 'measure'
-        auto = getattr(self, '_auto', None)
         before = self.act_exponents()
         self.recalibrate()
         if agree is not None:
@@ -343,13 +371,12 @@ class R2LEngine:
             # the maxima behind the new exponents come from a forward pass with clamped operands: the re-render is
             # range-guarded as well, so that the next check sees every set of the frame under the new scales
             self.set_guard_period(self._guard_period)
-        if auto is not None:
-            mode = self._mode_for(top_e, auto[0])
-            if mode != self.precision and (mode == PREC_FP16X3_ASM or self.precision == PREC_FP16_FP8):   # never back up the ladder
-                self.set_precision(mode)
-                if log:
-                    log(msg + f'; exponents now up to {top_e} -> {PREC_NAMES[mode]}, frame rendered again')
-                return PREC_NAMES[mode]
+        if want > cur:       # never back up the ladder
+            mode = self.LADDER[want]
+            self.set_precision(mode)
+            if log:
+                log(msg + f'; exponents now up to {top_e}, largest |activation| {st["stream_max"]:.2f} -> {PREC_NAMES[mode]}, frame rendered again')
+            return PREC_NAMES[mode]
         if log:
             log(msg + ('; exponents raised (up to %d)' % top_e if after != before else '; exponents unchanged') +
                 (', frame rendered again' if clamped else '') +
@@ -501,9 +528,9 @@ class NeRF_v3_2:
         if getattr(args, 'layerwise_netwidths', '') or getattr(args, 'linear_tail', False):
             raise R2LError('layerwise_netwidths / linear_tail variants are not supported')
         if getattr(args, 'act', 'relu').lower() != 'relu' or getattr(trial, 'inact', 'relu').lower() != 'relu' \
-                or getattr(trial, 'outact', 'none').lower() != 'none' \
-                or float(getattr(trial, 'res_scale', 1.)) != 1. or int(getattr(trial, 'n_learnable', 2)) != 2:
-            raise R2LError('only act=relu, trial.inact=relu, trial.outact=none, res_scale=1, n_learnable=2')
+                or getattr(trial, 'outact', 'none').lower() != 'none' or int(getattr(trial, 'n_learnable', 2)) != 2:
+            raise R2LError('only act=relu, trial.inact=relu, trial.outact=none, n_learnable=2 (any trial.res_scale)')
+        self.res_scale = float(getattr(trial, 'res_scale', 1.))
         n_block = int(getattr(trial, 'n_block', -1))
         self.n_block = n_block if n_block > 0 else (D - 2) // 2
         self.use_residual = bool(getattr(args, 'use_residual', False))
@@ -531,7 +558,8 @@ class NeRF_v3_2:
             if self._state is None:
                 raise R2LError('NeRF_v3_2 called before load_state_dict')
             eng = R2LEngine(sampler.H, sampler.W, sampler.focal, sampler.near, sampler.far,
-                            n_block=self.n_block, use_residual=self.use_residual, precision=self.precision)
+                            n_block=self.n_block, use_residual=self.use_residual, precision=self.precision,
+                            res_scale=self.res_scale)
             eng.load_state_dict(self._state)
             self._engines[key] = eng
         return eng

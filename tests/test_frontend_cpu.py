@@ -154,14 +154,15 @@ def test_png_writer(fe, tmp_path):
 
 
 def test_build_engine_refuses_flags_the_kernels_do_not_honour(fe):
-    """A checkpoint trained with another activation / res_scale / depth must raise, not render silently wrong
-    images (the reference's ResMLP honours these flags: model/nerf_raybased.py:443-465)."""
+    """A checkpoint trained with another activation / block depth must raise, not render silently wrong images (the
+    reference's ResMLP honours these flags: model/nerf_raybased.py:443-465; --trial.res_scale is honoured here too, folded
+    into the second layer: tests/test_r2l_gpu.py)."""
     import _pkg
     _pkg.load()
     from efficient_nerf_amd import R2LError
     base = ['--model_name', 'R2L', '--dataset_type', 'blender', '--netdepth', '88', '--n_sample_per_ray', '16', '--trial.ON',
             '--trial.body_arch', 'resmlp', '--use_residual']
-    for extra in (['--act', 'gelu'], ['--trial.inact', 'lrelu'], ['--trial.outact', 'relu'], ['--trial.res_scale', '0.5'],
+    for extra in (['--act', 'gelu'], ['--trial.inact', 'lrelu'], ['--trial.outact', 'relu'],
                   ['--trial.n_learnable', '3'], ['--linear_tail'], ['--dataset_type', 'llff']):
         with pytest.raises(R2LError):
             fe.build_engine(fe.parse_args(base + extra), (8, 8, 10.), {})

@@ -45,7 +45,7 @@ struct Cfg {
 // slot s of 16 holds floor((s + 1) n / 16) - floor(s n / 16) instructions of a class with n per iteration
 #define SLOTS(n, text) ".rept ((eps_s + 1) * %c[" #n "]) / 16 - (eps_s * %c[" #n "]) / 16\n" text ".endr\n"
 
-template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A>
+template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A, int K, int LS>
 __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, const char* __restrict__ stream, int iters, float* sink) {
     i32x4* l = reinterpret_cast<i32x4*>(smem);
     for (int i = threadIdx.x; i < 4096; i += 256) l[i] = data[i];
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
     f32x16 c0 = {0}, c1 = {0};
     f32x4 h0 = {0, 0, 0, 0}, h1 = h0;
     int sc = 127;
-    f32x4 d0 = {0, 0, 0, 0}, d1 = d0, g0 = d0;
+    f32x4 d0 = {0, 0, 0, 0}, g0 = d0;
+    f32x4 d1 = __builtin_bit_cast(f32x4, l[1500 + lane]);     // ds_write data: random bits
     i32x16 src;
 #pragma unroll
     for (int j = 0; j < 16; ++j) src[j] = l[2200 + 64 * (j >> 2) + lane][j & 3];   // 32 f16 activations per lane
@@ -74,7 +75,11 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
     unsigned waddr = 65536 + wave * 8192 + lane * 16;
     // the stream: every wave walks the 19 MiB buffer in 1 KiB steps from its own offset (blocks start spread over it)
     const char* gbase = stream;
-    unsigned goff = (unsigned)(((blockIdx.x * 4 + wave) * 73 * 1024) % (STREAM_BYTES - (1u << 20))) + lane * 16;
+    // LS = 0: every wave walks its own part of the buffer (no two CUs share a line: the stream comes from the Infinity Cache);
+    // LS = 1: all workgroups walk the SAME addresses in step, wave w taking every 4th KiB -- the generated kernels' pattern
+    // (every CU streams the same weights at about the same time: L2 hits behind the first CU of an XCD)
+    unsigned goff = LS ? (unsigned)(wave * 1024 + lane * 16)
+                       : (unsigned)(((blockIdx.x * 4 + wave) * 73 * 1024) % (STREAM_BYTES - (1u << 20))) + lane * 16;
     const unsigned lds_dma_base = __builtin_amdgcn_readfirstlane(98304 + wave * 4096);    // M0: where the wave's LDS-DMA pieces land (4 KiB window per wave)
     for (int i = 0; i < iters; ++i) {
         asm volatile(
@@ -83,14 +88,16 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
             ".set eps_s, 0\n"
             ".rept 16\n"
             SLOTS(nM, ".if (eps_s & 1)\n v_mfma_f32_32x32x16_f16 %[c1], %[a1], %[b1], %[c1]\n .else\n v_mfma_f32_32x32x16_f16 %[c0], %[a0], %[b0], %[c0]\n .endif\n")
-            SLOTS(nG, "global_load_lds_dwordx4 %[goff], %[gbase]\n v_add_u32 %[goff], 0x400, %[goff]\n")
+            SLOTS(nG, "global_load_lds_dwordx4 %[goff], %[gbase]\n v_add_u32 %[goff], %[gstep], %[goff]\n")
             SLOTS(nR, "ds_read_b128 %[d0], %[addr] offset:(1024 * (eps_s & 15))\n")
             SLOTS(nF, "v_fma_f32 %[v2], %[v0], %[v1], %[v2]\n")
             SLOTS(nH, ".if (eps_s & 1)\n v_mfma_f32_16x16x32_f16 %[h1], %[a3], %[b3], %[h1]\n .else\n v_mfma_f32_16x16x32_f16 %[h0], %[a2], %[b2], %[h0]\n .endif\n")
             SLOTS(nP, "v_cvt_pk_f16_f32 %[x0], %[v0], %[v1]\n")
             SLOTS(nB, ".if (eps_s & 1)\n v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], %[a1x], %[b1x], %[c1], %[sc], %[sc] op_sel_hi:[0,0,0] cbsz:3 blgp:3\n .else\n"
                       " v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], %[a0x], %[b0x], %[c0], %[sc], %[sc] op_sel_hi:[0,0,0] cbsz:3 blgp:3\n .endif\n")
-            SLOTS(nL, "global_load_dwordx4 %[g0], %[goff], %[gbase]\n v_add_u32 %[goff], 0x400, %[goff]\n")
+            SLOTS(nL, "global_load_dwordx4 %[g0], %[goff], %[gbase]\n v_add_u32 %[goff], %[gstep], %[goff]\n")
+            SLOTS(nK, ".if (eps_s & 1)\n v_mfma_scale_f32_16x16x128_f8f6f4 %[h1], %[a1x], %[b1x], %[h1], %[sc], %[sc] op_sel_hi:[0,0,0] cbsz:3 blgp:3\n .else\n"
+                      " v_mfma_scale_f32_16x16x128_f8f6f4 %[h0], %[a0x], %[b0x], %[h0], %[sc], %[sc] op_sel_hi:[0,0,0] cbsz:3 blgp:3\n .endif\n")
             SLOTS(nW, "ds_write_b128 %[waddr], %[d1] offset:(1024 * (eps_s & 7))\n")
             SLOTS(nX, "v_fma_mixlo_f16 %[x1], %[x0], %[scale], %[v0] op_sel_hi:[1,0,0]\n v_fma_mixhi_f16 %[x1], %[x0], %[scale], %[v1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
             SLOTS(nC, ".if (eps_s & 1)\n v_cvt_scalef32_pk32_bf6_f16 %[cv], %[src2], %[scale]\n .else\n v_cvt_scalef32_pk32_bf6_f16 %[cv], %[src], %[scale]\n .endif\n")
@@ -101,8 +108,10 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
             "v_cmp_lt_u32 vcc, %[wrap], %[goff]\n"
             "v_subrev_u32 %[goff], %[wrap], %[goff]\n"
             "v_add_u32 %[goff], %[wrap], %[goff]\n"
-            "v_cndmask_b32 %[goff], %[goff], %[lane16], vcc\n"
-            "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+            "v_cndmask_b32 %[goff], %[goff], %[start], vcc\n"
+            // the loads of THIS iteration stay in flight across the loop edge (the generated kernels prefetch chunks ahead): only
+            // the previous iteration's are waited for
+            "s_waitcnt vmcnt(%c[nG] + %c[nL]) lgkmcnt(0)\n"
             : [c0] "+v"(c0), [c1] "+v"(c1), [h0] "+v"(h0), [h1] "+v"(h1), [v2] "+v"(v2), [d0] "+v"(d0), [g0] "+v"(g0), [goff] "+v"(goff),
               [x0] "+v"(x0), [x1] "+v"(x1), [cv] "+v"(cv), [acct] "+v"(acc_t)
             : [a0] "v"(__builtin_shufflevector(a[0], a[0], 0, 1, 2, 3)), [a1] "v"(__builtin_shufflevector(a[1], a[1], 0, 1, 2, 3)),
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
               [b2] "v"(__builtin_shufflevector(b[2], b[2], 0, 1, 2, 3)), [b3] "v"(__builtin_shufflevector(b[3], b[3], 0, 1, 2, 3)),
               [a0x] "v"(a[0]), [a1x] "v"(a[1]), [b0x] "v"(b[0]), [b1x] "v"(b[1]), [sc] "v"(sc), [v0] "v"(v0), [v1] "v"(v1),
               [addr] "v"(addr), [waddr] "v"(waddr), [d1] "v"(d1), [gbase] "s"(gbase), [src] "v"(src), [src2] "v"(src2), [scale] "v"(scale),
-              [m0v] "s"(lds_dma_base), [wrap] "v"(STREAM_BYTES - (2u << 20)), [lane16] "v"((unsigned)lane * 16),
+              [m0v] "s"(lds_dma_base), [wrap] "v"(STREAM_BYTES - (2u << 20)), [start] "v"(LS ? (unsigned)(wave * 1024 + lane * 16) : (unsigned)lane * 16), [gstep] "v"(LS ? 4096u : 1024u), [nK] "i"(K),
               [nM] "i"(M), [nH] "i"(H), [nB] "i"(B), [nR] "i"(R), [nW] "i"(W), [nG] "i"(G), [nL] "i"(L), [nC] "i"(C), [nX] "i"(X),
               [nP] "i"(P), [nF] "i"(F), [nA] "i"(A)
             : "a0", "vcc", "memory");
@@ -138,9 +147,9 @@ static const i32x4* g_data;
 static const char* g_stream;
 static float* g_sink;
 
-template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A>
+template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A, int K = 0, int LS = 0>
 void run(const char* tag) {
-    auto kern = probe<M, H, B, R, W, G, L, C, X, P, F, A>;
+    auto kern = probe<M, H, B, R, W, G, L, C, X, P, F, A, K, LS>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     // calibrate the iteration count to ~2.5 ms per launch
     hipEvent_t e0, e1;
@@ -156,7 +165,7 @@ void run(const char* tag) {
     hipEventElapsedTime(&ms, e0, e1);
     int iters = (int)(200 * 2.5 / (ms > 1e-3 ? ms : 1e-3));
     if (iters < 50) iters = 50;
-    const int warm = 400, window = 1000;
+    const int warm = 300, window = 800;
     for (int i = 0; i < warm; ++i) kern<<<256, 256, 131072>>>(g_data, g_stream, iters, g_sink);
     hipEventRecord(e0);
     for (int i = 0; i < window; ++i) kern<<<256, 256, 131072>>>(g_data, g_stream, iters, g_sink);
@@ -174,8 +183,8 @@ void run(const char* tag) {
     hipError_t err = hipGetLastError();
     hipEventElapsedTime(&ms, e0, e1);
     const double it_per_s = (double)iters * window / (ms * 1e-3);        // per wave; x 1024 waves on the chip
-    printf("%-28s M %2d H %2d B %2d R %2d W %2d G %2d L %2d C %2d X %2d P %2d F %2d A %2d   iter/s/wave %.4e   power %7.1f W   sclk %6.0f MHz   (%d samples)%s\n",
-           tag, M, H, B, R, W, G, L, C, X, P, F, A, it_per_s, n ? pw_sum / n : 0.0, n ? ck_sum / n : 0.0, n,
+    printf("%-34s M %2d H %2d B %2d K %2d R %2d W %2d G %2d L %2d%s C %2d X %2d P %2d F %2d A %2d   iter/s/wave %.4e   power %7.1f W   sclk %6.0f MHz   (%d samples)%s\n",
+           tag, M, H, B, K, R, W, G, L, LS ? " lockstep" : "         ", C, X, P, F, A, it_per_s, n ? pw_sum / n : 0.0, n ? ck_sum / n : 0.0, n,
            err == hipSuccess ? "" : hipGetErrorString(err));
     fflush(stdout);
 }
@@ -222,37 +231,59 @@ int main() {
         }
         printf("%-28s power %7.1f W   sclk %6.0f MHz\n", "idle (no kernel)", p / 20, c / 20);
     }
-    //   M  H  B  R  W  G  L  C  X  P  F  A
+    //   M  H  B  R  W  G  L  C  X  P  F  A [K LS]
+    if (getenv("EP_AB") != nullptr) {
+        // A/B of the energy account's first lever (profiles/r04_energy_account.txt): the body kernel's mix with the SAME bytes,
+        // VALU and MACs in 32x32 and in 16x16 MFMA shapes, loads in flight across the loop edge (power-bound, not latency-bound)
+        run<11, 0, 5, 22, 0, 5, 0, 1, 5, 5, 8, 4, 0, 1>("body replica (32x32 shapes)");
+        run<0, 22, 0, 22, 0, 5, 0, 1, 5, 5, 8, 4, 10, 1>("body replica in 16x16 shapes");
+        run<0, 22, 5, 22, 0, 5, 0, 1, 5, 5, 8, 4, 0, 1>("body replica, f16 16x16 + bf6 32x32");
+        run<11, 0, 5, 22, 0, 0, 0, 1, 5, 5, 8, 4, 0, 1>("body replica (32x32), no DMA");
+        run<0, 22, 0, 22, 0, 0, 0, 1, 5, 5, 8, 4, 10, 1>("body replica (16x16), no DMA");
+        run<11, 0, 5, 11, 3, 0, 5, 1, 5, 5, 8, 4, 0, 1>("B-from-LDS variant (32x32)");
+        run<0, 22, 0, 11, 3, 0, 5, 1, 5, 5, 8, 4, 10, 1>("B-from-LDS variant (16x16)");
+        run<0, 22, 0, 20, 0, 4, 0, 1, 8, 8, 10, 3, 10, 1>("chain replica (16x16)");
+        run<0, 22, 0, 8, 3, 0, 4, 1, 8, 8, 10, 3, 10, 1>("chain, weights in registers");
+        run<11, 0, 5, 22, 0, 5, 0, 1, 5, 5, 8, 4, 0, 1>("body replica (32x32 shapes) again");
+        run<0, 22, 0, 22, 0, 5, 0, 1, 5, 5, 8, 4, 10, 1>("body replica in 16x16 shapes again");
+        rsmi_shut_down();
+        return 0;
+    }
     run<0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0>("spin (loop overhead only)");
-    run<0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0>("v_fma_f32 x16");
     run<0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0>("v_fma_f32 x64");
     run<0, 0, 0, 0, 0, 0, 0, 0, 0, 32, 0, 0>("v_cvt_pk_f16_f32 x32");
     run<0, 0, 0, 0, 0, 0, 0, 0, 32, 0, 0, 0>("v_fma_mix pair x32");
     run<0, 0, 0, 0, 0, 0, 0, 8, 0, 0, 0, 0>("cvt_pk32_bf6 x8");
     run<0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32>("accvgpr pair x32");
     run<0, 0, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0>("ds_read_b128 x16");
-    run<0, 0, 0, 48, 0, 0, 0, 0, 0, 0, 0, 0>("ds_read_b128 x48");
-    run<0, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0, 0>("ds_write_b128 x16");
-    run<0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 0>("LDS-DMA x4");
-    run<0, 0, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0>("LDS-DMA x16");
-    run<0, 0, 0, 0, 0, 0, 16, 0, 0, 0, 0, 0>("global_load_dwordx4 x16");
+    run<0, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0, 0>("ds_write_b128 x16 (random data)");
+    run<0, 0, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0>("LDS-DMA x16 (Infinity Cache)");
+    run<0, 0, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0, 0, 1>("LDS-DMA x16 (L2, lockstep)");
+    run<0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 0, 0, 1>("LDS-DMA x4 (L2, lockstep)");
+    run<0, 0, 0, 0, 0, 0, 16, 0, 0, 0, 0, 0, 0, 1>("global_load x16 (L2, lockstep)");
     run<16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 32x32x16 f16 x16");
     run<0, 32, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 16x16x32 f16 x32");
     run<0, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 32x32x64 bf6 x16");
-    run<11, 0, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma f16:bf6 2:1");
-    // the body kernel's ratios per 16 MFMA (per block: 256 f16 + 128 bf6 MFMA, 547 ds_read, 113 LDS-DMA, 763 VALU of which
-    // 16 cvt_pk32, 128 cvt_pk, 256 fma_mix, ~190 accvgpr, rest plain)
+    run<0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32>("mfma 16x16x128 bf6 x32");
+    run<11, 0, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 32x32 f16:bf6 2:1");
+    run<0, 22, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 10>("mfma 16x16 f16:bf6 2:1");
+    // the body kernel's ratios per 16 MFMA (per block: 256 f16 + 128 bf6 MFMA, 547 ds_read, 113 LDS-DMA per wave, 763 VALU of
+    // which 16 cvt_pk32, 128 cvt_pk, 256 fma_mix, ~190 accvgpr, rest plain)
     run<16, 0, 0, 22, 0, 0, 0, 0, 0, 0, 0, 0>("mfma16 + ds_read 1.4/MFMA");
-    run<16, 0, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0>("mfma16 + LDS-DMA 0.3/MFMA");
-    run<16, 0, 0, 0, 0, 0, 5, 0, 0, 0, 0, 0>("mfma16 + gload 0.3/MFMA");
+    run<16, 0, 0, 0, 0, 5, 0, 0, 0, 0, 0, 0, 0, 1>("mfma16 + LDS-DMA 0.3/MFMA (L2)");
     run<16, 0, 0, 0, 0, 0, 0, 1, 5, 5, 8, 4>("mfma16 + VALU 2/MFMA");
-    run<11, 0, 5, 22, 0, 5, 0, 1, 5, 5, 8, 4>("body replica");
-    run<11, 0, 5, 22, 0, 0, 0, 1, 5, 5, 8, 4>("body replica, no DMA");
-    run<11, 0, 5, 0, 0, 5, 0, 1, 5, 5, 8, 4>("body replica, no ds_read");
-    run<11, 0, 5, 22, 0, 5, 0, 0, 0, 0, 0, 0>("body replica, no VALU");
-    run<11, 0, 5, 11, 3, 0, 5, 1, 5, 5, 8, 4>("B-from-LDS variant");
-    // the teacher chain: 16x16 shapes, per tile 3,732 MFMA (2/3 f16), 2,508 ds_read, 529 LDS-DMA, 3,452 VALU
-    run<0, 22, 5, 11, 0, 2, 0, 1, 4, 4, 6, 0>("chain replica (16x16)");
+    run<11, 0, 5, 22, 0, 5, 0, 1, 5, 5, 8, 4, 0, 1>("body replica (32x32 shapes)");
+    run<11, 0, 5, 22, 0, 0, 0, 1, 5, 5, 8, 4, 0, 1>("body replica, no DMA");
+    run<11, 0, 5, 0, 0, 5, 0, 1, 5, 5, 8, 4, 0, 1>("body replica, no ds_read");
+    run<11, 0, 5, 22, 0, 5, 0, 0, 0, 0, 0, 0, 0, 1>("body replica, no VALU");
+    run<0, 22, 0, 22, 0, 5, 0, 1, 5, 5, 8, 4, 10, 1>("body replica in 16x16 shapes");
+    run<0, 22, 5, 22, 0, 5, 0, 1, 5, 5, 8, 4, 0, 1>("body replica, f16 16x16 + bf6 32x32");
+    // weights from global into registers, activations through LDS: half the ds_read, + ds_write, no LDS-DMA
+    run<11, 0, 5, 11, 3, 0, 5, 1, 5, 5, 8, 4, 0, 1>("B-from-LDS variant (32x32)");
+    run<0, 22, 0, 11, 3, 0, 5, 1, 5, 5, 8, 4, 10, 1>("B-from-LDS variant (16x16)");
+    // the teacher chain: 16x16 shapes, per tile 3,732 MFMA (2/3 f16), 2,508 ds_read, 529 LDS-DMA per wave, 3,452 VALU
+    run<0, 22, 0, 20, 0, 4, 0, 1, 8, 8, 10, 3, 10, 1>("chain replica (16x16)");
+    run<0, 22, 0, 8, 3, 0, 4, 1, 8, 8, 10, 3, 10, 1>("chain, weights in registers");
     rsmi_shut_down();
     return 0;
 }
