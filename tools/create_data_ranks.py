@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Config 5 at the reference's group size with SEVERAL ranks on one GPU (gloo between them: a rehearsal of the multi-GPU path's
+logic at real sizes, not of its speed -- the ranks share one card and the all-to-all goes through the host): `world` processes
+render 100 random poses at 400x400 between them (pose j of the group on rank j % world), one all-to-all hands every rank the rows of
+the shards it writes, the directory is compared with the one-rank run's file by file (sha256).
+    python tools/create_data_ranks.py [world] [n_pose] [H]          (through gpurun; world <= 4)"""
+import hashlib
+import os
+import shutil
+import socket
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def worker(rank, world, port, out, n_pose, H, ret):
+    sys.path.insert(0, ROOT)
+    import torch
+    import _pkg
+    _pkg.load()
+    from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8, dist as D
+    from efficient_nerf_amd.create_data import RandStream, create_rand
+    from oracle import r2l_oracle as O
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world), R2L_DIST_BACKEND='gloo')
+        D.init()
+        torch.cuda.set_device(D.local_device(rank))
+    focal = O.focal_from_angle(H)
+    eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    eng.render(O.novel_poses(1)[0][:3, :4])
+    torch.cuda.synchronize()
+    tm = {}
+    t0 = time.perf_counter()
+    n = create_rand(eng, H, H, focal, n_pose, out, i_save=min(100, n_pose), split_size=4096, stream=RandStream(), log=lambda *a, **k: None,
+                    timings=tm)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(f'world {world}: {n} shards, {dt:.2f} s = {n_pose / dt:.2f} poses/s; rank 0: MLP kernels {tm.get("mlp_kernel_ms", 0) / 1e3:.2f} s '
+              f'({tm.get("mlp_launches")} launches), assemble + exchange {tm.get("assemble_ms", 0):.0f} ms, D2H {tm.get("d2h_ms", 0):.0f} ms, '
+              f'tail {tm.get("tail_s", 0):.2f} s, planner {tm.get("permutation_s", 0):.2f} s, writers {tm.get("writer_busy_s", 0):.2f} s', flush=True)
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def digest(d):
+    return {n: hashlib.sha256(open(os.path.join(d, n), 'rb').read()).hexdigest() for n in sorted(os.listdir(d)) if n.endswith('.npy')}
+
+
+if __name__ == '__main__':
+    import torch.multiprocessing as mp
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    n_pose = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    H = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+    d1, dn = '/tmp/r2l_pseudo_w1', '/tmp/r2l_pseudo_w%d' % world
+    for d in (d1, dn):
+        shutil.rmtree(d, ignore_errors=True)
+    mp.spawn(worker, args=(1, 0, d1, n_pose, H, None), nprocs=1, join=True)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(worker, args=(world, port, dn, n_pose, H, None), nprocs=world, join=True)
+    a, b = digest(d1), digest(dn)
+    same = a == b
+    print(f'{len(a)} files of the one-rank directory, {len(b)} of the {world}-rank one: {"byte-identical" if same else "DIFFERENT"}')
+    for d in (d1, dn):
+        shutil.rmtree(d, ignore_errors=True)
+    sys.exit(0 if same and len(a) > 0 else 1)
