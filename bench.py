@@ -115,9 +115,11 @@ def create_data_leg(torch, O, precision):
 
 
 def middle_rung(torch, O, R2LEngine, sd, poses, focal):
-    """secondary, outside the timed region: a W256D88 network with every body weight x 1.12 (activation exponent 4: beyond
-    the bf6 terms' reach) through `--precision auto`: must come out as fp16_e4m3, inside 1e-4 of the CPU oracle, at its rate"""
-    msd = {k: (v * 1.12 if k.startswith('body.') and k.endswith('weight') else v) for k, v in sd.items()}
+    """secondary, outside the timed region: a W256D88 network with every body weight x 1.08 (largest |activation| ~ 9.5: beyond
+    the bf6 terms' limit of 8, inside the e4m3 terms' 12) through `--precision auto`: must come out as fp16_e4m3, inside 1e-4 of
+    the CPU oracle, at its rate"""
+    GAIN = 1.08
+    msd = {k: (v * GAIN if k.startswith('body.') and k.endswith('weight') else v) for k, v in sd.items()}
     eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(msd)
     chosen, top = eng.choose_precision(c2w=poses[0])
     band = (H // 2 - 20, H // 2 + 20)
@@ -130,10 +132,11 @@ def middle_rung(torch, O, R2LEngine, sd, poses, focal):
         eng.render(poses[2 + s_])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / 5
-    st = eng.range_status()
-    out = {'body_weight_gain': 1.12, 'max_act_exponent': int(top), 'auto_precision': chosen,
+    out = {'body_weight_gain': GAIN, 'max_act_exponent': int(top), 'max_abs_activation': float(eng.stream_max), 'auto_precision': chosen,
            'linf_vs_cpu_oracle': (got - ref).abs().max().item(), 'rays_checked': int(got.shape[0]), 'value': H * W / dt,
-           'unit': 'rays/s', 'ms_per_frame': dt * 1e3, 'worst_fill': st['worst_fill']}
+           'unit': 'rays/s', 'ms_per_frame': dt * 1e3}
+    if chosen in ('fp16_fp8', 'fp16_e4m3'):
+        out['worst_fill'] = eng.range_status()['worst_fill']
     eng.close()
     return out
 
@@ -363,7 +366,7 @@ def main():
             out['alt_precision'] = alt
             eng.set_precision(prec)
         if world == 1 and not args.no_cpu_baseline and args.precision == 'fp16_fp8':
-            # the middle rung of `--precision auto` on the networks it is for (body weights x 1.12: activation exponent 4)
+            # the middle rung of `--precision auto` on the networks it is for (body weights x 1.08: largest |activation| ~ 9.5)
             out['e4m3_mode'] = middle_rung(torch, O, R2LEngine, sd, poses, focal)
             # secondary, outside the timed region: SURVEY 8(d)'s stress weights (every body weight x 1.3) through
             # `--precision auto`: their residual stream is too large for the bf6 terms, the library must notice and take fp16x3
@@ -380,7 +383,7 @@ def main():
                 seng.render(poses[2 + s_])
             torch.cuda.synchronize()
             sdt = (time.perf_counter() - t1) / 3
-            out['stress_weights'] = {'body_weight_gain': 1.3, 'max_act_exponent': int(top), 'auto_precision': chosen,
+            out['stress_weights'] = {'body_weight_gain': 1.3, 'max_act_exponent': int(top), 'max_abs_activation': float(seng.stream_max), 'auto_precision': chosen,
                                      'linf_vs_cpu_oracle': (sg - sref).abs().max().item(), 'rays_checked': int(sg.shape[0]),
                                      'value': H * W / sdt, 'unit': 'rays/s'}
             seng.close()

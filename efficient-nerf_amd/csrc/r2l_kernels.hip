@@ -393,7 +393,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             for (int c = 0; c < 2; ++c) {
                 if (p.use_residual) {
                     const f32x4 h0 = *reinterpret_cast<const f32x4*>(scr + (u * 2 + c) * 256);
-                    x[u][c] = x[u][c] + h0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[u][c][r] += h0[r];      // element-wise on purpose: no packed-fp32 VALU (csrc/Makefile)
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) split_store<NP>(x[u][c][r], Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);

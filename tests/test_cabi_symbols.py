@@ -69,3 +69,27 @@ def test_collective_entry_points_check_their_arguments(pkg, built_lib):
     st = _lib.RangeStatus()
     assert L.r2l_get_range_status(None, ctypes.byref(st), 0) == R2L_EINVAL
     assert L.r2l_set_guard_period(None, 1) == R2L_EINVAL and L.r2l_recalibrate(None, None) == R2L_EINVAL
+
+
+def test_no_packed_fp32_valu_in_the_device_code(built_lib, tmp_path):
+    """csrc/Makefile builds with -fno-slp-vectorize: beside another process's nerf_chain_kernel a get_rays kernel with packed-fp32
+    VALU ops (v_pk_mul_f32 / v_pk_add_f32 on SGPR pairs, formed by the SLP vectorizer) returned wrong values on MI355X
+    (tests/test_gpu_sharing_gpu.py, profiles/r04_gpu_sharing.txt).  The flag is what keeps them out; this checks the built library."""
+    import shutil
+    import subprocess
+    import pytest
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('ROCm llvm-objdump not found')
+    so = str(tmp_path / 'lib.so')
+    shutil.copy(built_lib, so)
+    subprocess.run([objdump, '--offloading', so], cwd=str(tmp_path), check=True, capture_output=True)
+    parts = [f for f in os.listdir(tmp_path) if f.endswith('gfx950')]
+    assert parts
+    n_pk = n_mfma = 0
+    for f in parts:
+        dis = subprocess.run([objdump, '-d', str(tmp_path / f)], capture_output=True, text=True).stdout
+        n_pk += sum(1 for ln in dis.splitlines() if 'v_pk_' in ln and '_f32' in ln)
+        n_mfma += dis.count('v_mfma')
+    assert n_mfma > 1000            # the disassembly is the library's device code
+    assert n_pk == 0, f'{n_pk} packed-fp32 VALU instructions in the device code'

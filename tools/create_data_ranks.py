@@ -67,6 +67,19 @@ if __name__ == '__main__':
     mp.spawn(worker, args=(world, port, dn, n_pose, H, None), nprocs=world, join=True)
     a, b = digest(d1), digest(dn)
     same = a == b
+    if not same:
+        import numpy as np
+        bad = [k for k in a if a[k] != b.get(k)]
+        print(f'{len(bad)} of {len(a)} files differ, e.g. {bad[:3]}')
+        for k in bad[:3]:
+            x, y = np.load(os.path.join(d1, k)), np.load(os.path.join(dn, k))
+            rows = np.nonzero((x != y).any(1))[0]
+            print(f'  {k}: {len(rows)} of {len(x)} rows differ; columns {np.nonzero((x != y).any(0))[0].tolist()}; max |diff| {np.abs(x - y).max():.3e}; '
+                  f'first rows {rows[:5].tolist()}; is the w1 row anywhere in the wN file: {any((y == x[r]).all(1).any() for r in rows[:3])}')
+            np.set_printoptions(precision=8, linewidth=200)
+            for r in rows[:3]:
+                print('    w1', x[r])
+                print('    wN', y[r])
     print(f'{len(a)} files of the one-rank directory, {len(b)} of the {world}-rank one: {"byte-identical" if same else "DIFFERENT"}')
     for d in (d1, dn):
         shutil.rmtree(d, ignore_errors=True)

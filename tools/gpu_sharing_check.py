@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Two processes time-sharing ONE GPU (what the N-rank rehearsals on a one-GPU box do; NOT the deployment, which is one process per
+GPU): a heavy process loops one kind of kernel for 12 s, a light process beside it runs nerf_get_rays and a torch elementwise chain
+40 times and compares both with the CPU bit for bit.
+    python tools/gpu_sharing_check.py MODE      t: teacher frames   c: nerf_chain_kernel only   s: the scan kernels only
+                                                g: get_rays only    r: R2L frames               m: torch fp16 matmuls
+Round 4 finding (profiles/r04_gpu_sharing.txt): beside the chain kernel -- and only beside it -- a build of nerf_get_rays_kernel in
+which the SLP vectorizer had formed packed-fp32 ops (v_pk_mul_f32 / v_pk_add_f32 with SGPR-pair operands) returned wrong d.x in
+groups of 16 lanes; the scalar build (-fno-slp-vectorize, csrc/Makefile) does not.  Exit code 1 when anything differs."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+def worker(rank, world, mode):
+    sys.path.insert(0, ROOT)
+    import torch, time
+    import _pkg; _pkg.load()
+    from efficient_nerf_amd import NeRFEngine, R2LEngine, PREC_FP16_FP8
+    from efficient_nerf_amd.create_data import RandStream
+    from efficient_nerf_amd.teacher import get_rays
+    from oracle import r2l_oracle as O
+    H = 400
+    focal = O.focal_from_angle(H)
+    if rank == 0:     # the heavy process: teacher chain (mode t), R2L body (mode r), or a big torch matmul loop (mode m)
+        if mode in ('c', 's', 'g'):
+            from efficient_nerf_amd.teacher import raw2outputs, sample_pdf, merge_sorted
+            eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+            pose = O.novel_poses(1)[0]
+            ro, rd = get_rays(H, H, focal, pose[:3, :4], device='cuda')
+            ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
+            z = torch.linspace(2., 6., 64, device='cuda').expand(ro.shape[0], 64).contiguous()
+            raw = torch.randn(ro.shape[0], 64, 4, device='cuda')
+            t0 = time.time()
+            while time.time() - t0 < 12:
+                if mode == 'c':      # the chain kernel alone
+                    eng.run_network(0, ro, rd, z)
+                elif mode == 's':    # the scan kernels alone
+                    rgb, disp, acc, w, depth = raw2outputs(raw, z, rd, white_bkgd=True)
+                    zm = .5 * (z[:, 1:] + z[:, :-1])
+                    zs = sample_pdf(zm, w[:, 1:-1], 128, det=True)
+                    merge_sorted(z, zs)
+                else:                # get_rays alone
+                    for _ in range(50):
+                        get_rays(H, H, focal, pose[:3, :4], device='cuda')
+                torch.cuda.synchronize()
+        elif mode == 't':
+            eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+            pose = O.novel_poses(1)[0][:3, :4]
+            t0 = time.time()
+            while time.time() - t0 < 12:
+                eng.render(pose)
+                torch.cuda.synchronize()
+        elif mode == 'r':
+            eng = R2LEngine(800, 800, O.focal_from_angle(800), precision=PREC_FP16_FP8).load_state_dict(O.make_r2l_state(0))
+            pose = O.novel_poses(1)[0][:3, :4]
+            t0 = time.time()
+            while time.time() - t0 < 12:
+                for _ in range(5):
+                    eng.render(pose)
+                torch.cuda.synchronize()
+        else:
+            a = torch.randn(8192, 8192, device='cuda', dtype=torch.float16)
+            t0 = time.time()
+            while time.time() - t0 < 12:
+                for _ in range(10):
+                    b = a @ a
+                torch.cuda.synchronize()
+        print('heavy process done', flush=True)
+        return
+    time.sleep(3)
+    st = RandStream()
+    bad_rays = bad_torch = 0
+    n = 0
+    xs = torch.arange(0, 160000 * 3, device='cuda', dtype=torch.float32)
+    want = (torch.arange(0, 160000 * 3, dtype=torch.float32) * 1.5 + 2.0) * 0.25 - 1.0
+    for k in range(40):
+        p, f = st.rand_pose(), focal * st.rand_focal_scale()
+        ro, rd = get_rays(H, H, f, p[:3, :4], device='cuda')
+        y = (xs * 1.5 + 2.0) * 0.25 - 1.0
+        cro, crd = O.get_rays(H, H, f, p[:3, :4])
+        bad_rays += (rd.reshape(-1, 3).cpu() != crd.reshape(-1, 3)).any(1).sum().item()
+        bad_torch += (y.cpu() != want).sum().item()
+        n += 1
+    print(f'mode {mode}: light process, {n} iterations beside the heavy one: get_rays rays differing from the CPU oracle {bad_rays}; '
+          f'torch elementwise values differing from the CPU {bad_torch}', flush=True)
+    if bad_rays or bad_torch:
+        sys.exit(1)
+
+if __name__ == '__main__':
+    import torch.multiprocessing as mp
+    mp.spawn(worker, args=(2, sys.argv[1]), nprocs=2, join=True)
