@@ -20,11 +20,14 @@ cd $d
 # a variant generated with `--fmt bf6r` streams 22 KiB chunks: its packer and LDS size are selected at compile time
 DEF=""
 case " $* " in *" --fmt bf6r "*) DEF="-DR2L_BF6R_STREAM";; esac
-for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_kernels nerf_capi; do
-  if [ $f = r2l_body ] || [ $f = r2l_kernels -a -n "$HEAD_OPTS" ] || [ $f = r2l_capi -a -n "$DEF$CAPI_DEF" ] || [ ! -f $root/efficient-nerf_amd/csrc/$f.o ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $DEF $CAPI_DEF -c $f.hip -o $f.o
+# VARIANT_FLAGS replaces the product's -fno-slp-vectorize (csrc/Makefile) and recompiles every file: VARIANT_FLAGS=" " builds the
+# library WITH the SLP vectorizer's packed-fp32 ops (the A/B of profiles/r04_gpu_sharing.txt)
+CF=${VARIANT_FLAGS--fno-slp-vectorize}
+for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_kernels nerf_capi np_shuffle; do
+  if [ -n "${VARIANT_FLAGS+x}" ] || [ $f = r2l_body ] || [ $f = r2l_kernels -a -n "$HEAD_OPTS" ] || [ $f = r2l_capi -a -n "$DEF$CAPI_DEF" ] || [ ! -f $root/efficient-nerf_amd/csrc/$f.o ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off $CF $DEF $CAPI_DEF -c $f.hip -o $f.o
   else cp $root/efficient-nerf_amd/csrc/$f.o $f.o; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build_variants/libr2l_$name.so r2l_kernels.o r2l_body.o r2l_capi.o r2l_comm.o nerf_kernels.o nerf_capi.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build_variants/libr2l_$name.so r2l_kernels.o r2l_body.o r2l_capi.o r2l_comm.o nerf_kernels.o nerf_capi.o np_shuffle.o -ldl
 rm -rf $d
 echo built build_variants/libr2l_$name.so
