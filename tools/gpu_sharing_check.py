@@ -6,7 +6,10 @@ GPU): a heavy process loops one kind of kernel for 12 s, a light process beside 
                                                 g: get_rays only    r: R2L frames               m: torch fp16 matmuls
 Round 4 finding (profiles/r04_gpu_sharing.txt): beside the chain kernel -- and only beside it -- a build of nerf_get_rays_kernel in
 which the SLP vectorizer had formed packed-fp32 ops (v_pk_mul_f32 / v_pk_add_f32 with SGPR-pair operands) returned wrong d.x in
-groups of 16 lanes; the scalar build (-fno-slp-vectorize, csrc/Makefile) does not.  Exit code 1 when anything differs."""
+groups of 16 lanes; the scalar build (-fno-slp-vectorize, csrc/Makefile) does not.  The order matters: the heavy process must be
+running while the light one initialises (the default here; GS_LIGHT_FIRST=1 reverses it and nothing differs in either build).
+The fp16x3 frame of the light process (r2l_resmlp_kernel, compiler-scheduled; GS_NO_X3=1 skips it) is compared with its own first
+render.  Exit code 1 when anything differs."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,6 +17,8 @@ sys.path.insert(0, ROOT)
 def worker(rank, world, mode):
     sys.path.insert(0, ROOT)
     import torch, time
+    if rank == 0 and os.environ.get('GS_LIGHT_FIRST'):
+        time.sleep(4)          # GS_LIGHT_FIRST=1: the light process initialises on a quiet card first -- in that order nothing was ever wrong
     import _pkg; _pkg.load()
     from efficient_nerf_amd import NeRFEngine, R2LEngine, PREC_FP16_FP8
     from efficient_nerf_amd.create_data import RandStream
@@ -67,6 +72,12 @@ def worker(rank, world, mode):
                 torch.cuda.synchronize()
         print('heavy process done', flush=True)
         return
+    # the light process: references while the card is still its own (the heavy one needs ~3 s to load), then the loop beside it
+    bad_x3 = 0
+    if not os.environ.get('GS_NO_X3'):
+        x3 = R2LEngine(200, 200, O.focal_from_angle(200), n_block=8).load_state_dict(O.make_r2l_state(seed=2, netdepth=18))   # fp16x3: compiler-scheduled
+        x3_pose = O.novel_poses(3)[1][:3, :4]
+        x3_ref = x3.render(x3_pose).clone()
     time.sleep(3)
     st = RandStream()
     bad_rays = bad_torch = 0
@@ -80,10 +91,13 @@ def worker(rank, world, mode):
         cro, crd = O.get_rays(H, H, f, p[:3, :4])
         bad_rays += (rd.reshape(-1, 3).cpu() != crd.reshape(-1, 3)).any(1).sum().item()
         bad_torch += (y.cpu() != want).sum().item()
+        if not os.environ.get('GS_NO_X3'):       # GS_NO_X3=1: get_rays and the torch chain only (the round-4 reproduction)
+            bad_x3 += (x3.render(x3_pose) != x3_ref).any(1).sum().item()
         n += 1
     print(f'mode {mode}: light process, {n} iterations beside the heavy one: get_rays rays differing from the CPU oracle {bad_rays}; '
-          f'torch elementwise values differing from the CPU {bad_torch}', flush=True)
-    if bad_rays or bad_torch:
+          f'torch elementwise values differing from the CPU {bad_torch}; rays of a 200x200 fp16x3 frame (r2l_resmlp_kernel) differing from '
+          f'its own quiet render {bad_x3}', flush=True)
+    if bad_rays or bad_torch or bad_x3:
         sys.exit(1)
 
 if __name__ == '__main__':
