@@ -242,15 +242,16 @@ def _all_to_all_rows(send, send_counts, recv_counts, group=None):
 
 
 def create_rand(engine, H, W, focal, n_pose_kd, datadir_new, use_rand_focal=True, i_save=100, split_size=4096,
-                stream=None, rm_existing_data=False, log=print, save_png=5, get_rays_fn=None, timings=None, writer_threads=8):
+                stream=None, rm_existing_data=False, log=print, save_png=5, get_rays_fn=None, timings=None, writer_threads=4):
     """Returns the number of `.npy` shards of this call (the same on every rank).
 
     Multi-rank (torch.distributed initialised): pose j of a save group (j = index INSIDE the group) is rendered
     by rank j % world; ONE all-to-all per group hands every rank the rows of the shards it writes (k % world == rank)
     under the group's two permutations (all ranks draw the same numpy stream), so the directory is byte-identical for
     any world size.  `timings` (dict, optional) receives the wall-clock split of the call.  writer_threads: the host threads
-    that create the shard files (3,906 per group at the reference's sizes: 0.2-1.9 s of file-system time by box; the last
-    group's writes are the one thing nothing overlaps, so they are spread over 8 threads)."""
+    that create the shard files (3,906 per group at the reference's sizes: 0.2-1.9 s of file-system time by box and moment --
+    file creation in one directory does not scale with threads: 8 threads took 1.5-7.2 s summed; the last group's writes are the
+    one thing nothing overlaps: 0.1-0.9 s of tail per JOB)."""
     import torch.distributed as tdist
     world = tdist.get_world_size() if tdist.is_initialized() else 1
     rank = tdist.get_rank() if tdist.is_initialized() else 0

@@ -107,3 +107,32 @@ def test_two_gpu_ranks_write_the_single_rank_directory(pkg, tmp_path):
         return {n: hashlib.sha256(open(os.path.join(d, n), 'rb').read()).hexdigest() for n in sorted(os.listdir(d)) if n.endswith('.npy')}
     a, b = digest(d1), digest(d2)
     assert len(a) == (n_pose // i_save) * (i_save * H * H // 100) and a == b
+
+
+def test_create_data_command_line(pkg, tmp_path):
+    """README.md:79 of the reference: `python utils/create_data.py --create_data rand --config configs/lego.txt --teacher_ckpt X.tar
+    --n_pose_kd N --datadir_kd old:new`, here `create_data.py` at the repo root with the CLI's default `--precision auto`: shards of
+    the group against the oracle-driven reference stream (ray columns bit-exact, rgb within the teacher tolerance), then the reader"""
+    import subprocess
+    import sys
+    from efficient_nerf_amd import frontend as fe
+    from efficient_nerf_amd.create_data import BlenderDataset_v2, RandStream
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sd0, sd1 = O.make_teacher_state(1), O.make_teacher_state(2)
+    ck = str(tmp_path / 'nerf.tar')
+    fe.save_checkpoint(ck, sd0, sd1)
+    out = str(tmp_path / 'pseudo')
+    r = subprocess.run([sys.executable, os.path.join(root, 'create_data.py'), '--create_data', 'rand', '--config', 'configs/lego.txt',
+                        '--teacher_ckpt', ck, '--n_pose_kd', '5', '--datadir_kd', f'unused:{out}', '--create_data_chunk', '2',
+                        '--split_size', '100', '--H', '24', '--synthetic_poses', '1'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert 'wrote 4 shard(s) of 100 rays; 5 poses in' in r.stdout, r.stdout[-800:]
+    H = 12          # half_res of --H 24 (configs/lego.txt)
+    want = oracle_create_rand(sd0, sd1, H, H, O.focal_from_angle(24) / 2., 5, 2, 100, RandStream())
+    assert len(want) == 4
+    for k, w in enumerate(want, 1):
+        got = np.load(os.path.join(out, f'data_{k}.npy'))
+        np.testing.assert_array_equal(got[:, :6], w[:, :6])
+        assert np.abs(got[:, 6:] - w[:, 6:]).max() <= 1e-4
+    ds = BlenderDataset_v2(out, pseudo_ratio=-1)
+    assert len(ds) == 4 and all(t.shape == (100, 3) for t in ds[0])
