@@ -377,8 +377,9 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
 
 class _ImageWriter:
     """PNG encoding off the render loop (the reference writes with imageio inside its loop, main.py:337-341; here rank 0
-    would hold the next collective while it deflates 1.9 MB in Python).  Frames are handed over as device tensors; a worker
-    thread copies them to the host and encodes them (zlib releases the GIL) while the loop goes on rendering."""
+    would hold the next collective while it deflates 1.9 MB in Python).  Frames are handed over as pinned host tensors whose
+    copy from the device is still in flight on a side stream, with the event behind that copy; a worker thread waits for the
+    event and encodes (zlib releases the GIL) while the loop goes on rendering.  Errors surface in close()."""
 
     def __init__(self, n_threads=4):
         import queue
