@@ -232,8 +232,8 @@ def check_ranges(eng, log=None, group=None):
     """R2LEngine.check_ranges for row-sharded runs: a rank whose rows left the calibrated range makes EVERY rank act
     -- render range-guarded ('measure'), raise its exponents to the common maximum, fall back together when `--precision
     auto`'s limit is exceeded --, so the rows of one assembled frame never come from different arithmetic.  Returns None or
-    the reason to render the batch again (R2LEngine.check_ranges).  ONE small all-reduce per call when nothing trips (the
-    three flags travel together); plain eng.check_ranges for one rank."""
+    the reason to render the batch again (R2LEngine.check_ranges).  ONE small all-reduce per call when nothing trips (its
+    four decision values travel together); plain eng.check_ranges for one rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return eng.check_ranges(log=log)
 

@@ -19,4 +19,4 @@ def test_get_rays_is_exact_beside_another_process_chain_kernel():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gpu_sharing_check.py'), 'c'], cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('mode c')]
-    assert r.returncode == 0 and line and 'oracle 0;' in line[0] and 'CPU 0;' in line[0] and line[0].rstrip().endswith('quiet render 0'), r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.returncode == 0 and line and 'oracle 0;' in line[0] and 'CPU 0;' in line[0] and 'first render 0;' in line[0] and line[0].rstrip().endswith('(generated head + body) 0'), r.stdout[-1500:] + r.stderr[-1500:]

@@ -73,8 +73,11 @@ def worker(rank, world, mode):
         print('heavy process done', flush=True)
         return
     # the light process: references while the card is still its own (the heavy one needs ~3 s to load), then the loop beside it
-    bad_x3 = 0
+    bad_x3 = bad_x8 = 0
     if not os.environ.get('GS_NO_X3'):
+        # ... and a frame of the generated kernels (head launch + r2l_body_kernel), against its own first render
+        x8 = R2LEngine(200, 200, O.focal_from_angle(200), n_block=8, precision=PREC_FP16_FP8).load_state_dict(O.make_r2l_state(seed=2, netdepth=18))
+        x8_ref = x8.render(O.novel_poses(3)[1][:3, :4]).clone()
         x3 = R2LEngine(200, 200, O.focal_from_angle(200), n_block=8).load_state_dict(O.make_r2l_state(seed=2, netdepth=18))   # fp16x3: compiler-scheduled
         x3_pose = O.novel_poses(3)[1][:3, :4]
         x3_ref = x3.render(x3_pose).clone()
@@ -93,11 +96,12 @@ def worker(rank, world, mode):
         bad_torch += (y.cpu() != want).sum().item()
         if not os.environ.get('GS_NO_X3'):       # GS_NO_X3=1: get_rays and the torch chain only (the round-4 reproduction)
             bad_x3 += (x3.render(x3_pose) != x3_ref).any(1).sum().item()
+            bad_x8 += (x8.render(x3_pose) != x8_ref).any(1).sum().item()
         n += 1
     print(f'mode {mode}: light process, {n} iterations beside the heavy one: get_rays rays differing from the CPU oracle {bad_rays}; '
           f'torch elementwise values differing from the CPU {bad_torch}; rays of a 200x200 fp16x3 frame (r2l_resmlp_kernel) differing from '
-          f'its own quiet render {bad_x3}', flush=True)
-    if bad_rays or bad_torch or bad_x3:
+          f'its own first render {bad_x3}; of a 200x200 fp16_fp8 frame (generated head + body) {bad_x8}', flush=True)
+    if bad_rays or bad_torch or bad_x3 or bad_x8:
         sys.exit(1)
 
 if __name__ == '__main__':
