@@ -442,15 +442,16 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     # the frame stack is allocated once and every batch is gathered straight into its slots: the collective's own buffer is
     # reused from call to call (dist.RowGather.gather), so keeping views of it would keep N copies of the LAST frame
     rgbs = torch.empty((n_frames, H, W, 3), dtype=torch.float32, device=eng.device)
-    local = torch.empty((B, n_local, 3), dtype=torch.float32, device=eng.device)
+    local = torch.empty((B, n_local, 3), dtype=torch.float32, device=eng.device) if world > 1 else None
     pose_dev = None
     if given_rays is None and kind == 'R2L' and n_frames:
         pose_dev = torch.stack([torch.as_tensor(p)[:3, :4].float() for p in render_poses], 0).contiguous().to(eng.device)
 
     def render_local(i0, nb):
-        """row shard of frames i0 .. i0 + nb - 1 into local[:nb]"""
+        """row shard of frames i0 .. i0 + nb - 1 into local[:nb] (one rank: straight into the frame stack, nothing to assemble)"""
+        dst = local[:nb] if world > 1 else rgbs[i0:i0 + nb].view(nb, n_local, 3)
         if pose_dev is not None:
-            eng.render_batch(pose_dev[i0:i0 + nb], rows=(r0, r1), out=local[:nb])
+            eng.render_batch(pose_dev[i0:i0 + nb], rows=(r0, r1), out=dst)
             return
         for f in range(nb):
             i = i0 + f
@@ -460,7 +461,7 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
                 got = eng.render_rays(ro, rd)
             else:
                 got = eng.render(render_poses[i][:3, :4], rows=(r0, r1))
-            local[f].copy_(got if kind == 'R2L' else got['rgb_map'])
+            dst[f].copy_(got if kind == 'R2L' else got['rgb_map'])
 
     if kind == 'R2L' and world > 1 and n_frames > 0:
         # an explicit fp16_fp8 measures its activation ranges on the first render's own rays: one agreed set for all row
@@ -484,8 +485,9 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
             n_again += again
         else:
             render_local(i0, nb)
-        D.gather_rows(local[:nb], H, W, world, out=rgbs[i0:i0 + nb])
-        n_coll += 1 if world > 1 else 0
+        if world > 1:
+            D.gather_rows(local[:nb], H, W, world, out=rgbs[i0:i0 + nb])
+            n_coll += 1
         n_batches += 1
         if writer is not None:      # D2H on a side stream behind the gather; the worker waits for the event, the loop does not
             done = torch.cuda.Event()
