@@ -160,6 +160,9 @@ struct r2l_ctx {
     int body_mode = -1;                       // ... of this mode (bf6 or e4m3 terms: chunk geometry and operand codes differ)
     size_t body_bytes, aux_off, tail_off;
     std::vector<int> act;                     // FP16_FP8: 2 n_block + 1 activation exponents (packed into the aux blocks)
+    // activations as slopes (act(v) = max(v, s v): 0 relu, 0.01 LeakyReLU, 1 none): head, inside a block, behind a block.  The
+    // generated kernels are built for (0, 0, 1); anything else runs in the compiler-scheduled modes only (r2l_set_activations)
+    float act_head = 0.0f, act_in = 0.0f, act_out = 1.0f;
     int fuse_tail = 1;                        // FP16_FP8 with the global skip: rgb written by the body kernel's fused tail
     int calib_pending = 0;                    // the next FP16_FP8 render derives them from its own head output (device side)
     int calib_started = 0;                    // maxima of earlier, smaller calls are in d_stats: the next measurement adds to them
@@ -296,8 +299,14 @@ static int ensure_x(r2l_ctx* c, int tiles, bool need_xb);
 static int pack_body_v3(const r2l_ctx* c, int e4m3, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
 static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out, int f16 = 0);
 
+static bool default_acts(const r2l_ctx* c) { return c->act_head == 0.0f && c->act_in == 0.0f && c->act_out == 1.0f; }
+
 static int build_image(r2l_ctx* c, int mode) {
     std::vector<char> img;
+    if (split_mode(mode) && !default_acts(c))
+        return r2l_set_error(R2L_EINVAL, "activation slopes head %g / inner %g / out %g: the generated kernels (fp16_fp8, fp16_e4m3, "
+                                         "fp16x3_asm) are built for relu / relu / none (act=relu, trial.inact=relu, trial.outact=none); "
+                                         "fp16x3 renders the others", c->act_head, c->act_in, c->act_out);
     if (split_mode(mode)) {
         // head launch: the stream of r2l_head_kernel (bf6 terms in both modes); body + tail: the v3 stream of the mode
         int rc = pack_head_v1(c, img, mode == R2L_PREC_FP16X3_ASM);
@@ -918,6 +927,10 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
 int r2l_set_precision(r2l_ctx* c, int mode) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (!mode_ok(mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
+    if (split_mode(mode) && !default_acts(c))     // also when an image of that mode was packed before the slopes were set
+        return r2l_set_error(R2L_EINVAL, "activation slopes head %g / inner %g / out %g: the generated kernels (fp16_fp8, fp16_e4m3, "
+                                         "fp16x3_asm) are built for relu / relu / none; fp16x3 renders the others",
+                             c->act_head, c->act_in, c->act_out);
     if (c->loaded && split_mode(mode) && scaled_mode(c->body_mode) && c->d_body && c->body_mode != mode && c->n_block > 0 &&
         !c->calib_pending) {
         // the other split mode's body stream is about to replace this one: the exponents the device calibrated live only
@@ -934,6 +947,23 @@ int r2l_set_precision(r2l_ctx* c, int mode) {
         if (rc) c->mode = prev;      // weights this mode cannot pack: the context keeps rendering in the mode it had
         return rc;
     }
+    return R2L_OK;
+}
+
+int r2l_set_activations(r2l_ctx* c, float head_slope, float inner_slope, float out_slope) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    const float s[3] = {head_slope, inner_slope, out_slope};
+    for (float v : s)
+        if (!(v >= 0.0f && v <= 1.0f)) return r2l_set_error(R2L_EINVAL, "activation slope %g is outside [0, 1]", v);
+    const bool dflt = head_slope == 0.0f && inner_slope == 0.0f && out_slope == 1.0f;
+    if (!dflt && split_mode(c->mode))
+        return r2l_set_error(R2L_EINVAL, "activation slopes %g / %g / %g need a compiler-scheduled mode (R2L_PREC_FP16X3 / _FP16X1): the "
+                                         "generated kernels of the current mode are built for relu / relu / none",
+                             head_slope, inner_slope, out_slope);
+    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
+    c->act_head = head_slope;
+    c->act_in = inner_slope;
+    c->act_out = out_slope;
     return R2L_OK;
 }
 
@@ -958,6 +988,9 @@ static void fill_common(const r2l_ctx* c, R2LParams& p) {
     p.W = c->W;
     p.n_block = c->n_block;
     p.use_residual = c->use_residual;
+    p.act_head = c->act_head;
+    p.act_in = c->act_in;
+    p.act_out = c->act_out;
     p.chunks_per_tile = r2l_chunks_per_tile(c->n_block);
     p.scratch = c->d_scratch;
 }

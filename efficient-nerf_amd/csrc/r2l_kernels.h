@@ -18,6 +18,9 @@ struct R2LParams {
     float neg1;  // -1.0f (kept opaque to the compiler: selects v_fma_mix for the hi/lo residuals)
     int W, pix_begin, rays_per_pose, n_rays, n_tiles, n_block, use_residual, chunks_per_tile;
     unsigned* range;       // head launch: [0] <- atomicMax of the f32 bits of max h0 (act_scale domain) over its rays; nullable
+    // activations of the compiler-scheduled kernels as slopes s: act(v) = max(v, s v) -- 0 relu, 0.01 LeakyReLU, 1 none
+    // (model/nerf_raybased.py:468-476 get_activation): head (args.act), inside a ResMLP block (trial.inact), behind it (trial.outact)
+    float act_head, act_in, act_out;
 };
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*

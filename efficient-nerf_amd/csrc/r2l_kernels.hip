@@ -125,19 +125,23 @@ __global__ void r2l_embed_kernel(const float* __restrict__ x_in, long long total
 // ------------------------------------------------------------------------------------
 // epilogue of accumulator register r of row tile u (one column tile); activations are kept
 // multiplied by act_scale (`inv` = act_scale / layer scale):
-// SECOND = false: out = relu(acc/scale)              (ResMLP body.0 + inact)
-// SECOND = true : x = x + acc/scale; out = x         (ResMLP body.2 + residual)
+// SECOND = false: out = inact(acc/scale)            (ResMLP body.0 + inact)
+// SECOND = true : x = outact(x + acc/scale); out = x (ResMLP body.2 + residual [+ outact])
+// slope: the activation as act(v) = max(v, slope v): 0 relu (the exact fmaxf(v, 0) form), 0.01 LeakyReLU, 1 none
+__device__ __forceinline__ float r2l_act(float v, float slope) {
+    return slope == 0.0f ? fmaxf(v, 0.0f) : (slope == 1.0f ? v : fmaxf(v, slope * v));
+}
 template <int NP, bool SECOND>
 __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1, f32x4& xu, f16x8& nh, f16x8& nl, int u,
-                                        int r) {
+                                        int r, float slope) {
     // r = pair index (0, 1): registers 2r, 2r+1 -> dword 2(u&1) + r of the fragments
     float v[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (!SECOND) {
-            v[k] = fmaxf(acc[2 * r + k] * inv, 0.0f);
+            v[k] = r2l_act(acc[2 * r + k] * inv, slope);
         } else {
-            v[k] = fmaf(acc[2 * r + k], inv, xu[2 * r + k]);
+            v[k] = r2l_act(fmaf(acc[2 * r + k], inv, xu[2 * r + k]), slope);
             xu[2 * r + k] = v[k];
         }
     }
@@ -151,7 +155,8 @@ __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1,
 template <int NP, bool SECOND, bool HAVE_PREV>
 __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
-                                           const f32x4 (&prev)[2], float inv, float neg1, f32x4 (&xprev)[2], int uprev, int q) {
+                                           const f32x4 (&prev)[2], float inv, float neg1, f32x4 (&xprev)[2], int uprev, int q,
+                                           float slope) {
     const uint32_t slot = R.use_off;
     const uint32_t lane_base = slot + R.lane * 16;
     const uint32_t next_base = ring_next_off<NP>(slot) + R.lane * 16;
@@ -166,7 +171,7 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
         acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
         if (HAVE_PREV && (s & 1))
             epi_reg<NP, SECOND>(prev[s >> 2], inv, neg1, xprev[s >> 2], Nh[uprev >> 1][s >> 2], Nl[uprev >> 1][s >> 2], uprev,
-                                (s >> 1) & 1);
+                                (s >> 1) & 1, slope);
         R.pre = nxt;
     }
     if (upos == 1) ring_next<NP>(R);
@@ -176,20 +181,20 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
 template <int NP, bool SECOND>
 __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&x)[16][2],
-                                           float act_scale, float neg1, int q) {
+                                           float act_scale, float neg1, int q, float slope) {
     const float inv = aux_inv_scale<NP>(R.use_off) * act_scale;  // same for the 8 chunks of a layer
     f32x4 acc[2], prev[2];
-    body_rtile<NP, SECOND, false>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[0], 0, q);
+    body_rtile<NP, SECOND, false>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[0], 0, q, slope);
 #pragma unroll
     for (int u = 1; u < R2L_RTILES; ++u) {
         prev[0] = acc[0];
         prev[1] = acc[1];
-        body_rtile<NP, SECOND, true>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[u - 1], u - 1, q);
+        body_rtile<NP, SECOND, true>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[u - 1], u - 1, q, slope);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         epi_reg<NP, SECOND>(acc[i >> 1], inv, neg1, x[R2L_RTILES - 1][i >> 1], Nh[(R2L_RTILES - 1) >> 1][i >> 1],
-                            Nl[(R2L_RTILES - 1) >> 1][i >> 1], R2L_RTILES - 1, i & 1);
+                            Nl[(R2L_RTILES - 1) >> 1][i >> 1], R2L_RTILES - 1, i & 1, slope);
 }
 
 // one head k-step (one chunk): 16 row tiles against the generated B fragments of both column
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             R2L_HEAD_STEP(bh, bl, {});
         }
 
-        // head epilogue: h0 = relu(acc/scale) (scaled domain); keep a copy for the global skip
+        // head epilogue: h0 = act(acc/scale) (scaled domain); keep a copy for the global skip
         float* scr = p.scratch + ((size_t)(blockIdx.x * R2L_WAVES + R.wave) * 32) * 256 + lane * 4;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = fmaxf(x[u][c][r] * inv_head, 0.0f);
+                    const float v = r2l_act(x[u][c][r] * inv_head, p.act_head);
                     x[u][c][r] = v;
                     split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
@@ -382,8 +387,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
-            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q);
-            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q);
+            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q, p.act_in);
+            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q, p.act_out);
         }
 
         // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------

@@ -45,12 +45,17 @@ class R2LEngine:
     """One r2l_ctx: geometry + weights + launches (include/r2l_hip.h)."""
 
     def __init__(self, H, W, focal, near=2., far=6., n_sample=16, L=10, width=256, n_block=43,
-                 use_residual=True, precision=PREC_FP16X3, device=None, z_vals=None, res_scale=1.0):
+                 use_residual=True, precision=PREC_FP16X3, device=None, z_vals=None, res_scale=1.0, act='relu', inact='relu',
+                 outact='none'):
         """res_scale: ResMLP's `--trial.res_scale` (model/nerf_raybased.py:461: x = body(x).mul(res_scale) + x).  The kernels
         compute x += W2 h + b2; the factor is folded into W2 and b2 when the weights are loaded (exact for powers of two, one
-        fp32 rounding per weight otherwise: far inside the 1e-4 contract)."""
+        fp32 rounding per weight otherwise: far inside the 1e-4 contract).
+        act / inact / outact: args.act (behind the head layer), trial.inact (inside a ResMLP block), trial.outact (behind it) of the
+        reference (model/nerf_raybased.py:468-476, 497-522): 'relu' | 'lrelu' | 'none'.  Other than relu / relu / none renders in
+        the compiler-scheduled modes only; the generated ones refuse (r2l_set_activations)."""
         self.device = _dev(device)
         self.res_scale = float(res_scale)
+        self.acts = tuple(self.ACT_SLOPES[str(a).lower()] if str(a).lower() in self.ACT_SLOPES else self._bad_act(a) for a in (act, inact, outact))
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.n_block = int(n_block)
         self._ctx = C.c_void_p()
@@ -58,6 +63,8 @@ class R2LEngine:
             check(lib().r2l_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
                                    int(n_sample), int(L), int(width), self.n_block, int(bool(use_residual)),
                                    int(precision)))
+        if self.acts != (0.0, 0.0, 1.0):
+            check(lib().r2l_set_activations(self._ctx, *self.acts))
         self.precision = int(precision)
         self._loaded = False
         # model/nerf_raybased.py:88-90, evaluated with the host's torch exactly as the
@@ -66,6 +73,13 @@ class R2LEngine:
             t_vals = torch.linspace(0., 1., steps=int(n_sample))
             z_vals = float(near) * (1 - t_vals) + float(far) * (t_vals)
         self.set_z_vals(z_vals)
+
+    #: get_activation (model/nerf_raybased.py:468-476) as the slope s of act(v) = max(v, s v)
+    ACT_SLOPES = {'relu': 0.0, 'lrelu': 0.01, 'none': 1.0}
+
+    @staticmethod
+    def _bad_act(a):
+        raise R2LError(f'activation {a!r}: the reference knows relu, lrelu and none (model/nerf_raybased.py:468-476)')
 
     def set_z_vals(self, z_vals):
         z = torch.as_tensor(z_vals).detach().to('cpu', torch.float32).contiguous()
@@ -527,10 +541,10 @@ class NeRF_v3_2:
             raise R2LError('only --trial.ON --trial.body_arch resmlp networks are supported')
         if getattr(args, 'layerwise_netwidths', '') or getattr(args, 'linear_tail', False):
             raise R2LError('layerwise_netwidths / linear_tail variants are not supported')
-        if getattr(args, 'act', 'relu').lower() != 'relu' or getattr(trial, 'inact', 'relu').lower() != 'relu' \
-                or getattr(trial, 'outact', 'none').lower() != 'none' or int(getattr(trial, 'n_learnable', 2)) != 2:
-            raise R2LError('only act=relu, trial.inact=relu, trial.outact=none, n_learnable=2 (any trial.res_scale)')
+        if int(getattr(trial, 'n_learnable', 2)) != 2:
+            raise R2LError('only trial.n_learnable=2 (two Linear layers per ResMLP block)')
         self.res_scale = float(getattr(trial, 'res_scale', 1.))
+        self.acts = (getattr(args, 'act', 'relu'), getattr(trial, 'inact', 'relu'), getattr(trial, 'outact', 'none'))
         n_block = int(getattr(trial, 'n_block', -1))
         self.n_block = n_block if n_block > 0 else (D - 2) // 2
         self.use_residual = bool(getattr(args, 'use_residual', False))
@@ -559,7 +573,7 @@ class NeRF_v3_2:
                 raise R2LError('NeRF_v3_2 called before load_state_dict')
             eng = R2LEngine(sampler.H, sampler.W, sampler.focal, sampler.near, sampler.far,
                             n_block=self.n_block, use_residual=self.use_residual, precision=self.precision,
-                            res_scale=self.res_scale)
+                            res_scale=self.res_scale, act=self.acts[0], inact=self.acts[1], outact=self.acts[2])
             eng.load_state_dict(self._state)
             self._engines[key] = eng
         return eng

@@ -117,6 +117,12 @@ void r2l_destroy(r2l_ctx* ctx);
  *   tail.0.weight[3,256], tail.0.bias[3]                                            */
 int r2l_load_weights(r2l_ctx* ctx, const float* const* tensors, int n_tensors);
 int r2l_set_precision(r2l_ctx* ctx, int precision_mode);
+/* Activations of NeRF_v3_2 / ResMLP other than the README's (model/nerf_raybased.py:443-476, 497-522: args.act behind the head layer,
+ * trial.inact inside a block, trial.outact behind it), as slopes s of act(v) = max(v, s v): 0 = ReLU, 0.01 = LeakyReLU (torch's
+ * default negative_slope), 1 = none.  Defaults 0, 0, 1 (act=relu, inact=relu, outact=none).  Anything else renders in the
+ * compiler-scheduled modes (R2L_PREC_FP16X3, _FP16X1) only: the generated kernels are specialised, and r2l_set_precision /
+ * r2l_load_weights refuse them with a message (`--precision auto` then stays in fp16x3). */
+int r2l_set_activations(r2l_ctx* ctx, float head_slope, float inner_slope, float out_slope);
 /* Override PointSampler.z_vals (model/nerf_raybased.py:88-90).  r2l_create fills them with
  * near*(1-t)+far*t, t = linspace(0,1,n) by the scalar formula; torch.linspace on the CPU is
  * vector-width dependent in the last ulp (AVX2 vs AVX-512 builds differ), so a front-end

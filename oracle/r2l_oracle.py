@@ -168,8 +168,20 @@ def make_r2l_state(seed=0, netdepth=88, netwidth=256, input_dim=1008, body_gain=
     return sd
 
 
+def _activation(name):
+    """model/nerf_raybased.py:468-476 get_activation: relu | lrelu (nn.LeakyReLU default slope 0.01) | none"""
+    name = name.lower()
+    if name == 'relu':
+        return F.relu
+    if name == 'lrelu':
+        return F.leaky_relu
+    if name == 'none':
+        return lambda t: t
+    raise NotImplementedError(name)
+
+
 def r2l_forward(sd, x, use_residual=True, res_scale=1.0, dtype=torch.float32,
-                return_layers=False):
+                return_layers=False, act='relu', inact='relu', outact='none'):
     """model/nerf_raybased.py:539-544 (NeRF_v3_2.forward) with ResMLP blocks :461-465.
 
     head: ReLU(W x + b); body: x = (W2 ReLU(W1 x + b1) + b2)*res_scale + x, no outact;
@@ -177,12 +189,13 @@ def r2l_forward(sd, x, use_residual=True, res_scale=1.0, dtype=torch.float32,
     n_block = sum(1 for k in sd if k.endswith('body.0.weight'))
     c = lambda t: t.to(dtype)
     x = c(x)
-    h = F.relu(F.linear(x, c(sd['head.0.weight']), c(sd['head.0.bias'])))
+    a_head, a_in, a_out = _activation(act), _activation(inact), _activation(outact)   # :497, :443-465
+    h = a_head(F.linear(x, c(sd['head.0.weight']), c(sd['head.0.bias'])))
     layers = [h]
     h0 = h
     for i in range(n_block):
-        t = F.relu(F.linear(h, c(sd[f'body.{i}.body.0.weight']), c(sd[f'body.{i}.body.0.bias'])))
-        h = F.linear(t, c(sd[f'body.{i}.body.2.weight']), c(sd[f'body.{i}.body.2.bias'])).mul(res_scale) + h
+        t = a_in(F.linear(h, c(sd[f'body.{i}.body.0.weight']), c(sd[f'body.{i}.body.0.bias'])))
+        h = a_out(F.linear(t, c(sd[f'body.{i}.body.2.weight']), c(sd[f'body.{i}.body.2.bias'])).mul(res_scale) + h)
         if return_layers:
             layers.append(h)
     if use_residual:

@@ -154,16 +154,16 @@ def test_png_writer(fe, tmp_path):
 
 
 def test_build_engine_refuses_flags_the_kernels_do_not_honour(fe):
-    """A checkpoint trained with another activation / block depth must raise, not render silently wrong images (the
-    reference's ResMLP honours these flags: model/nerf_raybased.py:443-465; --trial.res_scale is honoured here too, folded
-    into the second layer: tests/test_r2l_gpu.py)."""
+    """A checkpoint trained with an unknown activation / another block depth must raise, not render silently wrong images (the
+    reference's ResMLP honours these flags: model/nerf_raybased.py:443-465; --trial.res_scale and the relu / lrelu / none
+    activations are honoured here too: tests/test_r2l_gpu.py), and a generated precision must refuse a non-relu network."""
     import _pkg
     _pkg.load()
     from efficient_nerf_amd import R2LError
     base = ['--model_name', 'R2L', '--dataset_type', 'blender', '--netdepth', '88', '--n_sample_per_ray', '16', '--trial.ON',
             '--trial.body_arch', 'resmlp', '--use_residual']
-    for extra in (['--act', 'gelu'], ['--trial.inact', 'lrelu'], ['--trial.outact', 'relu'],
-                  ['--trial.n_learnable', '3'], ['--linear_tail'], ['--dataset_type', 'llff']):
+    for extra in (['--act', 'gelu'], ['--trial.inact', 'lrelu', '--precision', 'fp16_fp8'],
+                  ['--trial.outact', 'relu', '--precision', 'fp16x3_asm'], ['--trial.n_learnable', '3'], ['--linear_tail'], ['--dataset_type', 'llff']):
         with pytest.raises(R2LError):
             fe.build_engine(fe.parse_args(base + extra), (8, 8, 10.), {})
     nerf = ['--model_name', 'nerf', '--dataset_type', 'blender', '--use_viewdirs', '--N_importance', '128']

@@ -316,3 +316,23 @@ def test_render_path_batches_frames_per_collective_two_ranks(pkg, tmp_path):
         ref = O.r2l_render(sd, H, H, focal, c2w).view(H, H, 3).numpy()
         assert np.abs(rgbs[i] - ref).max() <= 1e-4, i
         assert os.path.getsize(os.path.join(out, f'{i:03d}.png')) > 100
+
+
+def test_cli_activation_variants(pkg, tmp_path):
+    """`--act lrelu --trial.inact lrelu --trial.outact relu` (model/nerf_raybased.py:468-476, 497-522) through the command line with
+    its default --precision auto: the generated modes refuse the network, auto says so and renders in fp16x3 within the contract"""
+    from efficient_nerf_amd import frontend as fe
+    sd = O.make_r2l_state(seed=9, netdepth=8)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    out = str(tmp_path / 'out')
+    log = run_main(['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256',
+                    '--netdepth', '8', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--act', 'lrelu', '--trial.inact', 'lrelu',
+                    '--trial.outact', 'relu', '--trial.res_scale', '0.5', '--pretrained_ckpt', ck, '--render_only', '--synthetic_poses', '1',
+                    '--H', '48', '--outdir', out])
+    assert '[precision] auto' in log and 'relu / relu / none' in log and '-> fp16x3' in log, log
+    H = 24
+    c2w = O.novel_poses(1)[0]
+    pts = O.sample_test(O.camera_dirs(H, H, O.focal_from_angle(48) / 2.), O.sampler_z_vals(16, 2., 6.), c2w[:3, :4])
+    ref = O.r2l_forward(sd, O.positional_embed(pts, 10), res_scale=0.5, act='lrelu', inact='lrelu', outact='relu').view(H, H, 3).numpy()
+    assert np.abs(np.load(os.path.join(out, 'rgbs.npy'))[0] - ref).max() <= 1e-4

@@ -356,3 +356,30 @@ def test_res_scale_is_folded_into_the_second_layer(pkg, res_scale):
         err = (eng.render(c2w).cpu() - ref).abs().max().item()
         assert err <= TOL_X3, (name, err)
     eng.close()
+
+
+@pytest.mark.parametrize('act,inact,outact', [('lrelu', 'lrelu', 'none'), ('relu', 'relu', 'relu'), ('lrelu', 'none', 'lrelu'), ('none', 'relu', 'none')])
+def test_activation_variants_of_the_constructor(pkg, act, inact, outact):
+    """NeRF_v3_2 accepts --act / --trial.inact / --trial.outact in {relu, lrelu, none} (model/nerf_raybased.py:468-476, 497-522);
+    no reference config uses other than relu / relu / none, and the generated kernels are specialised to that -- the others render
+    in the compiler-scheduled fp16x3 (r2l_set_activations: slopes of act(v) = max(v, s v)), `auto` stays there and says why, and
+    a generated mode refuses instead of rendering the wrong network."""
+    from efficient_nerf_amd import PREC_FP16X3, PREC_FP16_FP8, R2LEngine, R2LError
+    H, nb = 40, 5
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=17, netdepth=2 + 2 * nb)
+    c2w = O.pose_spherical(-60., -35., 4.)
+    pts = O.sample_test(O.camera_dirs(H, H, focal), O.sampler_z_vals(16, 2., 6.), c2w[:3, :4])
+    emb = O.positional_embed(pts, 10)
+    ref = O.r2l_forward(sd, emb, act=act, inact=inact, outact=outact)
+    assert (ref - O.r2l_forward(sd, emb)).abs().max().item() > 1e-3          # the variant is a different network
+    eng = R2LEngine(H, H, focal, n_block=nb, act=act, inact=inact, outact=outact).load_state_dict(sd)
+    assert (eng.render(c2w).cpu() - ref).abs().max().item() <= TOL_X3
+    with pytest.raises(R2LError, match='relu / relu / none'):
+        eng.set_precision(PREC_FP16_FP8)
+    name, top = eng.choose_precision(c2w=c2w)
+    assert (name, top) == ('fp16x3', None) and eng.precision == PREC_FP16X3 and 'relu / relu / none' in eng.auto_note
+    assert (eng.render(c2w).cpu() - ref).abs().max().item() <= TOL_X3
+    eng.close()
+    with pytest.raises(R2LError, match='compiler-scheduled'):
+        R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8, act=act, inact=inact, outact=outact)
