@@ -270,7 +270,7 @@ def main():
                    'gather': D.gather_backend(dev.index, world)},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP16_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
-                     'kernel': {'fp16x3': 'r2l_resmlp_kernel<2, false, false>', 'fp16x1': 'r2l_resmlp_kernel<1, false, false>',
+                     'kernel': {'fp16x3': 'r2l_resmlp_kernel<2, false>', 'fp16x1': 'r2l_resmlp_kernel<1, false>',
                                 'fp16_fp8': 'r2l_body_kernel', 'fp16_e4m3': 'r2l_body8_kernel', 'fp16x3_asm': 'r2l_bodyx_kernel'}[args.precision],
                      'avg_kernel_ms': avg_kernel_s * 1e3, 'launches': n_launch,
                      'algorithmic_flops_per_ray': kflops_per_ray, 'executed_mfma_passes': passes,

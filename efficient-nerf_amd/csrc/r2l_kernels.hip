@@ -128,10 +128,14 @@ __global__ void r2l_embed_kernel(const float* __restrict__ x_in, long long total
 // SECOND = false: out = inact(acc/scale)            (ResMLP body.0 + inact)
 // SECOND = true : x = outact(x + acc/scale); out = x (ResMLP body.2 + residual [+ outact])
 // slope: the activation as act(v) = max(v, slope v): 0 relu (the exact fmaxf(v, 0) form), 0.01 LeakyReLU, 1 none
+// GA = false: the README's network (relu / relu / none), the code of rounds 1-3 exactly; GA = true: slopes from the parameters
+// (a second instantiation of the kernel: as run-time selects in the one kernel they cost the relu network 21 %)
+template <bool GA, bool SECOND>
 __device__ __forceinline__ float r2l_act(float v, float slope) {
+    if (!GA) return SECOND ? v : fmaxf(v, 0.0f);
     return slope == 0.0f ? fmaxf(v, 0.0f) : (slope == 1.0f ? v : fmaxf(v, slope * v));
 }
-template <int NP, bool SECOND>
+template <int NP, bool SECOND, bool GA>
 __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1, f32x4& xu, f16x8& nh, f16x8& nl, int u,
                                         int r, float slope) {
     // r = pair index (0, 1): registers 2r, 2r+1 -> dword 2(u&1) + r of the fragments
@@ -139,9 +143,9 @@ __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1,
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (!SECOND) {
-            v[k] = r2l_act(acc[2 * r + k] * inv, slope);
+            v[k] = r2l_act<GA, false>(acc[2 * r + k] * inv, slope);
         } else {
-            v[k] = r2l_act(fmaf(acc[2 * r + k], inv, xu[2 * r + k]), slope);
+            v[k] = r2l_act<GA, true>(fmaf(acc[2 * r + k], inv, xu[2 * r + k]), slope);
             xu[2 * r + k] = v[k];
         }
     }
@@ -152,7 +156,7 @@ __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1,
 // fragments are read one step ahead (the chunk's last step prefetches fragment 0 of the next
 // chunk, certified by this chunk's ring_mid).  The 8 accumulator values of the previous row
 // tile get their VALU epilogue interleaved, one register pair every second k-step.
-template <int NP, bool SECOND, bool HAVE_PREV>
+template <int NP, bool SECOND, bool HAVE_PREV, bool GA>
 __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
                                            const f32x4 (&prev)[2], float inv, float neg1, f32x4 (&xprev)[2], int uprev, int q,
@@ -170,7 +174,7 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
         acc[0] = mfma_step<NP>(R.pre, Bh[s][0], Bl[s][0], acc[0]);
         acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
         if (HAVE_PREV && (s & 1))
-            epi_reg<NP, SECOND>(prev[s >> 2], inv, neg1, xprev[s >> 2], Nh[uprev >> 1][s >> 2], Nl[uprev >> 1][s >> 2], uprev,
+            epi_reg<NP, SECOND, GA>(prev[s >> 2], inv, neg1, xprev[s >> 2], Nh[uprev >> 1][s >> 2], Nl[uprev >> 1][s >> 2], uprev,
                                 (s >> 1) & 1, slope);
         R.pre = nxt;
     }
@@ -178,22 +182,22 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
 }
 
 // One body Linear(256,256): in = (Bh,Bl) fragments, out fragments -> (Nh,Nl).
-template <int NP, bool SECOND>
+template <int NP, bool SECOND, bool GA>
 __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&x)[16][2],
                                            float act_scale, float neg1, int q, float slope) {
     const float inv = aux_inv_scale<NP>(R.use_off) * act_scale;  // same for the 8 chunks of a layer
     f32x4 acc[2], prev[2];
-    body_rtile<NP, SECOND, false>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[0], 0, q, slope);
+    body_rtile<NP, SECOND, false, GA>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[0], 0, q, slope);
 #pragma unroll
     for (int u = 1; u < R2L_RTILES; ++u) {
         prev[0] = acc[0];
         prev[1] = acc[1];
-        body_rtile<NP, SECOND, true>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[u - 1], u - 1, q, slope);
+        body_rtile<NP, SECOND, true, GA>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[u - 1], u - 1, q, slope);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        epi_reg<NP, SECOND>(acc[i >> 1], inv, neg1, x[R2L_RTILES - 1][i >> 1], Nh[(R2L_RTILES - 1) >> 1][i >> 1],
+        epi_reg<NP, SECOND, GA>(acc[i >> 1], inv, neg1, x[R2L_RTILES - 1][i >> 1], Nh[(R2L_RTILES - 1) >> 1][i >> 1],
                             Nl[(R2L_RTILES - 1) >> 1][i >> 1], R2L_RTILES - 1, i & 1, slope);
 }
 
@@ -220,7 +224,7 @@ __device__ __forceinline__ float sel4(int q, float a, float b, float c, float d)
     return (q & 2) ? ((q & 1) ? d : c) : ((q & 1) ? b : a);
 }
 
-template <int NP>
+template <int NP, bool GA>
 __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
     typedef KCfg<NP> C;
     Ring<NP> R;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = r2l_act(x[u][c][r] * inv_head, p.act_head);
+                    const float v = r2l_act<GA, false>(x[u][c][r] * inv_head, p.act_head);
                     x[u][c][r] = v;
                     split_store<NP>(v, Bh[u >> 1][c], Bl[u >> 1][c], 4 * (u & 1) + r);
                 }
@@ -387,8 +391,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
-            body_layer<NP, false>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q, p.act_in);
-            body_layer<NP, true>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q, p.act_out);
+            body_layer<NP, false, GA>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q, p.act_in);
+            body_layer<NP, true, GA>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q, p.act_out);
         }
 
         // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------
@@ -442,21 +446,27 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
-template <int NP>
-static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream) {
+template <int NP, bool GA>
+static hipError_t launch_resmlp_ga(const R2LParams& p, int grid, hipStream_t stream) {
     // the > 64 KiB dynamic-LDS opt-in is per device: a process may drive several GPUs
     static std::atomic<bool> attr_set[64];  // zero-initialised; the opt-in call itself is idempotent
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&r2l_resmlp_kernel<NP, GA>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, KCfg<NP>::LDS);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((r2l_resmlp_kernel<NP>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
+    hipLaunchKernelGGL((r2l_resmlp_kernel<NP, GA>), dim3(grid), dim3(256), KCfg<NP>::LDS, stream, p);
     return hipGetLastError();
+}
+template <int NP>
+static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream) {
+    // relu / relu / none: the specialised instantiation; any other slopes (r2l_set_activations): the general one
+    if (p.act_head == 0.0f && p.act_in == 0.0f && p.act_out == 1.0f) return launch_resmlp_ga<NP, false>(p, grid, stream);
+    return launch_resmlp_ga<NP, true>(p, grid, stream);
 }
 
 // ------------------------------------------------------------------------------------
