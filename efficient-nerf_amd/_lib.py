@@ -48,6 +48,7 @@ SIGNATURES = {
     'r2l_load_weights': (C.c_int, [_vp, C.POINTER(_vp), C.c_int]),
     'r2l_set_precision': (C.c_int, [_vp, C.c_int]),
     'r2l_set_activations': (C.c_int, [_vp, C.c_float, C.c_float, C.c_float]),
+    'r2l_set_network_form': (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_int]),
     'r2l_set_z_vals': (C.c_int, [_vp, _vp, C.c_int]),
     'r2l_render': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'r2l_render_rays': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),

@@ -163,6 +163,7 @@ struct r2l_ctx {
     // activations as slopes (act(v) = max(v, s v): 0 relu, 0.01 LeakyReLU, 1 none): head, inside a block, behind a block.  The
     // generated kernels are built for (0, 0, 1); anything else runs in the compiler-scheduled modes only (r2l_set_activations)
     float act_head = 0.0f, act_in = 0.0f, act_out = 1.0f;
+    int block_resid = 1;                      // 0: trial.body_arch = mlp (pairs of plain Linear + act layers, no residual inside the pair)
     int fuse_tail = 1;                        // FP16_FP8 with the global skip: rgb written by the body kernel's fused tail
     int calib_pending = 0;                    // the next FP16_FP8 render derives them from its own head output (device side)
     int calib_started = 0;                    // maxima of earlier, smaller calls are in d_stats: the next measurement adds to them
@@ -299,7 +300,7 @@ static int ensure_x(r2l_ctx* c, int tiles, bool need_xb);
 static int pack_body_v3(const r2l_ctx* c, int e4m3, std::vector<char>& out, size_t* aux_off, size_t* tail_off);
 static int pack_head_v1(const r2l_ctx* c, std::vector<char>& out, int f16 = 0);
 
-static bool default_acts(const r2l_ctx* c) { return c->act_head == 0.0f && c->act_in == 0.0f && c->act_out == 1.0f; }
+static bool default_acts(const r2l_ctx* c) { return c->act_head == 0.0f && c->act_in == 0.0f && c->act_out == 1.0f && c->block_resid == 1; }
 
 static int build_image(r2l_ctx* c, int mode) {
     std::vector<char> img;
@@ -951,19 +952,24 @@ int r2l_set_precision(r2l_ctx* c, int mode) {
 }
 
 int r2l_set_activations(r2l_ctx* c, float head_slope, float inner_slope, float out_slope) {
+    return r2l_set_network_form(c, head_slope, inner_slope, out_slope, 1);
+}
+
+int r2l_set_network_form(r2l_ctx* c, float head_slope, float inner_slope, float out_slope, int block_residual) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     const float s[3] = {head_slope, inner_slope, out_slope};
     for (float v : s)
         if (!(v >= 0.0f && v <= 1.0f)) return r2l_set_error(R2L_EINVAL, "activation slope %g is outside [0, 1]", v);
-    const bool dflt = head_slope == 0.0f && inner_slope == 0.0f && out_slope == 1.0f;
+    const bool dflt = head_slope == 0.0f && inner_slope == 0.0f && out_slope == 1.0f && block_residual;
     if (!dflt && split_mode(c->mode))
-        return r2l_set_error(R2L_EINVAL, "activation slopes %g / %g / %g need a compiler-scheduled mode (R2L_PREC_FP16X3 / _FP16X1): the "
-                                         "generated kernels of the current mode are built for relu / relu / none",
-                             head_slope, inner_slope, out_slope);
+        return r2l_set_error(R2L_EINVAL, "activation slopes %g / %g / %g%s need a compiler-scheduled mode (R2L_PREC_FP16X3 / _FP16X1): the "
+                                         "generated kernels of the current mode are built for relu / relu / none ResMLP blocks",
+                             head_slope, inner_slope, out_slope, block_residual ? "" : " without the block residual");
     if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
     c->act_head = head_slope;
     c->act_in = inner_slope;
     c->act_out = out_slope;
+    c->block_resid = block_residual ? 1 : 0;
     return R2L_OK;
 }
 
@@ -991,6 +997,7 @@ static void fill_common(const r2l_ctx* c, R2LParams& p) {
     p.act_head = c->act_head;
     p.act_in = c->act_in;
     p.act_out = c->act_out;
+    p.block_resid = c->block_resid ? 1.0f : 0.0f;
     p.chunks_per_tile = r2l_chunks_per_tile(c->n_block);
     p.scratch = c->d_scratch;
 }

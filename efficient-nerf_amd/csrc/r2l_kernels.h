@@ -21,6 +21,7 @@ struct R2LParams {
     // activations of the compiler-scheduled kernels as slopes s: act(v) = max(v, s v) -- 0 relu, 0.01 LeakyReLU, 1 none
     // (model/nerf_raybased.py:468-476 get_activation): head (args.act), inside a ResMLP block (trial.inact), behind it (trial.outact)
     float act_head, act_in, act_out;
+    float block_resid;     // 1: x = x + W2 h + b2 (ResMLP, trial.body_arch = resmlp); 0: x = W2 h + b2 (pairs of plain layers, = mlp)
 };
 
 hipError_t r2l_launch_resmlp(const R2LParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*

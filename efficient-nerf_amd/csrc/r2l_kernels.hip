@@ -137,7 +137,7 @@ __device__ __forceinline__ float r2l_act(float v, float slope) {
 }
 template <int NP, bool SECOND, bool GA>
 __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1, f32x4& xu, f16x8& nh, f16x8& nl, int u,
-                                        int r, float slope) {
+                                        int r, float slope, float resid) {
     // r = pair index (0, 1): registers 2r, 2r+1 -> dword 2(u&1) + r of the fragments
     float v[2];
 #pragma unroll
@@ -145,7 +145,8 @@ __device__ __forceinline__ void epi_reg(const f32x4& acc, float inv, float neg1,
         if (!SECOND) {
             v[k] = r2l_act<GA, false>(acc[2 * r + k] * inv, slope);
         } else {
-            v[k] = r2l_act<GA, true>(fmaf(acc[2 * r + k], inv, xu[2 * r + k]), slope);
+            // GA: resid = 0 drops the block's residual (trial.body_arch = mlp: two plain layers per "block")
+            v[k] = r2l_act<GA, true>(fmaf(acc[2 * r + k], inv, GA ? resid * xu[2 * r + k] : xu[2 * r + k]), slope);
             xu[2 * r + k] = v[k];
         }
     }
@@ -160,7 +161,7 @@ template <int NP, bool SECOND, bool HAVE_PREV, bool GA>
 __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&acc)[2],
                                            const f32x4 (&prev)[2], float inv, float neg1, f32x4 (&xprev)[2], int uprev, int q,
-                                           float slope) {
+                                           float slope, float resid) {
     const uint32_t slot = R.use_off;
     const uint32_t lane_base = slot + R.lane * 16;
     const uint32_t next_base = ring_next_off<NP>(slot) + R.lane * 16;
@@ -175,7 +176,7 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
         acc[1] = mfma_step<NP>(R.pre, Bh[s][1], Bl[s][1], acc[1]);
         if (HAVE_PREV && (s & 1))
             epi_reg<NP, SECOND, GA>(prev[s >> 2], inv, neg1, xprev[s >> 2], Nh[uprev >> 1][s >> 2], Nl[uprev >> 1][s >> 2], uprev,
-                                (s >> 1) & 1, slope);
+                                (s >> 1) & 1, slope, resid);
         R.pre = nxt;
     }
     if (upos == 1) ring_next<NP>(R);
@@ -185,20 +186,20 @@ __device__ __forceinline__ void body_rtile(Ring<NP>& R, int upos, const f16x8 (&
 template <int NP, bool SECOND, bool GA>
 __device__ __forceinline__ void body_layer(Ring<NP>& R, const f16x8 (&Bh)[8][2], const f16x8 (&Bl)[8][2],
                                            f16x8 (&Nh)[8][2], f16x8 (&Nl)[8][2], f32x4 (&x)[16][2],
-                                           float act_scale, float neg1, int q, float slope) {
+                                           float act_scale, float neg1, int q, float slope, float resid) {
     const float inv = aux_inv_scale<NP>(R.use_off) * act_scale;  // same for the 8 chunks of a layer
     f32x4 acc[2], prev[2];
-    body_rtile<NP, SECOND, false, GA>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[0], 0, q, slope);
+    body_rtile<NP, SECOND, false, GA>(R, 0, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[0], 0, q, slope, resid);
 #pragma unroll
     for (int u = 1; u < R2L_RTILES; ++u) {
         prev[0] = acc[0];
         prev[1] = acc[1];
-        body_rtile<NP, SECOND, true, GA>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[u - 1], u - 1, q, slope);
+        body_rtile<NP, SECOND, true, GA>(R, u & 1, Bh, Bl, Nh, Nl, acc, prev, inv, neg1, x[u - 1], u - 1, q, slope, resid);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         epi_reg<NP, SECOND, GA>(acc[i >> 1], inv, neg1, x[R2L_RTILES - 1][i >> 1], Nh[(R2L_RTILES - 1) >> 1][i >> 1],
-                            Nl[(R2L_RTILES - 1) >> 1][i >> 1], R2L_RTILES - 1, i & 1, slope);
+                            Nl[(R2L_RTILES - 1) >> 1][i >> 1], R2L_RTILES - 1, i & 1, slope, resid);
 }
 
 // one head k-step (one chunk): 16 row tiles against the generated B fragments of both column
@@ -391,8 +392,8 @@ __global__ __launch_bounds__(256, 1) void r2l_resmlp_kernel(R2LParams p) {
 
         // ---------------- body: n_block x ResMLP ----------------------------------------
         for (int blk = 0; blk < p.n_block; ++blk) {
-            body_layer<NP, false, GA>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q, p.act_in);
-            body_layer<NP, true, GA>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q, p.act_out);
+            body_layer<NP, false, GA>(R, Bh, Bl, Nh, Nl, x, act_scale, neg1, q, p.act_in, 1.0f);
+            body_layer<NP, true, GA>(R, Nh, Nl, Bh, Bl, x, act_scale, neg1, q, p.act_out, p.block_resid);
         }
 
         // ---------------- global skip + tail: sigmoid(Linear(256,3)) -----------------------
@@ -465,7 +466,7 @@ static hipError_t launch_resmlp_ga(const R2LParams& p, int grid, hipStream_t str
 template <int NP>
 static hipError_t launch_resmlp(const R2LParams& p, int grid, hipStream_t stream) {
     // relu / relu / none: the specialised instantiation; any other slopes (r2l_set_activations): the general one
-    if (p.act_head == 0.0f && p.act_in == 0.0f && p.act_out == 1.0f) return launch_resmlp_ga<NP, false>(p, grid, stream);
+    if (p.act_head == 0.0f && p.act_in == 0.0f && p.act_out == 1.0f && p.block_resid == 1.0f) return launch_resmlp_ga<NP, false>(p, grid, stream);
     return launch_resmlp_ga<NP, true>(p, grid, stream);
 }
 

@@ -323,8 +323,12 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
             raise R2LError('the R2L path is built for world-space rays (blender / --no_ndc)')
         if args.plucker or args.learn_depth or args.linear_tail or args.layerwise_netwidths:
             raise R2LError('plucker / learn_depth / linear_tail / layerwise_netwidths variants are not built')
-        if not args.trial.ON or args.trial.body_arch != 'resmlp':
-            raise R2LError('R2L rendering needs --trial.ON --trial.body_arch resmlp (README.md:51)')
+        arch = args.trial.body_arch if args.trial.ON else 'mlp'     # model/nerf_raybased.py:499-518: resmlp only under the trial flags
+        if arch not in ('resmlp', 'mlp'):
+            raise R2LError(f'--trial.body_arch {arch}: resmlp (README.md:51) or mlp')
+        if arch == 'mlp' and ((args.netdepth - 2) % 2 or args.netdepth < 4):
+            raise R2LError(f'--trial.body_arch mlp with netdepth={args.netdepth}: the kernels take the body layers in pairs '
+                           f'(netdepth - 2 must be even)')
         if int(args.trial.n_learnable) != 2:
             raise R2LError(f'trial.n_learnable={args.trial.n_learnable}: the ResMLP kernels are built for two Linear layers per block '
                            f'(model/nerf_raybased.py:443-465); --trial.res_scale, --act, --trial.inact, --trial.outact are honoured')
@@ -332,15 +336,17 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
         for a in acts:
             if a not in R2LEngine.ACT_SLOPES:
                 raise R2LError(f'activation {a!r}: the reference knows relu, lrelu and none (model/nerf_raybased.py:468-476)')
-        if acts != ('relu', 'relu', 'none'):
-            # lrelu / none variants (model/nerf_raybased.py:468-476) render in the compiler-scheduled fp16x3 only
+        if arch == 'mlp' and acts[0] == 'none':
+            raise R2LError('--trial.body_arch mlp with --act none: the reference cannot build that network either (nn.Sequential of None)')
+        if acts != ('relu', 'relu', 'none') or arch == 'mlp':
+            # lrelu / none variants (model/nerf_raybased.py:468-476) and the plain-MLP body render in the compiler-scheduled fp16x3 only
             if args.precision not in ('auto', 'fp16x3', 'fp16x1'):
-                raise R2LError(f'act={acts[0]} trial.inact={acts[1]} trial.outact={acts[2]}: --precision {args.precision} is a generated '
-                               f'kernel built for relu / relu / none; use --precision auto (or fp16x3)')
+                raise R2LError(f'act={acts[0]} trial.inact={acts[1]} trial.outact={acts[2]} body_arch={arch}: --precision {args.precision} is a '
+                               f'generated kernel built for relu / relu / none ResMLP blocks; use --precision auto (or fp16x3)')
         n_block = args.trial.n_block if args.trial.n_block > 0 else (args.netdepth - 2) // 2
         eng = R2LEngine(H, W, focal, near, far, n_sample=args.n_sample_per_ray, L=args.multires,
                         width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec,
-                        res_scale=float(args.trial.res_scale), act=acts[0], inact=acts[1], outact=acts[2])
+                        res_scale=float(args.trial.res_scale), act=acts[0], inact=acts[1], outact=acts[2], body_arch=arch)
         eng.load_state_dict(ckpt['network_fn_state_dict'])
         if auto:
             if probe_pose is None and probe_rays is None:

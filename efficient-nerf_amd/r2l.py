@@ -46,15 +46,24 @@ class R2LEngine:
 
     def __init__(self, H, W, focal, near=2., far=6., n_sample=16, L=10, width=256, n_block=43,
                  use_residual=True, precision=PREC_FP16X3, device=None, z_vals=None, res_scale=1.0, act='relu', inact='relu',
-                 outact='none'):
+                 outact='none', body_arch='resmlp'):
         """res_scale: ResMLP's `--trial.res_scale` (model/nerf_raybased.py:461: x = body(x).mul(res_scale) + x).  The kernels
         compute x += W2 h + b2; the factor is folded into W2 and b2 when the weights are loaded (exact for powers of two, one
         fp32 rounding per weight otherwise: far inside the 1e-4 contract).
         act / inact / outact: args.act (behind the head layer), trial.inact (inside a ResMLP block), trial.outact (behind it) of the
         reference (model/nerf_raybased.py:468-476, 497-522): 'relu' | 'lrelu' | 'none'.  Other than relu / relu / none renders in
-        the compiler-scheduled modes only; the generated ones refuse (r2l_set_activations)."""
+        the compiler-scheduled modes only; the generated ones refuse (r2l_set_activations).
+        body_arch: 'resmlp' (the README's), or 'mlp' (model/nerf_raybased.py:515-518: 2 n_block plain Linear + act layers, state_dict
+        keys body.{0,2,4,...}; two consecutive layers ride in one block without its residual; inact / outact / res_scale do not
+        apply) -- compiler-scheduled modes only."""
         self.device = _dev(device)
         self.res_scale = float(res_scale)
+        if body_arch not in ('resmlp', 'mlp'):
+            raise R2LError(f'body_arch={body_arch!r}: resmlp or mlp (model/nerf_raybased.py:499-518)')
+        self.body_arch = body_arch
+        if body_arch == 'mlp':
+            inact = outact = act          # every layer is Linear + act
+            self.res_scale = 1.0
         self.acts = tuple(self.ACT_SLOPES[str(a).lower()] if str(a).lower() in self.ACT_SLOPES else self._bad_act(a) for a in (act, inact, outact))
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.n_block = int(n_block)
@@ -63,8 +72,8 @@ class R2LEngine:
             check(lib().r2l_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
                                    int(n_sample), int(L), int(width), self.n_block, int(bool(use_residual)),
                                    int(precision)))
-        if self.acts != (0.0, 0.0, 1.0):
-            check(lib().r2l_set_activations(self._ctx, *self.acts))
+        if self.acts != (0.0, 0.0, 1.0) or body_arch == 'mlp':
+            check(lib().r2l_set_network_form(self._ctx, *self.acts, int(body_arch == 'resmlp')))
         self.precision = int(precision)
         self._loaded = False
         # model/nerf_raybased.py:88-90, evaluated with the host's torch exactly as the
@@ -106,6 +115,21 @@ class R2LEngine:
         """state_dict of the reference's NeRF_v3_2 (``module.`` prefixes tolerated,
         utils/run_nerf_raybased_helpers.py:408-425)."""
         sd = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        if self.body_arch == 'mlp':       # nn.Sequential(Linear, act, Linear, act, ...): Linear k at index 2 k; pairs -> blocks
+            sd = dict(sd)
+            for i in range(self.n_block):
+                for j, src in ((0, 4 * i), (2, 4 * i + 2)):
+                    for kind in ('weight', 'bias'):
+                        if f'body.{src}.{kind}' in sd:
+                            sd[f'body.{i}.body.{j}.{kind}'] = sd[f'body.{src}.{kind}']
+        elif self.n_block and 'body.0.body.2.weight' not in sd and 'body.0.body.1.weight' in sd:
+            # trial.inact = none: ResMLP's nn.Sequential holds no activation module, its second Linear is body.{i}.body.1
+            # (model/nerf_raybased.py:450-454)
+            sd = dict(sd)
+            for i in range(self.n_block):
+                for kind in ('weight', 'bias'):
+                    if f'body.{i}.body.1.{kind}' in sd:
+                        sd[f'body.{i}.body.2.{kind}'] = sd[f'body.{i}.body.1.{kind}']
         names = self.state_names(self.n_block)
         missing = [n for n in names if n not in sd]
         if missing:
@@ -537,8 +561,9 @@ class NeRF_v3_2:
         trial = getattr(args, 'trial', None)
         if W != 256 or input_dim != 1008 or output_dim != 3:
             raise R2LError(f'unsupported R2L shape W={W} input_dim={input_dim} output_dim={output_dim}')
-        if trial is None or getattr(trial, 'body_arch', 'resmlp') != 'resmlp':
-            raise R2LError('only --trial.ON --trial.body_arch resmlp networks are supported')
+        self.body_arch = 'resmlp' if trial is None else getattr(trial, 'body_arch', 'resmlp')
+        if self.body_arch not in ('resmlp', 'mlp') or (self.body_arch == 'mlp' and (D - 2) % 2):
+            raise R2LError('--trial.body_arch resmlp, or mlp with an even number of body layers (netdepth - 2)')
         if getattr(args, 'layerwise_netwidths', '') or getattr(args, 'linear_tail', False):
             raise R2LError('layerwise_netwidths / linear_tail variants are not supported')
         if int(getattr(trial, 'n_learnable', 2)) != 2:
@@ -573,7 +598,8 @@ class NeRF_v3_2:
                 raise R2LError('NeRF_v3_2 called before load_state_dict')
             eng = R2LEngine(sampler.H, sampler.W, sampler.focal, sampler.near, sampler.far,
                             n_block=self.n_block, use_residual=self.use_residual, precision=self.precision,
-                            res_scale=self.res_scale, act=self.acts[0], inact=self.acts[1], outact=self.acts[2])
+                            res_scale=self.res_scale, act=self.acts[0], inact=self.acts[1], outact=self.acts[2],
+                            body_arch=self.body_arch)
             eng.load_state_dict(self._state)
             self._engines[key] = eng
         return eng

@@ -123,6 +123,11 @@ int r2l_set_precision(r2l_ctx* ctx, int precision_mode);
  * compiler-scheduled modes (R2L_PREC_FP16X3, _FP16X1) only: the generated kernels are specialised, and r2l_set_precision /
  * r2l_load_weights refuse them with a message (`--precision auto` then stays in fp16x3). */
 int r2l_set_activations(r2l_ctx* ctx, float head_slope, float inner_slope, float out_slope);
+/* ... and the body architecture: block_residual = 1 is `--trial.body_arch resmlp` (x = outact(x + W2 inact(W1 x + b1) + b2),
+ * model/nerf_raybased.py:461-465), 0 is `--trial.body_arch mlp` with an even number of body layers (:515-518: Linear + act repeated;
+ * two consecutive layers ride in one "block": x = act(W2 act(W1 x + b1) + b2), the tensors passed as body.{i}.body.{0,2}.*).
+ * r2l_set_activations(...) = r2l_set_network_form(..., 1). */
+int r2l_set_network_form(r2l_ctx* ctx, float head_slope, float inner_slope, float out_slope, int block_residual);
 /* Override PointSampler.z_vals (model/nerf_raybased.py:88-90).  r2l_create fills them with
  * near*(1-t)+far*t, t = linspace(0,1,n) by the scalar formula; torch.linspace on the CPU is
  * vector-width dependent in the last ulp (AVX2 vs AVX-512 builds differ), so a front-end

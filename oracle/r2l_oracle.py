@@ -137,14 +137,16 @@ def r2l_state_names(n_block=43):
     return names
 
 
-def make_r2l_state(seed=0, netdepth=88, netwidth=256, input_dim=1008, body_gain=1.0):
+def make_r2l_state(seed=0, netdepth=88, netwidth=256, input_dim=1008, body_gain=1.0, inact='relu'):
     """Seeded synthetic W{netwidth}D{netdepth} state_dict with nn.Linear default init.
 
     Reproduces, RNG draw for RNG draw, what ``NeRF_v3_2.__init__`` does under
     ``torch.manual_seed(seed)`` (model/nerf_raybased.py:483-537): head Linear, then the
     D-2 plain Linear layers of the first ``body`` list (created and discarded when
     ``--trial.body_arch resmlp`` replaces it, :503-524), then (D-2)//2 ResMLP blocks of
-    two Linear each (:443-457), then the tail Linear (:534-537)."""
+    two Linear each (:443-457), then the tail Linear (:534-537).  With trial.inact = none the block's nn.Sequential holds
+    no activation module and its second Linear sits at index 1, not 2 (:450-454): the keys follow."""
+    j2 = 1 if inact.lower() == 'none' else 2
     g = torch.random.get_rng_state()
     torch.manual_seed(seed)
     D, W = netdepth, netwidth
@@ -157,7 +159,7 @@ def make_r2l_state(seed=0, netdepth=88, netwidth=256, input_dim=1008, body_gain=
     for i in range(n_block):
         l0, l2 = nn.Linear(W, W), nn.Linear(W, W)
         sd[f'body.{i}.body.0.weight'], sd[f'body.{i}.body.0.bias'] = l0.weight.data, l0.bias.data
-        sd[f'body.{i}.body.2.weight'], sd[f'body.{i}.body.2.bias'] = l2.weight.data, l2.bias.data
+        sd[f'body.{i}.body.{j2}.weight'], sd[f'body.{i}.body.{j2}.bias'] = l2.weight.data, l2.bias.data
     tail = nn.Linear(W, 3)
     sd['tail.0.weight'], sd['tail.0.bias'] = tail.weight.data, tail.bias.data
     torch.random.set_rng_state(g)
@@ -187,6 +189,7 @@ def r2l_forward(sd, x, use_residual=True, res_scale=1.0, dtype=torch.float32,
     head: ReLU(W x + b); body: x = (W2 ReLU(W1 x + b1) + b2)*res_scale + x, no outact;
     global skip body(x)+x when use_residual; tail: sigmoid(W x + b)."""
     n_block = sum(1 for k in sd if k.endswith('body.0.weight'))
+    j2 = 2 if 'body.0.body.2.weight' in sd or n_block == 0 else 1     # trial.inact = none: the second Linear is body.{i}.body.1
     c = lambda t: t.to(dtype)
     x = c(x)
     a_head, a_in, a_out = _activation(act), _activation(inact), _activation(outact)   # :497, :443-465
@@ -195,13 +198,49 @@ def r2l_forward(sd, x, use_residual=True, res_scale=1.0, dtype=torch.float32,
     h0 = h
     for i in range(n_block):
         t = a_in(F.linear(h, c(sd[f'body.{i}.body.0.weight']), c(sd[f'body.{i}.body.0.bias'])))
-        h = a_out(F.linear(t, c(sd[f'body.{i}.body.2.weight']), c(sd[f'body.{i}.body.2.bias'])).mul(res_scale) + h)
+        h = a_out(F.linear(t, c(sd[f'body.{i}.body.{j2}.weight']), c(sd[f'body.{i}.body.{j2}.bias'])).mul(res_scale) + h)
         if return_layers:
             layers.append(h)
     if use_residual:
         h = h + h0
     out = torch.sigmoid(F.linear(h, c(sd['tail.0.weight']), c(sd['tail.0.bias'])))
     return (out, layers) if return_layers else out
+
+
+def r2l_forward_mlp(sd, x, use_residual=True, act='relu', dtype=torch.float32):
+    """NeRF_v3_2.forward with `trial.body_arch = mlp` (model/nerf_raybased.py:497-518, 539-544): head Linear + act, body
+    nn.Sequential(Linear, act, Linear, act, ...) under state_dict keys body.{0,2,4,...}, global skip, sigmoid tail."""
+    c = lambda t: t.to(dtype)
+    a = _activation(act)
+    h0 = a(F.linear(c(x), c(sd['head.0.weight']), c(sd['head.0.bias'])))
+    h = h0
+    k = 0
+    while f'body.{k}.weight' in sd:
+        h = a(F.linear(h, c(sd[f'body.{k}.weight']), c(sd[f'body.{k}.bias'])))
+        k += 2
+    if use_residual:
+        h = h + h0
+    return torch.sigmoid(F.linear(h, c(sd['tail.0.weight']), c(sd['tail.0.bias'])))
+
+
+def make_r2l_mlp_state(seed=0, netdepth=8, W=256, input_dim=1008):
+    """state_dict of NeRF_v3_2 with body_arch = mlp: nn.Linear default init in the constructor's order (model/nerf_raybased.py:
+    497-518: head, the first body list -- built and then replaced by an identical one under the trial flags: same RNG
+    consumption --, the body that is kept, tail)"""
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    sd = OrderedDict()
+    lin = torch.nn.Linear(input_dim, W)
+    sd['head.0.weight'], sd['head.0.bias'] = lin.weight.detach().clone(), lin.bias.detach().clone()
+    for _ in range(netdepth - 2):
+        torch.nn.Linear(W, W)        # the first list, discarded
+    for i in range(netdepth - 2):
+        lin = torch.nn.Linear(W, W)
+        sd[f'body.{2 * i}.weight'], sd[f'body.{2 * i}.bias'] = lin.weight.detach().clone(), lin.bias.detach().clone()
+    lin = torch.nn.Linear(W, 3)
+    sd['tail.0.weight'], sd['tail.0.bias'] = lin.weight.detach().clone(), lin.bias.detach().clone()
+    torch.random.set_rng_state(g)
+    return sd
 
 
 def r2l_render(sd, H, W, focal, c2w, near=2., far=6., n_sample=16, L=10, chunk=40000,

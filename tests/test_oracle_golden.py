@@ -179,3 +179,26 @@ def test_oracle_randomness_matches_reference_streams(golden_dir):
         assert np.array_equal(r[3].numpy(), gr[f'noise_weights_{S}_1'], equal_nan=True)
     zc = O.perturb_z_vals(O.coarse_z_vals(2., 6., 64, gr['rr_z_coarse'].shape[0]), pytest=True)
     assert np.array_equal(zc.numpy(), gr['rr_z_coarse'])
+
+
+def test_variants_of_the_constructor_match_the_reference():
+    """tests/golden/r2l_variants.npz: the reference's own NeRF_v3_2 with other activations, res_scale and the plain-MLP body
+    (generated by make_golden_variants.py from the imported reference class); the oracle rebuilds each seeded network -- RNG draw
+    for RNG draw -- and must reproduce the reference's rgb"""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'r2l_variants.npz'))
+    H, focal = int(g['H']), float(g['focal'])
+    c2w = torch.from_numpy(g['c2w'])
+    pts = O.sample_test(O.camera_dirs(H, H, focal), O.sampler_z_vals(16, 2., 6.), c2w[:3, :4])
+    emb = O.positional_embed(pts[torch.from_numpy(g['idx'])], 10)
+    names = [k[:-4] for k in g.files if k.endswith('_cfg')]
+    assert len(names) == 5
+    for name in names:
+        _, D, arch, act, inact, outact, rs, seed = [str(x) for x in g[name + '_cfg']]
+        if arch == 'mlp':
+            out = O.r2l_forward_mlp(O.make_r2l_mlp_state(int(seed), netdepth=int(D)), emb, act=act)
+        else:
+            out = O.r2l_forward(O.make_r2l_state(int(seed), netdepth=int(D), inact=inact), emb, res_scale=float(rs), act=act, inact=inact,
+                                outact=outact)
+        assert (out - torch.from_numpy(g[name + '_rgb'])).abs().max().item() <= 2e-6, name

@@ -383,3 +383,25 @@ def test_activation_variants_of_the_constructor(pkg, act, inact, outact):
     eng.close()
     with pytest.raises(R2LError, match='compiler-scheduled'):
         R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8, act=act, inact=inact, outact=outact)
+
+
+def test_constructor_variants_against_the_reference_golden(pkg):
+    """HIP (compiler-scheduled fp16x3 through r2l_set_network_form) against the reference's own NeRF_v3_2 for the variants of
+    tests/golden/r2l_variants.npz: lrelu everywhere; outact relu with res_scale 0.5; lrelu / none / lrelu with res_scale 0.3 (the
+    state_dict then names the second Linear body.{i}.body.1); the plain-MLP body with relu and with lrelu"""
+    import os
+    from efficient_nerf_amd import R2LEngine
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'r2l_variants.npz'))
+    H, focal = int(g['H']), float(g['focal'])
+    c2w = torch.from_numpy(g['c2w'])
+    idx = torch.from_numpy(g['idx'])
+    for name in [k[:-4] for k in g.files if k.endswith('_cfg')]:
+        _, D, arch, act, inact, outact, rs, seed = [str(x) for x in g[name + '_cfg']]
+        D = int(D)
+        sd = O.make_r2l_mlp_state(int(seed), netdepth=D) if arch == 'mlp' else O.make_r2l_state(int(seed), netdepth=D, inact=inact)
+        eng = R2LEngine(H, H, focal, n_block=(D - 2) // 2, res_scale=float(rs), act=act, inact=inact, outact=outact,
+                        body_arch=arch).load_state_dict(sd)
+        err = (eng.render(c2w).cpu()[idx] - torch.from_numpy(g[name + '_rgb'])).abs().max().item()
+        print(f'{name}: L_inf vs the reference {err:.2e}')
+        assert err <= TOL_X3, (name, err)
+        eng.close()
