@@ -119,7 +119,7 @@ def create_data_leg(torch, O, precision):
 
 def middle_rung(torch, O, R2LEngine, sd, poses, focal):
     """secondary, outside the timed region: a W256D88 network with every body weight x 1.08 (largest |activation| ~ 9.5: beyond
-    the bf6 terms' limit of 8, inside the e4m3 terms' 12) through `--precision auto`: must come out as fp16_e4m3, inside 1e-4 of
+    the bf6 terms' limit of 8, inside the e4m3 terms' 10) through `--precision auto`: must come out as fp16_e4m3, inside 1e-4 of
     the CPU oracle, at its rate"""
     GAIN = 1.08
     msd = {k: (v * GAIN if k.startswith('body.') and k.endswith('weight') else v) for k, v in sd.items()}

@@ -51,7 +51,7 @@ def test_bench_line_schema():
     assert d['calibration']['measured_on'].startswith('every ray')
     # the middle rung of the ladder on the networks it is for
     em = d['e4m3_mode']
-    assert em['auto_precision'] == 'fp16_e4m3' and em['max_act_exponent'] == 4 and 8 < em['max_abs_activation'] <= 12 and em['linf_vs_cpu_oracle'] <= 1e-4
+    assert em['auto_precision'] == 'fp16_e4m3' and em['max_act_exponent'] == 4 and 8 < em['max_abs_activation'] <= 10 and em['linf_vs_cpu_oracle'] <= 1e-4
     # the stress weights of SURVEY 8(d) must not be rendered with the bf6 terms: the library's own range check decides
     sw = d['stress_weights']
     assert sw['auto_precision'] == 'fp16x3_asm' and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4

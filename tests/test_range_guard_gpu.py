@@ -135,7 +135,7 @@ def test_edge_rays_beyond_the_centre_probe_are_caught(pkg):
     eng.close()
 
 
-@pytest.mark.parametrize('gain,want', [(1.10, 'fp16_e4m3'), (1.3, 'fp16x3_asm')])
+@pytest.mark.parametrize('gain,want', [(1.08, 'fp16_e4m3'), (1.3, 'fp16x3_asm')])
 def test_auto_falls_back_when_a_later_pose_leaves_the_range(pkg, gain, want):
     """`--precision auto` = choose_precision + check_ranges after every frame: exponents forced low (as if the first frame
     had been a tame one) -> the next frame trips the watch, the context moves down the ladder (fp16_fp8 -> fp16_e4m3 at
@@ -146,7 +146,7 @@ def test_auto_falls_back_when_a_later_pose_leaves_the_range(pkg, gain, want):
     sd = O.make_r2l_state(seed=0)
     for k in sd:
         if k.startswith('body.') and k.endswith('weight'):
-            sd[k] = sd[k] * gain                  # largest |activation| ~ 10 (gain 1.10: the e4m3 rung) / 5-6 (1.3): beyond fp16_fp8's limit
+            sd[k] = sd[k] * gain                  # largest |activation| ~ 9 (gain 1.08: the e4m3 rung) / 5-6 (1.3): beyond fp16_fp8's limit
     c2w = O.pose_spherical(40., -30., 4.)
     eng = R2LEngine(H, H, focal).load_state_dict(sd)
     name, top = eng.choose_precision(c2w=c2w, max_exp=8)      # limit lifted: stays in fp16_fp8 ...
