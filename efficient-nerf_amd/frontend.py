@@ -76,6 +76,8 @@ FLAGS = [
     ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
+    # frames rendered per launch / collective / range check / host sync (0: the world size, i.e. one frame on one GPU)
+    ('--frames_per_batch', dict(type=int, default=0)),
 ]
 
 
@@ -595,7 +597,8 @@ def main(argv=None):
     t_ = time.time()
     st = {}
     with torch.no_grad():
-        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log, given_rays=given, stats=st)
+        rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log, given_rays=given, stats=st,
+                                 frames_per_batch=args.frames_per_batch or None)
     dt = time.time() - t_
     if rank == 0:
         np.save(os.path.join(outdir, 'rgbs.npy'), st['host_frames'].numpy() if 'host_frames' in st else rgbs.cpu().numpy())

@@ -18,17 +18,19 @@ from efficient_nerf_amd import frontend as fe  # noqa: E402
 from oracle import r2l_oracle as O  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+fpb = sys.argv[2] if len(sys.argv) > 2 else '0'       # --frames_per_batch
 d = tempfile.mkdtemp(prefix='r2l_cli_')
 ck = os.path.join(d, 'r2l.tar')
 fe.save_checkpoint(ck, O.make_r2l_state(seed=0))
 cmd = [sys.executable, os.path.join(ROOT, 'main.py'), '--model_name', 'R2L', '--config', 'configs/lego_noview_800x800.txt',
        '--n_sample_per_ray', '16', '--netwidth', '256', '--netdepth', '88', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp',
-       '--pretrained_ckpt', ck, '--render_only', '--synthetic_poses', str(n), '--H', '800', '--outdir', os.path.join(d, 'out')]
+       '--pretrained_ckpt', ck, '--render_only', '--synthetic_poses', str(n), '--H', '800', '--outdir', os.path.join(d, 'out'),
+       '--frames_per_batch', fpb]
 r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
 lines = r.stdout.splitlines()
 keep = [ln for ln in lines if ln.startswith(('[precision]', 'Render loop', 'Rendered'))]
 times = [float(ln.split('time for this frame: ')[1].rstrip('s')) for ln in lines if 'time for this frame' in ln]
-print('$ main.py --model_name R2L --config configs/lego_noview_800x800.txt ... --render_only --synthetic_poses %d   (rc %d)' % (n, r.returncode))
+print('$ main.py --model_name R2L --config configs/lego_noview_800x800.txt ... --render_only --synthetic_poses %d --frames_per_batch %s   (rc %d)' % (n, fpb, r.returncode))
 for ln in keep:
     print(ln)
 if times:
