@@ -6,8 +6,10 @@ GPU): a heavy process loops one kind of kernel for 12 s, a light process beside 
                                                 g: get_rays only    r: R2L frames               m: torch fp16 matmuls
 Round 4 finding (profiles/r04_gpu_sharing.txt): beside the chain kernel -- and only beside it -- a build of nerf_get_rays_kernel in
 which the SLP vectorizer had formed packed-fp32 ops (v_pk_mul_f32 / v_pk_add_f32 with SGPR-pair operands) returned wrong d.x in
-groups of 16 lanes; the scalar build (-fno-slp-vectorize, csrc/Makefile) does not.  The order matters: the heavy process must be
-running while the light one initialises (the default here; GS_LIGHT_FIRST=1 reverses it and nothing differs in either build).
+groups of 16 lanes; the scalar build (-fno-slp-vectorize, csrc/Makefile) does not.  Cause (profiles/r04_coresidency.txt,
+tools/coresidency_probe.hip): the chain kernel leaves 112 registers per SIMD lane free, so the light kernel's waves run between its
+v_mfma_f32_16x16x32_f16, beside which a v_pk_*_f32 with op_sel:[0,1] loses the hi half of src1 in lanes 48..63 -- one process with two
+streams shows the same.  (GS_LIGHT_FIRST=1 starts the light process first; that order showed nothing -- the kernels did not overlap.)
 The fp16x3 frame of the light process (r2l_resmlp_kernel, compiler-scheduled; GS_NO_X3=1 skips it) is compared with its own first
 render.  Exit code 1 when anything differs."""
 import os, sys
@@ -36,7 +38,7 @@ def worker(rank, world, mode):
             z = torch.linspace(2., 6., 64, device='cuda').expand(ro.shape[0], 64).contiguous()
             raw = torch.randn(ro.shape[0], 64, 4, device='cuda')
             t0 = time.time()
-            while time.time() - t0 < 12:
+            while time.time() - t0 < float(os.environ.get("GS_HEAVY_SECONDS", 12)):
                 if mode == 'c':      # the chain kernel alone
                     eng.run_network(0, ro, rd, z)
                 elif mode == 's':    # the scan kernels alone
@@ -52,21 +54,21 @@ def worker(rank, world, mode):
             eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
             pose = O.novel_poses(1)[0][:3, :4]
             t0 = time.time()
-            while time.time() - t0 < 12:
+            while time.time() - t0 < float(os.environ.get("GS_HEAVY_SECONDS", 12)):
                 eng.render(pose)
                 torch.cuda.synchronize()
         elif mode == 'r':
             eng = R2LEngine(800, 800, O.focal_from_angle(800), precision=PREC_FP16_FP8).load_state_dict(O.make_r2l_state(0))
             pose = O.novel_poses(1)[0][:3, :4]
             t0 = time.time()
-            while time.time() - t0 < 12:
+            while time.time() - t0 < float(os.environ.get("GS_HEAVY_SECONDS", 12)):
                 for _ in range(5):
                     eng.render(pose)
                 torch.cuda.synchronize()
         else:
             a = torch.randn(8192, 8192, device='cuda', dtype=torch.float16)
             t0 = time.time()
-            while time.time() - t0 < 12:
+            while time.time() - t0 < float(os.environ.get("GS_HEAVY_SECONDS", 12)):
                 for _ in range(10):
                     b = a @ a
                 torch.cuda.synchronize()
@@ -106,4 +108,7 @@ def worker(rank, world, mode):
 
 if __name__ == '__main__':
     import torch.multiprocessing as mp
+    if os.environ.get('GS_HEAVY_ONLY'):      # only the heavy process (tools/pk_sgpr_run.sh brings its own light one)
+        worker(0, 2, sys.argv[1])
+        sys.exit(0)
     mp.spawn(worker, args=(2, sys.argv[1]), nprocs=2, join=True)
