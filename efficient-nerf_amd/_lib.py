@@ -97,6 +97,12 @@ SIGNATURES = {
     'nerf_kernel_time_ms': (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     'r2l_np_legacy_permutation': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_longlong, _vp]),
     'nerf_merge_sorted': (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    'r2l_linear_create': (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_int, C.c_int]),
+    'r2l_linear_destroy': (None, [_vp]),
+    'r2l_linear_forward': (C.c_int, [_vp, _vp, C.c_longlong, C.c_int, _vp, C.c_longlong, _vp, C.c_longlong, C.c_float, C.c_int, _vp,
+                                     C.c_longlong, _vp]),
+    'r2l_sample_points': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    'nerf_embed': (C.c_int, [_vp, C.c_longlong, C.c_int, C.c_int, C.c_int, _vp, C.c_longlong, _vp]),
 }
 
 _lib = None

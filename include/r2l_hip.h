@@ -365,6 +365,36 @@ int nerf_sample_pdf_ex(const float* bins, const float* weights, int n, int n_bin
 int nerf_merge_sorted(const float* a, int na, const float* b, int nb, int n, float* out,
                       void* stream);
 
+/* ---- generic fp32 layer path (csrc/r2l_generic.hip) ---------------------------------------------------------------
+ * The variants the reference's constructors accept that the fused kernels are not built for: NeRF_v3_2 with netwidth != 256,
+ * --layerwise_netwidths, trial.n_learnable != 2, n_sample_per_ray != 16, multires != 10, odd mlp depths
+ * (model/nerf_raybased.py:483-537); NeRF with netdepth / netwidth other than 8 x 256 (:339-401).  One launch per nn.Linear,
+ * fp32 products and accumulation on the fp32 MFMA (the reference's own precision), activations through HBM in caller buffers.
+ * The host mirror composes them (efficient-nerf_amd/generic.py). */
+typedef struct r2l_linear r2l_linear;
+#define R2L_ACT_NONE 0
+#define R2L_ACT_RELU 1      /* nn.ReLU */
+#define R2L_ACT_LRELU 2     /* nn.LeakyReLU(), slope 0.01 (model/nerf_raybased.py:468-476) */
+#define R2L_ACT_SIGMOID 3   /* the tail's nn.Sigmoid (:534-537) */
+/* one nn.Linear: w_host [out_dim, in_dim] row-major as in the state_dict, b_host [out_dim] or NULL; copied to the device */
+int r2l_linear_create(r2l_linear** out, const float* w_host, const float* b_host, int out_dim, int in_dim);
+void r2l_linear_destroy(r2l_linear* lin);
+/* y[r, :out] = post[r, :] + act((x[r, :in] W^T + b) * res_scale + res[r, :])  for r < n; res_dev / post_dev may be NULL (then
+ * res_scale is not applied); row strides ld* in floats (>= the row's width: a layer can read a column slice of a wider buffer
+ * and write into one, which is how the reference's torch.cat inputs are formed).  res_dev / post_dev may alias y_dev; x_dev
+ * must not overlap y_dev.  ResMLP.forward (model/nerf_raybased.py:461-465): res = the block's input, act = outact;
+ * NeRF_v3_2.forward's global skip (:542): post = the head's output on the last body layer. */
+int r2l_linear_forward(const r2l_linear* lin, const float* x_dev, long long ldx, int n, float* y_dev, long long ldy,
+                       const float* res_dev, long long ldr, float res_scale, int act, const float* post_dev, long long ldp,
+                       void* stream);
+/* PointSampler.sample_test / sample_train (model/nerf_raybased.py:100-102, 114-126) for any n_sample, and main.py:701 with
+ * per-ray z: pts[r, 3 s + k] = rays_o[r, k] + rays_d[r, k] * z[s] (z_per_ray = 0: z_dev [n_sample]; 1: z_dev [n, n_sample]) */
+int r2l_sample_points(const float* rays_o_dev, const float* rays_d_dev, int n, const float* z_dev, int n_sample, int z_per_ray,
+                      float* pts_out_dev, void* stream);
+/* Embedder.embed (utils/run_nerf_raybased_helpers.py:24-56; include_input, log_sampling): out[r, :] = [x, sin(x), cos(x),
+ * sin(2 x), cos(2 x), ..., cos(2^(multires-1) x)] of x = x_dev[r, :dim]; row strides ldi / ldo in floats */
+int nerf_embed(const float* x_dev, long long ldi, int n, int dim, int multires, float* out_dev, long long ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -243,6 +243,79 @@ def make_r2l_mlp_state(seed=0, netdepth=8, W=256, input_dim=1008):
     return sd
 
 
+
+def _v3_2_widths(netdepth, netwidth, layerwise_netwidths=''):
+    """model/nerf_raybased.py:488-493"""
+    if layerwise_netwidths:
+        return [int(x) for x in layerwise_netwidths.split(',')] + [3]
+    return [netwidth] * (netdepth - 1) + [3]
+
+
+def make_v3_2_state(seed, netdepth, netwidth, input_dim, layerwise_netwidths='', act='relu', trial=None):
+    """state_dict of ANY NeRF_v3_2 the constructor builds (model/nerf_raybased.py:483-537), nn.Linear default init, RNG draw for
+    RNG draw: head; the first body list (always built, :499-501); under the trial flags the body that replaces it (:503-518:
+    n_block ResMLP blocks of n_learnable Linear layers at netwidth, or the plain list again); tail.  `trial`: None or a dict
+    with body_arch, n_block, n_learnable, inact.  Keys follow nn.Sequential's indices (an activation module takes a slot)."""
+    D, W = netdepth, netwidth
+    Ws = _v3_2_widths(D, W, layerwise_netwidths)
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    sd = OrderedDict()
+
+    def put(key, lin):
+        sd[key + '.weight'], sd[key + '.bias'] = lin.weight.detach().clone(), lin.bias.detach().clone()
+
+    put('head.0', nn.Linear(input_dim, Ws[0]))
+    first = [nn.Linear(Ws[i - 1], Ws[i]) for i in range(1, D - 1)]
+    step = 2 if act.lower() != 'none' else 1
+    if trial is None:
+        for i, lin in enumerate(first):
+            put(f'body.{step * i}', lin)
+    elif trial['body_arch'] == 'resmlp':
+        n_block = trial.get('n_block', -1)
+        if n_block <= 0:
+            n_block = (D - 2) // 2
+        sub_step = 1 if trial.get('inact', 'relu').lower() == 'none' else 2
+        for b in range(n_block):
+            for j in range(trial.get('n_learnable', 2)):
+                put(f'body.{b}.body.{sub_step * j}', nn.Linear(W, W))
+    else:
+        for i in range(1, D - 1):
+            put(f'body.{step * (i - 1)}', nn.Linear(Ws[i - 1], Ws[i]))
+    put('tail.0', nn.Linear(Ws[D - 2], 3))
+    torch.random.set_rng_state(g)
+    return sd
+
+
+def v3_2_forward(sd, x, netdepth, act='relu', use_residual=True, trial=None):
+    """NeRF_v3_2.forward (model/nerf_raybased.py:539-544) for the state_dicts of make_v3_2_state: the Linear layers are taken
+    in key order; ResMLP.forward (:461-465) under trial.body_arch = resmlp."""
+    a = _activation(act)
+    h0 = a(F.linear(x, sd['head.0.weight'], sd['head.0.bias']))
+    h = h0
+    if trial is not None and trial['body_arch'] == 'resmlp':
+        inact, outact = _activation(trial.get('inact', 'relu')), _activation(trial.get('outact', 'none'))
+        rs = trial.get('res_scale', 1.0)
+        sub_step = 1 if trial.get('inact', 'relu').lower() == 'none' else 2
+        b = 0
+        while f'body.{b}.body.0.weight' in sd:
+            t, j = h, 0
+            while f'body.{b}.body.{sub_step * j}.weight' in sd:
+                if j > 0:
+                    t = inact(t)
+                t = F.linear(t, sd[f'body.{b}.body.{sub_step * j}.weight'], sd[f'body.{b}.body.{sub_step * j}.bias'])
+                j += 1
+            h = outact(t.mul(rs) + h)
+            b += 1
+    else:
+        keys = sorted({int(k.split('.')[1]) for k in sd if k.startswith('body.')})
+        for k in keys:
+            h = a(F.linear(h, sd[f'body.{k}.weight'], sd[f'body.{k}.bias']))
+    if use_residual:
+        h = h + h0
+    return torch.sigmoid(F.linear(h, sd['tail.0.weight'], sd['tail.0.bias']))
+
+
 def r2l_render(sd, H, W, focal, c2w, near=2., far=6., n_sample=16, L=10, chunk=40000,
                rows=None, dtype=torch.float32):
     """main.py:401-404 render_func == main.py:300-309: model(embed(sample_test(c2w)))."""
