@@ -10,8 +10,8 @@
 //
 // Arithmetic: fp32 products, fp32 accumulate on the fp32 MFMA (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU, 1/16 of the fp16
 // rate) -- the reference's own precision, nothing to calibrate; the only difference from F.linear is the summation order
-// (~1e-6).  This is the path for the long tail of shapes, not the headline: the README's W256D88 runs at ~1/8 of the fused
-// fp16_fp8 kernels here.
+// (~2e-7 measured on ten network variants).  This is the path for the long tail of shapes, not the headline: the README's W256D88
+// runs at 3.7e6 rays/s here (44 TFLOP/s, 0.28 of the fp32 MFMA peak), 1/17 of the fused fp16_fp8 kernels (profiles/r04_generic_time.txt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

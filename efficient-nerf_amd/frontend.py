@@ -73,7 +73,7 @@ FLAGS = [
     # auto (default): fp16_fp8 (fp16 MFMA pass + bf6 correction terms, 1.7x the speed) when the checkpoint's own activation
     # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
     # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher takes fp16_fp8
-    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'auto'])),
+    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp32', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
     # frames rendered per launch / collective / range check / host sync (0: the world size, i.e. one frame on one GPU)
@@ -305,7 +305,7 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     # auto: the weights are loaded in fp16x3 -- the mode that packs ANY checkpoint (per-layer scales) -- and choose_precision
     # moves to the generated modes from there; a layer they cannot pack (max|w| outside 2^-12 .. 2^6) then ends in its
     # documented fp16x3 fallback instead of failing r2l_load_weights.  The teacher's `auto` starts from fp16_fp8.
-    prec = PRECISIONS[args.precision] if not auto else PRECISIONS['fp16x3' if args.model_name in ('R2L', 'nerf_v3.2') else 'fp16_fp8']
+    prec = PRECISIONS.get(args.precision) if not auto else PRECISIONS['fp16x3' if args.model_name in ('R2L', 'nerf_v3.2') else 'fp16_fp8']
     llff_ndc = args.dataset_type == 'llff' and not args.no_ndc
     if args.dataset_type == 'blender':
         near, far = 2., 6.  # main.py:930-931
@@ -323,17 +323,33 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     if args.model_name in ('R2L', 'nerf_v3.2'):
         if llff_ndc:
             raise R2LError('the R2L path is built for world-space rays (blender / --no_ndc)')
-        if args.plucker or args.learn_depth or args.linear_tail or args.layerwise_netwidths:
-            raise R2LError('plucker / learn_depth / linear_tail / layerwise_netwidths variants are not built')
+        if args.plucker or args.learn_depth or args.linear_tail:
+            raise R2LError('plucker / learn_depth / linear_tail variants are not built (linear_tail: the reference builds Linear(input_dim, 3) '
+                           'on the body output and cannot run it either, model/nerf_raybased.py:532-537)')
         arch = args.trial.body_arch if args.trial.ON else 'mlp'     # model/nerf_raybased.py:499-518: resmlp only under the trial flags
         if arch not in ('resmlp', 'mlp'):
             raise R2LError(f'--trial.body_arch {arch}: resmlp (README.md:51) or mlp')
-        if arch == 'mlp' and ((args.netdepth - 2) % 2 or args.netdepth < 4):
-            raise R2LError(f'--trial.body_arch mlp with netdepth={args.netdepth}: the kernels take the body layers in pairs '
-                           f'(netdepth - 2 must be even)')
-        if int(args.trial.n_learnable) != 2:
-            raise R2LError(f'trial.n_learnable={args.trial.n_learnable}: the ResMLP kernels are built for two Linear layers per block '
-                           f'(model/nerf_raybased.py:443-465); --trial.res_scale, --act, --trial.inact, --trial.outact are honoured')
+        # shapes the fused kernels are not built for render on the generic fp32 layer path (generic.py: one launch per nn.Linear):
+        # other widths / sample counts / frequencies, --layerwise_netwidths, trial.n_learnable != 2, an odd number of mlp body layers
+        generic = (args.netwidth != 256 or args.n_sample_per_ray != 16 or args.multires != 10 or bool(args.layerwise_netwidths)
+                   or (args.trial.ON and arch == 'resmlp' and int(args.trial.n_learnable) != 2)
+                   or (arch == 'mlp' and ((args.netdepth - 2) % 2 or args.netdepth < 4)) or args.precision == 'fp32')
+        if generic:
+            if args.precision not in ('auto', 'fp32'):
+                raise R2LError(f'--precision {args.precision} is a mode of the fused W256 kernels; this network (netwidth={args.netwidth} '
+                               f'n_sample_per_ray={args.n_sample_per_ray} multires={args.multires} layerwise_netwidths={args.layerwise_netwidths!r} '
+                               f'n_learnable={args.trial.n_learnable} netdepth={args.netdepth} {arch}) renders on the generic path: --precision auto or fp32')
+            from .generic import GenericR2L
+            trial = dict(body_arch=arch, n_block=args.trial.n_block, n_learnable=int(args.trial.n_learnable), res_scale=float(args.trial.res_scale),
+                         inact=args.trial.inact, outact=args.trial.outact) if args.trial.ON else None
+            eng = GenericR2L(H, W, focal, near, far, n_sample=args.n_sample_per_ray, L=args.multires, netdepth=args.netdepth,
+                             netwidth=args.netwidth, layerwise_netwidths=args.layerwise_netwidths, act=args.act, use_residual=args.use_residual,
+                             trial=trial)
+            eng.load_state_dict(ckpt['network_fn_state_dict'])
+            if log:
+                log(f'[precision] {args.precision}: this network is outside the fused kernels\' shapes -> generic fp32 layer path '
+                    f'({len(eng.plan)} Linear launches per chunk, {eng.flops_per_ray / 1e6:.2f} MFLOP/ray)')
+            return 'R2L', eng
         acts = (args.act.lower(), args.trial.inact.lower(), args.trial.outact.lower())
         for a in acts:
             if a not in R2LEngine.ACT_SLOPES:
@@ -361,12 +377,30 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
                     f'fp16_fp8 up to {eng.AUTO_MAX_ABS:g}, fp16_e4m3 up to {eng.AUTO_MAX_ABS_E4M3:g}) -> {name}')
         return 'R2L', eng
     if args.model_name == 'nerf':
-        if not args.use_viewdirs or args.N_importance <= 0:
-            raise R2LError('the teacher path is built for use_viewdirs=True, N_importance>0 (configs/lego.txt)')
-        if (args.netdepth, args.netwidth, args.netdepth_fine, args.netwidth_fine) != (8, 256, 8, 256) or args.i_embed != 0:
-            raise R2LError(f'netdepth/netwidth(_fine) = {args.netdepth}/{args.netwidth}/{args.netdepth_fine}/'
-                           f'{args.netwidth_fine}, i_embed={args.i_embed}: the teacher kernels are built for the 8 x 256 NeRF '
-                           f'with positional encoding (model/nerf_raybased.py:339-401)')
+        # the fused teacher kernels are the 8 x 256 NeRF with view directions, L = 10 / 4 and a fine pass (configs/*.txt); every other
+        # network create_nerf builds (main.py:407-453) renders on the generic fp32 layer path (generic.GenericNeRF)
+        generic = (not args.use_viewdirs or args.N_importance <= 0 or args.i_embed != 0 or (args.multires, args.multires_views) != (10, 4)
+                   or (args.netdepth, args.netwidth, args.netdepth_fine, args.netwidth_fine) != (8, 256, 8, 256) or args.precision == 'fp32')
+        if generic:
+            if args.precision not in ('auto', 'fp32'):
+                raise R2LError(f'--precision {args.precision} is a mode of the fused 8 x 256 teacher kernels; netdepth/netwidth(_fine) = '
+                               f'{args.netdepth}/{args.netwidth}/{args.netdepth_fine}/{args.netwidth_fine}, i_embed={args.i_embed}, multires='
+                               f'{args.multires}/{args.multires_views}, use_viewdirs={args.use_viewdirs}, N_importance={args.N_importance} '
+                               f'renders on the generic path: --precision auto or fp32')
+            if args.i_embed not in (0, -1):
+                raise R2LError(f'i_embed={args.i_embed}: 0 (positional encoding) or -1 (none), utils/run_nerf_raybased_helpers.py:59-74')
+            if args.N_importance > 0 and 'network_fine_state_dict' not in ckpt:
+                raise KeyError("checkpoint lacks 'network_fine_state_dict'")
+            from .generic import GenericNeRF
+            eng = GenericNeRF(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance, multires=args.multires,
+                              multires_views=args.multires_views, i_embed=args.i_embed, netdepth=args.netdepth, netwidth=args.netwidth,
+                              netdepth_fine=args.netdepth_fine, netwidth_fine=args.netwidth_fine, use_viewdirs=args.use_viewdirs,
+                              white_bkgd=args.white_bkgd, lindisp=args.lindisp, ndc=llff_ndc)
+            eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt.get('network_fine_state_dict'))
+            if log:
+                log(f'[precision] {args.precision}: this teacher is outside the fused kernels\' shapes -> generic fp32 layer path '
+                    f'({eng.flops_per_ray / 1e6:.1f} MFLOP/ray)')
+            return 'nerf', eng
         if 'network_fine_state_dict' not in ckpt:
             raise KeyError("checkpoint lacks 'network_fine_state_dict'")
         eng = NeRFEngine(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance,

@@ -5,8 +5,9 @@ The fused kernels (r2l.R2LEngine, teacher.NeRFEngine) are built for the README's
 8 x 256 NeRF.  The reference's constructors accept more (model/nerf_raybased.py:483-537, 339-401): other widths,
 --layerwise_netwidths, trial.n_learnable != 2, other n_sample_per_ray / multires, odd mlp depths, other teacher depths and
 widths, no view directions.  Those run here: fp32 products and accumulation on the fp32 MFMA (the reference's own
-precision: nothing to calibrate, L_inf vs the reference ~1e-6), activations through HBM.  Slower by an order of magnitude than
-the fused kernels; the front end takes this path only for what they refuse.
+precision: nothing to calibrate, L_inf vs the reference ~2e-7), activations through HBM.  The README's own networks run 17 x (R2L
+W256D88: 3.7e6 rays/s) and 21 x (8 x 256 teacher: 1.1e5 rays/s) slower here than on the fused kernels
+(profiles/r04_generic_time.txt); the front end takes this path only for what those refuse.
 
 The module structure (which state_dict key is which Linear, where activations and residuals sit) is restated from the
 constructors cited at each function; tests/golden/make_golden_generic.py pins it against the reference's own classes.
@@ -15,6 +16,7 @@ import ctypes as C
 
 import torch
 
+from . import _lib
 from ._lib import R2LError, check, current_stream, dptr, lib
 
 ACT_CODES = {'none': 0, 'relu': 1, 'lrelu': 2, 'sigmoid': 3}
@@ -56,9 +58,8 @@ class Linear:
                                           self.out_dim, self.in_dim))
 
     def close(self):
-        from . import _lib
-        if getattr(self, '_h', None) and self._h.value and _lib._lib is not None:
-            lib().r2l_linear_destroy(self._h)
+        if getattr(self, '_h', None) and self._h.value and _lib is not None and _lib._lib is not None:
+            _lib._lib.r2l_linear_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -139,6 +140,12 @@ class GenericR2L:
     render / render_batch / render_rays."""
 
     precision_name = 'fp32'
+    precision = -1          # none of the library's fp16 modes: nothing to calibrate, agree on or watch (dist.agree_act_exponents)
+    n_block = 0
+
+    def render_checked(self, render, log=None, check=None):
+        """R2LEngine.render_checked's shape: fp32 has no operand ranges to leave, so one render and no re-render"""
+        return render(), 0
 
     def __init__(self, H, W, focal, near=2., far=6., n_sample=16, L=10, netdepth=88, netwidth=256, layerwise_netwidths='',
                  act='relu', use_residual=True, trial=None, chunk=1 << 16, device=None, z_vals=None):
@@ -269,3 +276,193 @@ class GenericR2L:
         for i in range(P):
             self.render(host[i], rows=(r0, r1), out=out[i])
         return out
+
+
+def nerf_plan(D, W, input_ch, input_ch_views, output_ch, skips=(4,), use_viewdirs=True):
+    """The Linear layers of NeRF (model/nerf_raybased.py:357-375) as (key, in_dim, out_dim)."""
+    plan = [(f'pts_linears.{i}', (input_ch if i == 0 else (W + input_ch if (i - 1) in skips else W)), W) for i in range(D)]
+    if use_viewdirs:
+        plan += [('alpha_linear', W, 1), ('feature_linear', W, W), ('views_linears.0', input_ch_views + W, W // 2), ('rgb_linear', W // 2, 3)]
+    else:
+        plan += [('output_linear', W, output_ch)]
+    return plan
+
+
+class _NeRFNet:
+    """One NeRF module (model/nerf_raybased.py:339-401) as generic layer launches.  The reference's torch.cat inputs are column
+    slices of wider buffers: [input_pts | h] behind a skip layer, [feature | input_views] in front of views_linears."""
+
+    def __init__(self, sd, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, device):
+        sd = _strip(sd)
+        self.D, self.W, self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = D, W, input_ch, input_ch_views, tuple(skips), use_viewdirs
+        self.output_ch = output_ch
+        self.lin = {}
+        for key, i, o in nerf_plan(D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs):
+            if key + '.weight' not in sd:
+                raise R2LError(f"state_dict lacks {key}.weight (has e.g. {sorted(sd)[:4]})")
+            if tuple(sd[key + '.weight'].shape) != (o, i):
+                raise R2LError(f"{key}.weight is {tuple(sd[key + '.weight'].shape)}, the flags describe ({o}, {i})")
+            self.lin[key] = Linear(sd[key + '.weight'], sd[key + '.bias'], device)
+        self.macs = sum(i * o for _, i, o in nerf_plan(D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs))
+
+    def forward(self, cat, views, work, raw):
+        """cat [m, input_ch + W]: the embedded points in its first input_ch columns (kept: the skip layer reads the whole row);
+        views [m, W + input_ch_views]: the embedded directions in its LAST input_ch_views columns; work: two [m, W] buffers;
+        raw [m, 4 | output_ch] receives [rgb, alpha] (:396-399)."""
+        ic, W = self.input_ch, self.W
+        x = cat[:, :ic]
+        pp = 0
+        for i in range(self.D):
+            into_cat = i in self.skips           # h = cat([input_pts, h]): this layer's output lands behind the points
+            y = cat[:, ic:] if into_cat else work[pp]
+            if not into_cat:
+                pp ^= 1
+            self.lin[f'pts_linears.{i}'](x, y, act='relu')
+            x = cat if into_cat else y
+        if x is cat and x.shape[1] != W:
+            raise R2LError('the last pts_linears layer is a skip layer: alpha_linear / feature_linear take W inputs (the reference fails too)')
+        if not self.use_viewdirs:
+            self.lin['output_linear'](x, raw)
+            return raw
+        self.lin['alpha_linear'](x, raw[:, 3:4])
+        self.lin['feature_linear'](x, views[:, :W])
+        h = work[pp][:, :W // 2]
+        if h.data_ptr() == x.data_ptr():
+            h = work[pp ^ 1][:, :W // 2]
+        self.lin['views_linears.0'](views, h, act='relu')
+        self.lin['rgb_linear'](h, raw[:, :3])
+        return raw
+
+
+class GenericNeRF:
+    """render / render_rays of main.py:107-186, 624-756 at test time (perturb = 0, raw_noise_std = 0) for ANY pair of networks
+    create_nerf builds (main.py:407-453): the scan stages are the library's stand-alone kernels (nerf_raw2outputs,
+    nerf_sample_pdf, nerf_merge_sorted: the ones NeRFEngine fuses behind its 8 x 256 MLP kernel), the networks are generic
+    layer launches.  Returns what NeRFEngine returns."""
+
+    precision_name = 'fp32'
+
+    def __init__(self, H, W, focal, near=2., far=6., N_samples=64, N_importance=128, multires=10, multires_views=4, i_embed=0,
+                 netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, use_viewdirs=True, white_bkgd=False, lindisp=False,
+                 ndc=False, chunk=1 << 13, device=None):
+        if not torch.cuda.is_available():
+            raise R2LError('no HIP device visible to torch: the teacher path has no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.H, self.W, self.focal, self.near, self.far = int(H), int(W), float(focal), float(near), float(far)
+        self.N_samples, self.N_importance = int(N_samples), int(N_importance)
+        self.multires, self.multires_views, self.i_embed = int(multires), int(multires_views), int(i_embed)
+        if self.i_embed not in (0, -1):
+            raise R2LError(f'i_embed={i_embed}: 0 (positional encoding) or -1 (none), utils/run_nerf_raybased_helpers.py:59-74')
+        self.use_viewdirs, self.white_bkgd, self.lindisp, self.ndc = bool(use_viewdirs), bool(white_bkgd), bool(lindisp), bool(ndc)
+        self.shape = ((int(netdepth), int(netwidth)), (int(netdepth_fine), int(netwidth_fine)))
+        self.input_ch = 3 if self.i_embed == -1 else 3 * (2 * self.multires + 1)
+        self.input_ch_views = 0 if not self.use_viewdirs else (3 if self.i_embed == -1 else 3 * (2 * self.multires_views + 1))
+        self.output_ch = 5 if self.N_importance > 0 else 4          # main.py:426
+        self.chunk = int(chunk)
+        # main.py:673-682 on the host as the reference's first ray computes it (near, far are the same for every ray)
+        t = torch.linspace(0., 1., steps=self.N_samples)
+        nr, fr = torch.tensor([self.near]), torch.tensor([self.far])
+        z = nr * (1. - t) + fr * t if not self.lindisp else 1. / (1. / nr * (1. - t) + 1. / fr * t)
+        self.z_coarse = z.to(torch.float32).contiguous()
+        self._z_dev = self.z_coarse.to(self.device)
+        self.nets = None
+
+    @property
+    def flops_per_ray(self):
+        m0, m1 = self.nets[0].macs, self.nets[1].macs if self.nets[1] is not None else 0
+        return 2 * (m0 * self.N_samples + m1 * (self.N_samples + self.N_importance if self.N_importance > 0 else 0))
+
+    def load_state_dicts(self, network_fn_state_dict, network_fine_state_dict=None):
+        with torch.cuda.device(self.device):
+            mk = lambda sd, dw: _NeRFNet(sd, dw[0], dw[1], self.input_ch, self.input_ch_views, self.output_ch, (4,), self.use_viewdirs, self.device)
+            coarse = mk(network_fn_state_dict, self.shape[0])
+            fine = None
+            if self.N_importance > 0:
+                if network_fine_state_dict is None:
+                    raise R2LError('N_importance > 0 needs network_fine_state_dict (main.py:436-445)')
+                fine = mk(network_fine_state_dict, self.shape[1])
+            self.nets = (coarse, fine)
+        return self
+
+    def _embed(self, x, L, out):
+        """get_embedder(L, i_embed) of x [m, 3] into the view `out` [m, 3 (2 L + 1)] (or [m, 3] for i_embed = -1)"""
+        if self.i_embed == -1:
+            out.copy_(x)
+            return
+        op, ldo = _view(out)
+        check(lib().nerf_embed(dptr(x), 3, x.shape[0], 3, L, op, ldo, current_stream()))
+
+    def run_network(self, which, rays_o, rays_d, z_vals, viewdirs=None):
+        """network_query_fn(pts, viewdirs, network) of main.py:447-453 with pts = rays_o + rays_d * z_vals: raw [n, S, 4]
+        (or output_ch without view directions)."""
+        net = self.nets[which]
+        if net is None:
+            raise R2LError('no fine network (N_importance = 0)')
+        n = rays_o.shape[0]
+        shared = z_vals.dim() == 1
+        S = z_vals.shape[-1]
+        m = n * S
+        dev = self.device
+        W = net.W
+        pts = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        cat = torch.empty((m, self.input_ch + W), dtype=torch.float32, device=dev)
+        views = torch.empty((m, W + self.input_ch_views), dtype=torch.float32, device=dev) if self.use_viewdirs else None
+        work = [torch.empty((m, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        raw = torch.empty((m, 4 if self.use_viewdirs else self.output_ch), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().r2l_sample_points(dptr(rays_o), dptr(rays_d), n, dptr(z_vals.contiguous()), S, 0 if shared else 1, dptr(pts),
+                                          current_stream()))
+            self._embed(pts, self.multires, cat[:, :self.input_ch])
+            if self.use_viewdirs:
+                if viewdirs is None:
+                    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)            # main.py:148-157
+                dirs = viewdirs[:, None, :].expand(n, S, 3).reshape(m, 3).contiguous()       # main.py:76-77
+                self._embed(dirs, self.multires_views, views[:, W:])
+            net.forward(cat, views, work, raw)
+        return raw.view(n, S, -1)
+
+    def _raw4(self, raw):
+        return raw if raw.shape[-1] == 4 else raw[..., :4].contiguous()       # raw2outputs reads channels 0..3 (main.py:588-600)
+
+    def _render_rays_chunk(self, ro, rd, viewdirs):
+        from .teacher import merge_sorted, raw2outputs, sample_pdf
+        n = ro.shape[0]
+        z = self._z_dev
+        raw0 = self.run_network(0, ro, rd, z, viewdirs)
+        rgb, disp, acc, weights, depth = raw2outputs(self._raw4(raw0), z.expand(n, self.N_samples), rd, white_bkgd=self.white_bkgd)
+        ret = {}
+        if self.N_importance > 0:
+            ret.update(rgb0=rgb, disp0=disp, acc0=acc)
+            z_mid = .5 * (z[1:] + z[:-1])
+            z_samples = sample_pdf(z_mid.expand(n, self.N_samples - 1), weights[:, 1:-1], self.N_importance, det=True)
+            z_all = merge_sorted(z.expand(n, self.N_samples), z_samples)
+            raw = self.run_network(1, ro, rd, z_all, viewdirs)
+            rgb, disp, acc, weights, depth = raw2outputs(self._raw4(raw), z_all, rd, white_bkgd=self.white_bkgd)
+            ret.update(z_samples=z_samples, z_vals=z_all, z_std=torch.std(z_samples, dim=-1, unbiased=False), raw=raw)
+        else:
+            ret.update(raw=raw0)
+        ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth)
+        return ret
+
+    def render_rays(self, rays_o, rays_d, extras=False, perturb=0., raw_noise_std=0., pytest=False):
+        if perturb > 0. or raw_noise_std > 0.:
+            raise R2LError('the generic teacher path renders the test-time configuration (perturb = 0, raw_noise_std = 0); the jittered '
+                           'paths exist in NeRFEngine (8 x 256)')
+        ro = torch.as_tensor(rays_o).to(self.device, torch.float32).reshape(-1, 3).contiguous()
+        rd = torch.as_tensor(rays_d).to(self.device, torch.float32).reshape(-1, 3).contiguous()
+        vd = None
+        if self.use_viewdirs:
+            vd = rd / torch.norm(rd, dim=-1, keepdim=True)                   # main.py:148-157, before the NDC projection
+        if self.ndc:                                                         # main.py:160-162
+            from .teacher import ndc_rays
+            ro, rd = ndc_rays(self.H, self.W, self.focal, 1., ro, rd)
+        outs = [self._render_rays_chunk(ro[s:s + self.chunk], rd[s:s + self.chunk], None if vd is None else vd[s:s + self.chunk])
+                for s in range(0, ro.shape[0], self.chunk)]
+        keep = ('rgb_map', 'disp_map', 'acc_map', 'depth_map') + (tuple(k for k in outs[0] if k not in ('rgb_map', 'disp_map', 'acc_map', 'depth_map'))
+                                                                   if extras else ())
+        return {k: (outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], 0)) for k in keep}
+
+    def render(self, c2w, rows=None, extras=False):
+        from .teacher import get_rays
+        ro, rd = get_rays(self.H, self.W, self.focal, c2w, rows=None if rows is None else (int(rows[0]), int(rows[1])), device=self.device)
+        return self.render_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), extras=extras)

@@ -497,6 +497,8 @@ class LazyEmbedding:
     def materialize(self):
         if self.pts.rays is not None:
             raise R2LError('embedding of a given-rays bundle is only consumed by the fused kernel')
+        if self.L != 10:
+            raise R2LError(f'multires={self.L}: the stand-alone sampler + embedder kernel is built for 10 (PositionalEmbedder on a tensor takes any L)')
         return self.pts.sampler._geometry_engine().sample_embed(self.pts.c2w, want_pts=False)[1]
 
     tensor = property(materialize)
@@ -507,13 +509,16 @@ class PointSampler:
     sample_train(rays_o, rays_d, perturb=0) return lazy handles (see module docstring)."""
 
     def __init__(self, H, W, focal, n_sample, near, far):
-        if n_sample != 16:
-            raise R2LError(f'n_sample_per_ray={n_sample}: the HIP path is built for 16')
+        if int(n_sample) < 1:
+            raise R2LError(f'n_sample_per_ray={n_sample}')
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.n_sample, self.near, self.far = int(n_sample), float(near), float(far)
         self._geo = None
 
     def _geometry_engine(self):
+        if self.n_sample != 16:
+            raise R2LError(f'n_sample_per_ray={self.n_sample}: the stand-alone sampler kernel is built for 16; the model consumes the handle '
+                           f'on the generic path (generic.GenericR2L)')
         if self._geo is None:  # weight-less ctx: enough for the stand-alone K1+K2 kernels
             self._geo = R2LEngine(self.H, self.W, self.focal, self.near, self.far, n_block=0)
         return self._geo
@@ -539,9 +544,7 @@ class PositionalEmbedder:
 
     def __call__(self, x):
         if isinstance(x, LazyPoints):
-            if self.L != 10:
-                raise R2LError(f'multires={self.L}: the fused HIP path is built for 10')
-            return LazyEmbedding(x, self.L)
+            return LazyEmbedding(x, self.L)        # L != 10 / n_sample != 16: consumed by the model on the generic path
         # plain tensor [n, dim] on the device: stand-alone HIP embedder
         x = x.contiguous()
         out = torch.empty((x.shape[0], x.shape[1] * self.embed_dim), dtype=torch.float32, device=x.device)
@@ -559,15 +562,18 @@ class NeRF_v3_2:
     def __init__(self, args, input_dim, output_dim, precision=PREC_FP16X3):
         D, W = int(args.netdepth), int(args.netwidth)
         trial = getattr(args, 'trial', None)
-        if W != 256 or input_dim != 1008 or output_dim != 3:
-            raise R2LError(f'unsupported R2L shape W={W} input_dim={input_dim} output_dim={output_dim}')
-        self.body_arch = 'resmlp' if trial is None else getattr(trial, 'body_arch', 'resmlp')
-        if self.body_arch not in ('resmlp', 'mlp') or (self.body_arch == 'mlp' and (D - 2) % 2):
-            raise R2LError('--trial.body_arch resmlp, or mlp with an even number of body layers (netdepth - 2)')
-        if getattr(args, 'layerwise_netwidths', '') or getattr(args, 'linear_tail', False):
-            raise R2LError('layerwise_netwidths / linear_tail variants are not supported')
-        if int(getattr(trial, 'n_learnable', 2)) != 2:
-            raise R2LError('only trial.n_learnable=2 (two Linear layers per ResMLP block)')
+        if output_dim != 3:
+            raise R2LError(f'unsupported R2L output_dim={output_dim}')
+        if getattr(args, 'linear_tail', False):
+            raise R2LError('linear_tail: the reference builds Linear(input_dim, 3) on the body output and cannot run it either')
+        self.body_arch = 'mlp' if trial is None else getattr(trial, 'body_arch', 'resmlp')
+        if self.body_arch not in ('resmlp', 'mlp'):
+            raise R2LError('--trial.body_arch resmlp or mlp')
+        # shapes the fused kernels are not built for run on the generic fp32 layer path (generic.GenericR2L), fed by the same handles
+        self._generic = (W != 256 or input_dim != 1008 or bool(getattr(args, 'layerwise_netwidths', ''))
+                         or (self.body_arch == 'resmlp' and int(getattr(trial, 'n_learnable', 2)) != 2)
+                         or (self.body_arch == 'mlp' and ((D - 2) % 2 or D < 4)))
+        self._args = args
         self.res_scale = float(getattr(trial, 'res_scale', 1.))
         self.acts = (getattr(args, 'act', 'relu'), getattr(trial, 'inact', 'relu'), getattr(trial, 'outact', 'none'))
         n_block = int(getattr(trial, 'n_block', -1))
@@ -596,6 +602,19 @@ class NeRF_v3_2:
         if eng is None:
             if self._state is None:
                 raise R2LError('NeRF_v3_2 called before load_state_dict')
+            if self._generic:
+                from .generic import GenericR2L
+                a, per = self._args, 3 * sampler.n_sample
+                if self.input_dim % per or (self.input_dim // per) % 2 == 0:
+                    raise R2LError(f'input_dim={self.input_dim} is not 3 x n_sample x (2 L + 1) for n_sample={sampler.n_sample}')
+                t = getattr(a, 'trial', None)
+                eng = GenericR2L(sampler.H, sampler.W, sampler.focal, sampler.near, sampler.far, n_sample=sampler.n_sample,
+                                 L=(self.input_dim // per - 1) // 2, netdepth=a.netdepth, netwidth=a.netwidth,
+                                 layerwise_netwidths=getattr(a, 'layerwise_netwidths', ''), act=getattr(a, 'act', 'relu'),
+                                 use_residual=self.use_residual, trial=None if t is None else vars(t) if hasattr(t, '__dict__') else dict(t))
+                eng.load_state_dict(self._state)
+                self._engines[key] = eng
+                return eng
             eng = R2LEngine(sampler.H, sampler.W, sampler.focal, sampler.near, sampler.far,
                             n_block=self.n_block, use_residual=self.use_residual, precision=self.precision,
                             res_scale=self.res_scale, act=self.acts[0], inact=self.acts[1], outact=self.acts[2],
@@ -610,6 +629,8 @@ class NeRF_v3_2:
                            'handles; pre-materialised [N,1008] inputs have no kernel (the embedding never '
                            'touches HBM in the fused path)')
         pts = x.pts
+        if x.shape[1] != self.input_dim:
+            raise R2LError(f'embedded input has {x.shape[1]} features, the network takes {self.input_dim}')
         eng = self.engine_for(pts.sampler)
         if pts.rays is not None:
             return eng.render_rays(pts.rays[0].contiguous(), pts.rays[1].contiguous())

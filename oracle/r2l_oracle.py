@@ -559,6 +559,93 @@ def teacher_render(sd_coarse, sd_fine, H, W, focal, c2w, rows=None, chunk=4096, 
 
 # --------------------------------------------------------------------------------------
 # metrics (utils/run_nerf_raybased_helpers.py:19-20)
+
+# -- any NeRF the reference's constructor builds (netdepth / netwidth / multires / use_viewdirs / N_importance variants) -----
+def make_nerf_state(seed, D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=(4,), use_viewdirs=True,
+                    sigma_bias_shift=0.5):
+    """state_dict of NeRF(D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs) with nn.Linear default init in the
+    module creation order of model/nerf_raybased.py:357-375: pts_linears, views_linears (always built), then feature / alpha /
+    rgb under use_viewdirs, output_linear otherwise.  The density bias is shifted so the scan paths see non-trivial weights."""
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    sd = OrderedDict()
+
+    def put(key, lin):
+        sd[key + '.weight'], sd[key + '.bias'] = lin.weight.detach().clone(), lin.bias.detach().clone()
+
+    lins = [nn.Linear(input_ch, W)] + [nn.Linear(W, W) if i not in skips else nn.Linear(W + input_ch, W) for i in range(D - 1)]
+    views = nn.Linear(input_ch_views + W, W // 2)
+    for i, l in enumerate(lins):
+        put(f'pts_linears.{i}', l)
+    put('views_linears.0', views)
+    if use_viewdirs:
+        feature, alpha, rgb = nn.Linear(W, W), nn.Linear(W, 1), nn.Linear(W // 2, 3)
+        put('feature_linear', feature), put('alpha_linear', alpha), put('rgb_linear', rgb)
+        sd['alpha_linear.bias'] = sd['alpha_linear.bias'] + sigma_bias_shift
+    else:
+        put('output_linear', nn.Linear(W, output_ch))
+        sd['output_linear.bias'][3] += sigma_bias_shift
+    torch.random.set_rng_state(g)
+    return sd
+
+
+def nerf_forward(sd, x, input_ch=63, skips=(4,), use_viewdirs=True):
+    """NeRF.forward (model/nerf_raybased.py:377-401) for any depth: the pts_linears are counted from the state_dict"""
+    input_pts, input_views = x[..., :input_ch], x[..., input_ch:]
+    h = input_pts
+    i = 0
+    while f'pts_linears.{i}.weight' in sd:
+        h = F.relu(F.linear(h, sd[f'pts_linears.{i}.weight'], sd[f'pts_linears.{i}.bias']))
+        if i in skips:
+            h = torch.cat([input_pts, h], -1)
+        i += 1
+    if not use_viewdirs:
+        return F.linear(h, sd['output_linear.weight'], sd['output_linear.bias'])
+    alpha = F.linear(h, sd['alpha_linear.weight'], sd['alpha_linear.bias'])
+    feature = F.linear(h, sd['feature_linear.weight'], sd['feature_linear.bias'])
+    h = torch.cat([feature, input_views], -1)
+    h = F.relu(F.linear(h, sd['views_linears.0.weight'], sd['views_linears.0.bias']))
+    return torch.cat([F.linear(h, sd['rgb_linear.weight'], sd['rgb_linear.bias']), alpha], -1)
+
+
+def run_network_generic(sd, pts, viewdirs, multires=10, multires_views=4, i_embed=0, use_viewdirs=True, skips=(4,)):
+    """main.py:65-87 with get_embedder(multires, i_embed) (helpers:59-74: i_embed = -1 is the identity)"""
+    flat = pts.reshape(-1, 3)
+    emb = flat if i_embed == -1 else nerf_embed(flat, multires)
+    input_ch = emb.shape[-1]
+    if use_viewdirs:
+        dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)
+        emb = torch.cat([emb, dirs if i_embed == -1 else nerf_embed(dirs, multires_views)], -1)
+    out = nerf_forward(sd, emb, input_ch, skips, use_viewdirs)
+    return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
+
+
+def render_rays_generic(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=64, N_importance=128, white_bkgd=True,
+                        lindisp=False, viewdirs=None, **net):
+    """main.py:624-756 at test time (perturb = 0, raw_noise_std = 0) for any network create_nerf builds (main.py:407-453):
+    N_importance = 0 ends behind the coarse pass; network_fine = None runs the coarse network twice (:737)."""
+    use_viewdirs = net.get('use_viewdirs', True)
+    if viewdirs is None and use_viewdirs:
+        viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    t_vals = torch.linspace(0., 1., steps=N_samples)
+    z_vals = near_t * (1. - t_vals) + far_t * (t_vals) if not lindisp else 1. / (1. / near_t * (1. - t_vals) + 1. / far_t * (t_vals))
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw = run_network_generic(sd_coarse, pts, viewdirs, **net)
+    rgb, disp, acc, weights, depth = raw2outputs(raw, z_vals, rays_d, white_bkgd)
+    ret = dict(raw0=raw)
+    if N_importance > 0:
+        ret.update(rgb0=rgb, disp0=disp, acc0=acc)
+        z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=True)
+        z_vals = merge_z(z_vals, z_samples)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        raw = run_network_generic(sd_coarse if sd_fine is None else sd_fine, pts, viewdirs, **net)
+        rgb, disp, acc, weights, depth = raw2outputs(raw, z_vals, rays_d, white_bkgd)
+        ret.update(z_samples=z_samples, z_std=torch.std(z_samples, dim=-1, unbiased=False))
+    ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, raw=raw, z_vals=z_vals)
+    return ret
+
 # --------------------------------------------------------------------------------------
 def mse2psnr(mse):
     return -10. * math.log10(max(float(mse), 1e-30))

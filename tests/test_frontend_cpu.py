@@ -162,12 +162,16 @@ def test_build_engine_refuses_flags_the_kernels_do_not_honour(fe):
     from efficient_nerf_amd import R2LError
     base = ['--model_name', 'R2L', '--dataset_type', 'blender', '--netdepth', '88', '--n_sample_per_ray', '16', '--trial.ON',
             '--trial.body_arch', 'resmlp', '--use_residual']
+    # shapes outside the fused kernels render on the generic fp32 path (round 4) -- under `auto` / `fp32`; an explicit fused
+    # precision for such a network is refused, and so is what the reference itself cannot build
     for extra in (['--act', 'gelu'], ['--trial.inact', 'lrelu', '--precision', 'fp16_fp8'],
-                  ['--trial.outact', 'relu', '--precision', 'fp16x3_asm'], ['--trial.n_learnable', '3'], ['--linear_tail'], ['--dataset_type', 'llff']):
+                  ['--trial.outact', 'relu', '--precision', 'fp16x3_asm'], ['--trial.n_learnable', '3', '--precision', 'fp16_fp8'],
+                  ['--netwidth', '128', '--precision', 'fp16x3'], ['--layerwise_netwidths', '64,64', '--precision', 'fp16x3_asm'],
+                  ['--linear_tail'], ['--dataset_type', 'llff']):
         with pytest.raises(R2LError):
             fe.build_engine(fe.parse_args(base + extra), (8, 8, 10.), {})
     nerf = ['--model_name', 'nerf', '--dataset_type', 'blender', '--use_viewdirs', '--N_importance', '128']
-    for extra in (['--netdepth', '6'], ['--netwidth_fine', '128'], ['--i_embed', '-1'],
+    for extra in (['--netdepth', '6', '--precision', 'fp16_fp8'], ['--netwidth_fine', '128', '--precision', 'fp16x3'], ['--i_embed', '3'],
                   ['--dataset_type', 'llff', '--no_ndc']):   # no_ndc needs the scene bounds or --trial.near/far
         with pytest.raises(R2LError):
             fe.build_engine(fe.parse_args(nerf + extra), (8, 8, 10.), {})

@@ -354,3 +354,47 @@ def test_cli_plain_mlp_body(pkg, tmp_path):
     pts = O.sample_test(O.camera_dirs(H, H, O.focal_from_angle(48) / 2.), O.sampler_z_vals(16, 2., 6.), O.novel_poses(1)[0][:3, :4])
     ref = O.r2l_forward_mlp(sd, O.positional_embed(pts, 10)).view(H, H, 3).numpy()
     assert np.abs(np.load(os.path.join(out, 'rgbs.npy'))[0] - ref).max() <= 1e-4
+
+
+def test_cli_renders_shapes_outside_the_fused_kernels(pkg, tmp_path):
+    """The reference's command line with networks the fused kernels are not built for (another width / sample count / number of
+    frequencies, three Linear layers per block; a 4 x 128 teacher with a 6 x 96 fine network): `--precision auto` says it takes the
+    generic fp32 layer path and the frames are within the contract of the CPU oracle; an explicit fused precision is refused."""
+    from efficient_nerf_amd import frontend as fe
+    H = 24
+    focal = O.focal_from_angle(48) / 2.
+    trial = dict(body_arch='resmlp', n_block=3, n_learnable=3, res_scale=0.5, inact='lrelu', outact='none')
+    sd = O.make_v3_2_state(11, 12, 96, 3 * 8 * 13, '', 'relu', trial)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    out = str(tmp_path / 'out')
+    flags = ['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '8', '--multires', '6', '--netwidth', '96',
+             '--netdepth', '12', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--trial.n_block', '3', '--trial.n_learnable', '3',
+             '--trial.res_scale', '0.5', '--trial.inact', 'lrelu', '--pretrained_ckpt', ck, '--render_only', '--render_test', '--testskip', '1',
+             '--synthetic_poses', '2', '--H', '48', '--outdir', out]
+    log = run_main(flags)
+    assert 'generic fp32 layer path' in log, log[-1500:]
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    assert rgbs.shape == (2, H, H, 3)
+    for i, c2w in enumerate(O.novel_poses(2)):
+        pts = O.sample_test(O.camera_dirs(H, H, focal), O.sampler_z_vals(8, 2., 6.), c2w[:3, :4])
+        ref = O.v3_2_forward(sd, O.positional_embed(pts, 6), 12, 'relu', True, trial).view(H, H, 3).numpy()
+        assert np.abs(rgbs[i] - ref).max() <= 1e-4
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py')] + flags + ['--precision', 'fp16_fp8'], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0 and 'generic path' in (r.stdout + r.stderr)
+    # the teacher
+    t0 = O.make_nerf_state(21, 4, 128, 63, 27, 5, (4,), True)
+    t1 = O.make_nerf_state(22, 6, 96, 63, 27, 5, (4,), True)
+    ck = str(tmp_path / 'nerf.tar')
+    fe.save_checkpoint(ck, t0, t1)
+    out = str(tmp_path / 'out_nerf')
+    log = run_main(['--model_name', 'nerf', '--config', 'configs/lego.txt', '--netdepth', '4', '--netwidth', '128', '--netdepth_fine', '6',
+                    '--netwidth_fine', '96', '--pretrained_ckpt', ck, '--render_only', '--render_test', '--testskip', '1', '--synthetic_poses', '1',
+                    '--H', '16', '--outdir', out])
+    assert 'generic fp32 layer path' in log, log[-1500:]
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    assert rgbs.shape == (1, 8, 8, 3)
+    ro, rd = O.get_rays(8, 8, O.focal_from_angle(16) / 2., O.novel_poses(1)[0][:3, :4])
+    ref = O.render_rays_generic(t0, t1, ro.reshape(-1, 3).float(), rd.reshape(-1, 3).float(), 2., 6., 64, 128, True)
+    assert np.abs(rgbs[0].reshape(-1, 3) - ref['rgb_map'].numpy()).max() <= 1e-4
