@@ -451,10 +451,14 @@ def main(argv=None):
     torch.cuda.set_device(D.local_device(local_rank))
     ckpt = fe.load_checkpoint(own.teacher_ckpt)
     _, (H, W, focal) = fe.load_test_poses(args)
-    prec = PRECISIONS['fp16_fp8' if args.precision == 'auto' else args.precision]
-    eng = NeRFEngine(H, W, focal, 2., 6., N_samples=args.N_samples, N_importance=args.N_importance,
-                     white_bkgd=args.white_bkgd, precision=prec)
-    eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
+    if fe.teacher_needs_generic(args):     # a teacher the fused kernels are not built for: the generic fp32 layer path renders it
+        args.model_name, args.dataset_type = 'nerf', 'blender'
+        _, eng = fe.build_engine(args, (H, W, focal), ckpt, log=print if rank == 0 else None)
+    else:
+        prec = PRECISIONS['fp16_fp8' if args.precision == 'auto' else args.precision]
+        eng = NeRFEngine(H, W, focal, 2., 6., N_samples=args.N_samples, N_importance=args.N_importance,
+                         white_bkgd=args.white_bkgd, precision=prec)
+        eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
     tm = {}
     n = create_rand(eng, H, W, focal, own.n_pose_kd, own.datadir_kd.split(':')[1], not own.no_rand_focal,
                     i_save=own.create_data_chunk, split_size=own.split_size, rm_existing_data=own.rm_existing_data,

@@ -295,6 +295,13 @@ def mse2psnr(mse):
 # ----------------------------------------------------------------------------------------
 # render_path
 # ----------------------------------------------------------------------------------------
+def teacher_needs_generic(args):
+    """True when the teacher the flags describe is not the one the fused kernels are built for (8 x 256, view directions,
+    L = 10 / 4, a fine pass: configs/*.txt) or fp32 was asked for: it then renders on generic.GenericNeRF"""
+    return (not args.use_viewdirs or args.N_importance <= 0 or args.i_embed != 0 or (args.multires, args.multires_views) != (10, 4)
+            or (args.netdepth, args.netwidth, args.netdepth_fine, args.netwidth_fine) != (8, 256, 8, 256) or args.precision == 'fp32')
+
+
 def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     """Engine for the flags of the reference command line.  Every flag that changes what the reference network
     computes is either honoured or refused: a checkpoint trained with another activation / res_scale / depth must
@@ -379,9 +386,7 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     if args.model_name == 'nerf':
         # the fused teacher kernels are the 8 x 256 NeRF with view directions, L = 10 / 4 and a fine pass (configs/*.txt); every other
         # network create_nerf builds (main.py:407-453) renders on the generic fp32 layer path (generic.GenericNeRF)
-        generic = (not args.use_viewdirs or args.N_importance <= 0 or args.i_embed != 0 or (args.multires, args.multires_views) != (10, 4)
-                   or (args.netdepth, args.netwidth, args.netdepth_fine, args.netwidth_fine) != (8, 256, 8, 256) or args.precision == 'fp32')
-        if generic:
+        if teacher_needs_generic(args):
             if args.precision not in ('auto', 'fp32'):
                 raise R2LError(f'--precision {args.precision} is a mode of the fused 8 x 256 teacher kernels; netdepth/netwidth(_fine) = '
                                f'{args.netdepth}/{args.netwidth}/{args.netdepth_fine}/{args.netwidth_fine}, i_embed={args.i_embed}, multires='

@@ -12,13 +12,13 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def oracle_create_rand(sd0, sd1, H, W, focal, n_pose, i_save, split_size, stream):
+def oracle_create_rand(sd0, sd1, H, W, focal, n_pose, i_save, split_size, stream, render_rays=O.render_rays):
     shards, data = [], []
     for i in range(1, n_pose + 1):
         pose = stream.rand_pose()
         focal_ = focal * stream.rand_focal_scale()
         ro, rd = O.get_rays(H, W, focal_, pose[:3, :4])
-        out = O.render_rays(sd0, sd1, ro.reshape(-1, 3).float(), rd.reshape(-1, 3).float(), white_bkgd=True)
+        out = render_rays(sd0, sd1, ro.reshape(-1, 3).float(), rd.reshape(-1, 3).float(), white_bkgd=True)
         data.append(torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), out['rgb_map']], -1))
         if i % i_save == 0:
             d = torch.cat(data, 0)
@@ -136,3 +136,31 @@ def test_create_data_command_line(pkg, tmp_path):
         assert np.abs(got[:, 6:] - w[:, 6:]).max() <= 1e-4
     ds = BlenderDataset_v2(out, pseudo_ratio=-1)
     assert len(ds) == 4 and all(t.shape == (100, 3) for t in ds[0])
+
+
+def test_create_data_with_a_teacher_outside_the_fused_kernels(pkg, tmp_path):
+    """the same command line with a 4 x 64 teacher and a 6 x 96 fine network (--netdepth / --netwidth(_fine)): the generic fp32
+    layer path renders the poses, the writer and the numpy stream are the same"""
+    import subprocess
+    import sys
+    from efficient_nerf_amd import frontend as fe
+    from efficient_nerf_amd.create_data import RandStream
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sd0, sd1 = O.make_nerf_state(5, 4, 64), O.make_nerf_state(6, 6, 96)
+    ck = str(tmp_path / 'nerf.tar')
+    fe.save_checkpoint(ck, sd0, sd1)
+    out = str(tmp_path / 'pseudo')
+    r = subprocess.run([sys.executable, os.path.join(root, 'create_data.py'), '--create_data', 'rand', '--config', 'configs/lego.txt',
+                        '--netdepth', '4', '--netwidth', '64', '--netdepth_fine', '6', '--netwidth_fine', '96',
+                        '--teacher_ckpt', ck, '--n_pose_kd', '4', '--datadir_kd', f'unused:{out}', '--create_data_chunk', '2',
+                        '--split_size', '64', '--H', '20', '--synthetic_poses', '1'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert 'generic fp32 layer path' in r.stdout and 'wrote 6 shard(s) of 64 rays; 4 poses in' in r.stdout, r.stdout[-800:]
+    H = 10
+    want = oracle_create_rand(sd0, sd1, H, H, O.focal_from_angle(20) / 2., 4, 2, 64, RandStream(),
+                              render_rays=lambda a, b, ro, rd, white_bkgd: O.render_rays_generic(a, b, ro, rd, white_bkgd=white_bkgd))
+    assert len(want) == 6
+    for k, w in enumerate(want, 1):
+        got = np.load(os.path.join(out, f'data_{k}.npy'))
+        np.testing.assert_array_equal(got[:, :6], w[:, :6])
+        assert np.abs(got[:, 6:] - w[:, 6:]).max() <= 1e-4
