@@ -11,7 +11,8 @@
 // Arithmetic: fp32 products, fp32 accumulate on the fp32 MFMA (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU, 1/16 of the fp16
 // rate) -- the reference's own precision, nothing to calibrate; the only difference from F.linear is the summation order
 // (~2e-7 measured on ten network variants).  This is the path for the long tail of shapes, not the headline: the README's W256D88
-// runs at 3.7e6 rays/s here (44 TFLOP/s, 0.28 of the fp32 MFMA peak), 1/17 of the fused fp16_fp8 kernels (profiles/r04_generic_time.txt).
+// runs at 5.5e6 rays/s here (65 TFLOP/s, 0.41 of the fp32 MFMA peak; a 128 x 128 tile measures the same), 1/11 of the fused fp16_fp8
+// kernels (profiles/r04_generic_time.txt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -56,22 +57,39 @@ __global__ __launch_bounds__(256) void r2l_linear_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
     const int lc = tid & 31, lr = tid >> 5;      // loader: 8 rows of 32 consecutive k per pass
-    for (int k0 = 0; k0 < in_dim; k0 += GT_K) {
+    // a stage's 24 loads per thread are issued together into registers (out-of-range elements read a valid address and are
+    // zeroed: no branch between the loads), written to LDS behind the barrier, and the NEXT stage's loads are in flight while
+    // this stage's MFMAs run
+    // (the zeroing happens when the registers are written to LDS, so nothing waits for a load before the MFMAs)
+    float xv[GT_M / 8], wv[GT_N / 8];
+    unsigned okx = 0, okw = 0;
+    auto load_stage = [&](int k0) {
         const int k = k0 + lc;
         const bool kin = k < in_dim;
+        okx = okw = 0;
 #pragma unroll
         for (int i = 0; i < GT_M / 8; ++i) {
-            const int row = lr + 8 * i;
-            const long long ray = ray0 + row;
-            xs[row][lc] = (kin && ray < n) ? x[ray * ldx + k] : 0.0f;
+            const long long ray = ray0 + lr + 8 * i;
+            const bool ok = kin && ray < n;
+            xv[i] = x[ok ? ray * ldx + k : 0];
+            okx |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < GT_N / 8; ++i) {
-            const int row = lr + 8 * i;
-            const int o = out0 + row;
-            ws[row][lc] = (kin && o < out_dim) ? w[(long long)o * in_dim + k] : 0.0f;
+            const int o = out0 + lr + 8 * i;
+            const bool ok = kin && o < out_dim;
+            wv[i] = w[ok ? (long long)o * in_dim + k : 0];
+            okw |= (ok ? 1u : 0u) << i;
         }
+    };
+    load_stage(0);
+    for (int k0 = 0; k0 < in_dim; k0 += GT_K) {
+#pragma unroll
+        for (int i = 0; i < GT_M / 8; ++i) xs[lr + 8 * i][lc] = ((okx >> i) & 1) ? xv[i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < GT_N / 8; ++i) ws[lr + 8 * i][lc] = ((okw >> i) & 1) ? wv[i] : 0.0f;
         __syncthreads();
+        if (k0 + GT_K < in_dim) load_stage(k0 + GT_K);
 #pragma unroll
         for (int kk = 0; kk < GT_K; kk += 2) {
             const int kq = kk + (lane >> 5);
