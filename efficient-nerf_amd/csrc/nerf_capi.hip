@@ -198,6 +198,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
 struct nerf_ctx {
     int H, W, N_samples, N_importance, white_bkgd, mode, n_cu;
     int ndc = 0;            // render() projects the rays to NDC first (main.py:160-162)
+    bool split_scans = false;  // nerf_debug_set_split_scans: raw2outputs / sample_pdf / merge as three launches (A/B, parity tests)
     float ndc_near = 1.0f;
     double focal;
     float near_, far_, act_scale;
@@ -534,27 +535,40 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
     const int zc_stride = o.z_coarse ? S0 : 0;
     int rc = run_mlp(c, 0, rays_o, rays_d, zc, zc_stride, S0, n, c->d_raw0, s, vd);  // coarse network_fn
     if (rc) return rc;
-    HIPCHK(nerf_launch_raw2outputs(c->d_raw0, zc, zc_stride, rays_d, n, S0, c->white_bkgd, c->d_rgb0, c->d_disp0,
-                                   c->d_acc0, c->d_w0, nullptr, s, o.noise0), "raw2outputs(coarse)");
-    // sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0))   (main.py:722-728)
-    if (o.z_coarse)
-        HIPCHK(nerf_launch_sample_pdf(o.z_coarse, S0, 1, c->d_w0, S0, 1, n, S0 - 1, o.u ? o.u : c->d_u, o.u ? NI : 0, NI,
-                                      c->d_zs, nullptr, nullptr, s), "sample_pdf");
-    else
-        HIPCHK(nerf_launch_sample_pdf(c->d_zmid, 0, 0, c->d_w0, S0, 1, n, S0 - 1, o.u ? o.u : c->d_u, o.u ? NI : 0, NI,
-                                      c->d_zs, nullptr, nullptr, s), "sample_pdf");
-    // z_vals = sort(cat(z_vals, z_samples))                                 (main.py:730-732): both rows ascending ->
-    // rank merge; with random uniforms the samples are sorted first
-    const float* zs_sorted = c->d_zs;
-    if (o.u) {
-        HIPCHK(nerf_launch_sort_rows(c->d_zs, n, NI, c->d_zsort, s), "sort z_samples");
-        zs_sorted = c->d_zsort;
+    if (!o.u && !c->split_scans) {
+        // deterministic test path: raw2outputs(coarse) + sample_pdf + merge as ONE launch (nerf_coarse_scan_kernel: the weights,
+        // the cdf and the samples stay in LDS; bit-identical to the three launches below)
+        HIPCHK(nerf_launch_coarse_scan(c->d_raw0, zc, zc_stride, rays_d, n, S0, c->white_bkgd, o.noise0, c->d_u, NI, c->d_rgb0,
+                                       c->d_disp0, c->d_acc0, c->d_zs, c->d_zall, s), "coarse scan");
+    } else {
+        HIPCHK(nerf_launch_raw2outputs(c->d_raw0, zc, zc_stride, rays_d, n, S0, c->white_bkgd, c->d_rgb0, c->d_disp0,
+                                       c->d_acc0, c->d_w0, nullptr, s, o.noise0), "raw2outputs(coarse)");
+        // sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0))   (main.py:722-728)
+        if (o.z_coarse)
+            HIPCHK(nerf_launch_sample_pdf(o.z_coarse, S0, 1, c->d_w0, S0, 1, n, S0 - 1, o.u ? o.u : c->d_u, o.u ? NI : 0, NI,
+                                          c->d_zs, nullptr, nullptr, s), "sample_pdf");
+        else
+            HIPCHK(nerf_launch_sample_pdf(c->d_zmid, 0, 0, c->d_w0, S0, 1, n, S0 - 1, o.u ? o.u : c->d_u, o.u ? NI : 0, NI,
+                                          c->d_zs, nullptr, nullptr, s), "sample_pdf");
+        // z_vals = sort(cat(z_vals, z_samples))                                 (main.py:730-732): both rows ascending ->
+        // rank merge; with random uniforms the samples are sorted first
+        const float* zs_sorted = c->d_zs;
+        if (o.u) {
+            HIPCHK(nerf_launch_sort_rows(c->d_zs, n, NI, c->d_zsort, s), "sort z_samples");
+            zs_sorted = c->d_zsort;
+        }
+        HIPCHK(nerf_launch_merge(zc, zc_stride, S0, zs_sorted, NI, n, c->d_zall, s), "merge");
     }
-    HIPCHK(nerf_launch_merge(zc, zc_stride, S0, zs_sorted, NI, n, c->d_zall, s), "merge");
     rc = run_mlp(c, 1, rays_o, rays_d, c->d_zall, S1, S1, n, c->d_raw, s, vd);   // network_fine
     if (rc) return rc;
     HIPCHK(nerf_launch_raw2outputs(c->d_raw, c->d_zall, S1, rays_d, n, S1, c->white_bkgd, rgb, disp, acc, nullptr,
                                    depth, s, o.noise1), "raw2outputs(fine)");
+    return R2L_OK;
+}
+
+int nerf_debug_set_split_scans(nerf_ctx* c, int on) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    c->split_scans = on != 0;
     return R2L_OK;
 }
 

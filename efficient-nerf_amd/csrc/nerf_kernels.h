@@ -43,6 +43,12 @@ hipError_t nerf_launch_raw2outputs(const float* raw, const float* z, int z_strid
 hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, int bins_are_z, const float* weights, int w_stride,
                                   int w_off, int n, int n_bins, const float* u, int u_stride, int N, float* samples,
                                   float* cdf_out, int* inds_out, hipStream_t stream);
+// raw2outputs(coarse) + sample_pdf(z_mid, weights[..., 1:-1], N, det) + merge in one launch (main.py:705-732 with perturb = 0):
+// raw [n,S,4], z [n,S] (z_stride 0 = shared row), S <= 64; u null (= linspace) or one shared row [N]; writes the coarse maps
+// (any may be null), samples [n,N] and z_all [n, S + N]; bit-identical to the three stand-alone launches
+hipError_t nerf_launch_coarse_scan(const float* raw, const float* z, int z_stride, const float* rays_d, int n, int S, int white_bkgd,
+                                   const float* noise, const float* u, int N, float* rgb, float* disp, float* acc, float* samples,
+                                   float* z_all, hipStream_t stream);
 // out[i, :] = sort(x[i, :N]) ascending, N <= 256
 hipError_t nerf_launch_sort_rows(const float* x, int n, int N, float* out, hipStream_t stream);
 // out[i] = std(x[i, :N], unbiased=False)

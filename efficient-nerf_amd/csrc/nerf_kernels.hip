@@ -708,6 +708,147 @@ __global__ __launch_bounds__(256) void nerf_merge_kernel(const float* __restrict
 }
 
 // ====================================================================================
+// coarse pass -> fine depths in ONE launch (main.py:705-732 on the deterministic test path): raw2outputs of the coarse raw,
+// sample_pdf on weights[..., 1:-1] over the midpoints of z, and the merge of z with the samples -- one wave per ray, the weights,
+// the cdf and the samples never leave LDS (stand-alone: three launches, weights and samples through HBM twice).  The arithmetic
+// is the three kernels' above, statement for statement (same float / double orders: the results are bit-identical, asserted by
+// tests/test_teacher_gpu.py); S0 <= 64 coarse samples, N <= 256 fine ones, u one shared row (per-ray uniforms need the sort).
+// ====================================================================================
+__global__ __launch_bounds__(256) void nerf_coarse_scan_kernel(const float* __restrict__ raw, const float* __restrict__ z, int z_stride,
+                                                               const float* __restrict__ rays_d, int n, int S, int white_bkgd,
+                                                               const float* __restrict__ noise, const float* __restrict__ u_arr, int N,
+                                                               float* __restrict__ rgb_map, float* __restrict__ disp_map,
+                                                               float* __restrict__ acc_map, float* __restrict__ samples,
+                                                               float* __restrict__ z_all) {
+    __shared__ float s_z[4][64];
+    __shared__ float s_wt[4][64];
+    __shared__ float s_w[4][64];
+    __shared__ float s_cdf[4][64];
+    __shared__ float s_bins[4][64];
+    __shared__ float s_col[4][8];
+    __shared__ float s_s[4][256];
+    const int wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    const int lane = threadIdx.x & 63;
+    if (ray >= n) return;
+    // ---- raw2outputs, C = 1 (nerf_raw2outputs_kernel<1>)
+    const float* zr = z + (size_t)ray * z_stride;
+    const float dx = rays_d[(size_t)ray * 3 + 0], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(dx * dx, dy * dy), dz * dz));
+    const bool ok = lane < S;
+    const int ii = ok ? lane : S - 1;
+    const float zc = zr[ii];
+    const float zn = zr[ii + 1 < S ? ii + 1 : S - 1];
+    float dist = (ii < S - 1) ? (zn - zc) : 1e10f;
+    dist = dist * norm;
+    const f32x4 r4 = *reinterpret_cast<const f32x4*>(raw + ((size_t)ray * S + ii) * 4);
+    const float sig = fmaxf(noise ? r4[3] + noise[(size_t)ray * S + ii] : r4[3], 0.0f);
+    float a = 1.0f - expf(-sig * dist);
+    if (!ok) a = 0.0f;
+    const float cr = 1.0f / (1.0f + expf(-r4[0])), cg = 1.0f / (1.0f + expf(-r4[1])), cb = 1.0f / (1.0f + expf(-r4[2]));
+    const float pterm = ok ? ((1.0f - a) + 1e-10f) : 1.0f;
+    const double incl = wave_scan_mul((double)pterm, lane);
+    double excl = shfl_up_f64(incl, 1);
+    if (lane == 0) excl = 1.0;
+    const float T = (float)(excl * 1.0);
+    const float wgt = a * T;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    if (ok) {
+        sr = wgt * cr;
+        sg = wgt * cg;
+        sb = wgt * cb;
+        sd = wgt * zc;
+        sa = wgt;
+    }
+    s_wt[wv][lane] = ok ? wgt : 0.0f;
+    s_z[wv][lane] = zc;
+    sr = wave_sum(sr);
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    sd = wave_sum(sd);
+    sa = wave_sum(sa);
+    if (lane == 0) {
+        if (white_bkgd) {
+            const float bg = 1.0f - sa;
+            sr += bg;
+            sg += bg;
+            sb += bg;
+        }
+        if (rgb_map) {
+            rgb_map[(size_t)ray * 3 + 0] = sr;
+            rgb_map[(size_t)ray * 3 + 1] = sg;
+            rgb_map[(size_t)ray * 3 + 2] = sb;
+        }
+        if (acc_map) acc_map[ray] = sa;
+        if (disp_map) {
+            const float q = sd / sa;
+            const float m = (q != q) ? q : fmaxf(1e-10f, q);
+            disp_map[ray] = 1.0f / m;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- sample_pdf(z_mid, weights[..., 1:-1], N, det) (nerf_sample_pdf_kernel with bins_are_z, w_off = 1)
+    const int n_bins = S - 1, nw = n_bins - 1;
+    float w = 0.0f;
+    if (lane < nw) w = s_wt[wv][1 + lane] + 1e-5f;
+    s_w[wv][lane] = w;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float total = torch_cpu_row_sum(s_w[wv], s_col[wv], nw, lane);
+    const float pdf = (lane < nw) ? w / total : 0.0f;
+    const double cs = wave_scan_add((double)pdf, lane);
+    if (lane < nw) s_cdf[wv][lane + 1] = (float)cs;
+    if (lane == 63) s_cdf[wv][0] = 0.0f;
+    if (lane < n_bins) s_bins[wv][lane] = 0.5f * __fadd_rn(s_z[wv][lane + 1], s_z[wv][lane]);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float step = N > 1 ? 1.0f / (float)(N - 1) : 0.0f;
+    for (int k = lane; k < N; k += 64) {
+        float u;
+        if (u_arr) u = u_arr[k];
+        else u = (k < N / 2 || N == 1) ? __fmul_rn(step, (float)k) : __fsub_rn(1.0f, __fmul_rn(step, (float)(N - k - 1)));
+        int lo = 0, hi = n_bins;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cdf[wv][mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < n_bins - 1 ? lo : n_bins - 1;
+        const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
+        const float b0 = s_bins[wv][below], b1 = s_bins[wv][above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (u - c0) / denom;
+        const float smp = b0 + t * (b1 - b0);
+        s_s[wv][k] = smp;
+        samples[(size_t)ray * N + k] = smp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- sort(cat(z, samples)) of two ascending rows (nerf_merge_kernel)
+    float* o = z_all + (size_t)ray * (S + N);
+    if (lane < S) {
+        const float v = s_z[wv][lane];
+        int lo = 0, hi = N;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_s[wv][mid] < v) lo = mid + 1; else hi = mid;
+        }
+        o[lane + lo] = v;
+    }
+    for (int j = lane; j < N; j += 64) {
+        const float v = s_s[wv][j];
+        int lo = 0, hi = S;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_z[wv][mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        o[j + lo] = v;
+    }
+}
+
+// ====================================================================================
 // launchers
 // ====================================================================================
 template <typename K>
@@ -774,6 +915,15 @@ hipError_t nerf_launch_sample_pdf(const float* bins, int bins_stride, int bins_a
     if (n_bins < 2 || n_bins > 64 || N < 1) return hipErrorInvalidValue;  // the reference's sample_pdf itself fails on a single bin
     hipLaunchKernelGGL(nerf_sample_pdf_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, bins, bins_stride, bins_are_z,
                        weights, w_stride, w_off, n, n_bins, u, u_stride, N, samples, cdf_out, inds_out);
+    return hipGetLastError();
+}
+
+hipError_t nerf_launch_coarse_scan(const float* raw, const float* z, int z_stride, const float* rays_d, int n, int S, int white_bkgd,
+                                   const float* noise, const float* u, int N, float* rgb, float* disp, float* acc, float* samples,
+                                   float* z_all, hipStream_t stream) {
+    if (S < 3 || S > 64 || N < 1 || N > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nerf_coarse_scan_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, raw, z, z_stride, rays_d, n, S, white_bkgd,
+                       noise, u, N, rgb, disp, acc, samples, z_all);
     return hipGetLastError();
 }
 

@@ -298,6 +298,9 @@ int nerf_render_rays_ex(nerf_ctx* ctx, const float* rays_o_dev, const float* ray
 /* HIP-event timing of the teacher's MLP launches (nerf_chain_kernel / nerf_mlp_kernel: 99 % of a frame) on the stream they
  * are launched on, as r2l_timing_enable / r2l_kernel_time_ms: sum and count since the last reset (bench.py's create_data
  * and teacher legs). */
+/* parity tests / A-B timing: 1 = the coarse pass's raw2outputs, sample_pdf and merge as three launches instead of the one fused
+ * launch of the deterministic path (nerf_coarse_scan_kernel); the results are bit-identical */
+int nerf_debug_set_split_scans(nerf_ctx* ctx, int on);
 int nerf_timing_enable(nerf_ctx* ctx, int on);
 int nerf_kernel_time_ms(nerf_ctx* ctx, double* total_ms, int* n_launches, int reset);
 

@@ -270,3 +270,27 @@ def test_teacher_auto_precision_is_measured(pkg):
         ref = O.render_rays(sds[0], sds[1], ro.cpu(), rd.cpu(), white_bkgd=True)['rgb_map']
         assert (eng.render_rays(ro, rd)['rgb_map'].cpu() - ref).abs().max().item() <= 1e-4
         eng.close()
+
+
+@pytest.mark.parametrize('S0,NI,white', [(64, 128, True), (64, 64, False), (17, 33, True), (3, 5, False)])
+def test_fused_coarse_scan_equals_the_three_launches(pkg, S0, NI, white):
+    """The deterministic path runs raw2outputs(coarse) + sample_pdf + merge as ONE launch (nerf_coarse_scan_kernel); with
+    nerf_debug_set_split_scans the same context runs the three stand-alone kernels: every output of render_rays and every extra
+    (coarse maps, z_samples, merged depths, z_std, raw) must be bit-identical, also with density noise; ragged ray counts."""
+    from efficient_nerf_amd import NeRFEngine
+    from efficient_nerf_amd._lib import lib, check
+    H = 21
+    eng = NeRFEngine(H, H, O.focal_from_angle(H), N_samples=S0, N_importance=NI, white_bkgd=white)
+    eng.load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    ro, rd = O.get_rays(H, H, eng.focal, O.pose_spherical(12., -33., 4.)[:3, :4])
+    ro, rd = ro.reshape(-1, 3)[:H * H - 3].cuda().contiguous(), rd.reshape(-1, 3)[:H * H - 3].cuda().contiguous()
+    for noise in (0., 0.7):
+        outs = []
+        for split in (0, 1):
+            check(lib().nerf_debug_set_split_scans(eng._ctx, split))
+            outs.append(eng.render_rays(ro, rd, extras=True, raw_noise_std=noise, pytest=True))
+        check(lib().nerf_debug_set_split_scans(eng._ctx, 0))
+        assert set(outs[0]) == set(outs[1])
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (k, noise)
+    eng.close()
