@@ -194,3 +194,18 @@ def test_mirror_call_chain_on_a_generic_shape(g, pkg):
     assert torch.equal(rgb, rgb2)
     with pytest.raises(Exception):
         model(pe(PointSampler(H, H, focal, 16, 2., 6.).sample_test(T(g['c2w'])[:3, :4])))     # 1008 features into a 312-input network
+
+
+def test_linear_layer_random_shapes(pkg):
+    """24 seeded shapes (primes, 1-wide, just past the 128 x 64 x 32 tile edges) against F.linear in float64"""
+    from efficient_nerf_amd.generic import Linear
+    rng = np.random.RandomState(7)
+    edge = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 257, 1009]
+    for case in range(24):
+        n, i, o = int(rng.choice(edge + [3001])), int(rng.choice(edge)), int(rng.choice(edge))
+        gen = torch.Generator().manual_seed(case)
+        x, w, b = torch.randn(n, i, generator=gen), torch.randn(o, i, generator=gen) / i ** 0.5, torch.randn(o, generator=gen)
+        act = ('none', 'relu', 'lrelu', 'sigmoid')[case % 4]
+        want = ref_layer(x.double(), w.double(), b.double(), act, None, 1.0, None)
+        got = Linear(w, b)(x.cuda(), torch.empty(n, o, device='cuda'), act=act)
+        assert (got.cpu().double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), (n, i, o, act)
