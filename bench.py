@@ -86,7 +86,10 @@ def create_data_leg(torch, O, precision):
     from efficient_nerf_amd import create_data as CD
     th, n_pose = 400, 200
     focal = O.focal_from_angle(th)
-    eng = NeRFEngine(th, th, focal, precision=PRECISIONS[precision]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    auto = precision == 'auto'
+    eng = NeRFEngine(th, th, focal, precision=PRECISIONS['fp16x3' if auto else precision]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    if auto:       # what `python create_data.py` does by default: the fastest mode whose measured difference from fp16x3 is inside its limit
+        precision = teacher_auto(eng, O, th)[0]
     eng.render(O.novel_poses(1)[0][:3, :4])          # buffers allocated, kernels loaded
     torch.cuda.synchronize()
     out = tempfile.mkdtemp(prefix='r2l_pseudo_')
@@ -115,6 +118,14 @@ def create_data_leg(torch, O, precision):
             # 100 groups: 10,000 poses at the steady rate (the wall clock minus the one tail) plus the tail once
             'extrapolated_n_pose_kd_10000_hours_one_gpu': (1e4 / n_pose * (wall - (tm.get('tail_s') or 0.0)) + (tm.get('tail_s') or 0.0)) / 3600,
             'reference_quotes_hours': 24, 'reference_quote': 'README.md:87 "around 24 hrs" for --n_pose_kd 10000 (hardware unstated)'}
+
+
+def teacher_auto(eng, O, th):
+    """`--precision auto` of the teacher on the rays of test pose 0 (NeRFEngine.choose_precision): (mode, {candidate: difference})"""
+    from efficient_nerf_amd.teacher import get_rays
+    ro, rd = get_rays(th, th, O.focal_from_angle(th), O.novel_poses(1)[0][:3, :4], device=eng.device)
+    name, _ = eng.choose_precision(ro.reshape(-1, 3), rd.reshape(-1, 3))
+    return name, dict(eng.auto_diffs)
 
 
 def middle_rung(torch, O, R2LEngine, sd, poses, focal):
@@ -394,9 +405,15 @@ def main():
             # secondary, outside the timed region: NeRF teacher coarse+fine (BASELINE config 3)
             from efficient_nerf_amd import NeRFEngine
             th = 400
-            tprec = args.precision
+            # beside the default R2L mode the teacher runs as its own command line does (--precision auto: measured per checkpoint);
+            # an explicit --precision fp16x3 / fp16x1 is taken literally
+            tauto = args.precision not in ('fp16x3', 'fp16x1')
+            tprec = 'fp16x3' if tauto else args.precision
             teng = NeRFEngine(th, th, O.focal_from_angle(th), precision=PRECISIONS[tprec]).load_state_dicts(
                 O.make_teacher_state(1), O.make_teacher_state(2))
+            tdiffs = None
+            if tauto:
+                tprec, tdiffs = teacher_auto(teng, O, th)
             teng.render(poses[0])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -406,7 +423,10 @@ def main():
             tdt = (time.perf_counter() - t1) / 3
             out['teacher'] = {'workload': 'NeRF teacher lego 400x400 coarse 64 + fine 128', 'rays_per_s': th * th / tdt,
                               'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': 2 * 593408 * 256 * th * th / tdt / 1e12,
-                              'precision': tprec}
+                              'precision': tprec,
+                              'precision_chosen_by': ('auto: largest rgb / acc difference from fp16x3 on 4,096 rays of test pose 0 per candidate %s '
+                                                      '(limits: fp16x1 %g, fp16_fp8 %g)' % (tdiffs, teng.AUTO_MAX_DIFF_X1, teng.AUTO_MAX_DIFF)) if tauto else 'flag',
+                              'mfma_pass_equivalents': {'fp16x1': 1.0, 'fp16_fp8': 1.5, 'fp16x3': 3.0}[tprec]}
             if not args.no_cpu_baseline:  # parity of that frame against the CPU oracle on a strided ray subset
                 idx = torch.arange(0, th * th, th * th // 2048)[:2048]   # 2,048 rays spread over the frame
                 ro, rd = O.get_rays(th, th, O.focal_from_angle(th), poses[1])
@@ -417,7 +437,7 @@ def main():
                 out['teacher']['rays_checked'] = int(idx.numel())
             teng.close()
         if not args.no_create_data and world == 1:
-            out['create_data'] = create_data_leg(torch, O, args.precision if args.precision in ('fp16x3', 'fp16x1', 'fp16_fp8') else 'fp16_fp8')
+            out['create_data'] = create_data_leg(torch, O, args.precision if args.precision in ('fp16x3', 'fp16x1') else 'auto')
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

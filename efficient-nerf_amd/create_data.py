@@ -455,10 +455,17 @@ def main(argv=None):
         args.model_name, args.dataset_type = 'nerf', 'blender'
         _, eng = fe.build_engine(args, (H, W, focal), ckpt, log=print if rank == 0 else None)
     else:
-        prec = PRECISIONS['fp16_fp8' if args.precision == 'auto' else args.precision]
+        auto = args.precision == 'auto'
         eng = NeRFEngine(H, W, focal, 2., 6., N_samples=args.N_samples, N_importance=args.N_importance,
-                         white_bkgd=args.white_bkgd, precision=prec)
+                         white_bkgd=args.white_bkgd, precision=PRECISIONS['fp16x3' if auto else args.precision])
         eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
+        if auto:       # measured on this checkpoint, on the rays of a pose of the distribution the job samples (every rank the same)
+            from .teacher import get_rays
+            from .frontend import pose_spherical
+            ro, rd = get_rays(H, W, focal, pose_spherical(30., -45., 4.)[:3, :4], device=eng.device)
+            name, _ = eng.choose_precision(ro.reshape(-1, 3), rd.reshape(-1, 3))
+            if rank == 0:
+                print(f'[precision] auto: difference from fp16x3 on 4,096 rays of a probe pose: {eng.auto_diffs} -> {name}')
     tm = {}
     n = create_rand(eng, H, W, focal, own.n_pose_kd, own.datadir_kd.split(':')[1], not own.no_rand_focal,
                     i_save=own.create_data_chunk, split_size=own.split_size, rm_existing_data=own.rm_existing_data,

@@ -423,8 +423,8 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
                 ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, probe_pose, device=eng.device))
             name, diff = eng.choose_precision(ro, rd)
             if log:
-                log(f'[precision] auto: fp16_fp8 differs from fp16x3 by {diff:.1e} on {min(4096, ro.shape[0])} rays of the first '
-                    f'frame (limit {eng.AUTO_MAX_DIFF:.0e}) -> {name}')
+                tried = ', '.join(f'{k} {v:.1e} (limit {eng.AUTO_MAX_DIFF_X1 if k == "fp16x1" else eng.AUTO_MAX_DIFF:.0e})' for k, v in eng.auto_diffs.items())
+                log(f'[precision] auto: difference from fp16x3 on {min(4096, ro.shape[0])} rays of the first frame: {tried} -> {name}')
         return 'nerf', eng
     raise R2LError(f'model_name={args.model_name} is not a render path of this build')
 
