@@ -71,6 +71,14 @@ AUX_SCALES = 1152
 AUX_BYTES = 16384
 LDS_BYTES = LDS_AUX + AUX_BYTES
 ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
+# NERF_GEN_FMT=f16 (an environment variable: the tile / chunk / anchor tables below are built at import): the chain WITHOUT its
+# correction terms -- one fp16 pass on the 256-wide sources (the embedding k-steps keep their three passes): no K=128 MFMA, no
+# bf6 operand in the stream (1.25 MB per tile instead of 2.17), no residuals and no 32-wide conversions in the epilogues.
+# R2L_PREC_FP16X1 of the teacher: 1-3e-5 on rgb over whole frames (profiles/r04_teacher_x1.txt), `--precision auto`'s first rung.
+FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
+assert FMT in ('bf6', 'f16'), FMT
+X1 = FMT == 'f16'
+SUFFIX = 'x' if X1 else ''     # nerf_mlpx_asm.inc ...
 
 
 class Layer:
@@ -78,11 +86,13 @@ class Layer:
         self.name, self.src, self.dst, self.ks, self.extra, self.rt, self.epi = name, src, dst, ks, extra, rt, epi
         self.rt_per_chunk = rt_per_chunk
         self.fan_out = fan_out           # real output rows
-        self.nj = ks // 2                # K=128 MFMAs per row tile and column tile (2 terms x ks/4)
+        self.nj = 0 if X1 else ks // 2   # K=128 MFMAs per row tile and column tile (2 terms x ks/4)
         self.nx = len(extra)
 
     def j_order(self):
         """(term, t) of the K=128 MFMAs in issue order: term 0 = (w - hi) x bf6(a), 1 = w x bf6(a - hi)"""
+        if X1:
+            return []
         return [(0, 0), (1, 0), (0, 1), (1, 1)] if self.ks == 8 else [(0, 0), (1, 0)]
 
     def chunk_pieces(self):
@@ -221,11 +231,12 @@ def pack_teacher(tensors, act_scale=16.0):
         aux[a0:a0 + len(bias)] = (bias.astype(np.float64) * act_scale).astype(np.float32).view(np.uint32)
         el = ew = 0
         if Wm is not None:
+            hi = Wm.astype(np.float16)
+        if Wm is not None and not X1:       # the E8M0 scale bytes of the bf6 terms
             el, ew = weight_exps(layer_exponent(Wm))
             for qq in range(4):
                 aux[a0 + AUX_SCALES // 4 + 4 * qq] = 0x01010101 * (127 + el)
                 aux[a0 + AUX_SCALES // 4 + 4 * qq + 1] = 0x01010101 * (127 + ew)
-            hi = Wm.astype(np.float16)
         for u in range(L.rt):
             ci, k = TILE_CHUNK[TILE_OF[(li, u)]]
             base = CHUNK_OFF[ci]
@@ -457,6 +468,8 @@ def epilogue_ops(T, c):
     h23 = h01 + 1
     ops.append((v_cvt_pk_f16(h01, tv[0], tv[1]), ('hi', u >> 1)))
     ops.append((v_cvt_pk_f16(h23, tv[2], tv[3]), ('hi', u >> 1)))
+    if X1:
+        return ops
     # half-register writes: low halves first, then the high halves (never two writers of one register back to back)
     ops.append((v_resid16(lo, 0, h01, 0, tv[0]), None))
     ops.append((v_resid16(lo + 1, 0, h23, 0, tv[2]), None))
@@ -568,7 +581,7 @@ def build_fillers(opts):
     for T, t in enumerate(TILES):
         F.append(Filler(ds_read_b128(V_BIAS + (T & 1) * 4, V_AUX, t.li * AUX_LAYER + 64 * t.u, tag=('bias', T)),
                         afirst(T - 1) + 1 if T >= 1 else -1, afirst(T), ('aux',)))
-        if t.u == 0 and t.layer.ks:
+        if t.u == 0 and t.layer.ks and not X1:
             prev0 = TILE_OF[(t.li - 1, 0)]      # layer li-2 (same scale registers) is over once layer li-1 runs
             F.append(Filler(ds_read_b64(V_SC + 2 * (t.li & 1), V_AUX, t.li * AUX_LAYER + AUX_SCALES, tag=('scale', t.li)),
                             afirst(prev0) + 1, aidx(T, 'm6', 0, 0), ('aux',)))
@@ -793,12 +806,12 @@ def emit(dirname, opts):
     n = {}
     for ins in body:
         n[ins.kind] = n.get(ins.kind, 0) + 1
-    with open(os.path.join(dirname, 'nerf_mlp_asm.inc'), 'w') as f:
+    with open(os.path.join(dirname, 'nerf_mlp%s_asm.inc' % SUFFIX), 'w') as f:
         f.write('// GENERATED by gen/nerf_gen.py -- do not edit.  One 128-point tile of the teacher MLP: %s\n' %
                 ', '.join('%s %d' % kv for kv in sorted(n.items())))
         for line in setup + [i.text for i in body] + ['s_mov_b32 m0, %s' % sreg(S_M0SAVE)]:
             f.write('"%s\\n\\t"\n' % line)
-    with open(os.path.join(dirname, 'nerf_mlp_pro_asm.inc'), 'w') as f:
+    with open(os.path.join(dirname, 'nerf_mlp%s_pro_asm.inc' % SUFFIX), 'w') as f:
         f.write('// GENERATED by gen/nerf_gen.py -- do not edit.  Ring prologue: chunks 0..2 of the stream\n')
         for line in setup + [i.text for i in prologue_ops()] + ['s_mov_b32 m0, %s' % sreg(S_M0SAVE)]:
             f.write('"%s\\n\\t"\n' % line)
@@ -807,9 +820,9 @@ def emit(dirname, opts):
         regs += ['s%d' % i for i in range(N_SGPR_LO, N_SGPR_HI)] + ['vcc', 'scc', 'memory']
         return ', '.join('"%s"' % r for r in regs) + '\n'
 
-    with open(os.path.join(dirname, 'nerf_mlp_clobbers.inc'), 'w') as f:
+    with open(os.path.join(dirname, 'nerf_mlp%s_clobbers.inc' % SUFFIX), 'w') as f:
         f.write('// GENERATED by gen/nerf_gen.py: registers the tile block owns\n' + clob(0, N_VGPR_CLOBBER, N_AGPR_CLOBBER))
-    with open(os.path.join(dirname, 'nerf_mlp_pro_clobbers.inc'), 'w') as f:
+    with open(os.path.join(dirname, 'nerf_mlp%s_pro_clobbers.inc' % SUFFIX), 'w') as f:
         f.write('// GENERATED by gen/nerf_gen.py: registers the ring prologue owns\n' + clob(V_L0, N_VGPR_CLOBBER, 0))
     return n, body
 
@@ -856,7 +869,7 @@ def main():
                     'text (lgkm, dma, valu, ds, mfma6, mfma16, salu, nop): timing knock-outs, wrong results')
     a = ap.parse_args()
     opts = Opts(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap, pair=a.pair, wait_group=a.wait_group, drop=tuple(x for x in a.drop.split(',') if x))
-    print('tiles', NT, 'chunks', NCH, 'MFMAs', N_ANCH, 'stream bytes', STREAM_BYTES)
+    print('format', FMT, 'tiles', NT, 'chunks', NCH, 'MFMAs', N_ANCH, 'stream bytes', STREAM_BYTES)
     if a.emit:
         n, body = emit(a.emit, opts)
         print('wrote', a.emit, n, 'model cycles per tile', model_cycles(body))

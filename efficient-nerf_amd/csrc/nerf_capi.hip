@@ -99,8 +99,10 @@ struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding 
     bool is_pts;    // embedding k-steps: pts (nerf_pts_col) or view (nerf_view_col)
 };
 
-int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img) {
-    img.assign((size_t)NERF_CHAIN_STREAM_BYTES + NERF_CHAIN_AUX_BYTES, 0);
+// x1: the stream of R2L_PREC_FP16X1 -- the fp16 hi fragments and the embedding fragments only (NJ = 0), no scale bytes
+int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img, bool x1 = false) {
+    const size_t stream_bytes = x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES;
+    img.assign(stream_bytes + NERF_CHAIN_AUX_BYTES, 0);
     auto mat = [&](int ti, int ncol, int col0) {
         const float* p = w[ti].data();
         return [p, ncol, col0](int r, int col) -> float { return p[(size_t)r * ncol + col0 + col]; };
@@ -122,11 +124,11 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
     src[9] = {mat(T_VIEWS_W, 283, 0), mat(T_VIEWS_W, 283, 256), vec(T_VIEWS_B), false};  // cat([feature, views]) (:390)
     src[10] = {mat(T_RGB_W, 128, 0), nullptr, vec(T_RGB_B), true};
     size_t chunk_off = 0;
-    uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + NERF_CHAIN_STREAM_BYTES);
+    uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + stream_bytes);
     for (int li = 0; li < 11; ++li) {
         const ChainLayer& L = kChain[li];
         const ChainSrc& S = src[li];
-        const int nj = L.ks / 2, K = L.ks * 32;
+        const int nj = x1 ? 0 : L.ks / 2, K = L.ks * 32;
         const int pieces = L.rpc * L.ks + L.rpc * nj + (L.rpc * nj + 1) / 2 + L.rpc * L.nx * 2;
         const size_t chunk_bytes = (size_t)((pieces + 3) / 4) * 4096;
         uint32_t* al = aux + (size_t)li * NERF_CHAIN_AUX_LAYER / 4;
@@ -135,7 +137,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
             memcpy(&al[r], &v, 4);
         }
         int el = 0, ew = 0;
-        if (L.ks) {
+        if (L.ks && !x1) {
             std::vector<float> all((size_t)L.fan_out * K);
             for (int r = 0; r < L.fan_out; ++r)
                 for (int k = 0; k < K; ++k) all[(size_t)r * K + k] = S.main(r, k);
@@ -189,7 +191,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
         }
         chunk_off += (size_t)((L.rt + L.rpc - 1) / L.rpc) * chunk_bytes;
     }
-    if (chunk_off != NERF_CHAIN_STREAM_BYTES) return r2l_set_error(R2L_EINVAL, "internal: chain stream is %zu bytes", chunk_off);
+    if (chunk_off != stream_bytes) return r2l_set_error(R2L_EINVAL, "internal: chain stream is %zu bytes", chunk_off);
     return R2L_OK;
 }
 
@@ -343,9 +345,9 @@ static int upload_img(PackedNet& net, int mode, const std::vector<char>& img) {
 }
 
 static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
-    if (mode == R2L_PREC_FP16_FP8) {  // the layer chain's own stream (nerf_chain_kernel)
+    if (mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X1) {  // the layer chain's own streams (nerf_chain_kernel / nerf_chainx_kernel)
         std::vector<char> img;
-        int rc = pack_chain(net.host_w, c->act_scale, img);
+        int rc = pack_chain(net.host_w, c->act_scale, img, mode == R2L_PREC_FP16X1);
         return rc ? rc : upload_img(net, mode, img);
     }
     const int np = np_of(mode);
@@ -686,6 +688,13 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 }
 
 // run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
+static bool g_debug_chain_x1 = false;
+int nerf_debug_pack_chain_format(int fmt) {   // which stream nerf_debug_pack_chain_host packs: 0 fp16 + bf6 terms, 1 fp16 only (FP16X1)
+    if (fmt < 0 || fmt > 1) return r2l_set_error(R2L_EINVAL, "chain stream format %d", fmt);
+    g_debug_chain_x1 = fmt == 1;
+    return R2L_OK;
+}
+
 long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, char* out, long long cap, long long* offs) {
     if (!tensors || n_tensors != 24) return r2l_set_error(R2L_EINVAL, "expected 24 tensors");
     std::vector<std::vector<float>> w;
@@ -694,9 +703,9 @@ long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors,
         w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
     }
     std::vector<char> img;
-    int rc = pack_chain(w, 16.0f, img);
+    int rc = pack_chain(w, 16.0f, img, g_debug_chain_x1);
     if (rc) return rc;
-    if (offs) offs[0] = NERF_CHAIN_STREAM_BYTES;
+    if (offs) offs[0] = g_debug_chain_x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES;
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
 }

@@ -300,23 +300,36 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // points, valid in lane quarter 0.  The generator's CPU emulator checks the stream against a float64 network
 // (tests/test_nerf_gen_cpu.py).
 // ------------------------------------------------------------------------------------
+// X1 = true is R2L_PREC_FP16X1: the same chain generated without its correction terms (NERF_GEN_FMT=f16 -> nerf_mlpx_*.inc): one fp16
+// pass on the 256-wide sources, the embedding k-steps as before; 1.28 MB of stream per tile instead of 2.17.
+template <bool X1>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char nerf_chain_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     {   // resident table: per layer 272 f32 bias (act_scale domain) | E8M0 weight scales (nerf_common.h)
-        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + NERF_CHAIN_STREAM_BYTES);
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES));
         uint4* dst = reinterpret_cast<uint4*>(nerf_chain_lds + NERF_CHAIN_RING_BYTES);
         for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    asm volatile(
+    if constexpr (X1) {
+        asm volatile(
+#include "nerf_mlpx_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpx_pro_clobbers.inc"
+        );
+    } else {
+        asm volatile(
 #include "nerf_mlp_pro_asm.inc"
-        :
-        : [wimg] "s"(p.wimg), [wave] "s"(wave)
-        :
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
 #include "nerf_mlp_pro_clobbers.inc"
-    );
+        );
+    }
     const float inv = 1.0f / p.act_scale;
     NerfTileRaw raw;
     if ((int)blockIdx.x < p.n_tiles) nerf_tile_load(p, blockIdx.x, wave, lane, raw);
@@ -326,16 +339,28 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
         // the next tile's rays and depths travel while this tile's layers run (the values wait in AGPRs)
         if (tile + (int)gridDim.x < p.n_tiles) nerf_tile_load(p, tile + gridDim.x, wave, lane, raw);
         float o0, o1, o2, o3, o4, o5, o6, o7;
-        asm volatile(
-#include "nerf_mlp_asm.inc"
-            : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5),
-              [o6] "=&v"(o6), [o7] "=&v"(o7)
-            : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),
-              [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),
+#define NERF_CHAIN_OPERANDS                                                                                                       \
+            : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5),                     \
+              [o6] "=&v"(o6), [o7] "=&v"(o7)                                                                                      \
+            : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),             \
+              [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),       \
               [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
-            :
+        if constexpr (X1) {
+            asm volatile(
+#include "nerf_mlpx_asm.inc"
+                NERF_CHAIN_OPERANDS
+                :
+#include "nerf_mlpx_clobbers.inc"
+            );
+        } else {
+            asm volatile(
+#include "nerf_mlp_asm.inc"
+                NERF_CHAIN_OPERANDS
+                :
 #include "nerf_mlp_clobbers.inc"
-        );
+            );
+        }
+#undef NERF_CHAIN_OPERANDS
         if (lane < 16) {
             const unsigned pt0 = (unsigned)tile * NERF_TILE_PTS + wave * NERF_PTS_PER_WAVE + lane, pt1 = pt0 + 16;
             if (pt0 < (unsigned)p.n_pts) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt0 * 4) = f32x4{o0 * inv, o1 * inv, o2 * inv, o3 * inv};
@@ -869,9 +894,10 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
 
 hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream) {
     static std::atomic<bool> attr_set[3][64];  // zero-initialised; the opt-in call itself is idempotent
-    if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);
+    if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel<false>, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X3) return launch_big_lds(&nerf_mlp_kernel<2>, attr_set[1], KCfg<2>::LDS, p, grid, stream);
-    return launch_big_lds(&nerf_mlp_kernel<1>, attr_set[2], KCfg<1>::LDS, p, grid, stream);
+    // FP16X1: the generated chain without correction terms (round 4; the compiler-scheduled nerf_mlp_kernel<1> it replaces: 49.5 ms per frame)
+    return launch_big_lds(&nerf_chain_kernel<true>, attr_set[2], NERF_CHAIN_LDS, p, grid, stream);
 }
 
 hipError_t nerf_launch_ndc_rays(const float* rays_o, const float* rays_d, int n, int H, int W, double focal, float near_,

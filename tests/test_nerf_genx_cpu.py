@@ -1,0 +1,112 @@
+"""The teacher's layer chain generated WITHOUT its correction terms (NERF_GEN_FMT=f16 -> nerf_mlpx_*.inc, R2L_PREC_FP16X1:
+one fp16 pass on the 256-wide sources, three on the embedding k-steps), checked on the CPU like the bf6 chain
+(tests/test_nerf_gen_cpu.py): layout constants, the C++ packer against the generator's restatement byte for byte, the
+committed text against the generator, and the lane-accurate emulation of the exact instruction stream against a float64
+evaluation of NeRF.forward -- its error must be that of single-pass fp16 operands, not more."""
+import ctypes as C
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', 'gen'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import test_nerf_gen_cpu as T  # noqa: E402  (tensors, float64 reference, input fragments)
+
+import _pkg  # noqa: E402
+_pkg.load()
+from efficient_nerf_amd import _lib  # noqa: E402
+
+
+def _load_x():
+    """a second instance of the generator module with the f16 format (its tables are built at import)"""
+    old = os.environ.get('NERF_GEN_FMT')
+    os.environ['NERF_GEN_FMT'] = 'f16'
+    try:
+        spec = importlib.util.spec_from_file_location('nerf_genx', os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', 'gen', 'nerf_gen.py'))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        if old is None:
+            del os.environ['NERF_GEN_FMT']
+        else:
+            os.environ['NERF_GEN_FMT'] = old
+    return m
+
+
+GX = _load_x()
+
+
+def cxx_pack_x(tensors):
+    keep, arr = _lib.host_ptrs([torch.from_numpy(np.ascontiguousarray(t)) for t in tensors])
+    offs = (C.c_longlong * 1)()
+    L = _lib.lib()
+    assert L.nerf_debug_pack_chain_format(1) == 0
+    try:
+        n = L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs)
+        assert n > 0, L.r2l_last_error()
+        buf = np.zeros(n, dtype=np.uint8)
+        assert L.nerf_debug_pack_chain_host(arr, len(keep), C.c_void_p(buf.ctypes.data), n, offs) == n
+    finally:
+        L.nerf_debug_pack_chain_format(0)
+    return buf, int(offs[0])
+
+
+def test_layout_constants():
+    assert GX.X1 and GX.NCH == 80 and GX.NCH % GX.NSLOT == 0 and GX.N_ANCH == 2632 and GX.NT == 154
+    assert GX.STREAM_BYTES == 1282048          # NERF_CHAINX_STREAM_BYTES (csrc/nerf_common.h)
+    assert T.G.STREAM_BYTES == 2166784 and not T.G.X1      # the other instance is untouched
+
+
+def test_cxx_packer_matches_python_restatement():
+    t = T.make_tensors(seed=5)
+    buf, aux_off = cxx_pack_x(t)
+    img, aux = GX.pack_teacher(t)
+    assert aux_off == img.size == GX.STREAM_BYTES and buf.size == img.size + aux.size
+    assert np.array_equal(buf[:aux_off], img)
+    assert np.array_equal(buf[aux_off:], aux)
+    # any weight range packs: there is no bf6 split to outgrow (the bf6 stream refuses max|w| >= 2^6)
+    big = [x * (300.0 if i == 4 else 1.0) for i, x in enumerate(t)]
+    assert cxx_pack_x(big)[0].size == buf.size
+
+
+def test_committed_asm_is_the_generators_output(tmp_path):
+    GX.emit(str(tmp_path), GX.Opts())
+    for name in ('nerf_mlpx_asm.inc', 'nerf_mlpx_pro_asm.inc', 'nerf_mlpx_clobbers.inc', 'nerf_mlpx_pro_clobbers.inc'):
+        built = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)
+        assert open(os.path.join(str(tmp_path), name)).read() == open(built).read(), name
+
+
+@pytest.mark.parametrize('wave,n_tiles,gain', [(0, 1, 1.0), (3, 2, 1.0), (1, 1, 1.5)])
+def test_emulated_chain_vs_float64(wave, n_tiles, gain):
+    t = T.make_tensors(seed=wave, gain=gain)
+    rng = np.random.default_rng(10 + wave)
+    pts = rng.uniform(-2.5, 2.5, size=(32, 3)).astype(np.float32)
+    vd = rng.normal(size=(32, 3))
+    vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
+    ref, e, v = T.ref_mlp(t, pts, vd)
+    f16_err = np.abs(T.ref_mlp(t, pts, vd, f16_ops=True)[0] - ref).max()
+    buf, aux_off = cxx_pack_x(t)
+    out, errs = GX.emulate_tile(GX.Opts(), buf[:aux_off], buf[aux_off:], T.make_frags(e, v, 16.0), wave=wave, n_tiles=n_tiles)
+    assert not errs, errs[:10]
+    got = np.zeros((32, 4))
+    for c in range(2):
+        for k in range(4):
+            got[c * 16:(c + 1) * 16, k] = out[c * 4 + k][:16] / 16.0
+    err = np.abs(got - ref).max()
+    print('wave %d: L_inf %.3g (single-pass fp16 operands in float64: %.3g), |raw| max %.3g' % (wave, err, f16_err, np.abs(ref).max()))
+    assert err <= 1.5 * f16_err and err < 3e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_stream_has_no_correction_terms():
+    body = GX.block_stream(GX.Opts())
+    kinds = {}
+    for ins in body:
+        kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
+    assert kinds['mfma16'] == 2632 and 'mfma6' not in kinds and kinds['barrier'] == GX.NCH + 1
+    assert kinds['dma'] == sum(GX.CHUNKS[(c + 3) % GX.NCH]['pw'] for c in range(GX.NCH)) == 313
+    assert not any('bf6' in ins.text for ins in body)

@@ -10,8 +10,8 @@ cp $root/efficient-nerf_amd/csrc/*.hip $root/efficient-nerf_amd/csrc/*.h $root/e
 python3 $root/efficient-nerf_amd/csrc/gen/nerf_gen.py --emit $d "$@" | tail -1
 sed -i 's#"../../include/r2l_hip.h"#"'$root'/include/r2l_hip.h"#' $d/*.hip
 cd $d
-for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_capi; do cp $root/efficient-nerf_amd/csrc/$f.o $f.o; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -c nerf_kernels.hip -o nerf_kernels.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build_variants/libr2l_$name.so r2l_kernels.o r2l_body.o r2l_capi.o r2l_comm.o nerf_kernels.o nerf_capi.o -ldl
+for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_capi np_shuffle r2l_generic; do cp $root/efficient-nerf_amd/csrc/$f.o $f.o; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize -c nerf_kernels.hip -o nerf_kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build_variants/libr2l_$name.so r2l_kernels.o r2l_body.o r2l_capi.o r2l_comm.o nerf_kernels.o nerf_capi.o np_shuffle.o r2l_generic.o -ldl
 rm -rf $d
 echo built build_variants/libr2l_$name.so
