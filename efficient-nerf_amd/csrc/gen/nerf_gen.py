@@ -73,7 +73,7 @@ LDS_BYTES = LDS_AUX + AUX_BYTES
 ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # NERF_GEN_FMT=f16 (an environment variable: the tile / chunk / anchor tables below are built at import): the chain WITHOUT its
 # correction terms -- one fp16 pass on the 256-wide sources (the embedding k-steps keep their three passes): no K=128 MFMA, no
-# bf6 operand in the stream (1.25 MB per tile instead of 2.17), no residuals and no 32-wide conversions in the epilogues.
+# bf6 operand in the stream (1.27 MB per tile instead of 2.17, in 44 chunks instead of 80), no residuals and no 32-wide conversions in the epilogues.
 # R2L_PREC_FP16X1 of the teacher: 1-3e-5 on rgb over whole frames (profiles/r04_teacher_x1.txt), `--precision auto`'s first rung.
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
 assert FMT in ('bf6', 'f16'), FMT
@@ -102,15 +102,18 @@ class Layer:
 
 def chain():
     E2 = [('E', 0), ('E', 1)]
+    # row tiles per chunk: a chunk must fit a 32 KiB ring slot; without the bf6 operands twice as many row tiles do (44 chunks and
+    # rendezvous per tile instead of 80)
+    r_std, r_l5, r_v = (4, 2, 2) if X1 else (2, 1, 2)
     L = [Layer('L0', None, 'Q', 0, E2, 16, 'relu', 8, 256)]
     sets = ['Q', 'P']
     for i in range(1, 5):
-        L.append(Layer('L%d' % i, sets[(i - 1) % 2], sets[i % 2], 8, [], 16, 'relu', 2, 256))
-    L.append(Layer('L5', 'Q', 'P', 8, E2, 16, 'relu', 1, 256))
-    L.append(Layer('L6', 'P', 'Q', 8, [], 16, 'relu', 2, 256))
-    L.append(Layer('L7', 'Q', 'P', 8, [], 16, 'relu', 2, 256))
-    L.append(Layer('FA', 'P', 'Q', 8, [], 17, 'feat', 2, 257))
-    L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', 2, 128))
+        L.append(Layer('L%d' % i, sets[(i - 1) % 2], sets[i % 2], 8, [], 16, 'relu', r_std, 256))
+    L.append(Layer('L5', 'Q', 'P', 8, E2, 16, 'relu', r_l5, 256))
+    L.append(Layer('L6', 'P', 'Q', 8, [], 16, 'relu', r_std, 256))
+    L.append(Layer('L7', 'Q', 'P', 8, [], 16, 'relu', r_std, 256))
+    L.append(Layer('FA', 'P', 'Q', 8, [], 17, 'feat', r_std, 257))
+    L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', r_v, 128))
     L.append(Layer('RGB', 'P', None, 4, [], 1, 'rgb', 1, 3))
     return L
 

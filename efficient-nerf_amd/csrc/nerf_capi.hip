@@ -92,6 +92,10 @@ struct ChainLayer { int ks, nx, rt, rpc, fan_out; };
 const ChainLayer kChain[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
                                {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
                                {8, 0, 17, 2, 257}, {8, 1, 8, 2, 128},  {4, 0, 1, 1, 3}};
+// FP16X1 (no bf6 operands): twice the row tiles per chunk where a 32 KiB ring slot allows -- 44 chunks per tile instead of 80
+const ChainLayer kChainX[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 4, 256}, {8, 0, 16, 4, 256}, {8, 0, 16, 4, 256},
+                                {8, 0, 16, 4, 256}, {8, 2, 16, 2, 256}, {8, 0, 16, 4, 256}, {8, 0, 16, 4, 256},
+                                {8, 0, 17, 4, 257}, {8, 1, 8, 2, 128},  {4, 0, 1, 1, 3}};
 
 struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding column), bias(row); rows < fan_out
     std::function<float(int, int)> main, emb;
@@ -126,7 +130,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
     size_t chunk_off = 0;
     uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + stream_bytes);
     for (int li = 0; li < 11; ++li) {
-        const ChainLayer& L = kChain[li];
+        const ChainLayer& L = (x1 ? kChainX : kChain)[li];
         const ChainSrc& S = src[li];
         const int nj = x1 ? 0 : L.ks / 2, K = L.ks * 32;
         const int pieces = L.rpc * L.ks + L.rpc * nj + (L.rpc * nj + 1) / 2 + L.rpc * L.nx * 2;

@@ -31,8 +31,8 @@
 #define NERF_F0_RGB 1168
 // FP16_FP8: stream of gen/nerf_gen.py (80 chunks of whole row tiles, 1 KiB pieces) followed by the resident table
 #define NERF_CHAIN_STREAM_BYTES 2166784
-// FP16X1: the same chain without its correction terms (NERF_GEN_FMT=f16: no bf6 operand pieces; same 80 chunks, same table)
-#define NERF_CHAINX_STREAM_BYTES 1282048
+// FP16X1: the same chain without its correction terms (NERF_GEN_FMT=f16: no bf6 operand pieces, 44 chunks of up to 4 row tiles, same table)
+#define NERF_CHAINX_STREAM_BYTES 1298432
 #define NERF_CHAIN_AUX_BYTES 16384
 #define NERF_CHAIN_AUX_LAYER 1280   // per layer: 272 f32 bias | at byte 1152: 4 lane quarters x (swl, sw, 0, 0)
 #define NERF_CHAIN_AUX_SCALES 1152
