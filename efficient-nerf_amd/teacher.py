@@ -213,16 +213,17 @@ class NeRFEngine:
     #: `--precision auto`: largest difference of rgb / acc from fp16x3 on a probe of the caller's own rays that still selects a
     #: faster mode.  The contract is 1e-4 against the reference on every ray; fp16x3 is within 2e-7 of it.  The probe is 2.5 % of a
     #: frame's rays and one pose, so the limits keep a factor of three (single fp16 pass) / five (bf6 chain) to the contract:
-    #: measured over whole 400 x 400 frames of three poses (tools/teacher_x1_error.py, profiles/r04_teacher_x1.txt) a single
-    #: fp16 pass is 1.3-2.8e-5 from fp16x3 on the synthetic teachers (4.1e-5 with the trunk weights doubled), the chain 1e-6.
+    #: measured over whole 400 x 400 frames of three poses (tools/teacher_x1_error.py, profiles/r04_teacher_x1.txt) the single
+    #: fp16 pass is 0.6-1.6e-5 from fp16x3 on the synthetic teachers (3.6e-5 with the trunk weights doubled), the bf6 chain 1e-6.
     AUTO_MAX_DIFF = 2e-5           # fp16_fp8: the layer chain's bf6 terms run under FIXED activation exponents (no calibration)
     AUTO_MAX_DIFF_X1 = 3e-5        # fp16x1: one fp16 pass, no correction terms
 
     def choose_precision(self, rays_o, rays_d, max_diff=None, max_diff_x1=None):
         """`--precision auto` for the teacher, measured on THESE weights and rays: up to 4,096 of the given rays, spread over the
         set, are rendered coarse + fine in fp16x3 and in the candidates, fastest first:
-          fp16x1    one fp16 pass (1.0 pass-equivalents).  Eleven layers and the compositing over 192 samples average its rounding
-                    errors to 1-3e-5 on rgb where the 88-layer R2L student ends at 3.5e-4 -- for the teacher it is the fast mode;
+          fp16x1    the generated layer chain WITHOUT correction terms: one fp16 pass on the 256-wide sources (1.0 pass-equivalents).
+                    Eleven layers and the compositing over 192 samples average its rounding errors to ~1e-5 on rgb where the
+                    88-layer R2L student ends at 3.5e-4 -- for the teacher it is the fast mode (38.5 ms per 400 x 400 frame);
           fp16_fp8  the generated layer chain, fp16 + bf6 correction terms (1.5 pass-equivalents, ~1e-6), for weights whose
                     single-pass error is too large; its fixed exponents (|a| x 16 / 2^3 within bf6's +-28) are what is measured;
           fp16x3    three fp16 passes, unconditional.

@@ -1,11 +1,11 @@
-# PMC passes of the teacher's fp16_fp8 frame (run through gpurun): bash tools/teacher_pmc.sh <tag>
+# PMC passes of the teacher frame (T_PREC=fp16_fp8 | fp16x1) (run through gpurun): bash tools/teacher_pmc.sh <tag>
 set -x
 TAG=${1:-tXX}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/teacher_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export T_PREC=fp16_fp8 T_REP=2
+export T_PREC=${T_PREC:-fp16_fp8} T_REP=2
 python $R/tools/bench_teacher.py > $O/time.txt 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/tools/bench_teacher.py > $O/trace.log 2>&1 || exit 1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" \
