@@ -427,6 +427,17 @@ def main():
                               'precision_chosen_by': ('auto: largest rgb / acc difference from fp16x3 on 4,096 rays of test pose 0 per candidate %s '
                                                       '(limits: fp16x1 %g, fp16_fp8 %g)' % (tdiffs, teng.AUTO_MAX_DIFF_X1, teng.AUTO_MAX_DIFF)) if tauto else 'flag',
                               'mfma_pass_equivalents': {'fp16x1': 1.0, 'fp16_fp8': 1.5, 'fp16x3': 3.0}[tprec]}
+            if tauto and tprec == 'fp16x1':     # beside it: the same frames through the chain WITH its bf6 correction terms (auto's second rung)
+                from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X1
+                teng.set_precision(PREC_FP16_FP8)
+                teng.render(poses[0])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(3):
+                    teng.render(poses[i + 1])
+                torch.cuda.synchronize()
+                out['teacher']['fp16_fp8_ms_per_frame'] = (time.perf_counter() - t1) / 3 * 1e3
+                teng.set_precision(PREC_FP16X1)
             if not args.no_cpu_baseline:  # parity of that frame against the CPU oracle on a strided ray subset
                 idx = torch.arange(0, th * th, th * th // 2048)[:2048]   # 2,048 rays spread over the frame
                 ro, rd = O.get_rays(th, th, O.focal_from_angle(th), poses[1])
