@@ -3,7 +3,7 @@
 logic at real sizes, not of its speed -- the ranks share one card and the all-to-all goes through the host): `world` processes
 render 100 random poses at 400x400 between them (pose j of the group on rank j % world), one all-to-all hands every rank the rows of
 the shards it writes, the directory is compared with the one-rank run's file by file (sha256).
-    python tools/create_data_ranks.py [world] [n_pose] [H]          (through gpurun; world <= 4)"""
+    python tools/create_data_ranks.py [world] [n_pose] [H]          (through gpurun; world <= 4; CD_PREC=fp16x1 | fp16_fp8 | fp16x3)"""
 import hashlib
 import os
 import shutil
@@ -20,7 +20,7 @@ def worker(rank, world, port, out, n_pose, H, ret):
     import torch
     import _pkg
     _pkg.load()
-    from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8, dist as D
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS, dist as D
     from efficient_nerf_amd.create_data import RandStream, create_rand
     from oracle import r2l_oracle as O
     if world > 1:
@@ -29,7 +29,7 @@ def worker(rank, world, port, out, n_pose, H, ret):
         D.init()
         torch.cuda.set_device(D.local_device(rank))
     focal = O.focal_from_angle(H)
-    eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    eng = NeRFEngine(H, H, focal, precision=PRECISIONS[os.environ.get('CD_PREC', 'fp16x1')]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
     eng.render(O.novel_poses(1)[0][:3, :4])
     torch.cuda.synchronize()
     tm = {}
