@@ -335,7 +335,13 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     if ((int)blockIdx.x < p.n_tiles) nerf_tile_load(p, blockIdx.x, wave, lane, raw);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         f16x8 Eh[2][2], El[2][2], Vh[2][2], Vl[2][2];
+#ifdef NERF_SKIP_EMBED      // diagnostics only (wrong results): what the un-overlapped embedding prologue costs (tools/build_teacher_variant.sh)
+        for (int e = 0; e < 2; ++e)
+            for (int c = 0; c < 2; ++c)
+                for (int j = 0; j < 8; ++j) Eh[e][c][j] = El[e][c][j] = Vh[e][c][j] = Vl[e][c][j] = (f16)(raw.o[c][0] * (float)(e + j));
+#else
         nerf_tile_embed<2>(p, raw, lane, Eh, El, Vh, Vl);
+#endif
         // the next tile's rays and depths travel while this tile's layers run (the values wait in AGPRs)
         if (tile + (int)gridDim.x < p.n_tiles) nerf_tile_load(p, tile + gridDim.x, wave, lane, raw);
         float o0, o1, o2, o3, o4, o5, o6, o7;

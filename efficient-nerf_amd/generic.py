@@ -6,7 +6,7 @@ The fused kernels (r2l.R2LEngine, teacher.NeRFEngine) are built for the README's
 --layerwise_netwidths, trial.n_learnable != 2, other n_sample_per_ray / multires, odd mlp depths, other teacher depths and
 widths, no view directions.  Those run here: fp32 products and accumulation on the fp32 MFMA (the reference's own
 precision: nothing to calibrate, L_inf vs the reference ~2e-7), activations through HBM.  The README's own networks run 11 x (R2L
-W256D88: 5.5e6 rays/s) and 10 x (8 x 256 teacher: 2.4e5 rays/s) slower here than on the fused kernels
+W256D88: 5.5e6 rays/s) and 17 x (8 x 256 teacher: 2.4e5 rays/s) slower here than on the fused kernels
 (profiles/r04_generic_time.txt); the front end takes this path only for what those refuse.
 
 The module structure (which state_dict key is which Linear, where activations and residuals sit) is restated from the
