@@ -39,14 +39,17 @@ def cpu_threads():
 
 
 def kernel_sources_digest():
-    """sha256 over what is compiled (csrc/*.hip, *.h and the generated *.inc, which are committed and byte-reproducible from
-    the generators): identifies the build a PMC pass measured"""
+    """sha256 over what is compiled into the R2L student's kernels (csrc/r2l_*.hip, r2l_*.h and the generated r2l_*.inc, which are
+    committed and byte-reproducible from the generators; not the teacher's nerf_* files, the generic layer path or the RCCL
+    binding, which the measured launch does not contain): identifies the build a PMC pass measured"""
     import glob
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc')
-    for f in sorted(glob.glob(os.path.join(base, '*.hip')) + glob.glob(os.path.join(base, '*.h')) +
-                    glob.glob(os.path.join(base, '*.inc'))):
+    for f in sorted(glob.glob(os.path.join(base, 'r2l_*.hip')) + glob.glob(os.path.join(base, 'r2l_*.h')) +
+                    glob.glob(os.path.join(base, 'r2l_*.inc'))):
+        if os.path.basename(f) in ('r2l_generic.hip', 'r2l_comm.hip'):
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
