@@ -72,7 +72,8 @@ FLAGS = [
     # this front-end's own knobs
     # auto (default): fp16_fp8 (fp16 MFMA pass + bf6 correction terms, 1.7x the speed) when the checkpoint's own activation
     # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
-    # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher takes fp16_fp8
+    # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher measures fp16x1 (its layer chain as one
+    # fp16 pass), then fp16_fp8, against fp16x3 (NeRFEngine.choose_precision); fp32 = the generic layer path for any network shape
     ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp32', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
@@ -311,7 +312,7 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
     auto = args.precision == 'auto'
     # auto: the weights are loaded in fp16x3 -- the mode that packs ANY checkpoint (per-layer scales) -- and choose_precision
     # moves to the generated modes from there; a layer they cannot pack (max|w| outside 2^-12 .. 2^6) then ends in its
-    # documented fp16x3 fallback instead of failing r2l_load_weights.  The teacher's `auto` starts from fp16_fp8.
+    # documented fp16x3 fallback instead of failing r2l_load_weights.  The teacher's `auto` loads in fp16_fp8 and measures from there.
     prec = PRECISIONS.get(args.precision) if not auto else PRECISIONS['fp16x3' if args.model_name in ('R2L', 'nerf_v3.2') else 'fp16_fp8']
     llff_ndc = args.dataset_type == 'llff' and not args.no_ndc
     if args.dataset_type == 'blender':
