@@ -426,6 +426,7 @@ def main():
             tdt = (time.perf_counter() - t1) / 3
             out['teacher'] = {'workload': 'NeRF teacher lego 400x400 coarse 64 + fine 128', 'rays_per_s': th * th / tdt,
                               'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': 2 * 593408 * 256 * th * th / tdt / 1e12,
+                              'frac_of_fp16_mfma_peak': 2 * 593408 * 256 * th * th / tdt / 1e12 / PEAK_FP16_TFLOPS,
                               'precision': tprec,
                               'precision_chosen_by': ('auto: largest rgb / acc difference from fp16x3 on 4,096 rays of test pose 0 per candidate %s '
                                                       '(limits: fp16x1 %g, fp16_fp8 %g)' % (tdiffs, teng.AUTO_MAX_DIFF_X1, teng.AUTO_MAX_DIFF)) if tauto else 'flag',
