@@ -75,10 +75,29 @@ ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # correction terms -- one fp16 pass on the 256-wide sources (the embedding k-steps keep their three passes): no K=128 MFMA, no
 # bf6 operand in the stream (1.27 MB per tile instead of 2.17, in 44 chunks instead of 80), no residuals and no 32-wide conversions in the epilogues.
 # R2L_PREC_FP16X1 of the teacher: 1-3e-5 on rgb over whole frames (profiles/r04_teacher_x1.txt), `--precision auto`'s first rung.
+# NERF_GEN_FMT=f16c3: the f16 chain with THREE column tiles of 16 points per wave (192 points per workgroup tile): every weight
+# fragment read from LDS feeds three MFMAs instead of two and the stream is fetched once per 192 points -- what the bf6 chain has no
+# registers for fits once the bf6 operand sets are gone: activation set P in VGPRs, set Q in AGPRs (an MFMA takes B from
+# either file; Q's epilogues pay one v_accvgpr_write per packed register).
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
-assert FMT in ('bf6', 'f16'), FMT
-X1 = FMT == 'f16'
-SUFFIX = 'x' if X1 else ''     # nerf_mlpx_asm.inc ...
+assert FMT in ('bf6', 'f16', 'f16c3'), FMT
+X1 = FMT != 'bf6'
+NC = 3 if FMT == 'f16c3' else 2          # column tiles (16 points each) per wave
+SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3'}[FMT]     # nerf_mlpx_asm.inc ...
+if NC == 3:
+    V_SET = {'P': 0}              # fp16 B operands of set P (VGPR): + c*32 + s*4
+    A_SETH = {'Q': 0}             # ... of set Q (AGPR)
+    V_ACC, V_BIAS, V_HI, V_TMP = 96, 120, 128, 144       # ACC: + p*12 + c*4; TMP: + c*6
+    V_A6 = V_LO = None
+    V_L0, V_L1, V_L8A, V_L8B, V_AUX, V_LANE = 162, 163, 164, 165, 166, 167
+    V_SBA, V_SBL, V_CVA, V_CVL = 168, 169, 170, 171
+    V_SC = 172
+    V_LOFF = 176
+    N_VGPR_CLOBBER = 180
+    A_E = 96
+    N_AGPR_CLOBBER = 96
+else:
+    A_SETH = {}
 
 
 class Layer:
@@ -290,8 +309,8 @@ def pack_teacher(tensors, act_scale=16.0):
 # ---------------------------------------------------------------------------------------------
 def E_reg(kind, e, c, lo):
     if kind == 'E':
-        return A_E + (16 if lo else 0) + (e * 2 + c) * 4
-    return A_E + 32 + (8 if lo else 0) + c * 4
+        return A_E + (8 * NC if lo else 0) + (e * NC + c) * 4
+    return A_E + 16 * NC + (4 * NC if lo else 0) + c * 4
 
 
 def E_name(kind, e, c, lo):
@@ -300,8 +319,8 @@ def E_name(kind, e, c, lo):
     return '%%[v%s%d]' % ('l' if lo else 'h', c)
 
 
-INPUT_NAMES = ([('e%s%d%d' % (hl, e, c), E_reg('E', e, c, hl == 'l')) for hl in 'hl' for e in range(2) for c in range(2)] +
-               [('v%s%d' % (hl, c), E_reg('V', 0, c, hl == 'l')) for hl in 'hl' for c in range(2)])
+INPUT_NAMES = ([('e%s%d%d' % (hl, e, c), E_reg('E', e, c, hl == 'l')) for hl in 'hl' for e in range(2) for c in range(NC)] +
+               [('v%s%d' % (hl, c), E_reg('V', 0, c, hl == 'l')) for hl in 'hl' for c in range(NC)])
 
 
 def mfma16(d, a, bfile, b, c, tag='', btext=None):
@@ -395,11 +414,11 @@ def tile_anchors(L):
     out = []
     for xi in range(L.nx):
         for p in range(3):
-            for c in range(2):
+            for c in range(NC):
                 out.append(('x', xi, c, p))
     for s in range(L.ks):
-        out.append(('m16', s, 0, 0))
-        out.append(('m16', s, 1, 0))
+        for c in range(NC):
+            out.append(('m16', s, c, 0))
         j = s - (L.ks - L.nj)
         if j >= 0:
             out.append(('m6', j, 0, 0))
@@ -428,8 +447,13 @@ def operand_key(T, kind, k, p):
     return ('hi' if kind == 'm16' else 'a6', T, k)
 
 
+def hfile(name):
+    """register file of activation set `name` (f16c3: Q lives in AGPRs)"""
+    return 'a' if name in A_SETH else 'v'
+
+
 def hset(name, s, c):
-    return V_SET[name] + c * 32 + s * 4
+    return (A_SETH[name] if name in A_SETH else V_SET[name]) + c * 32 + s * 4
 
 
 def b6(name, term, t, c):
@@ -437,7 +461,7 @@ def b6(name, term, t, c):
 
 
 def ACC(p, c):
-    return V_ACC + p * 8 + c * 4
+    return V_ACC + p * 4 * NC + c * 4
 
 
 def LO(c):
@@ -445,7 +469,7 @@ def LO(c):
 
 
 def TMP(c):
-    return V_TMP + c * 10
+    return V_TMP + c * (10 if NC == 2 else 6)
 
 
 def epilogue_ops(T, c):
@@ -466,13 +490,20 @@ def epilogue_ops(T, c):
             ops.append((v_max0(tv[i], acc + i), None))
     else:
         tv = [acc + i for i in range(4)]
-    lo = LO(c) + 2 * (u & 7)
     h01 = hset(L.dst, u >> 1, c) + 2 * (u & 1)
     h23 = h01 + 1
+    if hfile(L.dst) == 'a':       # the packed pairs go through two temporaries into the AGPR set
+        p01, p23 = tb + 4, tb + 5
+        ops.append((v_cvt_pk_f16(p01, tv[0], tv[1]), None))
+        ops.append((v_cvt_pk_f16(p23, tv[2], tv[3]), None))
+        ops.append((v_accw(h01, p01), ('hi', u >> 1)))
+        ops.append((v_accw(h23, p23), ('hi', u >> 1)))
+        return ops
     ops.append((v_cvt_pk_f16(h01, tv[0], tv[1]), ('hi', u >> 1)))
     ops.append((v_cvt_pk_f16(h23, tv[2], tv[3]), ('hi', u >> 1)))
     if X1:
         return ops
+    lo = LO(c) + 2 * (u & 7)
     # half-register writes: low halves first, then the high halves (never two writers of one register back to back)
     ops.append((v_resid16(lo, 0, h01, 0, tv[0]), None))
     ops.append((v_resid16(lo + 1, 0, h23, 0, tv[2]), None))
@@ -591,7 +622,7 @@ def build_fillers(opts):
     # ---- epilogue of tile T-1 under tile T -------------------------------------------------------------
     for T in range(1, NT):
         tp = TILES[T - 1]
-        for c in range(2):
+        for c in range(NC):
             e0 = afirst(T) + 2 + c          # two further MFMAs behind the last writer of its accumulator
             for ins, cons in epilogue_ops(T - 1, c):
                 dl = afirst(T + 1)          # the accumulator buffer is reused by tile T+1
@@ -707,7 +738,7 @@ def schedule(opts):
             ins = mfma16(d, bufmap[key], 'a', E_reg(ek, e, c, p == 1), csrc, tag=('x', T, k, c, p), btext=E_name(ek, e, c, p == 1))
         elif kind == 'm16':
             sch.need(key, [('hi', T, k + g) for g in range(1, opts.wait_group)])
-            ins = mfma16(d, bufmap[key], 'v', hset(L.src, k, c), csrc, tag=('m16', T, k, c))
+            ins = mfma16(d, bufmap[key], hfile(L.src), hset(L.src, k, c), csrc, tag=('m16', T, k, c))
         else:
             sch.need(key + (1,))
             term, tt = L.j_order()[k]
@@ -787,7 +818,7 @@ def prologue_ops():
 def tail_ops():
     """exposed epilogue of the last row tile (RGB)"""
     ops = [s_nop(15), s_nop(15)]
-    for c in range(2):
+    for c in range(NC):
         ops += [ins for ins, _ in epilogue_ops(NT - 1, c)]
     return ops
 
@@ -850,7 +881,7 @@ def emulate_tile(opts, img, aux, frags, wave=0, n_tiles=1, check_hazards=True, b
         errs.append('%d LDS reads never waited for' % len(st.pend_ds))
     if check_hazards:
         errs += check_hazards_stream(body)
-    out = np.stack([st.out[k] for k in range(8)]).view(np.float32)
+    out = np.stack([st.out[k] for k in range(4 * NC)]).view(np.float32)
     return out, errs
 
 

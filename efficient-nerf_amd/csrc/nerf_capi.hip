@@ -444,6 +444,8 @@ int nerf_set_precision(nerf_ctx* c, int mode) {
     return R2L_OK;
 }
 
+static int g_x1_col_tiles = 3;     // nerf_debug_set_x1_col_tiles: 2 = the 128-point tiles of the other modes (A/B)
+
 static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* rays_d, const float* z, int z_stride,
                    int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr) {
     NerfMlpParams p;
@@ -460,7 +462,9 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     p.n_pts = (long long)n * S;
     if (p.n_pts >= (1ll << 31))   // the kernels index points with 32 bits
         return r2l_set_error(R2L_EINVAL, "%d rays x %d samples: more than 2^31 points in one call; render fewer rows at a time", n, S);
-    p.n_tiles = (int)((p.n_pts + NERF_TILE_PTS - 1) / NERF_TILE_PTS);
+    const int x1_nc = c->mode == R2L_PREC_FP16X1 ? g_x1_col_tiles : 2;     // the fp16-only chain: 192-point tiles (three column tiles per wave)
+    const int tile_pts = 64 * x1_nc;
+    p.n_tiles = (int)((p.n_pts + tile_pts - 1) / tile_pts);
     p.act_scale = c->act_scale;
     p.neg1 = -1.0f;
     memcpy(p.inv_scale, c->net[which].inv_scale[c->mode], sizeof p.inv_scale);
@@ -479,7 +483,7 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
         c->ev_used += 2;
         (void)hipEventRecord(e0, s);
     }
-    hipError_t e = nerf_launch_mlp(p, c->mode, grid, s);
+    hipError_t e = nerf_launch_mlp(p, c->mode, grid, s, x1_nc);
     if (c->timing) (void)hipEventRecord(e1, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
     return R2L_OK;
@@ -569,6 +573,12 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
     if (rc) return rc;
     HIPCHK(nerf_launch_raw2outputs(c->d_raw, c->d_zall, S1, rays_d, n, S1, c->white_bkgd, rgb, disp, acc, nullptr,
                                    depth, s, o.noise1), "raw2outputs(fine)");
+    return R2L_OK;
+}
+
+int nerf_debug_set_x1_col_tiles(int n) {
+    if (n != 2 && n != 3) return r2l_set_error(R2L_EINVAL, "column tiles per wave: 2 or 3");
+    g_x1_col_tiles = n;
     return R2L_OK;
 }
 

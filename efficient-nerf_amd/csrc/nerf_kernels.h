@@ -21,7 +21,8 @@ struct NerfMlpParams {
     float inv_scale[NERF_N_SCALES];  // per layer: 1 / (act_scale * weight_scale)
 };
 
-hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream);  // mode: R2L_PREC_*
+// mode: R2L_PREC_*; x1_col_tiles (FP16X1 only): 16-point column tiles per wave, 2 or 3 -- p.n_tiles must count tiles of 64 x that many points
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles = 2);
 
 // rays of rows [row_begin,row_end) of one frame (utils/run_nerf_raybased_helpers.py:231-257)
 hipError_t nerf_launch_get_rays(const float* c2w12_host, int W, float half_w, float half_h, float focal,

@@ -117,15 +117,18 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const ActSet& S, const f1
 //   nerf_tile_load   ray origin / direction / depth (and the given view direction) of the lane's two points
 //   nerf_tile_embed  pts = rays_o + rays_d * z (main.py:701), view directions (main.py:148-162) and the fragments of both
 //                    embeddings (nerf_common.h: nerf_pts_col / nerf_view_col), act_scale folded in, fp16 hi | lo B operands
-struct NerfTileRaw {
-    float o[2][3], d[2][3], v[2][3], z[2];
+template <int NC>
+struct NerfTileRawT {       // NC column tiles of 16 points per wave (2: 128-point workgroup tiles; 3: 192, the fp16x1 chain)
+    float o[NC][3], d[NC][3], v[NC][3], z[NC];
 };
+typedef NerfTileRawT<2> NerfTileRaw;
 
 // n_pts < 2^31 (checked by the host): 32-bit point and ray indices
-__device__ __forceinline__ void nerf_tile_load(const NerfMlpParams& p, int tile, int wave, int lane, NerfTileRaw& r) {
+template <int NC>
+__device__ __forceinline__ void nerf_tile_load(const NerfMlpParams& p, int tile, int wave, int lane, NerfTileRawT<NC>& r) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const unsigned pt_raw = (unsigned)tile * NERF_TILE_PTS + wave * NERF_PTS_PER_WAVE + c * 16 + (lane & 15);
+    for (int c = 0; c < NC; ++c) {
+        const unsigned pt_raw = (unsigned)tile * (64 * NC) + wave * (16 * NC) + c * 16 + (lane & 15);
         const unsigned last = (unsigned)p.n_pts - 1u;
         const unsigned pt = pt_raw < last ? pt_raw : last;   // tail lanes repeat the last point (their stores are masked)
         const unsigned ray = pt / (unsigned)p.S;
@@ -140,14 +143,14 @@ __device__ __forceinline__ void nerf_tile_load(const NerfMlpParams& p, int tile,
     }
 }
 
-template <int NP>
-__device__ __forceinline__ void nerf_tile_embed(const NerfMlpParams& p, const NerfTileRaw& r, int lane, f16x8 (&Eh)[2][2],
-                                                f16x8 (&El)[2][2], f16x8 (&Vh)[2][2], f16x8 (&Vl)[2][2]) {
+template <int NP, int NC = 2>
+__device__ __forceinline__ void nerf_tile_embed(const NerfMlpParams& p, const NerfTileRawT<NC>& r, int lane, f16x8 (&Eh)[2][NC],
+                                                f16x8 (&El)[2][NC], f16x8 (&Vh)[2][NC], f16x8 (&Vl)[2][NC]) {
     const int q = lane >> 4;
     const float act_scale = p.act_scale;
     const bool is_cos = (q & 1) != 0;   // odd lane quarters hold cosines in every k-step (nerf_common.h)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const float* d = r.d[c];
         // viewdirs = rays_d / ||rays_d||  (main.py:154-156); NDC renders carry those of the world-space rays (:148-162)
         const float nrm = sqrtf(__fadd_rn(__fadd_rn(d[0] * d[0], d[1] * d[1]), d[2] * d[2]));
@@ -302,8 +305,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // ------------------------------------------------------------------------------------
 // X1 = true is R2L_PREC_FP16X1: the same chain generated without its correction terms (NERF_GEN_FMT=f16 -> nerf_mlpx_*.inc): one fp16
 // pass on the 256-wide sources, the embedding k-steps as before; 1.28 MB of stream per tile instead of 2.17.
-template <bool X1>
+// NC = 3 (X1 only, NERF_GEN_FMT=f16c3 -> nerf_mlpx3_*.inc): three column tiles of 16 points per wave, 192 points per workgroup tile.
+template <bool X1, int NC>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
+    static_assert(NC == 2 || (X1 && NC == 3), "three column tiles exist for the fp16-only chain");
     extern __shared__ __attribute__((aligned(16))) char nerf_chain_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -313,7 +318,15 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
         for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    if constexpr (X1) {
+    if constexpr (X1 && NC == 3) {
+        asm volatile(
+#include "nerf_mlpx3_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpx3_pro_clobbers.inc"
+        );
+    } else if constexpr (X1) {
         asm volatile(
 #include "nerf_mlpx_pro_asm.inc"
             :
@@ -331,46 +344,62 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
         );
     }
     const float inv = 1.0f / p.act_scale;
-    NerfTileRaw raw;
-    if ((int)blockIdx.x < p.n_tiles) nerf_tile_load(p, blockIdx.x, wave, lane, raw);
+    NerfTileRawT<NC> raw;
+    if ((int)blockIdx.x < p.n_tiles) nerf_tile_load<NC>(p, blockIdx.x, wave, lane, raw);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        f16x8 Eh[2][2], El[2][2], Vh[2][2], Vl[2][2];
+        f16x8 Eh[2][NC], El[2][NC], Vh[2][NC], Vl[2][NC];
 #ifdef NERF_SKIP_EMBED      // diagnostics only (wrong results): what the un-overlapped embedding prologue costs (tools/build_teacher_variant.sh)
         for (int e = 0; e < 2; ++e)
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < NC; ++c)
                 for (int j = 0; j < 8; ++j) Eh[e][c][j] = El[e][c][j] = Vh[e][c][j] = Vl[e][c][j] = (f16)(raw.o[c][0] * (float)(e + j));
 #else
-        nerf_tile_embed<2>(p, raw, lane, Eh, El, Vh, Vl);
+        nerf_tile_embed<2, NC>(p, raw, lane, Eh, El, Vh, Vl);
 #endif
         // the next tile's rays and depths travel while this tile's layers run (the values wait in AGPRs)
-        if (tile + (int)gridDim.x < p.n_tiles) nerf_tile_load(p, tile + gridDim.x, wave, lane, raw);
-        float o0, o1, o2, o3, o4, o5, o6, o7;
-#define NERF_CHAIN_OPERANDS                                                                                                       \
-            : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5),                     \
-              [o6] "=&v"(o6), [o7] "=&v"(o7)                                                                                      \
+        if (tile + (int)gridDim.x < p.n_tiles) nerf_tile_load<NC>(p, tile + gridDim.x, wave, lane, raw);
+        float o[4 * NC];
+#define NERF_CHAIN_OUT2                                                                                                           \
+            : [o0] "=&v"(o[0]), [o1] "=&v"(o[1]), [o2] "=&v"(o[2]), [o3] "=&v"(o[3]), [o4] "=&v"(o[4]), [o5] "=&v"(o[5]),         \
+              [o6] "=&v"(o[6]), [o7] "=&v"(o[7])
+#define NERF_CHAIN_IN2                                                                                                            \
             : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),             \
               [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),       \
               [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
-        if constexpr (X1) {
+        if constexpr (X1 && NC == 3) {
+            asm volatile(
+#include "nerf_mlpx3_asm.inc"
+                NERF_CHAIN_OUT2, [o8] "=&v"(o[8]), [o9] "=&v"(o[9]), [o10] "=&v"(o[10]), [o11] "=&v"(o[11])
+                NERF_CHAIN_IN2, [eh02] "a"(Eh[0][2]), [eh12] "a"(Eh[1][2]), [el02] "a"(El[0][2]), [el12] "a"(El[1][2]),
+                  [vh2] "a"(Vh[0][2]), [vl2] "a"(Vl[0][2])
+                :
+#include "nerf_mlpx3_clobbers.inc"
+            );
+        } else if constexpr (X1) {
             asm volatile(
 #include "nerf_mlpx_asm.inc"
-                NERF_CHAIN_OPERANDS
+                NERF_CHAIN_OUT2
+                NERF_CHAIN_IN2
                 :
 #include "nerf_mlpx_clobbers.inc"
             );
         } else {
             asm volatile(
 #include "nerf_mlp_asm.inc"
-                NERF_CHAIN_OPERANDS
+                NERF_CHAIN_OUT2
+                NERF_CHAIN_IN2
                 :
 #include "nerf_mlp_clobbers.inc"
             );
         }
-#undef NERF_CHAIN_OPERANDS
+#undef NERF_CHAIN_OUT2
+#undef NERF_CHAIN_IN2
         if (lane < 16) {
-            const unsigned pt0 = (unsigned)tile * NERF_TILE_PTS + wave * NERF_PTS_PER_WAVE + lane, pt1 = pt0 + 16;
-            if (pt0 < (unsigned)p.n_pts) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt0 * 4) = f32x4{o0 * inv, o1 * inv, o2 * inv, o3 * inv};
-            if (pt1 < (unsigned)p.n_pts) *reinterpret_cast<f32x4*>(p.raw + (size_t)pt1 * 4) = f32x4{o4 * inv, o5 * inv, o6 * inv, o7 * inv};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned pt = (unsigned)tile * (64 * NC) + wave * (16 * NC) + c * 16 + lane;
+                if (pt < (unsigned)p.n_pts)
+                    *reinterpret_cast<f32x4*>(p.raw + (size_t)pt * 4) = f32x4{o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv};
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's refill of the ring
@@ -898,12 +927,14 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
     return hipGetLastError();
 }
 
-hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream) {
-    static std::atomic<bool> attr_set[3][64];  // zero-initialised; the opt-in call itself is idempotent
-    if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel<false>, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles) {
+    static std::atomic<bool> attr_set[4][64];  // zero-initialised; the opt-in call itself is idempotent
+    if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel<false, 2>, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X3) return launch_big_lds(&nerf_mlp_kernel<2>, attr_set[1], KCfg<2>::LDS, p, grid, stream);
-    // FP16X1: the generated chain without correction terms (round 4; the compiler-scheduled nerf_mlp_kernel<1> it replaces: 49.5 ms per frame)
-    return launch_big_lds(&nerf_chain_kernel<true>, attr_set[2], NERF_CHAIN_LDS, p, grid, stream);
+    // FP16X1: the generated chain without correction terms (round 4; the compiler-scheduled nerf_mlp_kernel<1> it replaces: 49.5 ms per
+    // frame), with three column tiles per wave (192-point workgroup tiles: p.n_tiles counts those) or two
+    if (x1_col_tiles == 3) return launch_big_lds(&nerf_chain_kernel<true, 3>, attr_set[3], NERF_CHAIN_LDS, p, grid, stream);
+    return launch_big_lds(&nerf_chain_kernel<true, 2>, attr_set[2], NERF_CHAIN_LDS, p, grid, stream);
 }
 
 hipError_t nerf_launch_ndc_rays(const float* rays_o, const float* rays_d, int n, int H, int W, double focal, float near_,

@@ -22,12 +22,12 @@ _pkg.load()
 from efficient_nerf_amd import _lib  # noqa: E402
 
 
-def _load_x():
-    """a second instance of the generator module with the f16 format (its tables are built at import)"""
+def _load_x(fmt='f16'):
+    """a further instance of the generator module with another format (its tables are built at import)"""
     old = os.environ.get('NERF_GEN_FMT')
-    os.environ['NERF_GEN_FMT'] = 'f16'
+    os.environ['NERF_GEN_FMT'] = fmt
     try:
-        spec = importlib.util.spec_from_file_location('nerf_genx', os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', 'gen', 'nerf_gen.py'))
+        spec = importlib.util.spec_from_file_location('nerf_gen_' + fmt, os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', 'gen', 'nerf_gen.py'))
         m = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(m)
     finally:
@@ -39,6 +39,7 @@ def _load_x():
 
 
 GX = _load_x()
+G3 = _load_x('f16c3')      # three 16-point column tiles per wave: the same stream, 192-point tiles, activation set Q in AGPRs
 
 
 def cxx_pack_x(tensors):
@@ -110,3 +111,64 @@ def test_stream_has_no_correction_terms():
     assert kinds['mfma16'] == 2632 and 'mfma6' not in kinds and kinds['barrier'] == GX.NCH + 1
     assert kinds['dma'] == sum(GX.CHUNKS[(c + 3) % GX.NCH]['pw'] for c in range(GX.NCH))
     assert not any('bf6' in ins.text for ins in body)
+
+
+# ---- f16c3: three column tiles per wave (what R2L_PREC_FP16X1 launches) -------------------------------------------------------
+def make_frags_nc(G, e, v, act):
+    """test_nerf_gen_cpu.make_frags for G.NC column tiles: e [16 NC, 63], v [16 NC, 27] -> {name: uint32 [4, 64]}"""
+    lanes = np.arange(64)
+    q, n = lanes >> 4, lanes & 15
+    fr = {}
+    for kind, ne, src in (('E', 2, e), ('V', 1, v)):
+        for ee in range(ne):
+            for c in range(G.NC):
+                H = np.zeros((64, 8), np.float16)
+                Lo = np.zeros((64, 8), np.float16)
+                for j in range(8):
+                    for l in range(64):
+                        col = G.pts_col(ee, q[l], j) if kind == 'E' else G.view_col(q[l], j)
+                        if col < 0:
+                            continue
+                        val = np.float32(src[c * 16 + n[l], col]) * np.float32(act)
+                        H[l, j] = np.float16(val)
+                        Lo[l, j] = np.float16(val - np.float32(H[l, j]))
+                hn, ln = (('eh%d%d' % (ee, c), 'el%d%d' % (ee, c)) if kind == 'E' else ('vh%d' % c, 'vl%d' % c))
+                fr[hn] = H.view(np.uint32).T.copy()
+                fr[ln] = Lo.view(np.uint32).T.copy()
+    return fr
+
+
+def test_three_column_tiles_layout_and_committed_text(tmp_path):
+    assert G3.X1 and G3.NC == 3 and G3.N_ANCH == 3948 and G3.NCH == 44 and G3.STREAM_BYTES == GX.STREAM_BYTES
+    assert len(G3.INPUT_NAMES) == 18 and G3.N_VGPR_CLOBBER + 12 <= 256 and G3.A_E + 72 <= 256
+    t = T.make_tensors(seed=9)
+    assert np.array_equal(G3.pack_teacher(t)[0], GX.pack_teacher(t)[0])          # the weight stream does not know about the tiling
+    G3.emit(str(tmp_path), G3.Opts())
+    for name in ('nerf_mlpx3_asm.inc', 'nerf_mlpx3_pro_asm.inc', 'nerf_mlpx3_clobbers.inc', 'nerf_mlpx3_pro_clobbers.inc'):
+        built = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)
+        assert open(os.path.join(str(tmp_path), name)).read() == open(built).read(), name
+
+
+@pytest.mark.parametrize('wave,n_tiles,gain', [(0, 1, 1.0), (2, 2, 1.5)])
+def test_emulated_three_column_chain_vs_float64(wave, n_tiles, gain):
+    t = T.make_tensors(seed=wave, gain=gain)
+    rng = np.random.default_rng(20 + wave)
+    pts = rng.uniform(-2.5, 2.5, size=(48, 3)).astype(np.float32)
+    vd = rng.normal(size=(48, 3))
+    vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
+    ref, e, v = T.ref_mlp(t, pts, vd)
+    f16_err = np.abs(T.ref_mlp(t, pts, vd, f16_ops=True)[0] - ref).max()
+    buf, aux_off = cxx_pack_x(t)
+    out, errs = G3.emulate_tile(G3.Opts(), buf[:aux_off], buf[aux_off:], make_frags_nc(G3, e, v, 16.0), wave=wave, n_tiles=n_tiles)
+    assert not errs, errs[:10]
+    got = np.zeros((48, 4))
+    for c in range(3):
+        for k in range(4):
+            got[c * 16:(c + 1) * 16, k] = out[c * 4 + k][:16] / 16.0
+    err = np.abs(got - ref).max()
+    print('wave %d: L_inf %.3g (single-pass fp16 operands in float64: %.3g)' % (wave, err, f16_err))
+    assert err <= 1.5 * f16_err and err < 3e-4 * max(1.0, np.abs(ref).max())
+    kinds = {}
+    for ins in G3.block_stream(G3.Opts()):
+        kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
+    assert kinds['mfma16'] == 3948 and 'mfma6' not in kinds and kinds['ds'] == 1398       # the reads of two column tiles feed three
