@@ -528,6 +528,9 @@ class Opts:
         self.dma_gap = 4       # anchors (16-cycle MFMAs) between two LDS-DMA pieces: 4 .. 6 are 1.7 % faster than 3, 2 is slower
         self.pair = False
         self.wait_group = 2    # fp16 fragments one s_waitcnt may cover (those already issued)
+        if NC == 3:            # three MFMAs per fragment: fewer filler slots behind each, LDS-DMA pieces further apart (same-box sweep:
+            self.cap = 2       # cap 2 / 3 / 4 / 5 = 36.9 / 37.2 / 37.3 / 37.6 ms per frame, gap 3 / 4 / 6 = 37.5 / 37.2 / 36.9, both: -1.4 %)
+            self.dma_gap = 6
         self.__dict__.update(kw)
 
 
@@ -893,16 +896,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--emit', help='directory for nerf_mlp_asm.inc / nerf_mlp_pro_asm.inc')
     ap.add_argument('--dump', help='write the tile block as plain text')
-    ap.add_argument('--lead', type=int, default=8)
-    ap.add_argument('--lead6', type=int, default=5)
-    ap.add_argument('--cap', type=int, default=3)
-    ap.add_argument('--dma-gap', type=int, default=4)
-    ap.add_argument('--wait-group', type=int, default=2)
+    ap.add_argument('--lead', type=int)
+    ap.add_argument('--lead6', type=int)
+    ap.add_argument('--cap', type=int)
+    ap.add_argument('--dma-gap', type=int)
+    ap.add_argument('--wait-group', type=int)
     ap.add_argument('--pair', action='store_true', help='fillers only behind the second MFMA of a column-tile pair')
     ap.add_argument('--drop', default='', help='diagnostics only: comma list of instruction classes left out of the emitted '
                     'text (lgkm, dma, valu, ds, mfma6, mfma16, salu, nop): timing knock-outs, wrong results')
     a = ap.parse_args()
-    opts = Opts(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap, pair=a.pair, wait_group=a.wait_group, drop=tuple(x for x in a.drop.split(',') if x))
+    given = {k: v for k, v in dict(lead=a.lead, lead6=a.lead6, cap=a.cap, dma_gap=a.dma_gap, wait_group=a.wait_group).items() if v is not None}
+    opts = Opts(pair=a.pair, drop=tuple(x for x in a.drop.split(',') if x), **given)
     print('format', FMT, 'tiles', NT, 'chunks', NCH, 'MFMAs', N_ANCH, 'stream bytes', STREAM_BYTES)
     if a.emit:
         n, body = emit(a.emit, opts)

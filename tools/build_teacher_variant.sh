@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 d=$root/build_variants/$name
 mkdir -p $d
 cp $root/efficient-nerf_amd/csrc/*.hip $root/efficient-nerf_amd/csrc/*.h $root/efficient-nerf_amd/csrc/*.inc $d/
-python3 $root/efficient-nerf_amd/csrc/gen/nerf_gen.py --emit $d "$@" | tail -1
+python3 $root/efficient-nerf_amd/csrc/gen/nerf_gen.py --emit $d "$@" | tail -1   # NERF_GEN_FMT=f16 / f16c3 in the environment selects which chain the options regenerate
 sed -i 's#"../../include/r2l_hip.h"#"'$root'/include/r2l_hip.h"#' $d/*.hip
 cd $d
 for f in r2l_kernels r2l_body r2l_capi r2l_comm nerf_capi np_shuffle r2l_generic; do cp $root/efficient-nerf_amd/csrc/$f.o $f.o; done
