@@ -75,27 +75,32 @@ ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # correction terms -- one fp16 pass on the 256-wide sources (the embedding k-steps keep their three passes): no K=128 MFMA, no
 # bf6 operand in the stream (1.27 MB per tile instead of 2.17, in 44 chunks instead of 80), no residuals and no 32-wide conversions in the epilogues.
 # R2L_PREC_FP16X1 of the teacher: 1-3e-5 on rgb over whole frames (profiles/r04_teacher_x1.txt), `--precision auto`'s first rung.
-# NERF_GEN_FMT=f16c3: the f16 chain with THREE column tiles of 16 points per wave (192 points per workgroup tile): every weight
-# fragment read from LDS feeds three MFMAs instead of two and the stream is fetched once per 192 points -- what the bf6 chain has no
-# registers for fits once the bf6 operand sets are gone: activation set P in VGPRs, set Q in AGPRs (an MFMA takes B from
-# either file; Q's epilogues pay one v_accvgpr_write per packed register).
+# NERF_GEN_FMT=f16c3 / f16c4: the f16 chain with THREE / FOUR column tiles of 16 points per wave (192 / 256 points per workgroup tile):
+# every weight fragment read from LDS feeds three / four MFMAs instead of two and the stream is fetched once per 192 / 256 points --
+# what the bf6 chain has no registers for fits once the bf6 operand sets are gone: activation set P in VGPRs, set Q in
+# AGPRs (an MFMA takes B from either file; Q's epilogues pay one v_accvgpr_write per packed register).  Four is the most that fits:
+# 224 VGPRs + 16 outputs, 128 + 96 AGPRs.
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
-assert FMT in ('bf6', 'f16', 'f16c3'), FMT
+assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4'), FMT
 X1 = FMT != 'bf6'
-NC = 3 if FMT == 'f16c3' else 2          # column tiles (16 points each) per wave
-SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3'}[FMT]     # nerf_mlpx_asm.inc ...
-if NC == 3:
+NC = {'f16c3': 3, 'f16c4': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
+SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4'}[FMT]     # nerf_mlpx_asm.inc ...
+if NC > 2:
     V_SET = {'P': 0}              # fp16 B operands of set P (VGPR): + c*32 + s*4
     A_SETH = {'Q': 0}             # ... of set Q (AGPR)
-    V_ACC, V_BIAS, V_HI, V_TMP = 96, 120, 128, 144       # ACC: + p*12 + c*4; TMP: + c*6
+    V_ACC = 32 * NC               # + p*4*NC + c*4
+    V_BIAS = V_ACC + 8 * NC
+    V_HI = V_BIAS + 8
+    V_TMP = V_HI + 16             # + c*6
     V_A6 = V_LO = None
-    V_L0, V_L1, V_L8A, V_L8B, V_AUX, V_LANE = 162, 163, 164, 165, 166, 167
-    V_SBA, V_SBL, V_CVA, V_CVL = 168, 169, 170, 171
-    V_SC = 172
-    V_LOFF = 176
-    N_VGPR_CLOBBER = 180
-    A_E = 96
-    N_AGPR_CLOBBER = 96
+    _m = V_TMP + 6 * NC
+    V_L0, V_L1, V_L8A, V_L8B, V_AUX, V_LANE = _m, _m + 1, _m + 2, _m + 3, _m + 4, _m + 5
+    V_SBA, V_SBL, V_CVA, V_CVL = _m + 6, _m + 7, _m + 8, _m + 9
+    V_SC = _m + 10
+    V_LOFF = _m + 14
+    N_VGPR_CLOBBER = (_m + 15 + 3) // 4 * 4
+    A_E = 32 * NC
+    N_AGPR_CLOBBER = 32 * NC
 else:
     A_SETH = {}
 
@@ -528,9 +533,9 @@ class Opts:
         self.dma_gap = 4       # anchors (16-cycle MFMAs) between two LDS-DMA pieces: 4 .. 6 are 1.7 % faster than 3, 2 is slower
         self.pair = False
         self.wait_group = 2    # fp16 fragments one s_waitcnt may cover (those already issued)
-        if NC == 3:            # three MFMAs per fragment: fewer filler slots behind each, LDS-DMA pieces further apart (same-box sweep:
+        if NC > 2:             # three (four) MFMAs per fragment: fewer filler slots behind each, LDS-DMA pieces further apart (same-box sweep:
             self.cap = 2       # cap 2 / 3 / 4 / 5 = 36.9 / 37.2 / 37.3 / 37.6 ms per frame, gap 3 / 4 / 6 = 37.5 / 37.2 / 36.9, both: -1.4 %)
-            self.dma_gap = 6
+            self.dma_gap = 2 * NC          # (four column tiles: gap 4 / 6 / 8 = 34.75 / 34.35 / 34.2 ms)
         self.__dict__.update(kw)
 
 

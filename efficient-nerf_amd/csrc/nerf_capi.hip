@@ -444,7 +444,7 @@ int nerf_set_precision(nerf_ctx* c, int mode) {
     return R2L_OK;
 }
 
-static int g_x1_col_tiles = 3;     // nerf_debug_set_x1_col_tiles: 2 = the 128-point tiles of the other modes (A/B)
+static int g_x1_col_tiles = 4;     // nerf_debug_set_x1_col_tiles: 3 or 2 (= the 128-point tiles of the other modes) for the A/B
 
 static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* rays_d, const float* z, int z_stride,
                    int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr) {
@@ -577,7 +577,7 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
 }
 
 int nerf_debug_set_x1_col_tiles(int n) {
-    if (n != 2 && n != 3) return r2l_set_error(R2L_EINVAL, "column tiles per wave: 2 or 3");
+    if (n < 2 || n > 4) return r2l_set_error(R2L_EINVAL, "column tiles per wave: 2, 3 or 4");
     g_x1_col_tiles = n;
     return R2L_OK;
 }

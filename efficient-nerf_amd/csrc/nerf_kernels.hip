@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // NC = 3 (X1 only, NERF_GEN_FMT=f16c3 -> nerf_mlpx3_*.inc): three column tiles of 16 points per wave, 192 points per workgroup tile.
 template <bool X1, int NC>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
-    static_assert(NC == 2 || (X1 && NC == 3), "three column tiles exist for the fp16-only chain");
+    static_assert(NC == 2 || (X1 && (NC == 3 || NC == 4)), "three / four column tiles exist for the fp16-only chain");
     extern __shared__ __attribute__((aligned(16))) char nerf_chain_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -318,7 +318,15 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
         for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    if constexpr (X1 && NC == 3) {
+    if constexpr (X1 && NC == 4) {
+        asm volatile(
+#include "nerf_mlpx4_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpx4_pro_clobbers.inc"
+        );
+    } else if constexpr (X1 && NC == 3) {
         asm volatile(
 #include "nerf_mlpx3_pro_asm.inc"
             :
@@ -365,7 +373,18 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
             : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),             \
               [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),       \
               [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
-        if constexpr (X1 && NC == 3) {
+        if constexpr (X1 && NC == 4) {
+            asm volatile(
+#include "nerf_mlpx4_asm.inc"
+                NERF_CHAIN_OUT2, [o8] "=&v"(o[8]), [o9] "=&v"(o[9]), [o10] "=&v"(o[10]), [o11] "=&v"(o[11]), [o12] "=&v"(o[12]),
+                  [o13] "=&v"(o[13]), [o14] "=&v"(o[14]), [o15] "=&v"(o[15])
+                NERF_CHAIN_IN2, [eh02] "a"(Eh[0][2]), [eh12] "a"(Eh[1][2]), [el02] "a"(El[0][2]), [el12] "a"(El[1][2]),
+                  [vh2] "a"(Vh[0][2]), [vl2] "a"(Vl[0][2]), [eh03] "a"(Eh[0][3]), [eh13] "a"(Eh[1][3]), [el03] "a"(El[0][3]),
+                  [el13] "a"(El[1][3]), [vh3] "a"(Vh[0][3]), [vl3] "a"(Vl[0][3])
+                :
+#include "nerf_mlpx4_clobbers.inc"
+            );
+        } else if constexpr (X1 && NC == 3) {
             asm volatile(
 #include "nerf_mlpx3_asm.inc"
                 NERF_CHAIN_OUT2, [o8] "=&v"(o[8]), [o9] "=&v"(o[9]), [o10] "=&v"(o[10]), [o11] "=&v"(o[11])
@@ -928,11 +947,12 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
 }
 
 hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles) {
-    static std::atomic<bool> attr_set[4][64];  // zero-initialised; the opt-in call itself is idempotent
+    static std::atomic<bool> attr_set[5][64];  // zero-initialised; the opt-in call itself is idempotent
     if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel<false, 2>, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X3) return launch_big_lds(&nerf_mlp_kernel<2>, attr_set[1], KCfg<2>::LDS, p, grid, stream);
     // FP16X1: the generated chain without correction terms (round 4; the compiler-scheduled nerf_mlp_kernel<1> it replaces: 49.5 ms per
     // frame), with three column tiles per wave (192-point workgroup tiles: p.n_tiles counts those) or two
+    if (x1_col_tiles == 4) return launch_big_lds(&nerf_chain_kernel<true, 4>, attr_set[4], NERF_CHAIN_LDS, p, grid, stream);
     if (x1_col_tiles == 3) return launch_big_lds(&nerf_chain_kernel<true, 3>, attr_set[3], NERF_CHAIN_LDS, p, grid, stream);
     return launch_big_lds(&nerf_chain_kernel<true, 2>, attr_set[2], NERF_CHAIN_LDS, p, grid, stream);
 }

@@ -40,6 +40,7 @@ def _load_x(fmt='f16'):
 
 GX = _load_x()
 G3 = _load_x('f16c3')      # three 16-point column tiles per wave: the same stream, 192-point tiles, activation set Q in AGPRs
+G4 = _load_x('f16c4')      # four: 256-point tiles (what R2L_PREC_FP16X1 launches)
 
 
 def cxx_pack_x(tensors):
@@ -113,7 +114,7 @@ def test_stream_has_no_correction_terms():
     assert not any('bf6' in ins.text for ins in body)
 
 
-# ---- f16c3: three column tiles per wave (what R2L_PREC_FP16X1 launches) -------------------------------------------------------
+# ---- f16c3 / f16c4: three / four column tiles per wave (four is what R2L_PREC_FP16X1 launches) -------------------------------------------------------
 def make_frags_nc(G, e, v, act):
     """test_nerf_gen_cpu.make_frags for G.NC column tiles: e [16 NC, 63], v [16 NC, 27] -> {name: uint32 [4, 64]}"""
     lanes = np.arange(64)
@@ -138,37 +139,41 @@ def make_frags_nc(G, e, v, act):
     return fr
 
 
-def test_three_column_tiles_layout_and_committed_text(tmp_path):
-    assert G3.X1 and G3.NC == 3 and G3.N_ANCH == 3948 and G3.NCH == 44 and G3.STREAM_BYTES == GX.STREAM_BYTES
-    assert len(G3.INPUT_NAMES) == 18 and G3.N_VGPR_CLOBBER + 12 <= 256 and G3.A_E + 72 <= 256
+@pytest.mark.parametrize('G', [G3, G4], ids=['three', 'four'])
+def test_more_column_tiles_layout_and_committed_text(G, tmp_path):
+    nc = G.NC
+    assert G.X1 and G.N_ANCH == 1316 * nc and G.NCH == 44 and G.STREAM_BYTES == GX.STREAM_BYTES
+    assert len(G.INPUT_NAMES) == 6 * nc and G.N_VGPR_CLOBBER + 4 * nc <= 256 and G.A_E + 24 * nc <= 256
     t = T.make_tensors(seed=9)
-    assert np.array_equal(G3.pack_teacher(t)[0], GX.pack_teacher(t)[0])          # the weight stream does not know about the tiling
-    G3.emit(str(tmp_path), G3.Opts())
-    for name in ('nerf_mlpx3_asm.inc', 'nerf_mlpx3_pro_asm.inc', 'nerf_mlpx3_clobbers.inc', 'nerf_mlpx3_pro_clobbers.inc'):
-        built = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)
-        assert open(os.path.join(str(tmp_path), name)).read() == open(built).read(), name
+    assert np.array_equal(G.pack_teacher(t)[0], GX.pack_teacher(t)[0])          # the weight stream does not know about the tiling
+    G.emit(str(tmp_path), G.Opts())
+    for name in ('nerf_mlpx%d_asm.inc', 'nerf_mlpx%d_pro_asm.inc', 'nerf_mlpx%d_clobbers.inc', 'nerf_mlpx%d_pro_clobbers.inc'):
+        built = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name % nc)
+        assert open(os.path.join(str(tmp_path), name % nc)).read() == open(built).read(), name % nc
 
 
-@pytest.mark.parametrize('wave,n_tiles,gain', [(0, 1, 1.0), (2, 2, 1.5)])
-def test_emulated_three_column_chain_vs_float64(wave, n_tiles, gain):
+@pytest.mark.parametrize('G,wave,n_tiles,gain', [(G3, 0, 1, 1.0), (G3, 2, 2, 1.5), (G4, 1, 1, 1.0), (G4, 3, 2, 1.5)])
+def test_emulated_wider_chain_vs_float64(G, wave, n_tiles, gain):
+    G3 = G
+    npt = 16 * G.NC
     t = T.make_tensors(seed=wave, gain=gain)
     rng = np.random.default_rng(20 + wave)
-    pts = rng.uniform(-2.5, 2.5, size=(48, 3)).astype(np.float32)
-    vd = rng.normal(size=(48, 3))
+    pts = rng.uniform(-2.5, 2.5, size=(npt, 3)).astype(np.float32)
+    vd = rng.normal(size=(npt, 3))
     vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
     ref, e, v = T.ref_mlp(t, pts, vd)
     f16_err = np.abs(T.ref_mlp(t, pts, vd, f16_ops=True)[0] - ref).max()
     buf, aux_off = cxx_pack_x(t)
     out, errs = G3.emulate_tile(G3.Opts(), buf[:aux_off], buf[aux_off:], make_frags_nc(G3, e, v, 16.0), wave=wave, n_tiles=n_tiles)
     assert not errs, errs[:10]
-    got = np.zeros((48, 4))
-    for c in range(3):
+    got = np.zeros((npt, 4))
+    for c in range(G.NC):
         for k in range(4):
             got[c * 16:(c + 1) * 16, k] = out[c * 4 + k][:16] / 16.0
     err = np.abs(got - ref).max()
-    print('wave %d: L_inf %.3g (single-pass fp16 operands in float64: %.3g)' % (wave, err, f16_err))
+    print('%d column tiles, wave %d: L_inf %.3g (single-pass fp16 operands in float64: %.3g)' % (G.NC, wave, err, f16_err))
     assert err <= 1.5 * f16_err and err < 3e-4 * max(1.0, np.abs(ref).max())
     kinds = {}
     for ins in G3.block_stream(G3.Opts()):
         kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
-    assert kinds['mfma16'] == 3948 and 'mfma6' not in kinds and kinds['ds'] == 1398       # the reads of two column tiles feed three
+    assert kinds['mfma16'] == 1316 * G.NC and 'mfma6' not in kinds and kinds['ds'] == 1398       # the reads of two column tiles feed three / four
