@@ -39,8 +39,8 @@ extern "C" {
  *   R2L_PREC_FP16X1  single pass on fp16-rounded operands, 3x fewer MFMAs.  R2L student: L_inf ~4e-4, outside the contract
  *                    (compiler-scheduled kernel, kept for reference).  NeRF teacher: 0.6-1.6e-5 on rgb over whole frames
  *                    (eleven layers, compositing over 192 samples) -- its FAST mode since round 4: the generated layer chain
- *                    without correction terms (nerf_chain_kernel<true, 3>: three 16-point column tiles per wave, embedding k-steps
- *                    still three passes), 0.51-0.535 of the fp16 MFMA peak; the front end's `--precision auto` measures it against FP16X3 per checkpoint.
+ *                    without correction terms (nerf_chain_kernel<true, 4>: four 16-point column tiles per wave, embedding k-steps
+ *                    still three passes), 0.55-0.57 of the fp16 MFMA peak; the front end's `--precision auto` measures it against FP16X3 per checkpoint.
  *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the block-scaled
  *                    low-precision MFMA (v_mfma_scale_f32_*_f8f6f4) with both operands in OCP bf6 (e3m2)
  *                    at 4x the fp16 rate: 1.5 pass-equivalents per k-step, L_inf ~3e-5 (< 1e-4).
@@ -305,7 +305,7 @@ int nerf_render_rays_ex(nerf_ctx* ctx, const float* rays_o_dev, const float* ray
 /* parity tests / A-B timing: 1 = the coarse pass's raw2outputs, sample_pdf and merge as three launches instead of the one fused
  * launch of the deterministic path (nerf_coarse_scan_kernel); the results are bit-identical */
 int nerf_debug_set_split_scans(nerf_ctx* ctx, int on);
-/* A-B timing: 16-point column tiles per wave of the FP16X1 chain, 3 (default: 192-point workgroup tiles) or 2 (128); process-wide */
+/* A-B timing: 16-point column tiles per wave of the FP16X1 chain, 4 (default: 256-point workgroup tiles), 3 (192) or 2 (128); process-wide */
 int nerf_debug_set_x1_col_tiles(int n);
 int nerf_timing_enable(nerf_ctx* ctx, int on);
 int nerf_kernel_time_ms(nerf_ctx* ctx, double* total_ms, int* n_launches, int reset);
