@@ -95,10 +95,9 @@ if NC > 2:
     V_A6 = V_LO = None
     _m = V_TMP + 6 * NC
     V_L0, V_L1, V_L8A, V_L8B, V_AUX, V_LANE = _m, _m + 1, _m + 2, _m + 3, _m + 4, _m + 5
-    V_SBA, V_SBL, V_CVA, V_CVL = _m + 6, _m + 7, _m + 8, _m + 9
-    V_SC = _m + 10
-    V_LOFF = _m + 14
-    N_VGPR_CLOBBER = (_m + 15 + 3) // 4 * 4
+    V_SBA = V_SBL = V_CVA = V_CVL = V_SC = None        # scales and divisors of the bf6 terms: not in this chain
+    V_LOFF = _m + 6
+    N_VGPR_CLOBBER = (_m + 7 + 3) // 4 * 4
     A_E = 32 * NC
     N_AGPR_CLOBBER = 32 * NC
 else:
@@ -791,10 +790,11 @@ def setup_ops():
     a('v_lshrrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_LANE)))
     a('v_lshlrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_AUX)))
     a('v_add_u32 %s, 0x%x, %s' % (vreg(V_AUX), LDS_AUX, vreg(V_AUX)))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBA), 0x01010101 * (127 + ACT_EXP)))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBL), 0x01010101 * (127 + RES_EXP)))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVA), f32_bits(2.0 ** ACT_EXP)))
-    a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVL), f32_bits(2.0 ** RES_EXP)))
+    if V_SBA is not None:
+        a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBA), 0x01010101 * (127 + ACT_EXP)))
+        a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBL), 0x01010101 * (127 + RES_EXP)))
+        a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVA), f32_bits(2.0 ** ACT_EXP)))
+        a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVL), f32_bits(2.0 ** RES_EXP)))
 
     def emu(st):
         lanes = np.arange(64, dtype=np.uint32)
@@ -805,10 +805,11 @@ def setup_ops():
         st.V[V_L8A] = lanes * 8
         st.V[V_L8B] = lanes * 8 + 65536
         st.V[V_AUX] = LDS_AUX + (lanes >> 4) * 16
-        st.V[V_SBA] = 0x01010101 * (127 + ACT_EXP)
-        st.V[V_SBL] = 0x01010101 * (127 + RES_EXP)
-        st.V[V_CVA] = f32_bits(2.0 ** ACT_EXP)
-        st.V[V_CVL] = f32_bits(2.0 ** RES_EXP)
+        if V_SBA is not None:
+            st.V[V_SBA] = 0x01010101 * (127 + ACT_EXP)
+            st.V[V_SBL] = 0x01010101 * (127 + RES_EXP)
+            st.V[V_CVA] = f32_bits(2.0 ** ACT_EXP)
+            st.V[V_CVL] = f32_bits(2.0 ** RES_EXP)
         st.S[S_W] = 0
         for k in range(8):
             st.S[S_WPW + k] = st.wave * (k + 1) * 1024

@@ -462,7 +462,9 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     p.n_pts = (long long)n * S;
     if (p.n_pts >= (1ll << 31))   // the kernels index points with 32 bits
         return r2l_set_error(R2L_EINVAL, "%d rays x %d samples: more than 2^31 points in one call; render fewer rows at a time", n, S);
-    const int x1_nc = c->mode == R2L_PREC_FP16X1 ? g_x1_col_tiles : 2;     // the fp16-only chain: 192-point tiles (three column tiles per wave)
+    // the fp16-only chain: 256-point tiles (four column tiles per wave); with given view directions (NDC renders) 192: the four-tile
+    // build has no register left to carry the next tile's directions across its asm block
+    const int x1_nc = c->mode == R2L_PREC_FP16X1 ? ((viewdirs && g_x1_col_tiles == 4) ? 3 : g_x1_col_tiles) : 2;
     const int tile_pts = 64 * x1_nc;
     p.n_tiles = (int)((p.n_pts + tile_pts - 1) / tile_pts);
     p.act_scale = c->act_scale;

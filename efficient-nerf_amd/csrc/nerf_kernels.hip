@@ -117,15 +117,15 @@ __device__ __forceinline__ void mlp_layer(Ring<NP>& R, const ActSet& S, const f1
 //   nerf_tile_load   ray origin / direction / depth (and the given view direction) of the lane's two points
 //   nerf_tile_embed  pts = rays_o + rays_d * z (main.py:701), view directions (main.py:148-162) and the fragments of both
 //                    embeddings (nerf_common.h: nerf_pts_col / nerf_view_col), act_scale folded in, fp16 hi | lo B operands
-template <int NC>
-struct NerfTileRawT {       // NC column tiles of 16 points per wave (2: 128-point workgroup tiles; 3: 192, the fp16x1 chain)
-    float o[NC][3], d[NC][3], v[NC][3], z[NC];
+template <int NC, bool VD = true>
+struct NerfTileRawT {       // NC column tiles of 16 points per wave (2: 128-point workgroup tiles; 3 / 4: 192 / 256, the fp16x1 chain)
+    float o[NC][3], d[NC][3], v[VD ? NC : 1][3], z[NC];      // VD = false: no given view directions (they are rays_d / |rays_d|)
 };
 typedef NerfTileRawT<2> NerfTileRaw;
 
 // n_pts < 2^31 (checked by the host): 32-bit point and ray indices
-template <int NC>
-__device__ __forceinline__ void nerf_tile_load(const NerfMlpParams& p, int tile, int wave, int lane, NerfTileRawT<NC>& r) {
+template <int NC, bool VD>
+__device__ __forceinline__ void nerf_tile_load(const NerfMlpParams& p, int tile, int wave, int lane, NerfTileRawT<NC, VD>& r) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const unsigned pt_raw = (unsigned)tile * (64 * NC) + wave * (16 * NC) + c * 16 + (lane & 15);
@@ -137,14 +137,14 @@ __device__ __forceinline__ void nerf_tile_load(const NerfMlpParams& p, int tile,
         for (int k = 0; k < 3; ++k) {
             r.o[c][k] = p.rays_o[(size_t)ray * 3 + k];
             r.d[c][k] = p.rays_d[(size_t)ray * 3 + k];
-            r.v[c][k] = p.viewdirs ? p.viewdirs[(size_t)ray * 3 + k] : 0.0f;
+            if constexpr (VD) r.v[c][k] = p.viewdirs ? p.viewdirs[(size_t)ray * 3 + k] : 0.0f;
         }
         r.z[c] = p.z[(size_t)ray * p.z_stride + smp];
     }
 }
 
-template <int NP, int NC = 2>
-__device__ __forceinline__ void nerf_tile_embed(const NerfMlpParams& p, const NerfTileRawT<NC>& r, int lane, f16x8 (&Eh)[2][NC],
+template <int NP, int NC = 2, bool VD = true>
+__device__ __forceinline__ void nerf_tile_embed(const NerfMlpParams& p, const NerfTileRawT<NC, VD>& r, int lane, f16x8 (&Eh)[2][NC],
                                                 f16x8 (&El)[2][NC], f16x8 (&Vh)[2][NC], f16x8 (&Vl)[2][NC]) {
     const int q = lane >> 4;
     const float act_scale = p.act_scale;
@@ -158,7 +158,8 @@ __device__ __forceinline__ void nerf_tile_embed(const NerfMlpParams& p, const Ne
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             xs[k] = __fadd_rn(r.o[c][k], __fmul_rn(d[k], r.z[c]));  // rays_o + rays_d * z  (main.py:701)
-            vs[k] = p.viewdirs ? r.v[c][k] : __fdiv_rn(d[k], nrm);
+            if constexpr (VD) vs[k] = p.viewdirs ? r.v[c][k] : __fdiv_rn(d[k], nrm);
+            else vs[k] = __fdiv_rn(d[k], nrm);
         }
         const Rev r0 = to_rev(xs[0]), r1 = to_rev(xs[1]), r2 = to_rev(xs[2]);
         {   // E step 0: coordinate q>>1, frequencies 0..7, sin|cos by q&1
@@ -352,8 +353,11 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
         );
     }
     const float inv = 1.0f / p.act_scale;
-    NerfTileRawT<NC> raw;
-    if ((int)blockIdx.x < p.n_tiles) nerf_tile_load<NC>(p, blockIdx.x, wave, lane, raw);
+    // four column tiles leave no register for the given view directions of the NEXT tile (they travel across the asm block): that
+    // build takes them as rays_d / |rays_d| only; renders with given directions (NDC) launch the three-tile build (nerf_launch_mlp)
+    constexpr bool VD = NC != 4;
+    NerfTileRawT<NC, VD> raw;
+    if ((int)blockIdx.x < p.n_tiles) nerf_tile_load<NC, VD>(p, blockIdx.x, wave, lane, raw);
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         f16x8 Eh[2][NC], El[2][NC], Vh[2][NC], Vl[2][NC];
 #ifdef NERF_SKIP_EMBED      // diagnostics only (wrong results): what the un-overlapped embedding prologue costs (tools/build_teacher_variant.sh)
@@ -361,10 +365,10 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
             for (int c = 0; c < NC; ++c)
                 for (int j = 0; j < 8; ++j) Eh[e][c][j] = El[e][c][j] = Vh[e][c][j] = Vl[e][c][j] = (f16)(raw.o[c][0] * (float)(e + j));
 #else
-        nerf_tile_embed<2, NC>(p, raw, lane, Eh, El, Vh, Vl);
+        nerf_tile_embed<2, NC, VD>(p, raw, lane, Eh, El, Vh, Vl);
 #endif
         // the next tile's rays and depths travel while this tile's layers run (the values wait in AGPRs)
-        if (tile + (int)gridDim.x < p.n_tiles) nerf_tile_load<NC>(p, tile + gridDim.x, wave, lane, raw);
+        if (tile + (int)gridDim.x < p.n_tiles) nerf_tile_load<NC, VD>(p, tile + gridDim.x, wave, lane, raw);
         float o[4 * NC];
 #define NERF_CHAIN_OUT2                                                                                                           \
             : [o0] "=&v"(o[0]), [o1] "=&v"(o[1]), [o2] "=&v"(o[2]), [o3] "=&v"(o[3]), [o4] "=&v"(o[4]), [o5] "=&v"(o[5]),         \
