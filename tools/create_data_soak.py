@@ -15,14 +15,14 @@ import torch  # noqa: E402
 import _pkg  # noqa: E402
 
 _pkg.load()
-from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8  # noqa: E402
+from efficient_nerf_amd import NeRFEngine, PRECISIONS  # noqa: E402
 from efficient_nerf_amd.create_data import RandStream, create_rand  # noqa: E402
 from oracle import r2l_oracle as O  # noqa: E402
 
 n_pose = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 focal = O.focal_from_angle(H)
-eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+eng = NeRFEngine(H, H, focal, precision=PRECISIONS[os.environ.get("CD_PREC", "fp16x1")]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
 
 
 def digest(d):
