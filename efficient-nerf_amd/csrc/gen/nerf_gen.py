@@ -85,6 +85,11 @@ assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4'), FMT
 X1 = FMT != 'bf6'
 NC = {'f16c3': 3, 'f16c4': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
 SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4'}[FMT]     # nerf_mlpx_asm.inc ...
+# passes of an embedding k-step: hi(W) hi(E), hi(W) lo(E), lo(W) hi(E).  The fp16-only chains drop the third (their 256-wide layers
+# carry no lo(W) term either; measured over whole frames, three seed pairs x three poses: rgb 6.5e-6 .. 1.9e-5 from fp16x3 with two
+# passes against 6.4e-6 .. 1.6e-5 with three, -4.4 % time; ONE pass -- no lo(E), i.e. fp16-rounded coordinates -- reads 1.3 .. 2.8e-5
+# for another -4 % and is not taken).  The stream keeps the lo(W) fragments (unread: 72 of 1,298 KiB).  NERF_GEN_XPASS overrides.
+XPASS = int(os.environ.get('NERF_GEN_XPASS', '2' if X1 else '3'))
 if NC > 2:
     V_SET = {'P': 0}              # fp16 B operands of set P (VGPR): + c*32 + s*4
     A_SETH = {'Q': 0}             # ... of set Q (AGPR)
@@ -417,7 +422,7 @@ def tile_anchors(L):
     1 Wh x El, 2 Wl x Eh), then ('m16', s, c, 0) and, behind the last nj main k-steps, ('m6', j, c, 0)"""
     out = []
     for xi in range(L.nx):
-        for p in range(3):
+        for p in range(XPASS):
             for c in range(NC):
                 out.append(('x', xi, c, p))
     for s in range(L.ks):

@@ -59,7 +59,7 @@ def cxx_pack_x(tensors):
 
 
 def test_layout_constants():
-    assert GX.X1 and GX.NCH == 44 and GX.NCH % GX.NSLOT == 0 and GX.N_ANCH == 2632 and GX.NT == 154
+    assert GX.X1 and GX.NCH == 44 and GX.NCH % GX.NSLOT == 0 and GX.N_ANCH == 2488 and GX.XPASS == 2 and GX.NT == 154
     assert GX.STREAM_BYTES == 1298432          # NERF_CHAINX_STREAM_BYTES (csrc/nerf_common.h)
     assert T.G.STREAM_BYTES == 2166784 and not T.G.X1      # the other instance is untouched
 
@@ -109,7 +109,7 @@ def test_stream_has_no_correction_terms():
     kinds = {}
     for ins in body:
         kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
-    assert kinds['mfma16'] == 2632 and 'mfma6' not in kinds and kinds['barrier'] == GX.NCH + 1
+    assert kinds['mfma16'] == 2488 and 'mfma6' not in kinds and kinds['barrier'] == GX.NCH + 1      # 2,632 less the lo(W) pass of the 72 embedding k-step tiles
     assert kinds['dma'] == sum(GX.CHUNKS[(c + 3) % GX.NCH]['pw'] for c in range(GX.NCH))
     assert not any('bf6' in ins.text for ins in body)
 
@@ -142,7 +142,7 @@ def make_frags_nc(G, e, v, act):
 @pytest.mark.parametrize('G', [G3, G4], ids=['three', 'four'])
 def test_more_column_tiles_layout_and_committed_text(G, tmp_path):
     nc = G.NC
-    assert G.X1 and G.N_ANCH == 1316 * nc and G.NCH == 44 and G.STREAM_BYTES == GX.STREAM_BYTES
+    assert G.X1 and G.N_ANCH == 1244 * nc and G.NCH == 44 and G.STREAM_BYTES == GX.STREAM_BYTES
     assert len(G.INPUT_NAMES) == 6 * nc and G.N_VGPR_CLOBBER + 4 * nc <= 256 and G.A_E + 24 * nc <= 256
     t = T.make_tensors(seed=9)
     assert np.array_equal(G.pack_teacher(t)[0], GX.pack_teacher(t)[0])          # the weight stream does not know about the tiling
@@ -176,4 +176,4 @@ def test_emulated_wider_chain_vs_float64(G, wave, n_tiles, gain):
     kinds = {}
     for ins in G3.block_stream(G3.Opts()):
         kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
-    assert kinds['mfma16'] == 1316 * G.NC and 'mfma6' not in kinds and kinds['ds'] == 1398       # the reads of two column tiles feed three / four
+    assert kinds['mfma16'] == 1244 * G.NC and 'mfma6' not in kinds and kinds['ds'] == 1326       # the reads of two column tiles feed three / four
