@@ -223,7 +223,7 @@ class NeRFEngine:
         set, are rendered coarse + fine in fp16x3 and in the candidates, fastest first:
           fp16x1    the generated layer chain WITHOUT correction terms: one fp16 pass on the 256-wide sources (1.0 pass-equivalents).
                     Eleven layers and the compositing over 192 samples average its rounding errors to ~1e-5 on rgb where the
-                    88-layer R2L student ends at 3.5e-4 -- for the teacher it is the fast mode (34.3-35.3 ms per 400 x 400 frame);
+                    88-layer R2L student ends at 3.5e-4 -- for the teacher it is the fast mode (33.4-35 ms per 400 x 400 frame);
           fp16_fp8  the generated layer chain, fp16 + bf6 correction terms (1.5 pass-equivalents, ~1e-6), for weights whose
                     single-pass error is too large; its fixed exponents (|a| x 16 / 2^3 within bf6's +-28) are what is measured;
           fp16x3    three fp16 passes, unconditional.

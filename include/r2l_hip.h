@@ -40,7 +40,7 @@ extern "C" {
  *                    (compiler-scheduled kernel, kept for reference).  NeRF teacher: 0.6-1.6e-5 on rgb over whole frames
  *                    (eleven layers, compositing over 192 samples) -- its FAST mode since round 4: the generated layer chain
  *                    without correction terms (nerf_chain_kernel<true, 4>: four 16-point column tiles per wave, embedding k-steps
- *                    still three passes), 0.55-0.57 of the fp16 MFMA peak; the front end's `--precision auto` measures it against FP16X3 per checkpoint.
+ *                    hi / lo on the embedding side), 0.56-0.58 of the fp16 MFMA peak; the front end's `--precision auto` measures it against FP16X3 per checkpoint.
  *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the block-scaled
  *                    low-precision MFMA (v_mfma_scale_f32_*_f8f6f4) with both operands in OCP bf6 (e3m2)
  *                    at 4x the fp16 rate: 1.5 pass-equivalents per k-step, L_inf ~3e-5 (< 1e-4).
