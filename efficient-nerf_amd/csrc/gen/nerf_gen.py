@@ -72,7 +72,7 @@ AUX_BYTES = 16384
 LDS_BYTES = LDS_AUX + AUX_BYTES
 ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # NERF_GEN_FMT=f16 (an environment variable: the tile / chunk / anchor tables below are built at import): the chain WITHOUT its
-# correction terms -- one fp16 pass on the 256-wide sources (the embedding k-steps keep their three passes): no K=128 MFMA, no
+# correction terms -- one fp16 pass on the 256-wide sources (the embedding k-steps keep hi(E) and lo(E): XPASS below): no K=128 MFMA, no
 # bf6 operand in the stream (1.27 MB per tile instead of 2.17, in 44 chunks instead of 80), no residuals and no 32-wide conversions in the epilogues.
 # R2L_PREC_FP16X1 of the teacher: 1-3e-5 on rgb over whole frames (profiles/r04_teacher_x1.txt), `--precision auto`'s first rung.
 # NERF_GEN_FMT=f16c3 / f16c4: the f16 chain with THREE / FOUR column tiles of 16 points per wave (192 / 256 points per workgroup tile):

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // (tests/test_nerf_gen_cpu.py).
 // ------------------------------------------------------------------------------------
 // X1 = true is R2L_PREC_FP16X1: the same chain generated without its correction terms (NERF_GEN_FMT=f16 -> nerf_mlpx_*.inc): one fp16
-// pass on the 256-wide sources, the embedding k-steps as before; 1.28 MB of stream per tile instead of 2.17.
+// pass on the 256-wide sources, the embedding k-steps hi(W) x (hi(E) + lo(E)); 1.30 MB of stream per tile instead of 2.17.
 // NC = 3 (X1 only, NERF_GEN_FMT=f16c3 -> nerf_mlpx3_*.inc): three column tiles of 16 points per wave, 192 points per workgroup tile.
 template <bool X1, int NC>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {

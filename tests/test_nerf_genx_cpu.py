@@ -1,5 +1,5 @@
 """The teacher's layer chain generated WITHOUT its correction terms (NERF_GEN_FMT=f16 -> nerf_mlpx_*.inc, R2L_PREC_FP16X1:
-one fp16 pass on the 256-wide sources, three on the embedding k-steps), checked on the CPU like the bf6 chain
+one fp16 pass on the 256-wide sources, hi(W) x (hi(E) + lo(E)) on the embedding k-steps), checked on the CPU like the bf6 chain
 (tests/test_nerf_gen_cpu.py): layout constants, the C++ packer against the generator's restatement byte for byte, the
 committed text against the generator, and the lane-accurate emulation of the exact instruction stream against a float64
 evaluation of NeRF.forward -- its error must be that of single-pass fp16 operands, not more."""
