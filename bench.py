@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py — R2L W256D88 ray throughput at 800x800 on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torchrun)
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
+
+N > 1 without a torchrun environment (WORLD_SIZE unset): this process starts the N ranks itself -- fresh child processes of
+this script, before anything here imports torch or touches the GPU (efficient-nerf_amd/launch.py) -- relays rank 0's JSON
+line and exits with the first non-zero rank code.
 
 A step renders N synthetic 800x800 Blender-style poses: every rank renders its row shard
 (800/N rows) of each of the N frames (fp16_fp8: head launch -> hand-scheduled body launch, which ends
@@ -20,6 +25,16 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def load_launcher():
+    """efficient-nerf_amd/launch.py by file path: standard library only, no import of torch or of the package"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('r2l_launch', os.path.join(ROOT, 'efficient-nerf_amd', 'launch.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
 
 H = W = 800
 N_BLOCK = 43  # W256 D88
@@ -177,7 +192,15 @@ def main():
                          '(default: exit non-zero -- a scaling record must time the collective it names)')
     ap.add_argument('--cpu-rays', type=int, default=H * W,
                     help='rays of one frame the CPU oracle renders for the baseline / parity check')
+    ap.add_argument('--launch-timeout', type=float, default=1500.,
+                    help='N > 1 started without torchrun: seconds after which the launcher stops its ranks and exits 124')
     args = ap.parse_args()
+
+    launch = load_launcher()
+    if launch.wants_spawn(args.gpus):
+        # `python bench.py --gpus N` (the driver's command): this process becomes the launcher of N fresh rank processes
+        # and never initialises the GPU itself
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout))
 
     import torch
     import _pkg

@@ -79,6 +79,8 @@ FLAGS = [
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
     # frames rendered per launch / collective / range check / host sync (0: the world size, i.e. one frame on one GPU)
     ('--frames_per_batch', dict(type=int, default=0)),
+    # N > 1 without torchrun: main.py / create_data.py start the N ranks themselves before importing torch (launch.py)
+    ('--gpus', dict(type=int, default=0)), ('--launch_timeout', dict(type=float, default=0.)),
 ]
 
 

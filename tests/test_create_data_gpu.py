@@ -164,3 +164,29 @@ def test_create_data_with_a_teacher_outside_the_fused_kernels(pkg, tmp_path):
         got = np.load(os.path.join(out, f'data_{k}.npy'))
         np.testing.assert_array_equal(got[:, :6], w[:, :6])
         assert np.abs(got[:, 6:] - w[:, 6:]).max() <= 1e-4
+
+
+def test_create_data_command_line_starts_its_own_ranks(pkg, tmp_path):
+    """`python create_data.py --gpus 2 …` without torchrun: the entry script starts the two ranks itself
+    (launch.py; gloo between them, both on this GPU) and the directory is byte-identical to the one-process command's"""
+    import hashlib
+    import subprocess
+    import sys
+    from efficient_nerf_amd import frontend as fe
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = str(tmp_path / 'nerf.tar')
+    fe.save_checkpoint(ck, O.make_teacher_state(1), O.make_teacher_state(2))
+    env = dict(os.environ, R2L_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    dirs = []
+    for gpus in (1, 2):
+        out = str(tmp_path / f'pseudo{gpus}')
+        r = subprocess.run([sys.executable, os.path.join(root, 'create_data.py'), '--create_data', 'rand', '--config', 'configs/lego.txt',
+                            '--teacher_ckpt', ck, '--n_pose_kd', '6', '--datadir_kd', f'unused:{out}', '--create_data_chunk', '3',
+                            '--split_size', '100', '--H', '24', '--synthetic_poses', '1', '--gpus', str(gpus), '--launch_timeout', '500'],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        assert f'on {gpus} GPU(s)' in r.stdout, r.stdout[-800:]
+        dirs.append({n: hashlib.sha256(open(os.path.join(out, n), 'rb').read()).hexdigest() for n in sorted(os.listdir(out)) if n.endswith('.npy')})
+    assert len(dirs[0]) == 2 * (3 * 144 // 100) and dirs[0] == dirs[1]
