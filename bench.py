@@ -106,8 +106,8 @@ def create_data_leg(torch, O, precision):
     focal = O.focal_from_angle(th)
     auto = precision == 'auto'
     eng = NeRFEngine(th, th, focal, precision=PRECISIONS['fp16x3' if auto else precision]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
-    if auto:       # what `python create_data.py` does by default: the fastest mode whose measured difference from fp16x3 is inside its limit
-        precision = teacher_auto(eng, O, th)[0]
+    if auto:       # what `python create_data.py` does by default: the fastest mode whose measured difference from fp16x3 is inside its
+        precision = CD.choose_precision_for_rand(eng, th, th, focal)      # limits on every probe pose; watched per save group
     eng.render(O.novel_poses(1)[0][:3, :4])          # buffers allocated, kernels loaded
     torch.cuda.synchronize()
     out = tempfile.mkdtemp(prefix='r2l_pseudo_')
@@ -133,6 +133,8 @@ def create_data_leg(torch, O, precision):
             # ... and what runs beside the renders on host threads
             'permutation_s_on_planner_thread': tm.get('permutation_s'), 'writer_busy_s': tm.get('writer_busy_s'),
             'writer_threads': tm.get('writer_threads'),
+            # the fast mode under watch: one spot check against fp16x3 per save group (2,048 rays of its first pose), fallbacks taken
+            'watch': tm.get('watch'),
             # 100 groups: 10,000 poses at the steady rate (the wall clock minus the one tail) plus the tail once
             'extrapolated_n_pose_kd_10000_hours_one_gpu': (1e4 / n_pose * (wall - (tm.get('tail_s') or 0.0)) + (tm.get('tail_s') or 0.0)) / 3600,
             'reference_quotes_hours': 24, 'reference_quote': 'README.md:87 "around 24 hrs" for --n_pose_kd 10000 (hardware unstated)'}
@@ -200,7 +202,7 @@ def main():
     if launch.wants_spawn(args.gpus):
         # `python bench.py --gpus N` (the driver's command): this process becomes the launcher of N fresh rank processes
         # and never initialises the GPU itself
-        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout))
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout, json_only=True))
 
     import torch
     import _pkg

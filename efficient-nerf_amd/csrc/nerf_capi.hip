@@ -205,6 +205,7 @@ struct nerf_ctx {
     int H, W, N_samples, N_importance, white_bkgd, mode, n_cu;
     int ndc = 0;            // render() projects the rays to NDC first (main.py:160-162)
     bool split_scans = false;  // nerf_debug_set_split_scans: raw2outputs / sample_pdf / merge as three launches (A/B, parity tests)
+    int x1_col_tiles = 4;      // nerf_debug_set_x1_col_tiles: 16-point column tiles per wave of the fp16-only chain (3 or 2 for the A/B)
     float ndc_near = 1.0f;
     double focal;
     float near_, far_, act_scale;
@@ -444,8 +445,6 @@ int nerf_set_precision(nerf_ctx* c, int mode) {
     return R2L_OK;
 }
 
-static int g_x1_col_tiles = 4;     // nerf_debug_set_x1_col_tiles: 3 or 2 (= the 128-point tiles of the other modes) for the A/B
-
 static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* rays_d, const float* z, int z_stride,
                    int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr) {
     NerfMlpParams p;
@@ -464,7 +463,8 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
         return r2l_set_error(R2L_EINVAL, "%d rays x %d samples: more than 2^31 points in one call; render fewer rows at a time", n, S);
     // the fp16-only chain: 256-point tiles (four column tiles per wave); with given view directions (NDC renders) 192: the four-tile
     // build has no register left to carry the next tile's directions across its asm block
-    const int x1_nc = c->mode == R2L_PREC_FP16X1 ? ((viewdirs && g_x1_col_tiles == 4) ? 3 : g_x1_col_tiles) : 2;
+    const int x1_tiles = c->x1_col_tiles;     // read once: tile size and kernel selection below must agree
+    const int x1_nc = c->mode == R2L_PREC_FP16X1 ? ((viewdirs && x1_tiles == 4) ? 3 : x1_tiles) : 2;
     const int tile_pts = 64 * x1_nc;
     p.n_tiles = (int)((p.n_pts + tile_pts - 1) / tile_pts);
     p.act_scale = c->act_scale;
@@ -578,9 +578,10 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
     return R2L_OK;
 }
 
-int nerf_debug_set_x1_col_tiles(int n) {
+int nerf_debug_set_x1_col_tiles(nerf_ctx* c, int n) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (n < 2 || n > 4) return r2l_set_error(R2L_EINVAL, "column tiles per wave: 2, 3 or 4");
-    g_x1_col_tiles = n;
+    c->x1_col_tiles = n;
     return R2L_OK;
 }
 

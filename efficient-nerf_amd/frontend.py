@@ -305,7 +305,7 @@ def teacher_needs_generic(args):
             or (args.netdepth, args.netwidth, args.netdepth_fine, args.netwidth_fine) != (8, 256, 8, 256) or args.precision == 'fp32')
 
 
-def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
+def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, probe_poses=None):
     """Engine for the flags of the reference command line.  Every flag that changes what the reference network
     computes is either honoured or refused: a checkpoint trained with another activation / res_scale / depth must
     not render silently wrong images (ResMLP honours them: model/nerf_raybased.py:443-465)."""
@@ -371,7 +371,8 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
             if args.precision not in ('auto', 'fp16x3', 'fp16x1'):
                 raise R2LError(f'act={acts[0]} trial.inact={acts[1]} trial.outact={acts[2]} body_arch={arch}: --precision {args.precision} is a '
                                f'generated kernel built for relu / relu / none ResMLP blocks; use --precision auto (or fp16x3)')
-        n_block = args.trial.n_block if args.trial.n_block > 0 else (args.netdepth - 2) // 2
+        # trial.n_block is read in the resmlp branch only (model/nerf_raybased.py:503-514); the mlp body has netdepth - 2 layers (:515-518)
+        n_block = args.trial.n_block if (arch == 'resmlp' and args.trial.n_block > 0) else (args.netdepth - 2) // 2
         eng = R2LEngine(H, W, focal, near, far, n_sample=args.n_sample_per_ray, L=args.multires,
                         width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec,
                         res_scale=float(args.trial.res_scale), act=acts[0], inact=acts[1], outact=acts[2], body_arch=arch)
@@ -418,16 +419,19 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None):
             raise R2LError(f'--precision {args.precision} is a mode of the R2L student (the teacher has fp16x3, fp16_fp8, fp16x1)')
         eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
         if auto:
-            # the chain's bf6 terms run under fixed activation exponents: measured against fp16x3 on the first frame's own rays
+            # one fp16 pass / the chain's bf6 terms under fixed activation exponents: measured against fp16x3 on rays of the job's
+            # own poses (first, middle, last of the path when the caller names them), and watched afterwards (render_path)
             from .teacher import get_rays
             if probe_rays is not None:
-                ro, rd = (t.to(eng.device, torch.float32) for t in probe_rays)
+                sets = [tuple(t.to(eng.device, torch.float32) for t in probe_rays)]
             else:
-                ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, probe_pose, device=eng.device))
-            name, diff = eng.choose_precision(ro, rd)
+                plist = list(probe_poses) if probe_poses is not None else [probe_pose]
+                sets = [tuple(t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(p)[:3, :4], device=eng.device)) for p in plist]
+            name, diff = eng.choose_precision(sets)
             if log:
                 tried = ', '.join(f'{k} {v:.1e} (limit {eng.AUTO_MAX_DIFF_X1 if k == "fp16x1" else eng.AUTO_MAX_DIFF:.0e})' for k, v in eng.auto_diffs.items())
-                log(f'[precision] auto: difference from fp16x3 on {min(4096, ro.shape[0])} rays of the first frame: {tried} -> {name}')
+                log(f'[precision] auto: largest rgb / acc difference from fp16x3 on {min(4096, sets[0][0].shape[0])} rays of each of '
+                    f'{len(sets)} probe frame(s): {tried} -> {name}')
         return 'nerf', eng
     raise R2LError(f'model_name={args.model_name} is not a render path of this build')
 
@@ -473,7 +477,7 @@ class _ImageWriter:
 
 
 def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=print, given_rays=None, frames_per_batch=None,
-                stats=None):
+                stats=None, watch_every=8):
     """main.py:189-398 for the R2L and nerf branches: render, per-frame timing lines, PSNR / SSIM when GT is given.
 
     The loop is the one bench.py times ("batch >= 8 frames per collective"): frames go in batches of
@@ -485,7 +489,11 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     `given_rays` = (all_rays_o, all_rays_d) [N, H*W, 3] replaces the camera rays (--given_render_path_rays,
     main.py:207-230: the DONERF test path through PointSampler.sample_train).
     `stats` (dict, optional) receives the loop's own numbers: render_loop_s (first launch to last sync, image encoding
-    excluded), batches, collectives, rerenders."""
+    excluded), batches, collectives, rerenders.
+    Teacher frames in a fast mode (fp16x1 / fp16_fp8, chosen once by `--precision auto` or by flag) are watched: every
+    `watch_every`-th frame (and the first) a rank re-renders NeRFEngine.WATCH_RAYS of its rays in fp16x3 and compares rgb / acc /
+    depth (NeRFEngine.spot_check); a miss on any rank moves every rank one rung down the ladder and the frame is rendered
+    again (`stats['watch']`).  0 switches the watch off."""
     from . import dist as D
     import torch.distributed as tdist
     H, W, focal = hwf
@@ -512,13 +520,49 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
             return
         for f in range(nb):
             i = i0 + f
+            ro = rd = None
             if given_rays is not None:
                 ro = given_rays[0][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
                 rd = given_rays[1][i].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
                 got = eng.render_rays(ro, rd)
             else:
                 got = eng.render(render_poses[i][:3, :4], rows=(r0, r1))
+            if watching and i % watch_every == 0:
+                got = watched(i, ro, rd, got)
             dst[f].copy_(got if kind == 'R2L' else got['rgb_map'])
+
+    # the teacher's fast modes under watch: fp16x1 / fp16_fp8 were chosen on a probe; every watch_every-th
+    # frame is checked against fp16x3 on a sample of its own rays, agreed between the ranks, with fallback + re-render
+    watching = kind != 'R2L' and watch_every > 0 and hasattr(eng, 'spot_check')
+    watch = {'checks': 0, 'fallbacks': [], 'worst': {}}
+
+    def watched(i, ro, rd, got):
+        from .teacher import get_rays
+        for _ in range(3):
+            if eng.precision_name == 'fp16x3':
+                break
+            if ro is None:
+                ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(render_poses[i])[:3, :4], rows=(r0, r1),
+                                                             device=eng.device))
+            ok, d = eng.spot_check(ro, rd, got)
+            watch['checks'] += 1
+            for k, v in d.items():
+                watch['worst'][k] = max(watch['worst'].get(k, 0.), v)
+            bad = 0 if ok else 1
+            if world > 1:     # every rank checks the same frames: one 4-byte all-reduce per check, all ranks act alike
+                t = torch.tensor([bad], dtype=torch.int32, device=eng.device if tdist.get_backend() == 'nccl' else 'cpu')
+                tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+                bad = int(t.item())
+            if not bad:
+                break
+            was = eng.precision_name
+            now = eng.step_down()
+            watch['fallbacks'].append({'frame': i, 'from': was, 'to': now, 'diffs': d})
+            if rank == 0:
+                log(f'[precision] frame {i}: {was} is {d} from fp16x3 on {eng.WATCH_RAYS} of its rays (limits '
+                    f'{eng.AUTO_MAX_DIFF_X1 if was == "fp16x1" else eng.AUTO_MAX_DIFF:.0e} x (1, 1, far)) -> {now}; frame rendered again')
+            got = eng.render_rays(ro, rd) if given_rays is not None else eng.render(render_poses[i][:3, :4], rows=(r0, r1))
+        return got
 
     if kind == 'R2L' and world > 1 and n_frames > 0:
         # an explicit fp16_fp8 measures its activation ranges on the first render's own rays: one agreed set for all row
@@ -575,6 +619,8 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     if stats is not None:
         stats.update(render_loop_s=t_loop, frames=n_frames, frames_per_batch=B, batches=n_batches, collectives=n_coll,
                      rerenders=n_again, world=world, rows_per_rank=r1 - r0)
+        if watching:
+            stats['watch'] = dict(watch, every=watch_every, precision=eng.precision_name)
         if host_stack is not None:
             stats['host_frames'] = host_stack          # complete: writer.close() has waited for every copy
     misc = {}
@@ -616,6 +662,7 @@ def main(argv=None):
             gt = gt[:, :hwf[0], :hwf[1]]
     kind, eng = build_engine(args, hwf, ckpt, probe_pose=None if given is not None else poses[0][:3, :4],
                              probe_rays=None if given is None else (given[0][0].reshape(-1, 3), given[1][0].reshape(-1, 3)),
+                             probe_poses=None if given is not None else [poses[k][:3, :4] for k in sorted({0, len(poses) // 2, len(poses) - 1})],
                              log=log)
     outdir = args.outdir or os.path.join(args.basedir, args.expname or 'render', 'gen_img')
     if rank == 0:
@@ -651,6 +698,10 @@ def main(argv=None):
             f'frame(s), {st["collectives"]} collective(s), {st["rerenders"]} re-render(s))')
         log(f'Rendered {len(rgbs)} view(s) {H}x{W} on {world} GPU(s) in {dt:.2f}s '
             f'({len(rgbs) * H * W / dt:.3e} rays/s incl. host I/O)')
+        if st.get('watch', {}).get('checks'):
+            w_ = st['watch']
+            log(f"[precision] watch: {w_['checks']} spot check(s) against fp16x3 (every {w_['every']} frames, {eng.WATCH_RAYS} rays), worst "
+                f"{ {k: float('%.2e' % v) for k, v in w_['worst'].items()} }, {len(w_['fallbacks'])} fallback(s); mode at the end: {w_['precision']}")
         if 'test_psnr' in misc:
             log(f"[TEST] TestPSNR {misc['test_psnr']:.4f} TestPSNRv2 {misc['test_psnr_v2']:.4f} "
                 f"TestSSIM {misc['test_ssim']:.4f}")

@@ -358,7 +358,12 @@ class GenericNeRF:
         self.input_ch = 3 if self.i_embed == -1 else 3 * (2 * self.multires + 1)
         self.input_ch_views = 0 if not self.use_viewdirs else (3 if self.i_embed == -1 else 3 * (2 * self.multires_views + 1))
         self.output_ch = 5 if self.N_importance > 0 else 4          # main.py:426
-        self.chunk = int(chunk)
+        # rays per call, sized from the widest network so that a call's per-point buffers stay near 2^18 points x ~1,100 floats
+        # at W = 256 (1.2 GB) and shrink as the width grows (8,192 rays x 192 samples x W floats grew linearly with netwidth)
+        wmax = max(int(netwidth), int(netwidth_fine))
+        pts_cap = max(1 << 14, (1 << 18) * 256 // max(wmax, 256))
+        self.chunk = max(64, min(int(chunk), pts_cap // max(1, self.N_samples + self.N_importance)))
+        self._pt_buffers = {}
         # main.py:673-682 on the host as the reference's first ray computes it (near, far are the same for every ray)
         t = torch.linspace(0., 1., steps=self.N_samples)
         nr, fr = torch.tensor([self.near]), torch.tensor([self.far])
@@ -404,11 +409,20 @@ class GenericNeRF:
         m = n * S
         dev = self.device
         W = net.W
-        pts = torch.empty((m, 3), dtype=torch.float32, device=dev)
-        cat = torch.empty((m, self.input_ch + W), dtype=torch.float32, device=dev)
-        views = torch.empty((m, W + self.input_ch_views), dtype=torch.float32, device=dev) if self.use_viewdirs else None
-        work = [torch.empty((m, W), dtype=torch.float32, device=dev) for _ in range(2)]
-        raw = torch.empty((m, 4 if self.use_viewdirs else self.output_ch), dtype=torch.float32, device=dev)
+        # per-point buffers of a call, cached on the engine by (points, width) like GenericR2L._buffers (~7 GB at W = 256
+        # were allocated twice per chunk): the coarse and the fine pass of a chunk each keep one set
+        key = (m, W)
+        buf = self._pt_buffers.get(key)
+        if buf is None:
+            if len(self._pt_buffers) >= 4:          # other chunk sizes seen before (ragged last chunk, another frame size): drop them
+                self._pt_buffers.clear()
+            buf = dict(pts=torch.empty((m, 3), dtype=torch.float32, device=dev),
+                       cat=torch.empty((m, self.input_ch + W), dtype=torch.float32, device=dev),
+                       views=torch.empty((m, W + self.input_ch_views), dtype=torch.float32, device=dev) if self.use_viewdirs else None,
+                       work=[torch.empty((m, W), dtype=torch.float32, device=dev) for _ in range(2)])
+            self._pt_buffers[key] = buf
+        pts, cat, views, work = buf['pts'], buf['cat'], buf['views'], buf['work']
+        raw = torch.empty((m, 4 if self.use_viewdirs else self.output_ch), dtype=torch.float32, device=dev)   # returned to the caller
         with torch.cuda.device(dev):
             check(lib().r2l_sample_points(dptr(rays_o), dptr(rays_d), n, dptr(z_vals.contiguous()), S, 0 if shared else 1, dptr(pts),
                                           current_stream()))

@@ -6,14 +6,17 @@ Standard library only, and loaded by file path (`load_launcher` in the entry scr
 neither torch nor the package: it never touches the GPU, it only starts fresh child processes of the same script with
 the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT), waits for
 them, and exits with the first non-zero child code.  A child that fails, or the time limit, takes the other ranks down
-(SIGTERM, then SIGKILL); a parent that dies takes its children with it (PR_SET_PDEATHSIG).  Rank 0 inherits stdout (the
-one JSON line of bench.py), the other ranks' stdout goes to stderr.  Under torchrun (WORLD_SIZE set) nothing here runs.
+(SIGTERM, then SIGKILL); a parent that dies takes its children with it (PR_SET_PDEATHSIG).  Rank 0 owns stdout, the other
+ranks' stdout goes to stderr; with `json_only` (bench.py: the driver parses ONE JSON line) only rank 0's lines that start
+with `{` reach stdout and whatever else a library prints there (gloo's and RCCL's connection notes) goes to stderr.  Under
+torchrun (WORLD_SIZE set) nothing here runs.
 """
 import os
 import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 
@@ -68,7 +71,16 @@ def _stop(procs, grace=10.0):
             p.wait()
 
 
-def spawn_ranks(script, argv, n_ranks, timeout=None, poll=0.1, log=None):
+def _relay_json_lines(pipe):
+    for raw in iter(pipe.readline, b''):
+        line = raw.decode('utf-8', 'replace')
+        dst = sys.stdout if line.lstrip().startswith('{') else sys.stderr
+        dst.write(line)
+        dst.flush()
+    pipe.close()
+
+
+def spawn_ranks(script, argv, n_ranks, timeout=None, poll=0.1, log=None, json_only=False):
     """Run `python script argv…` as ranks 0 … n_ranks − 1 of one job and return the job's exit code: 0 when every rank
     returned 0, else the first non-zero code seen (a rank killed by a signal: 128 + signal), 124 on the time limit."""
     log = log or (lambda m: print(m, file=sys.stderr, flush=True))
@@ -81,10 +93,15 @@ def spawn_ranks(script, argv, n_ranks, timeout=None, poll=0.1, log=None):
 
     old = {s: signal.signal(s, on_signal) for s in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
+    relay = None
     try:
         for r in range(n_ranks):
+            out = (subprocess.PIPE if json_only else None) if r == 0 else sys.stderr
             procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=rank_env(r, n_ranks, port),
-                                          stdout=None if r == 0 else sys.stderr, preexec_fn=_die_with_parent))
+                                          stdout=out, preexec_fn=_die_with_parent))
+        if json_only:
+            relay = threading.Thread(target=_relay_json_lines, args=(procs[0].stdout,), daemon=True)
+            relay.start()
         t_end = None if not timeout else time.monotonic() + timeout
         left = set(range(n_ranks))
         while left:
@@ -109,6 +126,8 @@ def spawn_ranks(script, argv, n_ranks, timeout=None, poll=0.1, log=None):
             time.sleep(poll)
     finally:
         _stop(procs)
+        if relay is not None:
+            relay.join(timeout=10)
         for s, h in old.items():
             signal.signal(s, h)
     return rc

@@ -134,6 +134,13 @@ class R2LEngine:
         missing = [n for n in names if n not in sd]
         if missing:
             raise R2LError(f'state_dict lacks {len(missing)} tensors, e.g. {missing[:3]}')
+        # a checkpoint with more body layers than this engine was built for must not render with the rest silently dropped
+        # (--trial.n_block with the mlp body): body.{k}... with k beyond what the plan consumes is an error
+        n_src = 4 * self.n_block if self.body_arch == 'mlp' else self.n_block
+        extra = sorted(k for k in sd if k.startswith('body.') and k.split('.')[1].isdigit() and int(k.split('.')[1]) >= n_src)
+        if extra:
+            raise R2LError(f'state_dict has body layers this engine (n_block={self.n_block}, body_arch={self.body_arch}) does not '
+                           f'consume, e.g. {extra[:3]}: netdepth / trial.n_block do not match the checkpoint')
         shapes = {'head.0.weight': (256, 1008), 'tail.0.weight': (3, 256), 'tail.0.bias': (3,)}
         for n in names:
             want = shapes.get(n, (256, 256) if n.endswith('weight') else (256,))
@@ -576,7 +583,8 @@ class NeRF_v3_2:
         self._args = args
         self.res_scale = float(getattr(trial, 'res_scale', 1.))
         self.acts = (getattr(args, 'act', 'relu'), getattr(trial, 'inact', 'relu'), getattr(trial, 'outact', 'none'))
-        n_block = int(getattr(trial, 'n_block', -1))
+        # trial.n_block counts ResMLP blocks only (model/nerf_raybased.py:503-514); the mlp body always has netdepth - 2 layers (:515-518)
+        n_block = int(getattr(trial, 'n_block', -1)) if self.body_arch == 'resmlp' else -1
         self.n_block = n_block if n_block > 0 else (D - 2) // 2
         self.use_residual = bool(getattr(args, 'use_residual', False))
         self.input_dim = input_dim

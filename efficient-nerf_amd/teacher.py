@@ -143,6 +143,7 @@ class NeRFEngine:
         self.device = _dev(device)
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.N_samples, self.N_importance = int(N_samples), int(N_importance)
+        self.near, self.far = float(near), float(far)
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             check(lib().nerf_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
@@ -210,44 +211,109 @@ class NeRFEngine:
             check(lib().nerf_set_precision(self._ctx, int(precision)))
         self.precision = int(precision)
 
-    #: `--precision auto`: largest difference of rgb / acc from fp16x3 on a probe of the caller's own rays that still selects a
-    #: faster mode.  The contract is 1e-4 against the reference on every ray; fp16x3 is within 2e-7 of it.  The probe is 2.5 % of a
-    #: frame's rays and one pose, so the limits keep a factor of three (single fp16 pass) / five (bf6 chain) to the contract:
+    #: `--precision auto`: largest difference of rgb / acc (and depth, below) from fp16x3 on probes of the caller's own rays that still
+    #: selects a faster mode.  The contract is 1e-4 against the reference on every ray; fp16x3 is within 2e-7 of it.  A probe is 2.5 %
+    #: of a frame's rays, so the limits keep a factor of three (single fp16 pass) / five (bf6 chain) to the contract:
     #: measured over whole 400 x 400 frames of three poses (tools/teacher_x1_error.py, profiles/r04_teacher_x1.txt) the single
     #: fp16 pass is 0.6-1.6e-5 from fp16x3 on the synthetic teachers (3.6e-5 with the trunk weights doubled), the bf6 chain 1e-6.
     AUTO_MAX_DIFF = 2e-5           # fp16_fp8: the layer chain's bf6 terms run under FIXED activation exponents (no calibration)
     AUTO_MAX_DIFF_X1 = 3e-5        # fp16x1: one fp16 pass, no correction terms
+    #: depth_map = sum(weights * z) carries the weights' error times z: its limit is the rgb limit times max(1, far) (scene units).
+    #: disp_map = 1 / max(1e-10, depth / acc) is ill-conditioned on empty rays in the reference itself and is not compared.
+    WATCH_KEYS = ('rgb_map', 'acc_map', 'depth_map')
+    LADDER = ('fp16x1', 'fp16_fp8', 'fp16x3')
+    #: rays of a spot check (spot_check): < 0.5 % of a 100-pose save group, < 2 % of one 400 x 400 frame
+    WATCH_RAYS = 2048
 
-    def choose_precision(self, rays_o, rays_d, max_diff=None, max_diff_x1=None):
-        """`--precision auto` for the teacher, measured on THESE weights and rays: up to 4,096 of the given rays, spread over the
-        set, are rendered coarse + fine in fp16x3 and in the candidates, fastest first:
+    def _limits(self, limit):
+        return {'rgb_map': limit, 'acc_map': limit, 'depth_map': limit * max(1., float(self.far))}
+
+    @staticmethod
+    def _strided(n, k, device):
+        return torch.arange(0, n, max(1, n // k), device=device)[:k]
+
+    def choose_precision(self, rays_o, rays_d=None, max_diff=None, max_diff_x1=None):
+        """`--precision auto` for the teacher, measured on THESE weights and rays.  `rays_o, rays_d`: one ray set, or a list of
+        (rays_o, rays_d) probe sets spanning what the job will render (create_data: top-down to horizontal poses, focal x 1 ... x 2;
+        render_path: the first, middle and last pose); up to 4,096 rays of every set, spread over it, are rendered coarse + fine in
+        fp16x3 and in the candidates, fastest first:
           fp16x1    the generated layer chain WITHOUT correction terms: one fp16 pass on the 256-wide sources (1.0 pass-equivalents).
                     Eleven layers and the compositing over 192 samples average its rounding errors to ~1e-5 on rgb where the
                     88-layer R2L student ends at 3.5e-4 -- for the teacher it is the fast mode (33.4-35 ms per 400 x 400 frame);
           fp16_fp8  the generated layer chain, fp16 + bf6 correction terms (1.5 pass-equivalents, ~1e-6), for weights whose
                     single-pass error is too large; its fixed exponents (|a| x 16 / 2^3 within bf6's +-28) are what is measured;
           fp16x3    three fp16 passes, unconditional.
-        A candidate is kept when rgb and acc agree with fp16x3 within its limit.  Returns (name, its largest difference).
-        Synchronous, once per weight load."""
+        A candidate is kept when rgb, acc and depth agree with fp16x3 within its limits on EVERY probe set.  Returns (name, its
+        largest rgb / acc difference); `auto_diffs` keeps the per-candidate maxima, `auto_detail` the per-set, per-output ones.
+        The choice is not final: spot_check / step_down keep watching what is rendered afterwards (create_data per save group,
+        render_path every few frames).  Synchronous, once per weight load."""
         from ._lib import PREC_FP16_FP8
         max_diff = self.AUTO_MAX_DIFF if max_diff is None else float(max_diff)
         max_diff_x1 = self.AUTO_MAX_DIFF_X1 if max_diff_x1 is None else float(max_diff_x1)
-        n = rays_o.shape[0]
-        idx = torch.arange(0, n, max(1, n // 4096), device=rays_o.device)[:4096]
-        ro, rd = rays_o[idx].contiguous(), rays_d[idx].contiguous()
+        sets = [(rays_o, rays_d)] if rays_d is not None else list(rays_o)
+        probes = []
+        for ro, rd in sets:
+            ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+            idx = self._strided(ro.shape[0], 4096, ro.device)
+            probes.append((ro[idx].contiguous(), rd[idx].contiguous()))
         self.set_precision(PREC_FP16X3)
-        ref = self.render_rays(ro, rd)
-        ref = {k: ref[k].clone() for k in ('rgb_map', 'acc_map')}
-        self.auto_diffs = {}
+        refs = []
+        for ro, rd in probes:
+            r = self.render_rays(ro, rd)
+            refs.append({k: r[k].clone() for k in self.WATCH_KEYS})
+        self.auto_diffs, self.auto_detail = {}, {}
+        diff = float('nan')
         for name, prec, limit in (('fp16x1', PREC_FP16X1, max_diff_x1), ('fp16_fp8', PREC_FP16_FP8, max_diff)):
             self.set_precision(prec)
-            got = self.render_rays(ro, rd)
-            diff = max(float((got[k] - ref[k]).abs().max()) for k in ref)
+            lim = self._limits(limit)
+            per_set, ok = [], True
+            for (ro, rd), ref in zip(probes, refs):
+                got = self.render_rays(ro, rd)
+                d = {k: float((got[k] - ref[k]).abs().max()) for k in ref}
+                per_set.append(d)
+                ok = ok and all(d[k] <= lim[k] for k in d)               # NaN fails
+            diff = max(max(d['rgb_map'], d['acc_map']) for d in per_set)
             self.auto_diffs[name] = diff
-            if diff <= limit:               # NaN fails
+            self.auto_detail[name] = per_set
+            if ok:
                 return name, diff
         self.set_precision(PREC_FP16X3)
         return 'fp16x3', diff
+
+    @property
+    def precision_name(self):
+        from ._lib import PRECISIONS
+        return next(k for k, v in PRECISIONS.items() if v == self.precision)
+
+    def spot_check(self, rays_o, rays_d, got, n_rays=None):
+        """The watch behind `--precision auto`'s one-time choice: `got` is what this engine just rendered for (rays_o, rays_d) in
+        its current fast mode; up to `n_rays` (default WATCH_RAYS) of those rays, spread over the set, are rendered again in
+        fp16x3 and rgb / acc / depth compared under the mode's limits (a ray's result does not depend on the batch it is in).
+        Returns (ok, {output: largest difference}).  fp16x3 itself: (True, {}).  Synchronous (one small render + three maxima)."""
+        from ._lib import PREC_FP16_FP8
+        cur = self.precision
+        if cur not in (PREC_FP16X1, PREC_FP16_FP8):
+            return True, {}
+        ro, rd = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        idx = self._strided(ro.shape[0], int(n_rays or self.WATCH_RAYS), ro.device)
+        lim = self._limits(self.AUTO_MAX_DIFF_X1 if cur == PREC_FP16X1 else self.AUTO_MAX_DIFF)
+        self.set_precision(PREC_FP16X3)
+        try:
+            ref = self.render_rays(ro[idx].contiguous(), rd[idx].contiguous())
+        finally:
+            self.set_precision(cur)
+        d = {k: float((got[k].reshape((-1,) + tuple(ref[k].shape[1:]))[idx] - ref[k]).abs().max()) for k in self.WATCH_KEYS}
+        self.watch_checks = getattr(self, 'watch_checks', 0) + 1
+        return all(d[k] <= lim[k] for k in d), d
+
+    def step_down(self):
+        """one rung down the ladder fp16x1 -> fp16_fp8 -> fp16x3 (after a failed spot_check); returns the new mode's name"""
+        from ._lib import PRECISIONS
+        name = self.precision_name
+        nxt = self.LADDER[min(self.LADDER.index(name) + 1, len(self.LADDER) - 1)] if name in self.LADDER else 'fp16x3'
+        self.set_precision(PRECISIONS[nxt])
+        self.watch_fallbacks = getattr(self, 'watch_fallbacks', 0) + 1
+        return nxt
 
     def timing(self, on=True):
         """HIP events around every MLP launch (nerf_chain_kernel / nerf_mlp_kernel), on its launch stream"""

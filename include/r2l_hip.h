@@ -305,8 +305,9 @@ int nerf_render_rays_ex(nerf_ctx* ctx, const float* rays_o_dev, const float* ray
 /* parity tests / A-B timing: 1 = the coarse pass's raw2outputs, sample_pdf and merge as three launches instead of the one fused
  * launch of the deterministic path (nerf_coarse_scan_kernel); the results are bit-identical */
 int nerf_debug_set_split_scans(nerf_ctx* ctx, int on);
-/* A-B timing: 16-point column tiles per wave of the FP16X1 chain, 4 (default: 256-point workgroup tiles), 3 (192) or 2 (128); process-wide */
-int nerf_debug_set_x1_col_tiles(int n);
+/* A-B timing / parity tests: 16-point column tiles per wave of this context's FP16X1 chain, 4 (default: 256-point workgroup
+ * tiles), 3 (192) or 2 (128); the results are bit-identical (the arithmetic per point does not depend on the tiling) */
+int nerf_debug_set_x1_col_tiles(nerf_ctx* ctx, int n);
 int nerf_timing_enable(nerf_ctx* ctx, int on);
 int nerf_kernel_time_ms(nerf_ctx* ctx, double* total_ms, int* n_launches, int reset);
 

@@ -3,8 +3,10 @@
 TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch-CPU fp32 restatement of the
 reference's algorithm (MingSun-Tse/Efficient-NeRF, paths cited per function as
 ``file:line`` relative to the reference checkout).  It is the *checker* for the HIP
-path: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
-leg may import it.  Nothing under ``efficient-nerf_amd/`` imports it and the product
+path: only ``tests/``, ``__graft_entry__.smoke()``, ``bench.py``'s ``cpu_baseline``
+leg and the fixture / measurement scripts under ``tools/`` (test infrastructure too: e.g.
+``tools/train_like.py`` fits the trained-like fixture with autograd on these functions)
+may import it.  Nothing under ``efficient-nerf_amd/`` imports it and the product
 path never falls back to it.
 
 Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference's own
@@ -120,7 +122,7 @@ def positional_embed(x, L=10, include_input=True):
     """model/nerf_raybased.py:191-208 (PositionalEmbedder.__call__).
 
     out[r, c*(2L+1) + (l | L+l | 2L)] = (sin(x*2^l) | cos(x*2^l) | x)."""
-    weights = 2**torch.linspace(0, L - 1, steps=L)
+    weights = (2**torch.linspace(0, L - 1, steps=L)).to(x.device)      # evaluated on the host as the reference does
     y = x[..., None] * weights
     y = torch.cat([torch.sin(y), torch.cos(y)], dim=-1)
     if include_input:
@@ -416,14 +418,14 @@ def raw_noise(shape, raw_noise_std, pytest=False):
 def raw2outputs(raw, z_vals, rays_d, white_bkgd=False, raw_noise_std=0., pytest=False, noise=None):
     """main.py:556-621: alpha-compositing along the ray (`noise`: explicit [n,S] tensor instead of a draw)."""
     dists = z_vals[..., 1:] - z_vals[..., :-1]
-    dists = torch.cat([dists, torch.Tensor([1e10]).expand(dists[..., :1].shape)], -1)
+    dists = torch.cat([dists, torch.Tensor([1e10]).to(dists.device).expand(dists[..., :1].shape)], -1)
     dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
     rgb = torch.sigmoid(raw[..., :3])
     if noise is None:
         noise = raw_noise(raw[..., 3].shape, raw_noise_std, pytest) if raw_noise_std > 0. else 0.
     alpha = 1. - torch.exp(-F.relu(raw[..., 3] + noise) * dists)
     weights = alpha * torch.cumprod(
-        torch.cat([torch.ones((alpha.shape[0], 1)), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+        torch.cat([torch.ones((alpha.shape[0], 1), device=alpha.device), 1. - alpha + 1e-10], -1), -1)[:, :-1]
     rgb_map = torch.sum(weights[..., None] * rgb, -2)
     depth_map = torch.sum(weights * z_vals, -1)
     disp_map = 1. / torch.max(1e-10 * torch.ones_like(depth_map),
@@ -455,7 +457,7 @@ def sample_pdf(bins, weights, N_samples, det=True, pytest=False, u=None, taps=Fa
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
     if u is None:
         u = sample_pdf_u(cdf.shape[:-1], N_samples, det, pytest)
-    u = u.expand(list(cdf.shape[:-1]) + [N_samples]).contiguous()
+    u = u.to(cdf.device).expand(list(cdf.shape[:-1]) + [N_samples]).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.max(torch.zeros_like(inds - 1), inds - 1)
     above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
@@ -476,7 +478,7 @@ def perturb_z_vals(z_vals, pytest=False, t_rand=None):
     upper = torch.cat([mids, z_vals[..., -1:]], -1)
     lower = torch.cat([z_vals[..., :1], mids], -1)
     if t_rand is None:
-        t_rand = torch.rand(z_vals.shape)
+        t_rand = torch.rand(z_vals.shape, device=z_vals.device)
         if pytest:
             np.random.seed(0)
             t_rand = torch.Tensor(np.random.rand(*list(z_vals.shape)))
@@ -517,7 +519,7 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=6
     n = rays_o.shape[0]
     near_t = near * torch.ones_like(rays_d[..., :1])
     far_t = far * torch.ones_like(rays_d[..., :1])
-    t_vals = torch.linspace(0., 1., steps=N_samples)
+    t_vals = torch.linspace(0., 1., steps=N_samples).to(rays_d.device)      # the host's linspace, as in the reference
     if not lindisp:
         z_vals = near_t * (1. - t_vals) + far_t * (t_vals)  # [n, N_samples] (main.py:673-682)
     else:
@@ -529,6 +531,7 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=6
     rgb0, disp0, acc0, weights0, depth0 = raw2outputs(raw0, z_vals, rays_d, white_bkgd, raw_noise_std, pytest)
     z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
     z_samples = sample_pdf(z_mid, weights0[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
+    z_samples = z_samples.detach()       # main.py:729 (no gradient through the sample positions; a no-op for inference)
     z_all = merge_z(z_vals, z_samples)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
     raw = run_network(sd_fine, pts, viewdirs, dtype=dtype)

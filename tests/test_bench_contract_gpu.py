@@ -71,7 +71,10 @@ def test_bench_line_round4_fields():
     cd = d['create_data']
     assert cd['poses'] == 200 and cd['groups'] == 2 and cd['shards'] == 2 * (100 * 160000 // 4096) == 7812
     assert cd['shard_bytes_total'] == 7812 * (128 + 4096 * 36)
-    assert abs(cd['poses_per_s'] - 200 / cd['wall_s']) < 1e-9 and cd['mlp_launches'] == 400
+    # 2 MLP launches per pose + 2 per spot check of the watch (one check per save group while the mode is a fast one)
+    assert cd['watch']['checks'] == 2 and cd['watch']['fallbacks'] == [] and cd['watch']['precision'] == cd['precision'] == 'fp16x1'
+    assert cd['watch']['worst']['rgb_map'] <= 3e-5
+    assert abs(cd['poses_per_s'] - 200 / cd['wall_s']) < 1e-9 and cd['mlp_launches'] == 400 + 2 * cd['watch']['checks']
     # the teacher's MLP launches are the leg: >= 90 % of its wall clock (VERDICT r3's bar; one group alone measured 0.94-0.96 on
     # boxes whose file system creates the 3,906 files in 0.2-0.3 s and 0.85-0.94 on one where that took up to 0.9 s: the exposed
     # tail of the LAST group -- shuffle gather, copy, file writes -- is paid once per job, here once per two groups)

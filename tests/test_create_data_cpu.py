@@ -183,3 +183,52 @@ def test_shards_are_the_reference_loops_bytes(tmp_path):
             data = []
     assert split == len([x for x in os.listdir(d) if x.endswith('.npy')]) == 2 * (3 * 48 // 64)
     assert os.path.exists(os.path.join(d, 'pseudo_sample_5.png'))
+
+
+def _run_failing(rank, world, port, out_dir, result_dir):
+    """rank body of the write-failure test: records what create_rand raised"""
+    sys.path.insert(0, ROOT)
+    import _pkg
+    _pkg.load()
+    from efficient_nerf_amd import dist as D
+    from efficient_nerf_amd.create_data import RandStream, ShardWriteError, create_rand
+    from oracle import r2l_oracle as O
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world))
+        D.init(backend='gloo')
+
+    def get_rays_fn(H, W, focal, c2w, device=None):
+        return O.get_rays(H, W, focal, c2w)
+    what = 'returned'
+    try:
+        create_rand(FakeTeacher(), 6, 8, O.focal_from_angle(8), 40, out_dir, i_save=4, split_size=64, stream=RandStream(),
+                    log=lambda *a, **k: None, get_rays_fn=get_rays_fn, writer_threads=2)
+    except ShardWriteError as e:
+        what = 'ShardWriteError: %s | cause %r' % (e, e.__cause__)
+    open(os.path.join(result_dir, f'rank{rank}'), 'w').write(what)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2])
+@pytest.mark.timeout(120)
+def test_a_failed_shard_write_raises_on_every_rank_instead_of_hanging(tmp_path, world):
+    """an exception inside the writer threads (ENOSPC, EIO; here: the path of shard 5 is a directory) used to skip the
+    release of the host buffer -- two groups later the render loop waited for a buffer forever and, multi-rank, the peers inside
+    the all-to-all.  Now the job raises ShardWriteError, on every rank, within a group or two of the failure."""
+    out, res = tmp_path / 'pseudo', tmp_path / 'res'
+    os.makedirs(out / 'data_5.npy')          # open(..., 'wb') of shard 5 fails (it also counts as an existing shard: numbering starts at 2)
+    os.makedirs(res)
+    if world == 1:
+        _run_failing(0, 1, 0, str(out), str(res))
+    else:
+        mp.spawn(_run_failing, args=(world, _free_port(), str(out), str(res)), nprocs=world, join=True)
+    got = [open(res / f'rank{r}').read() for r in range(world)]
+    assert all(g.startswith('ShardWriteError') for g in got), got
+    assert sum('IsADirectoryError' in g for g in got) >= 1, got                  # the rank that owns shard 5 names the cause
+    if world > 1:
+        assert any('another rank failed' in g for g in got), got                  # ... its peer raises with it
+    # the job stopped early: far fewer than the 10 groups x 3 shards were written
+    assert len([n for n in os.listdir(out) if n.endswith('.npy')]) < 20

@@ -57,6 +57,24 @@ def test_ranks_get_the_torchrun_environment_and_rank0_owns_stdout(tmp_path):
         assert e['argv'] == ['--x', '1'] and e['MASTER_PORT'] == out[0]['MASTER_PORT'] and int(e['MASTER_PORT']) > 0
 
 
+def test_json_only_keeps_library_chatter_off_stdout(tmp_path):
+    """bench.py's launcher: the driver parses ONE JSON line from stdout; what gloo / RCCL print there while connecting
+    ('[Gloo] Rank 0 is connected to ...' on the GPU box) is relayed to stderr"""
+    script = _script(tmp_path, '''
+        import os
+        print('[Gloo] Rank %s is connected to 1 peer ranks.' % os.environ['RANK'], flush=True)
+        print('{"rank": %s}' % os.environ['RANK'], flush=True)
+    ''')
+    code = ('import importlib.util, sys\n'
+            'spec = importlib.util.spec_from_file_location("l", %r)\n'
+            'm = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n'
+            'sys.exit(m.spawn_ranks(%r, [], 2, timeout=60, json_only=True))\n') % (os.path.join(ROOT, 'efficient-nerf_amd', 'launch.py'), script)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ['{"rank": 0}'], r.stdout
+    assert '[Gloo] Rank 0' in r.stderr and '[Gloo] Rank 1' in r.stderr and '{"rank": 1}' in r.stderr
+
+
 def test_first_failing_rank_stops_the_others_and_sets_the_exit_code(tmp_path):
     script = _script(tmp_path, '''
         import os, sys, time

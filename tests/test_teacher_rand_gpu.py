@@ -117,7 +117,7 @@ def test_render_rays_return_set(engine, g, gr):
     assert np.abs(out['z_std'].cpu().numpy() - gr['det_z_std']).max() <= 1e-6
 
 
-@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8'])
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8', 'fp16x1'])
 def test_full_teacher_frame(engine, g, prec):
     from efficient_nerf_amd import PRECISIONS
     engine.set_precision(PRECISIONS[prec])
@@ -135,7 +135,7 @@ def test_full_teacher_frame(engine, g, prec):
         part = engine.render(c2w, rows=(r0, r1))
         assert torch.equal(part['rgb_map'], rgb[r0 * W:r1 * W]), (r0, r1)
     # CPU oracle on a strided subset of 2,000 rays
-    idx = torch.arange(0, H * W, 80)[:2000]
+    idx = torch.arange(0, H * W, 80)[:2000]       # (the whole frame of fp16x1 against fp16x3: tests/test_teacher_gpu.py)
     ro, rd = O.get_rays(H, W, float(g['focal']), c2w[:3, :4])
     ref = O.render_rays(O.make_teacher_state(1), O.make_teacher_state(2), ro.reshape(-1, 3)[idx].float(),
                         rd.reshape(-1, 3)[idx].float(), white_bkgd=True)

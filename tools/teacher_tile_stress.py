@@ -26,9 +26,9 @@ for it in range(N):
     eng.set_precision(PREC_FP16X1)
     outs = {}
     for nc in (2, 3, 4):
-        check(lib().nerf_debug_set_x1_col_tiles(nc))
+        check(lib().nerf_debug_set_x1_col_tiles(eng._ctx, nc))
         outs[nc] = {k: v.clone() for k, v in eng.render_rays(ro, rd, extras=True).items()}
-    check(lib().nerf_debug_set_x1_col_tiles(4))
+    check(lib().nerf_debug_set_x1_col_tiles(eng._ctx, 4))
     same = all(torch.equal(outs[2][k], outs[4][k]) and torch.equal(outs[3][k], outs[4][k]) for k in outs[2])
     d = (outs[4]['rgb_map'] - ref).abs().max().item()
     worst = max(worst, d)

@@ -16,7 +16,7 @@ pose = O.novel_poses(1)[0][:3, :4]
 outs = {}
 for rnd in range(3):
     for nc in (2, 3, 4):
-        check(lib().nerf_debug_set_x1_col_tiles(nc))
+        check(lib().nerf_debug_set_x1_col_tiles(eng._ctx, nc))
         outs[nc] = {k: v.clone() for k, v in eng.render(pose, extras=True).items()}
         torch.cuda.synchronize()
         t0 = time.time()
@@ -24,5 +24,5 @@ for rnd in range(3):
             eng.render(pose)
         torch.cuda.synchronize()
         print(f'round {rnd}: {nc} column tiles per wave: {(time.time() - t0) * 100:.3f} ms per 400x400 frame', flush=True)
-check(lib().nerf_debug_set_x1_col_tiles(3))
+check(lib().nerf_debug_set_x1_col_tiles(eng._ctx, 3))
 print('every output and extra bitwise equal between the tilings:', all(torch.equal(outs[2][k], outs[3][k]) and torch.equal(outs[2][k], outs[4][k]) for k in outs[2]))
