@@ -140,6 +140,91 @@ def create_data_leg(torch, O, precision):
             'reference_quotes_hours': 24, 'reference_quote': 'README.md:87 "around 24 hrs" for --n_pose_kd 10000 (hardware unstated)'}
 
 
+def trained_like_leg(torch, O, cpu):
+    """secondary, outside the timed region: the committed trained-like fixture (tests/golden/trained_like/: an
+    8 x 256 teacher pair fitted to an analytic scene with the reference's loss, pseudo data made by the HIP create_data path, a
+    W256D88 student distilled from it: tools/train_like.py) through `--precision auto` -- which rung weights that went through
+    the pipeline get, their rate, and their error against the CPU oracle.  Returns None when the fixture is not in the tree."""
+    import numpy as np
+    from efficient_nerf_amd import NeRFEngine, PREC_NAMES, PRECISIONS, R2LEngine
+    from efficient_nerf_amd import create_data as CD
+    d = os.path.join(ROOT, 'tests', 'golden', 'trained_like')
+    if not os.path.exists(os.path.join(d, 'student_w256d88.npz')):
+        return None
+    ld = lambda n: {k: torch.from_numpy(v) for k, v in np.load(os.path.join(d, n)).items()}
+    tsds, ssd = (ld('teacher_coarse.npz'), ld('teacher_fine.npz')), ld('student_w256d88.npz')
+    out = {'fixture': 'tests/golden/trained_like (tools/train_like.py: teacher 4,000 Adam steps on an analytic scene, 300 pseudo poses, '
+                      'student 6,000 Adam steps; PSNR(student, teacher) ~ 30 dB)'}
+    # ---- student, 800 x 800 ----
+    focal = O.focal_from_angle(W)
+    test = O.novel_poses(200)
+    eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(ssd)
+    rung, top = eng.choose_precision(c2w=test[0][:3, :4])
+    s = {'rung': rung, 'max_act_exponent': None if top is None else int(top), 'max_abs_activation': float(eng.stream_max),
+         'ladder': 'fp16_fp8 up to %g, fp16_e4m3 up to %g, fp16x3_asm above' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)}
+    eng.render(test[1][:3, :4])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(10):
+        eng.render_checked(lambda: eng.render(test[2 + i][:3, :4]))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / 10
+    s.update(rays_per_s=H * W / dt, ms_per_frame=dt * 1e3, rung_after_10_frames=PREC_NAMES[eng.precision],
+             frac_of_fp16_mfma_peak=eng.flops_per_ray * H * W / dt / 1e12 / PEAK_FP16_TFLOPS)
+    if cpu:
+        frames = []
+        for pi in (0, 67, 133):
+            got = eng.render(test[pi][:3, :4]).cpu().view(H, W, 3)[::8].reshape(-1, 3)
+            want = O.r2l_render(ssd, H, W, focal, test[pi][:3, :4], rows=(0, H, 8), chunk=16384)
+            frames.append({'pose': pi, 'rays': int(got.shape[0]), 'linf': (got - want).abs().max().item()})
+        s.update(linf_vs_cpu_oracle=max(f['linf'] for f in frames), rays_checked=sum(f['rays'] for f in frames), frames=frames)
+    eng.close()
+    out['student'] = s
+    # ---- teacher, 400 x 400 ----
+    th = 400
+    tf = O.focal_from_angle(th)
+    teng = NeRFEngine(th, th, tf, precision=PRECISIONS['fp16x3']).load_state_dicts(*tsds)
+    name = CD.choose_precision_for_rand(teng, th, th, tf)
+    t = {'precision': name, 'probe_diffs_from_fp16x3': dict(teng.auto_diffs),
+         'limits': {'fp16x1': teng.AUTO_MAX_DIFF_X1, 'fp16_fp8': teng.AUTO_MAX_DIFF}}
+    poses = [O.pose_spherical(30., -30., 4.), O.pose_spherical(150., -85., 4.), O.pose_spherical(-100., -5., 4.)]
+    teng.render(poses[0])
+    teng.timing(True)
+    teng.kernel_time_ms(reset=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for p_ in poses:
+        teng.render(p_)
+    torch.cuda.synchronize()
+    tdt = (time.perf_counter() - t1) / 3
+    kms, kn = teng.kernel_time_ms(reset=True)
+    teng.timing(False)
+    t.update(ms_per_frame=tdt * 1e3, rays_per_s=th * th / tdt, mlp_kernel_ms_per_frame=kms / 3, mlp_launches=kn,
+             frac_of_fp16_mfma_peak=2 * 593408 * 256 * th * th / tdt / 1e12 / PEAK_FP16_TFLOPS)
+    # whole frames of the faster modes against fp16x3 (what the probe protects against): per mode the largest rgb difference
+    whole = {}
+    ref = teng.render(poses[0])['rgb_map'].clone()
+    acc = teng.render(poses[0])['acc_map']
+    t['acc_lt_0.05'], t['acc_gt_0.95'] = float((acc < .05).float().mean()), float((acc > .95).float().mean())
+    for pn in ('fp16x1', 'fp16_fp8'):
+        teng.set_precision(PRECISIONS[pn])
+        whole[pn] = (teng.render(poses[0])['rgb_map'] - ref).abs().max().item()
+    teng.set_precision_pair(PRECISIONS['fp16x3'], PRECISIONS['fp16_fp8'])
+    whole['coarse fp16x3 + fine fp16_fp8'] = (teng.render(poses[0])['rgb_map'] - ref).abs().max().item()
+    t['whole_frame_rgb_linf_from_fp16x3'] = whole
+    teng.set_precision(PRECISIONS[name])
+    if cpu:
+        idx = torch.arange(0, th * th, 10)[:16384]                     # 16,000 rays spread over the frame
+        ro, rd = O.get_rays(th, th, tf, poses[0][:3, :4])
+        want = O.render_rays(tsds[0], tsds[1], ro.reshape(-1, 3)[idx].float(), rd.reshape(-1, 3)[idx].float(), white_bkgd=True)
+        got = teng.render(poses[0])
+        t.update(linf_vs_cpu_oracle=(got['rgb_map'].cpu()[idx] - want['rgb_map']).abs().max().item(), rays_checked=int(idx.numel()),
+                 sigma_max=float(torch.relu(want['raw'][..., 3]).max()))
+    teng.close()
+    out['teacher'] = t
+    return out
+
+
 def teacher_auto(eng, O, th):
     """`--precision auto` of the teacher on the rays of test pose 0 (NeRFEngine.choose_precision): (mode, {candidate: difference})"""
     from efficient_nerf_amd.teacher import get_rays
@@ -189,6 +274,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-teacher', action='store_true', help='skip the secondary teacher measurement')
     ap.add_argument('--no-create-data', action='store_true', help='skip the secondary create_data (config 5) measurement')
+    ap.add_argument('--no-trained-like', action='store_true', help='skip the secondary legs on the committed trained-like fixture')
     ap.add_argument('--allow-fallback', action='store_true',
                     help='N > 1: accept torch.distributed as the assembling collective when the library cannot run r2l_gather_image '
                          '(default: exit non-zero -- a scaling record must time the collective it names)')
@@ -325,7 +411,9 @@ def main():
         # the rate is that of ONE rung of `--precision auto`'s ladder; which rung a checkpoint gets depends on its own activations
         out['value_valid_for'] = ('activation exponent <= 3 (max|a| <= %g over all operand sets of every ray: the rung --precision auto '
                                   'gives these weights; up to %g -> fp16_e4m3, above -> fp16x3_asm: e4m3_mode / stress_weights below; '
-                                  'limits from profiles/r04_range_sweep_dists.txt)' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)
+                                  'limits from profiles/r04_range_sweep_dists.txt).  The synthetic nn.Linear-init weights of this line sit at max|a| ~ 7; the '
+                                  'trained-like fixture (trained_like.student: weights that went through teacher fit -> pseudo data -> distillation) '
+                                  'reaches max|a| ~ 126 and renders on the last rung: its rate is trained_like.student.rays_per_s' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)
                                   if args.precision == 'fp16_fp8' else
                                   'max|a| <= %g over all operand sets of every ray (the middle rung of --precision auto)' % eng.AUTO_MAX_ABS_E4M3)
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
@@ -443,15 +531,28 @@ def main():
             if tauto:
                 tprec, tdiffs = teacher_auto(teng, O, th)
             teng.render(poses[0])
+            teng.timing(True)                   # HIP events around every MLP launch, on its launch stream (nerf_timing_enable)
+            teng.kernel_time_ms(reset=True)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(3):
                 teng.render(poses[i + 1])
             torch.cuda.synchronize()
             tdt = (time.perf_counter() - t1) / 3
-            out['teacher'] = {'workload': 'NeRF teacher lego 400x400 coarse 64 + fine 128', 'rays_per_s': th * th / tdt,
-                              'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': 2 * 593408 * 256 * th * th / tdt / 1e12,
-                              'frac_of_fp16_mfma_peak': 2 * 593408 * 256 * th * th / tdt / 1e12 / PEAK_FP16_TFLOPS,
+            tk_ms, tk_n = teng.kernel_time_ms(reset=True)
+            teng.timing(False)
+            t_flops = 2 * 593408 * 256 * th * th          # per frame: 64 coarse + 192 fine points per ray
+            out['teacher'] = {'workload': 'NeRF teacher lego 400x400 coarse 64 + fine 128 (synthetic nn.Linear-init weights: opaque volume; '
+                                          'trained-like weights: trained_like.teacher)', 'rays_per_s': th * th / tdt,
+                              'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': t_flops / tdt / 1e12,
+                              'frac_of_fp16_mfma_peak': t_flops / tdt / 1e12 / PEAK_FP16_TFLOPS,
+                              # the kernel-time record: the frame's two MLP launches (coarse 64, fine 192 samples)
+                              'roofline': {'bound': 'mfma', 'kernel': {'fp16x1': 'nerf_chain_kernel<true, 4>', 'fp16_fp8': 'nerf_chain_kernel<false, 2>',
+                                                                       'fp16x3': 'nerf_mlp_kernel<2>'}[tprec],
+                                           'launches': tk_n, 'avg_kernel_ms': tk_ms / max(tk_n, 1), 'kernel_ms_per_frame': tk_ms / 3,
+                                           'achieved': t_flops / (tk_ms / 3 * 1e-3) / 1e12, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
+                                           'frac': t_flops / (tk_ms / 3 * 1e-3) / 1e12 / PEAK_FP16_TFLOPS,
+                                           'algorithmic_flops_per_ray': 2 * 593408 * 256},
                               'precision': tprec,
                               'precision_chosen_by': ('auto: largest rgb / acc difference from fp16x3 on 4,096 rays of test pose 0 per candidate %s '
                                                       '(limits: fp16x1 %g, fp16_fp8 %g)' % (tdiffs, teng.AUTO_MAX_DIFF_X1, teng.AUTO_MAX_DIFF)) if tauto else 'flag',
@@ -468,7 +569,7 @@ def main():
                 out['teacher']['fp16_fp8_ms_per_frame'] = (time.perf_counter() - t1) / 3 * 1e3
                 teng.set_precision(PREC_FP16X1)
             if not args.no_cpu_baseline:  # parity of that frame against the CPU oracle on a strided ray subset
-                idx = torch.arange(0, th * th, th * th // 2048)[:2048]   # 2,048 rays spread over the frame
+                idx = torch.arange(0, th * th, 10)[:16000]   # 16,000 rays spread over the frame (round 4: 2,048)
                 ro, rd = O.get_rays(th, th, O.focal_from_angle(th), poses[1])
                 tref = O.render_rays(O.make_teacher_state(1), O.make_teacher_state(2), ro.reshape(-1, 3)[idx].float(),
                                      rd.reshape(-1, 3)[idx].float(), white_bkgd=True)
@@ -476,6 +577,10 @@ def main():
                 out['teacher']['linf_vs_cpu_oracle'] = (tg - tref['rgb_map']).abs().max().item()
                 out['teacher']['rays_checked'] = int(idx.numel())
             teng.close()
+        if not args.no_trained_like and world == 1:
+            tl = trained_like_leg(torch, O, cpu=not args.no_cpu_baseline)
+            if tl is not None:
+                out['trained_like'] = tl
         if not args.no_create_data and world == 1:
             out['create_data'] = create_data_leg(torch, O, args.precision if args.precision in ('fp16x3', 'fp16x1') else 'auto')
         print(json.dumps(out), flush=True)

@@ -203,6 +203,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
 
 struct nerf_ctx {
     int H, W, N_samples, N_importance, white_bkgd, mode, n_cu;
+    int mode_net[2] = {0, 0};   // precision of the coarse / the fine network's MLP launches (nerf_set_precision: both; nerf_set_precision_pair)
     int ndc = 0;            // render() projects the rays to NDC first (main.py:160-162)
     bool split_scans = false;  // nerf_debug_set_split_scans: raw2outputs / sample_pdf / merge as three launches (A/B, parity tests)
     int x1_col_tiles = 4;      // nerf_debug_set_x1_col_tiles: 16-point column tiles per wave of the fp16-only chain (3 or 2 for the A/B)
@@ -297,7 +298,7 @@ int nerf_create(nerf_ctx** out, int H, int W, double focal, float near_, float f
     nerf_ctx* c = new nerf_ctx();
     c->H = H; c->W = W; c->focal = focal; c->near_ = near_; c->far_ = far_;
     c->N_samples = N_samples; c->N_importance = N_importance; c->white_bkgd = white_bkgd ? 1 : 0;
-    c->mode = precision_mode; c->n_cu = n_cu; c->act_scale = 16.0f;
+    c->mode = c->mode_net[0] = c->mode_net[1] = precision_mode; c->n_cu = n_cu; c->act_scale = 16.0f;
     c->z_coarse.resize(N_samples);
     r2l_z_vals(N_samples, near_, far_, c->z_coarse.data());  // main.py:676-678
     c->u.resize(N_importance);
@@ -427,7 +428,7 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
             (void)hipFree(net.d_img[m]);
             net.d_img[m] = nullptr;
         }
-    int rc = build_net(c, net, c->mode);
+    int rc = build_net(c, net, c->mode_net[which]);
     if (rc) return rc;
     net.loaded = true;
     return R2L_OK;
@@ -436,12 +437,22 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
 int nerf_set_precision(nerf_ctx* c, int mode) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (!mode_ok(mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d", mode);
-    c->mode = mode;
-    for (auto& n : c->net)
-        if (n.loaded && !n.d_img[mode]) {
-            int rc = build_net(c, n, mode);
+    return nerf_set_precision_pair(c, mode, mode);
+}
+
+int nerf_set_precision_pair(nerf_ctx* c, int coarse_mode, int fine_mode) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (!mode_ok(coarse_mode) || !mode_ok(fine_mode)) return r2l_set_error(R2L_EINVAL, "bad precision_mode %d / %d", coarse_mode, fine_mode);
+    const int modes[2] = {coarse_mode, fine_mode};
+    for (int which = 0; which < 2; ++which) {
+        PackedNet& n = c->net[which];
+        if (n.loaded && !n.d_img[modes[which]]) {
+            int rc = build_net(c, n, modes[which]);
             if (rc) return rc;
         }
+        c->mode_net[which] = modes[which];
+    }
+    c->mode = fine_mode;
     return R2L_OK;
 }
 
@@ -450,7 +461,8 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     NerfMlpParams p;
     memset(&p, 0, sizeof p);
     p.viewdirs = viewdirs;
-    p.wimg = c->net[which].d_img[c->mode];
+    const int mode = c->mode_net[which];
+    p.wimg = c->net[which].d_img[mode];
     p.raw = raw;
     p.rays_o = rays_o;
     p.rays_d = rays_d;
@@ -464,12 +476,12 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     // the fp16-only chain: 256-point tiles (four column tiles per wave); with given view directions (NDC renders) 192: the four-tile
     // build has no register left to carry the next tile's directions across its asm block
     const int x1_tiles = c->x1_col_tiles;     // read once: tile size and kernel selection below must agree
-    const int x1_nc = c->mode == R2L_PREC_FP16X1 ? ((viewdirs && x1_tiles == 4) ? 3 : x1_tiles) : 2;
+    const int x1_nc = mode == R2L_PREC_FP16X1 ? ((viewdirs && x1_tiles == 4) ? 3 : x1_tiles) : 2;
     const int tile_pts = 64 * x1_nc;
     p.n_tiles = (int)((p.n_pts + tile_pts - 1) / tile_pts);
     p.act_scale = c->act_scale;
     p.neg1 = -1.0f;
-    memcpy(p.inv_scale, c->net[which].inv_scale[c->mode], sizeof p.inv_scale);
+    memcpy(p.inv_scale, c->net[which].inv_scale[mode], sizeof p.inv_scale);
     const int grid = balanced_grid(p.n_tiles, c->n_cu);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
@@ -485,7 +497,7 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
         c->ev_used += 2;
         (void)hipEventRecord(e0, s);
     }
-    hipError_t e = nerf_launch_mlp(p, c->mode, grid, s, x1_nc);
+    hipError_t e = nerf_launch_mlp(p, mode, grid, s, x1_nc);
     if (c->timing) (void)hipEventRecord(e1, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
     return R2L_OK;

@@ -149,7 +149,7 @@ class NeRFEngine:
             check(lib().nerf_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
                                     self.N_samples, self.N_importance, int(multires), int(multires_views),
                                     int(bool(white_bkgd)), int(precision)))
-        self.precision = int(precision)
+        self.precision = self.precision_coarse = int(precision)
         # main.py:676-678 / helpers:293 evaluated with the host's torch, as the reference does
         if z_coarse is None:
             t_vals = torch.linspace(0., 1., steps=self.N_samples)
@@ -209,7 +209,15 @@ class NeRFEngine:
     def set_precision(self, precision):
         with torch.cuda.device(self.device):
             check(lib().nerf_set_precision(self._ctx, int(precision)))
-        self.precision = int(precision)
+        self.precision = self.precision_coarse = int(precision)
+
+    def set_precision_pair(self, coarse, fine):
+        """one mode per network (include/r2l_hip.h nerf_set_precision_pair): the coarse pass decides where the fine samples go
+        (sample_pdf), which on rays that graze an object depends on weights at the 1e-4 level -- a trained teacher needs it at
+        fp32 grade (fp16x3) whatever the fine pass runs in"""
+        with torch.cuda.device(self.device):
+            check(lib().nerf_set_precision_pair(self._ctx, int(coarse), int(fine)))
+        self.precision, self.precision_coarse = int(fine), int(coarse)
 
     #: `--precision auto`: largest difference of rgb / acc (and depth, below) from fp16x3 on probes of the caller's own rays that still
     #: selects a faster mode.  The contract is 1e-4 against the reference on every ray; fp16x3 is within 2e-7 of it.  A probe is 2.5 %

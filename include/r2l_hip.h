@@ -266,6 +266,11 @@ void nerf_destroy(nerf_ctx* ctx);
  * feature_linear.{weight,bias}, alpha_linear.{weight,bias}, rgb_linear.{weight,bias}. */
 int nerf_load_weights(nerf_ctx* ctx, int which, const float* const* tensors, int n_tensors);
 int nerf_set_precision(nerf_ctx* ctx, int precision_mode);
+/* one mode per network: coarse_mode for network_fn's launches, fine_mode for network_fine's (main.py:700-741).  The fine samples
+ * are drawn from the coarse pass's weights (sample_pdf, helpers:283-330): on rays that graze an object those weights are ~0 and
+ * the pdf is decided by differences at the 1e-4 level, so a trained teacher needs the coarse pass at fp32 grade (FP16X3) whatever
+ * the fine pass runs in (profiles/r05_trained_like.txt). */
+int nerf_set_precision_pair(nerf_ctx* ctx, int coarse_mode, int fine_mode);
 /* Override the coarse depths z_vals[N_samples] (main.py:676-678) and/or the inverse-CDF
  * abscissae u[N_importance] = torch.linspace(0,1,N) (helpers:293) with the tensors the
  * reference computes on this host (torch.linspace's last ulp is CPU-vector-width dependent;

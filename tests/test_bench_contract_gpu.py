@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_schema():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
-                        '--cpu-rays', '8000', '--no-teacher'], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        '--cpu-rays', '8000', '--no-teacher', '--no-trained-like'], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -80,13 +80,20 @@ def test_bench_line_round4_fields():
     # tail of the LAST group -- shuffle gather, copy, file writes -- is paid once per job, here once per two groups)
     assert cd['mlp_kernel_share_of_wall'] >= 0.90, cd
     assert cd['tail_s'] < 1.5 and cd['extrapolated_n_pose_kd_10000_hours_one_gpu'] < 1.0 < cd['reference_quotes_hours']
+    # the trained-like fixture's rungs and rates in the line (CPU-oracle fields only with the CPU baseline on)
+    tl = d['trained_like']
+    assert tl['student']['rung'] == 'fp16x3_asm' and tl['student']['max_abs_activation'] > 10 and tl['student']['rays_per_s'] > 1e7
+    assert tl['teacher']['precision'] == 'fp16x3' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
+    assert tl['teacher']['mlp_launches'] == 6 and 0 < tl['teacher']['mlp_kernel_ms_per_frame'] <= tl['teacher']['ms_per_frame']
+    assert tl['teacher']['whole_frame_rgb_linf_from_fp16x3']['fp16x1'] > 1e-3
+    assert 'value_valid_for' in d and 'trained-like' in d['value_valid_for']
 
 
 def _torchrun_bench(extra, port):
     env = dict(os.environ, R2L_DIST_BACKEND='gloo')
     return subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                            '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
-                           '--warmup', '1', '--no-cpu-baseline', '--no-teacher'] + extra, cwd=ROOT, env=env, capture_output=True,
+                           '--warmup', '1', '--no-cpu-baseline', '--no-teacher', '--no-trained-like'] + extra, cwd=ROOT, env=env, capture_output=True,
                           text=True, timeout=900)
 
 
@@ -120,7 +127,7 @@ def _self_launched_bench(extra):
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-                           '--no-cpu-baseline', '--no-teacher', '--no-create-data', '--launch-timeout', '800'] + extra, cwd=ROOT,
+                           '--no-cpu-baseline', '--no-teacher', '--no-create-data', '--no-trained-like', '--launch-timeout', '800'] + extra, cwd=ROOT,
                           env=env, capture_output=True, text=True, timeout=900)
 
 
