@@ -93,7 +93,7 @@ def test_trained_like_pipeline_command_lines(pkg, tmp_path):
                         '--teacher_ckpt', tck, '--n_pose_kd', '2', '--datadir_kd', f'unused:{out}', '--create_data_chunk', '2',
                         '--split_size', '4096', '--H', '128', '--synthetic_poses', '1'], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert '-> fp16x3' in r.stdout and 'wrote 1 shard(s)' in r.stdout, r.stdout[-800:]
+    assert '-> fp16x3' in r.stdout and 'wrote 2 shard(s)' in r.stdout, r.stdout[-800:]
     r = subprocess.run([sys.executable, os.path.join(root, 'main.py'), '--model_name', 'R2L', '--config', 'configs/lego_noview.txt',
                         '--n_sample_per_ray', '16', '--netwidth', '256', '--netdepth', '88', '--use_residual', '--trial.ON',
                         '--trial.body_arch', 'resmlp', '--pretrained_ckpt', sck, '--render_only', '--synthetic_poses', '2', '--H', '64',
