@@ -97,6 +97,7 @@ SIGNATURES = {
     'nerf_render_rays_ex': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nerf_debug_set_split_scans': (C.c_int, [_vp, C.c_int]),
     'nerf_debug_set_x1_col_tiles': (C.c_int, [_vp, C.c_int]),
+    'nerf_debug_set_x1_stream_embed': (C.c_int, [_vp, C.c_int]),
     'nerf_timing_enable': (C.c_int, [_vp, C.c_int]),
     'nerf_kernel_time_ms': (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     'r2l_np_legacy_permutation': (C.c_int, [_vp, C.POINTER(C.c_int), C.c_longlong, _vp]),

@@ -38,7 +38,7 @@ import sys
 import numpy as np
 
 import isa as B
-from isa import (Ins, vr, ar, vreg, areg, sreg, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accw, v_cvt_pk_f16,
+from isa import (Ins, vr, ar, vreg, areg, sreg, waitcnt_lgkm, waitcnt_vm, barrier, valu, v_max0, v_accw, v_accr, v_cvt_pk_f16,
                  v_cvt_pk32_bf6, s_nop, salu, ds_read_b128, ds_read_b64, f_to_bf6, pack6, layer_exponent, weight_exps,
                  f32_bits, Filler, check_hazards_stream, kappa16 as kappa, mix16 as mix_feat)
 
@@ -80,11 +80,18 @@ ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # what the bf6 chain has no registers for fits once the bf6 operand sets are gone: activation set P in VGPRs, set Q in
 # AGPRs (an MFMA takes B from either file; Q's epilogues pay one v_accvgpr_write per packed register).  Four is the most that fits:
 # 224 VGPRs + 16 outputs, 128 + 96 AGPRs.
+# NERF_GEN_FMT=f16c4e (round 5): f16c4 as ONE asm statement that holds the tile loop -- rays and depths of the next tile are loaded
+# by the stream itself (12 global loads into AGPRs at the start of a block), its embedding fragments are computed as FILLER
+# instructions in the shadow of the MFMAs of L6 .. V (E in place once L5 has read it for the last time; V into the dead upper half
+# of set P and from there into its AGPRs behind the V layer's last embedding k-step), and raw is stored by the stream: the HIP prologue
+# that computed the embedding between two blocks while the matrix pipe idled (2.3 ms of a 33.4 ms frame, -DNERF_SKIP_EMBED) is gone.
+# The arithmetic per point is that of nerf_tile_embed (csrc/nerf_kernels.hip), operation for operation: bitwise-equal results.
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
-assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4'), FMT
+assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e'), FMT
 X1 = FMT != 'bf6'
-NC = {'f16c3': 3, 'f16c4': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
-SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4'}[FMT]     # nerf_mlpx_asm.inc ...
+EMB = FMT == 'f16c4e'
+NC = {'f16c3': 3, 'f16c4': 4, 'f16c4e': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
+SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e'}[FMT]     # nerf_mlpx_asm.inc ...
 # passes of an embedding k-step: hi(W) hi(E), hi(W) lo(E), lo(W) hi(E).  The fp16-only chains drop the third (their 256-wide layers
 # carry no lo(W) term either; measured over whole frames, three seed pairs x three poses: rgb 6.5e-6 .. 1.9e-5 from fp16x3 with two
 # passes against 6.4e-6 .. 1.6e-5 with three, -4.4 % time; ONE pass -- no lo(E), i.e. fp16-rounded coordinates -- reads 1.3 .. 2.8e-5
@@ -107,6 +114,22 @@ if NC > 2:
     N_AGPR_CLOBBER = 32 * NC
 else:
     A_SETH = {}
+if EMB:
+    V_OUT = N_VGPR_CLOBBER        # 16: (rgb, sigma) of the four column tiles -- and the embedding's temporaries until the RGB epilogue
+    V_SIG = V_OUT + 16            # 4: sigma of the column tiles (FA's last row tile), moved into V_OUT at the tail
+    V_G = V_SIG + 4               # 8: scratch of the address arithmetic (loads of the next tile's rays, stores of raw)
+    V_PL = V_G + 8                # wave * 64 + (lane & 15): the lane's point inside a column tile of the workgroup tile
+    assert V_PL < 256
+    N_VGPR_CLOBBER = 256
+    A_RAW = A_E + 24 * NC         # 32: per column tile c  o[3] | z at + 4 c,  d[3] at + 16 + 4 c  (even-aligned dwordx3 destinations)
+    N_AGPR_CLOBBER = 256
+    assert A_RAW + 32 == 256
+    S_PO, S_PD, S_PZ, S_PRAW = 56, 58, 60, 62          # pointers: rays_o, rays_d, z, raw
+    S_NPTS, S_LAST, S_S, S_ZS, S_MAGIC, S_SH1, S_SH2 = 64, 65, 66, 67, 68, 69, 70
+    S_TILE, S_NEXT, S_GRID, S_NTILES, S_TB = 71, 72, 73, 74, 75
+    S_C25, S_HI, S_LO, S_A16 = 76, 77, 78, 79          # 0.25, fl32(1 / 2 pi), 1 / 2 pi - fl32(1 / 2 pi)  (csrc/r2l_device.h), act_scale
+    S_MQ1, S_MQ2, S_MQ3, S_MQ0, S_MQ1E, S_ML16, S_TM = 80, 82, 84, 86, 88, 90, 92      # lane masks: q & 1, q & 2, q == 3, q == 0, q == 1, lane < 16, scratch
+    N_SGPR_HI = 96
 
 
 class Layer:
@@ -378,7 +401,13 @@ def mfma6(d, a, b_agpr, scale_a, scale_b, tag=''):
 
 
 def v_mov_out(k, src):
-    """output operand k <- v[src] (the emulator keeps outputs in st.out)"""
+    """output operand k <- v[src] (the emulator keeps outputs in st.out).  f16c4e: the outputs are the stream's own registers --
+    rgb straight into V_OUT (RGB's exposed epilogue: the embedding's temporaries are free by then), sigma, which FA's last row
+    tile delivers while those temporaries are in use, into V_SIG"""
+    if EMB:
+        dst = V_SIG + k // 4 if k % 4 == 3 else V_OUT + k
+        return B.v_mov_b32(dst, ('v', src))
+
     def emu(st):
         st.out[k] = st.V[src].copy()
     return valu('v_mov_b32 %%[o%d], %s' % (k, vreg(src)), vr(src), [], emu)
@@ -404,6 +433,7 @@ def dma_piece(i, pw, tag=''):
                 copies.append((dst, st.img[src:src + 16].copy()))
                 st.lds_pending[dst:dst + 16] = True
         st.pend_dma.append(copies)
+        st.vmq.append(('d', None))
     return Ins(text, 'dma', rd=vr(voffr), emu=emu, cost=8, tag=tag)
 
 
@@ -412,6 +442,10 @@ class NState(B.State):
         B.State.__init__(self, wave, img, np.zeros((1, 1024), dtype=np.uint32), 0, LDS_BYTES)
         self.lds[LDS_AUX:LDS_AUX + len(aux)] = aux
         self.out = {}
+        self.vmq = []                       # f16c4e: every vector memory operation in issue order ('d' LDS-DMA piece, 'v' register load, 'st' store)
+        self.gmem = {}                      # ... and the global buffers its loads and stores see: name -> flat numpy array
+        self.vcc = np.zeros(64, bool)
+        self.exec_ = np.ones(64, bool)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -529,6 +563,452 @@ def epilogue_ops(T, c):
     return ops
 
 
+# ---------------------------------------------------------------------------------------------
+# f16c4e: the embedding, the ray loads and the raw stores as part of the stream
+# ---------------------------------------------------------------------------------------------
+INV2PI_HI = np.float32(0.15915494)            # csrc/r2l_device.h R2L_INV2PI_HI / _LO
+INV2PI_LO = np.float32(6.4206382e-09)
+ACT = 16.0                                    # act_scale of the chain (nerf_capi.hip: c->act_scale)
+
+
+def RAW_O(c):
+    return A_RAW + 4 * c
+
+
+def RAW_Z(c):
+    return A_RAW + 4 * c + 3
+
+
+def RAW_D(c):
+    return A_RAW + 16 + 4 * c
+
+
+def _vv(n):
+    return ('v', n)
+
+
+def _mask(st, s):
+    return st.S[s]
+
+
+def v_cndmask(dst, a, b, smask):
+    """dst = mask ? b : a per lane; a, b: VGPR numbers or 0; mask: SGPR pair (VOP3)"""
+    ta = vreg(a) if a is not None else '0'
+    tb = vreg(b) if b is not None else '0'
+
+    def emu(st):
+        va = st.V[a] if a is not None else np.zeros(64, np.uint32)
+        vb = st.V[b] if b is not None else np.zeros(64, np.uint32)
+        st.V[dst] = np.where(_mask(st, smask), vb, va).astype(np.uint32)
+    rd = ([('v', a)] if a is not None else []) + ([('v', b)] if b is not None else [])
+    return valu('v_cndmask_b32_e64 %s, %s, %s, %s' % (vreg(dst), ta, tb, sreg(smask, 2)), rd, vr(dst), emu)
+
+
+def v_sub_abs(dst, sconst, a):
+    """dst = s[sconst] - |a|"""
+    def emu(st):
+        st.V[dst] = (np.float32(st.S[sconst]) - np.abs(st.f32('v', a))).astype(np.float32).view(np.uint32)
+    return valu('v_sub_f32_e64 %s, %s, |%s|' % (vreg(dst), sreg(sconst), vreg(a)), vr(a), vr(dst), emu)
+
+
+def v_fma_na(dst, a, b, c):
+    """dst = fma(-a, b, c); a, b VGPRs, c a VGPR or the inline constant 1.0"""
+    tc = vreg(c) if isinstance(c, int) else repr(float(c))
+
+    def emu(st):
+        cc = st.f32('v', c).astype(np.float64) if isinstance(c, int) else np.float64(c)
+        st.V[dst] = (-(st.f32('v', a).astype(np.float64) * st.f32('v', b).astype(np.float64)) + cc).astype(np.float32).view(np.uint32)
+    return valu('v_fma_f32 %s, -%s, %s, %s' % (vreg(dst), vreg(a), vreg(b), tc), vr(a) + vr(b) + (vr(c) if isinstance(c, int) else []), vr(dst), emu)
+
+
+def v_fmac(dst, a, b):
+    """dst = a * b + dst (one rounding)"""
+    def emu(st):
+        st.V[dst] = (st.f32('v', a).astype(np.float64) * st.f32('v', b).astype(np.float64) + st.f32('v', dst).astype(np.float64)
+                     ).astype(np.float32).view(np.uint32)
+    return valu('v_fmac_f32_e32 %s, %s, %s' % (vreg(dst), vreg(a), vreg(b)), vr(a) + vr(b) + vr(dst), vr(dst), emu)
+
+
+def _trans(text, rd, wr, emu):
+    ins = valu(text, rd, wr, emu)
+    ins.kind = 'trans'
+    ins.cost = 4
+    return ins
+
+
+def v_sin(dst, a):
+    ins = B.v_sin_f32(dst, _vv(a))
+    ins.cost = 4
+    return ins
+
+
+def v_sqrt(dst, a):
+    def emu(st):
+        st.V[dst] = np.sqrt(st.f32('v', a)).astype(np.float32).view(np.uint32)
+    return _trans('v_sqrt_f32_e32 %s, %s' % (vreg(dst), vreg(a)), vr(a), vr(dst), emu)
+
+
+def v_rcp(dst, a):
+    def emu(st):
+        st.V[dst] = (np.float32(1.0) / st.f32('v', a)).astype(np.float32).view(np.uint32)
+    return _trans('v_rcp_f32_e32 %s, %s' % (vreg(dst), vreg(a)), vr(a), vr(dst), emu)
+
+
+def v_addi(dst, imm, a):
+    """integer dst = a + imm (the neighbours of a float in v_sqrt's correction step)"""
+    def emu(st):
+        st.V[dst] = (st.V[a].astype(np.int64) + imm).astype(np.uint32)
+    return valu('v_add_u32_e32 %s, %d, %s' % (vreg(dst), imm, vreg(a)), vr(a), vr(dst), emu)
+
+
+def v_cmp0(op, smask, a):
+    """s[smask] = (0 op a) per lane, op in ge / lt"""
+    fn = {'ge': lambda x: 0.0 >= x, 'lt': lambda x: 0.0 < x}[op]
+
+    def emu(st):
+        st.S[smask] = fn(st.f32('v', a))
+    return valu('v_cmp_%s_f32_e64 %s, 0, %s' % (op, sreg(smask, 2), vreg(a)), vr(a), [], emu)
+
+
+def v_div_scale(dst, sdst, s0, s1, s2):
+    """v_div_scale_f32 dst, sdst, s0, s1, s2 (s1 denominator, s2 numerator; returns s0 scaled).  The emulator models the case the
+    stream is used in -- no operand near the ends of the exponent range: nothing is scaled, the flag is clear"""
+    def emu(st):
+        x = st.f32('v', s0)
+        ok = np.isfinite(x) & ((np.abs(x) > 2.0 ** -60) | (x == 0)) & (np.abs(x) < 2.0 ** 60)
+        if not ok.all():
+            st.errors.append('ins %d: v_div_scale_f32 operand outside the modelled range' % st.n_ins)
+        st.V[dst] = st.V[s0]
+        if sdst == 'vcc':
+            st.vcc = np.zeros(64, bool)
+        else:
+            st.S[sdst] = np.zeros(64, bool)
+    sd = 'vcc' if sdst == 'vcc' else sreg(sdst, 2)
+    return valu('v_div_scale_f32 %s, %s, %s, %s, %s' % (vreg(dst), sd, vreg(s0), vreg(s1), vreg(s2)), vr(s0) + vr(s1) + vr(s2), vr(dst), emu)
+
+
+def v_div_fmas(dst, a, b, c):
+    def emu(st):
+        assert not st.vcc.any()
+        st.V[dst] = (st.f32('v', a).astype(np.float64) * st.f32('v', b).astype(np.float64) + st.f32('v', c).astype(np.float64)
+                     ).astype(np.float32).view(np.uint32)
+    return valu('v_div_fmas_f32 %s, %s, %s, %s' % (vreg(dst), vreg(a), vreg(b), vreg(c)), vr(a) + vr(b) + vr(c), vr(dst), emu)
+
+
+def v_div_fixup(dst, q, den, num):
+    def emu(st):
+        st.V[dst] = st.V[q]          # finite, non-zero operands: the quotient passes through
+    return valu('v_div_fixup_f32 %s, %s, %s, %s' % (vreg(dst), vreg(q), vreg(den), vreg(num)), vr(q) + vr(den) + vr(num), vr(dst), emu)
+
+
+def v_mul(dst, a, b):
+    """dst = a * b: a a VGPR number, ('s', n) or a float literal; b a VGPR number"""
+    return B.v_f32_op('mul', dst, _vv(a) if isinstance(a, int) else a, _vv(b))
+
+
+def v_add(dst, a, b):
+    return B.v_f32_op('add', dst, _vv(a), _vv(b))
+
+
+def v_sub(dst, a, b):
+    return B.v_f32_op('sub', dst, _vv(a), _vv(b))
+
+
+def _separate(ops):
+    """the two adjacency rules of isa.check_hazards_stream hold inside the list whatever the scheduler puts in between: no reader
+    directly behind a transcendental or behind a half-register write of the same register"""
+    out = []
+    for ins in ops:
+        if out:
+            prev = out[-1]
+            touched = set(ins.rd) | (set(ins.wr) if ins.partial else set())
+            if (prev.kind == 'trans' and set(prev.wr) & set(ins.rd)) or (prev.partial and set(prev.wr) & touched):
+                out.append(s_nop(0))
+        out.append(ins)
+    return out
+
+
+def _to_rev(x, rh, rl, tmp):
+    """to_rev (r2l_device.h): rh = x * HI, rl = fma(x, LO, fma(x, HI, -rh))"""
+    return [v_mul(rh, ('s', S_HI), x),
+            B.v_fma_f32(tmp, _vv(x), ('s', S_HI), _vv(rh), neg_c=True),
+            B.v_fma_f32(rl, _vv(x), ('s', S_LO), _vv(tmp))]
+
+
+def _turn_fraction(RH, RL, g):
+    """g = frac(x 2^l / 2 pi) in [-1/2, 1/2] from the scaled pair (trig_pow2: t = rh 2^l, u = t - rint(t), g = fma(rl, 2^l, u); the
+    scalings by 2^l are exact, so rl 2^l + u rounds as the fma does)"""
+    return [B.v_rndne_f32(g, _vv(RH)), v_sub(g, RH, g), v_add(g, RL, g)]
+
+
+def v_mix16(dst, high, a, hsrc=None, hhalf=0):
+    """half `high` of dst = f16(a * 16 - h), h = 0 or the f16 half `hhalf` of v[hsrc]: v_fma_mixlo/hi_f16 with f32 a, f32 16.0 (SGPR) and
+    an f16 third source.  One instruction for split_store's `(f16)(v * act_scale)` (h = 0: the product by a power of two is exact,
+    one rounding) and one for its residual `(f16)fma((float)h, -1, v * act_scale)` (exact before the rounding to f16)"""
+    op = 'v_fma_mixhi_f16' if high else 'v_fma_mixlo_f16'
+    if hsrc is None:
+        text = '%s %s, %s, %s, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]' % (op, vreg(dst), vreg(a), sreg(S_A16))
+    else:
+        text = '%s %s, %s, %s, -%s op_sel:[0,0,%d] op_sel_hi:[0,0,1]' % (op, vreg(dst), vreg(a), sreg(S_A16), vreg(hsrc), hhalf)
+
+    def emu(st):
+        h = np.zeros(64) if hsrc is None else ((st.V[hsrc] >> (16 * hhalf)) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+        r = (st.f32('v', a).astype(np.float64) * ACT - h).astype(np.float32).astype(np.float16).view(np.uint16).astype(np.uint32)
+        st.V[dst] = (st.V[dst] & 0x0000ffff) | (r << 16) if high else (st.V[dst] & 0xffff0000) | r
+    return valu(text, vr(a) + (vr(hsrc) if hsrc is not None else []), vr(dst), emu, partial=True)
+
+
+def _pack_pair(dst_hi, dst_lo, a0, a1, tmp=None):
+    """split_store of two consecutive elements a0, a1 (before the factor act_scale): dword of the hi fragment = (f16(16 a0), f16(16 a1)),
+    of the lo fragment their fp16 residuals.  tmp = (hi, lo) VGPR temporaries when the fragments live in AGPRs"""
+    H, Lo = tmp if tmp else (dst_hi, dst_lo)
+    ops = [v_mix16(H, 0, a0), v_mix16(Lo, 0, a0, H, 0), v_mix16(H, 1, a1), v_mix16(Lo, 1, a1, H, 1)]
+    # (the lo half of Lo reads only the lo half of H, written two instructions earlier; _separate puts a nop where a reader would
+    # directly follow a half-register write of the register it reads)
+    if tmp:
+        ops += [v_accw(dst_hi, H), v_accw(dst_lo, Lo)]
+    return ops
+
+
+def _element(BH, BL, scale, S1, S2, cos_mask):
+    """S1 = sin or cos (lanes of cos_mask: cos; None: sin everywhere; 'all': cos everywhere) of 2 pi frac(scale (BH + BL)): trig_pow2 of
+    r2l_device.h with pow2l = scale -- t = rh 2^l, u = t - rint(t), g = fma(rl, 2^l, u), cos(2 pi g) = sin(2 pi (1/4 - |g|))"""
+    if scale == 1.0:
+        ops = [B.v_rndne_f32(S2, _vv(BH)), v_sub(S1, BH, S2), v_add(S1, BL, S1)]
+    else:
+        ops = [v_mul(S1, float(scale), BH), B.v_rndne_f32(S2, _vv(S1)), v_sub(S1, S1, S2), B.v_fmac_lit(S1, float(scale), BL)]
+    if cos_mask == 'all':
+        ops += [v_sub_abs(S1, S_C25, S1)]
+    elif cos_mask is not None:
+        ops += [v_sub_abs(S2, S_C25, S1), v_cndmask(S1, S1, S2, cos_mask)]
+    return ops
+
+
+def _normalise_ops(d, N, W):
+    """d[0..2] <- d / |d| (main.py:154-156) as hipcc expands sqrtf and __fdiv_rn for operands that need no scaling: v_sqrt_f32 and the
+    neighbour that squares closest; v_div_scale x 2, v_rcp_f32, the Newton steps, v_div_fmas, v_div_fixup"""
+    a, b, c2, r1, r2 = W
+    ops = [v_mul(N, d[0], d[0]), v_mul(a, d[1], d[1]), v_add(N, N, a), v_mul(a, d[2], d[2]), v_add(N, N, a)]
+    ops += [v_sqrt(a, N), v_addi(b, -1, a), v_addi(c2, 1, a), v_fma_na(r1, b, a, N), v_fma_na(r2, c2, a, N),
+            v_cmp0('ge', S_TM, r1), s_nop(1), v_cndmask(a, a, b, S_TM), v_cmp0('lt', S_TM, r2), s_nop(1), v_cndmask(N, a, c2, S_TM)]
+    DS, NS, R, Q, E = W
+    for k in range(3):
+        ops += [v_div_scale(DS, S_TM, N, N, d[k]), v_rcp(R, DS), v_div_scale(NS, 'vcc', d[k], N, d[k]), v_fma_na(E, DS, R, 1.0), v_fmac(R, E, R),
+                v_mul(Q, NS, R), v_fma_na(E, DS, Q, NS), v_fmac(Q, E, R), v_fma_na(E, DS, Q, NS), v_div_fmas(Q, E, R, Q), v_div_fixup(d[k], Q, N, d[k])]
+    return ops
+
+
+def emb_E_ops(c):
+    """E fragments (both k-steps, hi | lo) of column tile c from its (o, d, z) in the RAW AGPRs: nerf_tile_embed's E part; then the
+    view direction d / |d| back into d's RAW AGPRs (emb_V_ops reads it there: the normalisation runs in this, the longer, window)"""
+    T = [V_OUT + i for i in range(16)]
+    xs, rh, rl = T[0:3], [T[3], T[5], T[7]], [T[4], T[6], T[8]]
+    BH, BL, S1, S2, A, Hh = T[9], T[10], T[11], T[12], [T[13], T[14]], T[15]
+    ops = [v_accr(BH, RAW_Z(c))]
+    for k in range(3):
+        ops += [v_accr(S1, RAW_O(c) + k), v_accr(S2, RAW_D(c) + k), v_mul(S2, S2, BH), v_add(xs[k], S1, S2)]     # o + d * z  (main.py:701)
+    for k in range(3):
+        ops += _to_rev(xs[k], rh[k], rl[k], S1)
+    # k-step 0: coordinate q >> 1, frequencies 0..7; odd lane quarters hold the cosines
+    ops += [v_cndmask(BH, rh[0], rh[1], S_MQ2), v_cndmask(BL, rl[0], rl[1], S_MQ2)]
+    for j in range(8):
+        ops += _element(BH, BL, 2.0 ** j, S1, S2, S_MQ1) + [B.v_sin_f32(A[j & 1], _vv(S1))]
+        ops[-1].cost = 4
+        if j & 1:
+            ops += _pack_pair(E_reg('E', 0, c, False) + (j >> 1), E_reg('E', 0, c, True) + (j >> 1), A[0], A[1], (Hh, S2))
+    # k-step 1: lane quarters 0, 1: coordinate 2, frequencies 0..7; quarters 2, 3: frequencies 8, 9 of all three coordinates, then
+    # the identity.  Per element pair p one base pair: r2 in quarters 0, 1 and r_p 2^(8 - 2p) in quarters 2, 3, scaled by 4^p 2^e
+    for p in range(4):
+        if p < 3:
+            ops += [v_mul(S1, float(2 ** (8 - 2 * p)), rh[p]), v_cndmask(BH, rh[2], S1, S_MQ2),
+                    v_mul(S1, float(2 ** (8 - 2 * p)), rl[p]), v_cndmask(BL, rl[2], S1, S_MQ2)]
+            bh, bl = BH, BL
+        else:
+            bh, bl = rh[2], rl[2]
+        for e in range(2):
+            ops += _element(bh, bl, 4.0 ** p * 2.0 ** e, S1, S2, S_MQ1) + [B.v_sin_f32(A[e], _vv(S1))]
+            ops[-1].cost = 4
+            if p == 3:      # j = 6: q == 3 ? xs[2] : xs[0];  j = 7: q == 3 ? 0 : xs[1]   (quarters 2, 3 only)
+                ops += [v_cndmask(S2, xs[0], xs[2], S_MQ3) if e == 0 else v_cndmask(S2, xs[1], None, S_MQ3), v_cndmask(A[e], A[e], S2, S_MQ2)]
+        ops += _pack_pair(E_reg('E', 1, c, False) + p, E_reg('E', 1, c, True) + p, A[0], A[1], (Hh, S2))
+    d = T[0:3]
+    ops += [v_accr(d[k], RAW_D(c) + k) for k in range(3)]
+    ops += _normalise_ops(d, T[3], T[4:9])
+    ops += [v_accw(RAW_D(c) + k, d[k]) for k in range(3)]
+    return _separate(ops)
+
+
+def V_STAGE(c, lo):
+    """where the next tile's view fragments wait for the V layer's last embedding k-step: k-steps 4 (hi) and 5 (lo) of set P,
+    dead between FA's last read of P and L1's epilogue of the next block"""
+    return hset('P', 5 if lo else 4, c)
+
+
+def emb_V_ops(c):
+    """view fragments (hi | lo) of column tile c from d / |d| (left in d's RAW AGPRs by emb_E_ops): nerf_tile_embed's view step, into
+    V_STAGE.  Lane quarter q < 3: component q, elements j = 0..3 sin, 4..7 cos of frequencies 0..3; q = 3: the identity columns"""
+    T = [V_OUT + i for i in range(16)]
+    vs, BH, BL, S1, S2, As, Ac = T[0:3], T[9], T[10], T[11], T[12], [T[13], T[14]], [T[4], T[5]]
+    ops = [v_accr(vs[k], RAW_D(c) + k) for k in range(3)]
+    ops += [v_cndmask(S1, vs[2], vs[1], S_MQ1E), v_cndmask(S1, S1, vs[0], S_MQ0)]
+    ops += _to_rev(S1, BH, BL, S2)
+    for f in range(4):
+        ops += _element(BH, BL, 2.0 ** f, S1, S2, None)                     # g of frequency f
+        ops += [v_sub_abs(S2, S_C25, S1), v_sin(As[f & 1], S1), v_sin(Ac[f & 1], S2),
+                v_cndmask(As[f & 1], As[f & 1], vs[f] if f < 3 else None, S_MQ3), v_cndmask(Ac[f & 1], Ac[f & 1], None, S_MQ3)]
+        if f & 1:
+            r = f >> 1
+            ops += _pack_pair(V_STAGE(c, False) + r, V_STAGE(c, True) + r, As[0], As[1])            # elements 2 r, 2 r + 1: sines
+            ops += _pack_pair(V_STAGE(c, False) + 2 + r, V_STAGE(c, True) + 2 + r, Ac[0], Ac[1])    # elements 4 + 2 r, ...: cosines
+    return _separate(ops)
+
+
+def emb_V_commit_ops():
+    ops = []
+    for c in range(NC):
+        for lo in (False, True):
+            for r in range(4):
+                ops.append(v_accw(E_reg('V', 0, c, lo) + r, V_STAGE(c, lo) + r))
+    return ops
+
+
+# ---- the ray loads of a tile and the raw stores: address arithmetic in VALU, global_load into the RAW AGPRs -------------------------
+def _vop(text, rd, wr, emu):
+    return valu(text, rd, wr, emu)
+
+
+def _u32(st, x):
+    return st.V[x].astype(np.uint64) if isinstance(x, int) else np.full(64, np.uint64(st.S[x[1]]), dtype=np.uint64)
+
+
+def v_u32(op, dst, a, b):
+    """dst = a op b on 32-bit unsigned lanes; a: VGPR number, ('s', n) or a small int; b: VGPR number (VOP2 operand order: the
+    reverse forms are named explicitly)"""
+    names = {'add': 'v_add_u32_e32', 'sub': 'v_sub_u32_e32', 'min': 'v_min_u32_e32', 'lshr': 'v_lshrrev_b32_e32', 'lshl': 'v_lshlrev_b32_e32',
+             'and': 'v_and_b32_e32', 'mul_lo': 'v_mul_lo_u32', 'mul_hi': 'v_mul_hi_u32'}
+
+    def val(st, x):
+        if isinstance(x, int) and not isinstance(x, bool):
+            return st.V[x].astype(np.uint64)
+        if isinstance(x, tuple) and x[0] == 's':
+            return np.full(64, np.uint64(int(st.S[x[1]]) & 0xffffffff), dtype=np.uint64)
+        return np.full(64, np.uint64(x[1]), dtype=np.uint64)          # ('i', value)
+
+    def emu(st):
+        x, y = val(st, a), val(st, b)
+        if op == 'add':
+            r = x + y
+        elif op == 'sub':
+            r = x - y
+        elif op == 'min':
+            r = np.minimum(x, y)
+        elif op == 'lshr':        # b >> a  (rev form)
+            r = y >> (x & np.uint64(31))
+        elif op == 'lshl':
+            r = y << (x & np.uint64(31))
+        elif op == 'and':
+            r = x & y
+        elif op == 'mul_lo':
+            r = x * y
+        else:
+            r = (x * y) >> np.uint64(32)
+        st.V[dst] = (r & np.uint64(0xffffffff)).astype(np.uint32)
+
+    def txt(x):
+        if isinstance(x, int) and not isinstance(x, bool):
+            return vreg(x)
+        return sreg(x[1]) if x[0] == 's' else str(x[1])
+    return valu('%s %s, %s, %s' % (names[op], vreg(dst), txt(a), txt(b)), [('v', x) for x in (a, b) if isinstance(x, int) and not isinstance(x, bool)],
+                vr(dst), emu)
+
+
+def gload(adst, n, voff, sbase, buf):
+    """a[adst : adst + n] <- n dwords per lane from the global buffer `buf` at byte offset v[voff] (saddr form, vmcnt)"""
+    text = 'global_load_dword%s %s, %s, %s' % ({1: '', 3: 'x3'}[n], areg(adst, n), vreg(voff), sreg(sbase, 2))
+
+    def emu(st):
+        g = st.gmem[buf]
+        off = st.V[voff].astype(np.int64)
+        data = np.zeros((n, 64), dtype=np.uint32)
+        for l in range(64):
+            assert off[l] % 4 == 0 and 0 <= off[l] and off[l] + 4 * n <= g.nbytes, (buf, int(off[l]), g.nbytes)
+            data[:, l] = g.view(np.uint32).reshape(-1)[off[l] // 4:off[l] // 4 + n]
+        st.vmq.append(('v', ('a', adst, data)))
+        st.pend_regs.update(ar(adst, n))
+    return Ins(text, 'vload', rd=vr(voff), wr=ar(adst, n), emu=emu)
+
+
+def raw_load_ops():
+    """(o, d, z) of the lane's four points of tile s[S_NEXT] into the RAW AGPRs: nerf_tile_load (csrc/nerf_kernels.hip) for NC = 4
+    without given view directions.  pt / S by the round-up multiply of Granlund & Montgomery (host: magic, sh1, sh2)"""
+    G0, G1, G2, G3 = V_G, V_G + 1, V_G + 2, V_G + 3
+    ops = [salu('s_lshl_b32 %s, %s, 8' % (sreg(S_TB), sreg(S_NEXT)), lambda st: st.S.__setitem__(S_TB, (st.S[S_NEXT] << 8) & 0xffffffff))]
+    for c in range(NC):
+        ops += [v_u32('add', G0, ('s', S_TB), V_PL)]
+        if c:
+            ops += [v_u32('add', G0, ('i', 16 * c), G0)]
+        ops += [v_u32('min', G0, ('s', S_LAST), G0),                 # tail lanes repeat the last point (their stores are masked)
+                v_u32('mul_hi', G1, G0, ('s', S_MAGIC)), v_u32('sub', G2, G0, G1), v_u32('lshr', G2, ('s', S_SH1), G2), v_u32('add', G2, G1, G2),
+                v_u32('lshr', G2, ('s', S_SH2), G2),                 # ray = pt / S
+                v_u32('mul_lo', G1, G2, ('s', S_S)), v_u32('sub', G1, G0, G1),           # sample = pt - ray * S
+                v_u32('mul_lo', G3, G2, ('s', S_ZS)), v_u32('add', G3, G3, G1), v_u32('lshl', G3, ('i', 2), G3),
+                v_u32('mul_lo', G2, G2, ('i', 12)),
+                gload(RAW_O(c), 3, G2, S_PO, 'rays_o'), gload(RAW_D(c), 3, G2, S_PD, 'rays_d'), gload(RAW_Z(c), 1, G3, S_PZ, 'z')]
+    return ops
+
+
+def raw_store_ops():
+    """raw[pt] = (rgb, sigma) / act_scale of tile s[S_TILE] for lanes 0..15 and pt < n_pts (nerf_chain_kernel's store)"""
+    G0, G1 = V_G, V_G + 1
+    ops = [salu('s_lshl_b32 %s, %s, 8' % (sreg(S_TB), sreg(S_TILE)), lambda st: st.S.__setitem__(S_TB, (st.S[S_TILE] << 8) & 0xffffffff))]
+    for c in range(NC):
+        ops.append(B.v_mov_b32(V_OUT + 4 * c + 3, _vv(V_SIG + c)))
+        ops += [v_mul(V_OUT + 4 * c + k, 1.0 / ACT, V_OUT + 4 * c + k) for k in range(4)]
+        ops += [v_u32('add', G0, ('s', S_TB), V_PL)]
+        if c:
+            ops += [v_u32('add', G0, ('i', 16 * c), G0)]
+        ops += [v_u32('lshl', G1, ('i', 4), G0)]
+
+        def emu_cmp(st, G0=G0):
+            st.vcc = st.V[G0].astype(np.int64) < int(st.S[S_NPTS])
+        ops.append(valu('v_cmp_gt_u32_e32 vcc, %s, %s' % (sreg(S_NPTS), vreg(G0)), vr(G0), [], emu_cmp))
+
+        def emu_exec(st):
+            st.exec_ = st.vcc & st.S[S_ML16]
+        ops.append(salu('s_and_b64 exec, vcc, %s' % sreg(S_ML16, 2), emu_exec))
+
+        def emu_store(st, c=c, G1=G1):
+            g = st.gmem['raw'].view(np.uint32).reshape(-1)
+            off = st.V[G1].astype(np.int64)
+            for l in range(64):
+                if st.exec_[l]:
+                    assert off[l] % 16 == 0 and 0 <= off[l] and off[l] + 16 <= g.nbytes, (int(off[l]), g.nbytes)
+                    g[off[l] // 4:off[l] // 4 + 4] = st.V[V_OUT + 4 * c:V_OUT + 4 * c + 4, l]
+            st.vmq.append(('st', None))
+        ops.append(Ins('global_store_dwordx4 %s, %s, %s' % (vreg(G1), vreg(V_OUT + 4 * c, 4), sreg(S_PRAW, 2)), 'vstore',
+                       rd=vr(G1) + vr(V_OUT + 4 * c, 4), emu=emu_store))
+        ops.append(salu('s_mov_b64 exec, -1', lambda st: setattr(st, 'exec_', np.ones(64, bool))))
+    return ops
+
+
+def vm_wait(n):
+    """s_waitcnt vmcnt(n) over the ONE in-order queue of this stream's vector memory operations (LDS-DMA pieces, register loads,
+    stores): all but the youngest n have completed -- register loads land, and the LDS-DMA pieces among the youngest n are what
+    the next barrier must not certify (isa.barrier: st.cert)"""
+    def emu(st):
+        q = st.vmq
+        done, st.vmq = (q[:len(q) - n], q[len(q) - n:]) if n else (q, [])
+        for kind, payload in done:
+            if kind == 'v':
+                file, dst, data = payload
+                st.regs(file)[dst:dst + len(data)] = data
+                for r in (vr if file == 'v' else ar)(dst, len(data)):
+                    st.pend_regs.discard(r)
+        st.cert = sum(1 for kind, _ in st.vmq if kind == 'd')
+    return Ins('s_waitcnt vmcnt(%d)' % n, 'wait', emu=emu)
+
+
+
 class Opts:
     def __init__(self, **kw):
         self.lead = 8          # anchors a fragment read is issued ahead of its first MFMA
@@ -537,6 +1017,7 @@ class Opts:
         self.dma_gap = 4       # anchors (16-cycle MFMAs) between two LDS-DMA pieces: 4 .. 6 are 1.7 % faster than 3, 2 is slower
         self.pair = False
         self.wait_group = 2    # fp16 fragments one s_waitcnt may cover (those already issued)
+        self.cap_late = 2      # f16c4e: issue slots behind an MFMA once the embedding fillers may run (anchor >= a_emb)
         if NC > 2:             # three (four) MFMAs per fragment: fewer filler slots behind each, LDS-DMA pieces further apart (same-box sweep:
             self.cap = 2       # cap 2 / 3 / 4 / 5 = 36.9 / 37.2 / 37.3 / 37.6 ms per frame, gap 3 / 4 / 6 = 37.5 / 37.2 / 36.9, both: -1.4 %)
             self.dma_gap = 2 * NC          # (four column tiles: gap 4 / 6 / 8 = 34.75 / 34.35 / 34.2 ms)
@@ -653,7 +1134,7 @@ def build_fillers(opts):
         ar = rdv_anchor(ci)
         nxt = rdv_anchor(ci + 1) if ci + 1 < NCH else N_ANCH
         ch = ('dma',)
-        F.append(Filler(waitcnt_vm(group.get(ci + 2, 0)), ar - 1, ar + 1, ch))
+        F.append(Filler((vm_wait if EMB else waitcnt_vm)(group.get(ci + 2, 0)), ar - 1, ar + 1, ch))
         F.append(Filler(barrier(), ar - 1, ar + 1, ch))
         seq, pw = chunk_issue_seq(ci + 3, (ci + 3) % NSLOT)
         group[ci + 3] = pw
@@ -665,6 +1146,28 @@ def build_fillers(opts):
                 F.append(Filler(ins, min(ar + 1 + opts.dma_gap * k, nxt - 2), nxt - 1, ch))
                 if ins.kind == 'dma':
                     k += 1
+    if EMB:
+        # ---- the next tile's rays: 12 global loads into the RAW AGPRs, two instructions per anchor from the start of L0 ------------
+        # (their destinations were read for the last time by the previous block's embedding fillers)
+        for i, ins in enumerate(raw_load_ops()):
+            F.append(Filler(ins, i // 2, afirst(TILE_OF[(1, 0)]), ('raw',)))
+        # ---- the next tile's embedding: lowest priority (deadline = the end of the block), in the shadow of L6 .. RGB ---------------
+        TL5 = TILE_OF[(5, CHAIN[5].rt - 1)]
+        a_e = max(aidx(TL5, 'x', xi, c, p) for xi in range(CHAIN[5].nx) for c in range(NC) for p in range(XPASS)) + 2    # E was read for the last time
+        TFA = TILE_OF[(8, CHAIN[8].rt - 1)]
+        a_v = max(aidx(TFA, 'm16', s_, c, 0) for s_ in range(4, 8) for c in range(NC)) + 2         # FA was the last reader of P's upper half
+        TV = TILE_OF[(9, CHAIN[9].rt - 1)]
+        a_c = max(aidx(TV, 'x', 0, c, p) for c in range(NC) for p in range(XPASS)) + 2             # the V layer's last embedding k-step
+        ch = ('emb',)
+        for c in range(NC):
+            for ins in emb_E_ops(c):
+                F.append(Filler(ins, a_e, N_ANCH + 1, ch))
+        for c in range(NC):
+            for ins in emb_V_ops(c):
+                F.append(Filler(ins, a_v, N_ANCH + 1, ch))
+        for ins in emb_V_commit_ops():
+            F.append(Filler(ins, a_c, N_ANCH + 1, ch))
+        opts.a_emb = a_e
     return F, bufmap
 
 
@@ -747,7 +1250,8 @@ def schedule(opts):
         if kind == 'x':
             sch.need(key)
             ek, e = L.extra[k]
-            ins = mfma16(d, bufmap[key], 'a', E_reg(ek, e, c, p == 1), csrc, tag=('x', T, k, c, p), btext=E_name(ek, e, c, p == 1))
+            ins = mfma16(d, bufmap[key], 'a', E_reg(ek, e, c, p == 1), csrc, tag=('x', T, k, c, p),
+                         btext=None if EMB else E_name(ek, e, c, p == 1))
         elif kind == 'm16':
             sch.need(key, [('hi', T, k + g) for g in range(1, opts.wait_group)])
             ins = mfma16(d, bufmap[key], hfile(L.src), hset(L.src, k, c), csrc, tag=('m16', T, k, c))
@@ -760,6 +1264,8 @@ def schedule(opts):
                         tag=('m6', T, k, c))
         sch.emit(ins)
         budget = opts.cap if not opts.pair else (0 if c == 0 else 2 * opts.cap)   # pair: fillers only behind the c = 1 MFMA
+        if EMB and a >= opts.a_emb:
+            budget = opts.cap_late
         while budget > 0:
             r = ready(a)
             if not r:
@@ -838,7 +1344,151 @@ def tail_ops():
 
 
 def block_stream(opts):
+    if EMB:      # ... and the block ends with the stores of its own tile's raw
+        return [vm_wait(0), barrier()] + schedule(opts) + tail_ops() + raw_store_ops()
     return [waitcnt_vm(0), barrier()] + schedule(opts) + tail_ops()
+
+
+# ---- f16c4e: the kernel around the block (one asm statement: setup, ring prologue, first tile's embedding, tile loop) --------------
+KERNEL_OPERANDS = ('wimg', 'wave', 'ro', 'rd', 'z', 'raw', 'npts', 'S', 'zs', 'magic', 'sh1', 'sh2', 'tile', 'grid', 'ntiles')
+
+
+def kernel_setup_ops():
+    """(text lines, emulator function(st, args)) of the one-time setup: setup_ops' constants plus the operands of the kernel, the lane
+    masks and the constants of the embedding"""
+    L, emu0 = setup_ops()
+    a = L.append
+    for name, reg, wide in (('ro', S_PO, 1), ('rd', S_PD, 1), ('z', S_PZ, 1), ('raw', S_PRAW, 1), ('npts', S_NPTS, 0), ('S', S_S, 0), ('zs', S_ZS, 0),
+                            ('magic', S_MAGIC, 0), ('sh1', S_SH1, 0), ('sh2', S_SH2, 0), ('tile', S_TILE, 0), ('grid', S_GRID, 0), ('ntiles', S_NTILES, 0)):
+        a('s_mov_b%d %s, %%[%s]' % (64 if wide else 32, sreg(reg, 2 if wide else 1), name))
+    a('s_sub_u32 %s, %s, 1' % (sreg(S_LAST), sreg(S_NPTS)))
+    a('s_mov_b32 %s, 0x%08x' % (sreg(S_C25), f32_bits(0.25)))
+    a('s_mov_b32 %s, 0x%08x' % (sreg(S_HI), f32_bits(INV2PI_HI)))
+    a('s_mov_b32 %s, 0x%08x' % (sreg(S_LO), f32_bits(INV2PI_LO)))
+    a('s_mov_b32 %s, 0x%08x' % (sreg(S_A16), f32_bits(ACT)))
+    G0, G1 = V_G, V_G + 1
+    a('v_lshrrev_b32_e32 %s, 4, %s' % (vreg(G0), vreg(V_LANE)))                # lane quarter q
+    a('v_and_b32_e32 %s, 1, %s' % (vreg(G1), vreg(G0)))
+    a('v_cmp_ne_u32_e64 %s, 0, %s' % (sreg(S_MQ1, 2), vreg(G1)))
+    a('v_and_b32_e32 %s, 2, %s' % (vreg(G1), vreg(G0)))
+    a('v_cmp_ne_u32_e64 %s, 0, %s' % (sreg(S_MQ2, 2), vreg(G1)))
+    a('v_cmp_eq_u32_e64 %s, 3, %s' % (sreg(S_MQ3, 2), vreg(G0)))
+    a('v_cmp_eq_u32_e64 %s, 0, %s' % (sreg(S_MQ0, 2), vreg(G0)))
+    a('v_cmp_eq_u32_e64 %s, 1, %s' % (sreg(S_MQ1E, 2), vreg(G0)))
+    a('v_cmp_gt_u32_e64 %s, 16, %s' % (sreg(S_ML16, 2), vreg(V_LANE)))
+    a('v_and_b32_e32 %s, 15, %s' % (vreg(V_PL), vreg(V_LANE)))
+    a('s_lshl_b32 %s, %s, 6' % (sreg(S_TB), sreg(S_WAVE)))
+    a('v_add_u32_e32 %s, %s, %s' % (vreg(V_PL), sreg(S_TB), vreg(V_PL)))
+    a('s_nop 3')                                                               # the masks are read by VALU from here on
+
+    def emu(st, args):
+        emu0(st)
+        lanes = np.arange(64)
+        q = lanes >> 4
+        st.S[S_NPTS], st.S[S_LAST], st.S[S_S], st.S[S_ZS] = args['npts'], args['npts'] - 1, args['S'], args['zs']
+        st.S[S_MAGIC], st.S[S_SH1], st.S[S_SH2] = args['magic'], args['sh1'], args['sh2']
+        st.S[S_TILE], st.S[S_GRID], st.S[S_NTILES] = args['tile'], args['grid'], args['ntiles']
+        st.S[S_C25], st.S[S_HI], st.S[S_LO], st.S[S_A16] = 0.25, float(INV2PI_HI), float(INV2PI_LO), ACT
+        st.S[S_MQ1], st.S[S_MQ2], st.S[S_MQ3], st.S[S_MQ0], st.S[S_MQ1E] = (q & 1) != 0, (q & 2) != 0, q == 3, q == 0, q == 1
+        st.S[S_ML16] = lanes < 16
+        st.V[V_PL] = (st.wave * 64 + (lanes & 15)).astype(np.uint32)
+    return L, emu
+
+
+def div_magic(d):
+    """(magic, sh1, sh2) with n / d = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, magic), for every 32-bit n (Granlund & Montgomery,
+    "Division by invariant integers using multiplication", fig. 4.1) -- restated by nerf_capi.hip for the kernel's operands"""
+    assert 1 <= d < 2 ** 31
+    l = (d - 1).bit_length()
+    magic = (2 ** 32 * (2 ** l - d)) // d + 1
+    return magic & 0xffffffff, min(l, 1), max(l - 1, 0)
+
+
+def first_embed_ops():
+    ops = []
+    for c in range(NC):
+        ops += emb_E_ops(c)
+    for c in range(NC):
+        ops += emb_V_ops(c)
+    return ops + emb_V_commit_ops()
+
+
+def kernel_text(opts):
+    """the whole kernel as asm lines"""
+    setup, _ = kernel_setup_ops()
+    L = list(setup)
+    a = L.append
+    a('s_cmp_ge_u32 %s, %s' % (sreg(S_TILE), sreg(S_NTILES)))
+    a('s_cbranch_scc1 L_exit_%=')
+    L += [i.text for i in prologue_ops()]
+    a('s_mov_b32 %s, %s' % (sreg(S_NEXT), sreg(S_TILE)))
+    L += [i.text for i in raw_load_ops()]
+    a('s_waitcnt vmcnt(0)')
+    L += [i.text for i in first_embed_ops()]
+    a('s_add_u32 %s, %s, %s' % (sreg(S_NEXT), sreg(S_TILE), sreg(S_GRID)))
+    a('L_tile_%=:')
+    body = block_stream(opts)
+    L += [i.text for i in body]
+    a('s_mov_b32 %s, %s' % (sreg(S_TILE), sreg(S_NEXT)))
+    a('s_add_u32 %s, %s, %s' % (sreg(S_NEXT), sreg(S_NEXT), sreg(S_GRID)))
+    a('s_cmp_lt_u32 %s, %s' % (sreg(S_TILE), sreg(S_NTILES)))
+    a('s_cbranch_scc1 L_tile_%=')
+    a('L_exit_%=:')
+    a('s_waitcnt vmcnt(0)')
+    a('s_mov_b32 m0, %s' % sreg(S_M0SAVE))
+    return L, body
+
+
+def emit_kernel(dirname, opts):
+    lines, body = kernel_text(opts)
+    n = {}
+    for ins in body:
+        n[ins.kind] = n.get(ins.kind, 0) + 1
+    with open(os.path.join(dirname, 'nerf_mlp%s_asm.inc' % SUFFIX), 'w') as f:
+        f.write('// GENERATED by gen/nerf_gen.py (NERF_GEN_FMT=%s) -- do not edit.  The fp16-only teacher chain as one statement: ring prologue, first '
+                "tile's embedding, tile loop (ray loads, eleven layers, the next tile's embedding as fillers, raw stores).  Per tile: %s\n" %
+                (FMT, ', '.join('%s %d' % kv for kv in sorted(n.items()))))
+        for line in lines:
+            f.write('"%s\\n\\t"\n' % line)
+    regs = ['v%d' % i for i in range(256)] + ['a%d' % i for i in range(256)] + ['s%d' % i for i in range(N_SGPR_LO, N_SGPR_HI)] + ['vcc', 'scc', 'memory']
+    with open(os.path.join(dirname, 'nerf_mlp%s_clobbers.inc' % SUFFIX), 'w') as f:
+        f.write('// GENERATED by gen/nerf_gen.py: registers the kernel statement owns\n' + ', '.join('"%s"' % r for r in regs) + '\n')
+    return n, body
+
+
+def emulate_kernel(opts, img, aux, rays_o, rays_d, z, S, z_stride, n_pts, wave=0, block=0, grid=1, check_hazards=True, body=None):
+    """one wave of workgroup `block` of a `grid`-workgroup launch over n_pts points (rays_o / rays_d [n_rays, 3], z [n_rays, S] or
+    [S] with z_stride 0): returns (raw [n_pts, 4] float32 with the rows this wave stored filled in, NaN elsewhere; errors)"""
+    body = body or block_stream(opts)
+    st = NState(wave, img, aux)
+    n_tiles = (n_pts + 64 * NC - 1) // (64 * NC)
+    magic, sh1, sh2 = div_magic(S)
+    _, setup = kernel_setup_ops()
+    setup(st, dict(npts=n_pts, S=S, zs=z_stride, magic=magic, sh1=sh1, sh2=sh2, tile=block, grid=grid, ntiles=n_tiles))
+    st.gmem = {'rays_o': np.ascontiguousarray(rays_o, dtype=np.float32).reshape(-1), 'rays_d': np.ascontiguousarray(rays_d, dtype=np.float32).reshape(-1),
+               'z': np.ascontiguousarray(z, dtype=np.float32).reshape(-1), 'raw': np.full(n_pts * 4, np.nan, dtype=np.float32)}
+    errs = []
+    if block < n_tiles:
+        st.run(prologue_ops())
+        st.S[S_NEXT] = st.S[S_TILE]
+        st.run(raw_load_ops())
+        st.run([vm_wait(0)])
+        st.run(first_embed_ops())
+        st.S[S_NEXT] = st.S[S_TILE] + st.S[S_GRID]
+        while True:
+            st.run(body)
+            st.S[S_TILE] = st.S[S_NEXT]
+            st.S[S_NEXT] = st.S[S_NEXT] + st.S[S_GRID]
+            if not st.S[S_TILE] < st.S[S_NTILES]:
+                break
+    errs += list(st.errors)
+    if st.pend_ds:
+        errs.append('%d LDS reads never waited for' % len(st.pend_ds))
+    if check_hazards:
+        errs += check_hazards_stream(body)
+        errs += check_hazards_stream(first_embed_ops())
+    return st.gmem['raw'].reshape(n_pts, 4), errs
+
 
 
 def emit(dirname, opts):
@@ -920,7 +1570,7 @@ def main():
     opts = Opts(pair=a.pair, drop=tuple(x for x in a.drop.split(',') if x), **given)
     print('format', FMT, 'tiles', NT, 'chunks', NCH, 'MFMAs', N_ANCH, 'stream bytes', STREAM_BYTES)
     if a.emit:
-        n, body = emit(a.emit, opts)
+        n, body = (emit_kernel if EMB else emit)(a.emit, opts)
         print('wrote', a.emit, n, 'model cycles per tile', model_cycles(body))
     if a.dump:
         body = block_stream(opts)

@@ -207,6 +207,7 @@ struct nerf_ctx {
     int ndc = 0;            // render() projects the rays to NDC first (main.py:160-162)
     bool split_scans = false;  // nerf_debug_set_split_scans: raw2outputs / sample_pdf / merge as three launches (A/B, parity tests)
     int x1_col_tiles = 4;      // nerf_debug_set_x1_col_tiles: 16-point column tiles per wave of the fp16-only chain (3 or 2 for the A/B)
+    bool x1_stream_embed = true;   // nerf_debug_set_x1_stream_embed: the four-tile chain with its embedding in the stream (nerf_chain_emb_kernel)
     float ndc_near = 1.0f;
     double focal;
     float near_, far_, act_scale;
@@ -477,6 +478,16 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     // build has no register left to carry the next tile's directions across its asm block
     const int x1_tiles = c->x1_col_tiles;     // read once: tile size and kernel selection below must agree
     const int x1_nc = mode == R2L_PREC_FP16X1 ? ((viewdirs && x1_tiles == 4) ? 3 : x1_tiles) : 2;
+    // the one-statement build addresses raw with 32-bit byte offsets (16 B per point) and z with 4 B per point
+    const bool stream_embed = mode == R2L_PREC_FP16X1 && x1_nc == 4 && c->x1_stream_embed && !viewdirs && p.n_pts < (1ll << 28);
+    {   // pt / S by multiplication (Granlund & Montgomery: exact for every 32-bit pt; gen/nerf_gen.py div_magic)
+        const unsigned d = (unsigned)S;
+        unsigned l = 0;
+        while ((1ull << l) < d) ++l;
+        p.div_magic = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+        p.div_sh1 = l < 1 ? l : 1;
+        p.div_sh2 = l > 0 ? l - 1 : 0;
+    }
     const int tile_pts = 64 * x1_nc;
     p.n_tiles = (int)((p.n_pts + tile_pts - 1) / tile_pts);
     p.act_scale = c->act_scale;
@@ -497,7 +508,7 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
         c->ev_used += 2;
         (void)hipEventRecord(e0, s);
     }
-    hipError_t e = nerf_launch_mlp(p, mode, grid, s, x1_nc);
+    hipError_t e = nerf_launch_mlp(p, mode, grid, s, x1_nc, stream_embed);
     if (c->timing) (void)hipEventRecord(e1, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
     return R2L_OK;
@@ -594,6 +605,12 @@ int nerf_debug_set_x1_col_tiles(nerf_ctx* c, int n) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (n < 2 || n > 4) return r2l_set_error(R2L_EINVAL, "column tiles per wave: 2, 3 or 4");
     c->x1_col_tiles = n;
+    return R2L_OK;
+}
+
+int nerf_debug_set_x1_stream_embed(nerf_ctx* c, int on) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    c->x1_stream_embed = on != 0;
     return R2L_OK;
 }
 

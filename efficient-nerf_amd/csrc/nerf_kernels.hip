@@ -428,6 +428,33 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's refill of the ring
 }
 
+// R2L_PREC_FP16X1 without given view directions (round 5): the four-column-tile chain as ONE generated statement that holds the tile
+// loop (gen/nerf_gen.py NERF_GEN_FMT=f16c4e -> nerf_mlpx4e_asm.inc).  What nerf_chain_kernel<true, 4> does in HIP code between two
+// blocks while the matrix pipe idles -- nerf_tile_load, nerf_tile_embed, the raw stores: 2.3 ms of a 33.4 ms frame -- is part of the
+// stream here: 12 global loads into AGPRs at the start of a block, the NEXT tile's embedding as filler instructions in the shadow
+// of the MFMAs of L6 .. V (operation for operation nerf_tile_embed's arithmetic: the results are bitwise those of the other builds,
+// tests/test_teacher_watch_gpu.py), four masked global_store_dwordx4 at its end.  The statement owns every VGPR / AGPR and s40-s95.
+__global__ __launch_bounds__(256, 1) void nerf_chain_emb_kernel(NerfMlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char nerf_chain_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {   // resident table: per layer 272 f32 bias (act_scale domain) (nerf_common.h)
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + NERF_CHAINX_STREAM_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(nerf_chain_lds + NERF_CHAIN_RING_BYTES);
+        for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    asm volatile(
+#include "nerf_mlpx4e_asm.inc"
+        :
+        : [wimg] "s"(p.wimg), [wave] "s"(wave), [ro] "s"(p.rays_o), [rd] "s"(p.rays_d), [z] "s"(p.z), [raw] "s"(p.raw),
+          [npts] "s"((unsigned)p.n_pts), [S] "s"((unsigned)p.S), [zs] "s"((unsigned)p.z_stride), [magic] "s"(p.div_magic),
+          [sh1] "s"(p.div_sh1), [sh2] "s"(p.div_sh2), [tile] "s"((unsigned)blockIdx.x), [grid] "s"((unsigned)gridDim.x),
+          [ntiles] "s"((unsigned)p.n_tiles)
+        :
+#include "nerf_mlpx4e_clobbers.inc"
+    );
+}
+
 // ====================================================================================
 // get_rays
 // ====================================================================================
@@ -950,8 +977,10 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
     return hipGetLastError();
 }
 
-hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles) {
-    static std::atomic<bool> attr_set[5][64];  // zero-initialised; the opt-in call itself is idempotent
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles, bool stream_embed) {
+    static std::atomic<bool> attr_set[6][64];  // zero-initialised; the opt-in call itself is idempotent
+    if (mode == R2L_PREC_FP16X1 && x1_col_tiles == 4 && stream_embed)
+        return launch_big_lds(&nerf_chain_emb_kernel, attr_set[5], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel<false, 2>, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X3) return launch_big_lds(&nerf_mlp_kernel<2>, attr_set[1], KCfg<2>::LDS, p, grid, stream);
     // FP16X1: the generated chain without correction terms (round 4; the compiler-scheduled nerf_mlp_kernel<1> it replaces: 49.5 ms per

@@ -313,6 +313,9 @@ int nerf_debug_set_split_scans(nerf_ctx* ctx, int on);
 /* A-B timing / parity tests: 16-point column tiles per wave of this context's FP16X1 chain, 4 (default: 256-point workgroup
  * tiles), 3 (192) or 2 (128); the results are bit-identical (the arithmetic per point does not depend on the tiling) */
 int nerf_debug_set_x1_col_tiles(nerf_ctx* ctx, int n);
+/* A-B timing / parity tests: 0 = the four-tile FP16X1 chain with its embedding computed by HIP code between two tile blocks
+ * (nerf_chain_kernel<true, 4>, round 4) instead of inside the generated stream (nerf_chain_emb_kernel, round 5); bit-identical */
+int nerf_debug_set_x1_stream_embed(nerf_ctx* ctx, int on);
 int nerf_timing_enable(nerf_ctx* ctx, int on);
 int nerf_kernel_time_ms(nerf_ctx* ctx, double* total_ms, int* n_launches, int reset);
 

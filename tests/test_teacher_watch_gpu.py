@@ -174,8 +174,13 @@ def test_fp16x1_column_tilings_are_bitwise_equal(pkg, case):
         if not ndc and nc == 2:
             o2 = other.render_rays(ro, rd)
             assert torch.equal(o2['rgb_map'], outs[2]['rgb_map'])
+    # four column tiles run the one-statement build with the embedding in its stream (nerf_chain_emb_kernel, round 5) unless view
+    # directions are given; with nerf_debug_set_x1_stream_embed(0) the round-4 build whose embedding is HIP code between two blocks
+    check(lib().nerf_debug_set_x1_stream_embed(eng._ctx, 0))
+    outs['hip'] = {k: v.clone() for k, v in eng.render_rays(ro, rd, extras=True).items()}
+    check(lib().nerf_debug_set_x1_stream_embed(eng._ctx, 1))
     for k in outs[2]:
-        assert torch.equal(outs[2][k], outs[4][k]) and torch.equal(outs[3][k], outs[4][k]), (k, n, S0, NI)
+        assert torch.equal(outs[2][k], outs[4][k]) and torch.equal(outs[3][k], outs[4][k]) and torch.equal(outs['hip'][k], outs[4][k]), (k, n, S0, NI)
     assert (outs[4]['rgb_map'] - ref).abs().max().item() <= 1e-4
     with pytest.raises(Exception):
         check(lib().nerf_debug_set_x1_col_tiles(eng._ctx, 5))
