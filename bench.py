@@ -547,8 +547,8 @@ def main():
                               'ms_per_frame': tdt * 1e3, 'algorithmic_tflops': t_flops / tdt / 1e12,
                               'frac_of_fp16_mfma_peak': t_flops / tdt / 1e12 / PEAK_FP16_TFLOPS,
                               # the kernel-time record: the frame's two MLP launches (coarse 64, fine 192 samples)
-                              'roofline': {'bound': 'mfma', 'kernel': {'fp16x1': 'nerf_chain_kernel<true, 4>', 'fp16_fp8': 'nerf_chain_kernel<false, 2>',
-                                                                       'fp16x3': 'nerf_mlp_kernel<2>'}[tprec],
+                              'roofline': {'bound': 'mfma', 'kernel': {'fp16x1': 'nerf_chain_emb_kernel', 'fp16_fp8': 'nerf_chain_kernel<false, 2>',
+                                                                       'fp16x3': 'nerf_mlp_kernel<2>', 'fp16x3_asm': 'nerf_chain_kernel<false, 2, true>'}[tprec],
                                            'launches': tk_n, 'avg_kernel_ms': tk_ms / max(tk_n, 1), 'kernel_ms_per_frame': tk_ms / 3,
                                            'achieved': t_flops / (tk_ms / 3 * 1e-3) / 1e12, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
                                            'frac': t_flops / (tk_ms / 3 * 1e-3) / 1e12 / PEAK_FP16_TFLOPS,
@@ -556,7 +556,7 @@ def main():
                               'precision': tprec,
                               'precision_chosen_by': ('auto: largest rgb / acc difference from fp16x3 on 4,096 rays of test pose 0 per candidate %s '
                                                       '(limits: fp16x1 %g, fp16_fp8 %g)' % (tdiffs, teng.AUTO_MAX_DIFF_X1, teng.AUTO_MAX_DIFF)) if tauto else 'flag',
-                              'mfma_pass_equivalents': {'fp16x1': 1.0, 'fp16_fp8': 1.5, 'fp16x3': 3.0}[tprec]}
+                              'mfma_pass_equivalents': {'fp16x1': 1.0, 'fp16_fp8': 1.5, 'fp16x3': 3.0, 'fp16x3_asm': 3.0}[tprec]}
             if tauto and tprec == 'fp16x1':     # beside it: the same frames through the chain WITH its bf6 correction terms (auto's second rung)
                 from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X1
                 teng.set_precision(PREC_FP16_FP8)

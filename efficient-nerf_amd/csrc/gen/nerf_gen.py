@@ -87,16 +87,24 @@ ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # that computed the embedding between two blocks while the matrix pipe idled (2.3 ms of a 33.4 ms frame, -DNERF_SKIP_EMBED) is gone.
 # The arithmetic per point is that of nerf_tile_embed (csrc/nerf_kernels.hip), operation for operation: bitwise-equal results.
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
-assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e'), FMT
+assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3'), FMT
 X1 = FMT != 'bf6'
 EMB = FMT == 'f16c4e'
+# NERF_GEN_FMT=f16p3 (round 5): fp16x3's arithmetic on the generated chain -- per k-step three fp16 MFMAs on one accumulate chain,
+# hi(W) hi(a) + hi(W) lo(a) + lo(W) hi(a), lo = the fp16 rounding residual -- for teachers that need fp32-grade arithmetic: every
+# TRAINED one (profiles/r05_trained_like.txt: sharp densities amplify a single pass's 1e-5 to 3e-3, and the fine samples follow the
+# coarse weights discontinuously).  Two column tiles per wave; lo(W) is a second set of streamed fragments (84 chunks of <= 32 KiB),
+# lo(a) a second pair of activation sets in AGPRs; the stream holds W x 2^k (k per layer: max|w| 2^k in [2^12, 2^13)) so that lo(W) is
+# a normal fp16 number, the epilogue takes the factor out (one v_fma_mix per value does it together with the conversion to fp16).
+P3 = FMT == 'f16p3'
 NC = {'f16c3': 3, 'f16c4': 4, 'f16c4e': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
-SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e'}[FMT]     # nerf_mlpx_asm.inc ...
+SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e', 'f16p3': 'p3'}[FMT]     # nerf_mlpx_asm.inc ...
 # passes of an embedding k-step: hi(W) hi(E), hi(W) lo(E), lo(W) hi(E).  The fp16-only chains drop the third (their 256-wide layers
 # carry no lo(W) term either; measured over whole frames, three seed pairs x three poses: rgb 6.5e-6 .. 1.9e-5 from fp16x3 with two
 # passes against 6.4e-6 .. 1.6e-5 with three, -4.4 % time; ONE pass -- no lo(E), i.e. fp16-rounded coordinates -- reads 1.3 .. 2.8e-5
 # for another -4 % and is not taken).  The stream keeps the lo(W) fragments (unread: 72 of 1,298 KiB).  NERF_GEN_XPASS overrides.
-XPASS = int(os.environ.get('NERF_GEN_XPASS', '2' if X1 else '3'))
+XPASS = int(os.environ.get('NERF_GEN_XPASS', '2' if (X1 and not P3) else '3'))
+MPASS = 3 if P3 else 1          # MFMAs per main k-step and column tile
 if NC > 2:
     V_SET = {'P': 0}              # fp16 B operands of set P (VGPR): + c*32 + s*4
     A_SETH = {'Q': 0}             # ... of set Q (AGPR)
@@ -114,6 +122,13 @@ if NC > 2:
     N_AGPR_CLOBBER = 32 * NC
 else:
     A_SETH = {}
+if P3:
+    A_LOSET = {'P': 0, 'Q': 64}   # lo(a) B operands of the two activation sets (AGPR): + c*32 + s*4
+    A_E = 128
+    N_AGPR_CLOBBER = 128
+    N_FRAG_BUF = 6                # rotating weight-fragment buffers from V_HI (hi and lo fragments alike): into V_A6's registers, unused here
+else:
+    N_FRAG_BUF = 4
 if EMB:
     V_OUT = N_VGPR_CLOBBER        # 16: (rgb, sigma) of the four column tiles -- and the embedding's temporaries until the RGB epilogue
     V_SIG = V_OUT + 16            # 4: sigma of the column tiles (FA's last row tile), moved into V_OUT at the tail
@@ -148,6 +163,8 @@ class Layer:
 
     def chunk_pieces(self):
         r = self.rt_per_chunk
+        if P3:
+            return r * self.ks * 2 + r * self.nx * 2
         return r * self.ks + r * self.nj + (r * self.nj + 1) // 2 + r * self.nx * 2
 
 
@@ -155,7 +172,7 @@ def chain():
     E2 = [('E', 0), ('E', 1)]
     # row tiles per chunk: a chunk must fit a 32 KiB ring slot; without the bf6 operands twice as many row tiles do (44 chunks and
     # rendezvous per tile instead of 80)
-    r_std, r_l5, r_v = (4, 2, 2) if X1 else (2, 1, 2)
+    r_std, r_l5, r_v = (2, 1, 1) if P3 else ((4, 2, 2) if X1 else (2, 1, 2))
     L = [Layer('L0', None, 'Q', 0, E2, 16, 'relu', 8, 256)]
     sets = ['Q', 'P']
     for i in range(1, 5):
@@ -214,6 +231,10 @@ def piece_of(L, k, what, idx):
     (fp16 fragment of main k-step idx), 'b6' / 'b6b' (first 16 / last 8 bytes per lane of bf6 operand idx), 'xh' / 'xl'
     (hi / lo fragment of embedding k-step idx)"""
     r = L.rt_per_chunk
+    if P3:      # per row tile: its ks hi fragments, then its ks lo fragments; behind all row tiles the embedding k-steps (hi, lo)
+        if what in ('hi', 'lo'):
+            return k * L.ks * 2 + (L.ks if what == 'lo' else 0) + idx, 0
+        return r * L.ks * 2 + (k * L.nx + idx) * 2 + (1 if what == 'xl' else 0), 0
     if what == 'hi':
         return k * L.ks + idx, 0
     base = r * L.ks
@@ -284,6 +305,14 @@ def pack_teacher(tensors, act_scale=16.0):
         a0 = li * AUX_LAYER // 4
         aux[a0:a0 + len(bias)] = (bias.astype(np.float64) * act_scale).astype(np.float32).view(np.uint32)
         el = ew = 0
+        if P3:      # W x 2^k with max|w| 2^k in [2^12, 2^13) over everything that accumulates into this layer's rows (r2l_pow2_scale)
+            mx = max(float(np.abs(m).max()) for m in (Wm, We) if m is not None)
+            sw = np.float32(2.0 ** (12 - int(np.floor(np.log2(mx)))) if mx > 0 and np.isfinite(mx) else 1.0)
+            aux[a0:a0 + len(bias)] = (bias.astype(np.float64) * act_scale * float(sw)).astype(np.float32).view(np.uint32)
+            for qq in range(4):
+                aux[a0 + AUX_SCALES // 4 + 4 * qq] = np.array([1.0 / sw], dtype=np.float32).view(np.uint32)[0]
+            Wm = None if Wm is None else (Wm * sw).astype(np.float32)
+            We = None if We is None else (We * sw).astype(np.float32)
         if Wm is not None:
             hi = Wm.astype(np.float16)
         if Wm is not None and not X1:       # the E8M0 scale bytes of the bf6 terms
@@ -308,6 +337,12 @@ def pack_teacher(tensors, act_scale=16.0):
                 for j in range(8):
                     frag[:, j] = np.where(ok, hi[rws, kappa(s, q, j)], 0)
                 put('hi', s, frag)
+                if P3:
+                    frag = np.zeros((64, 8), dtype=np.float16)
+                    for j in range(8):
+                        kk = kappa(s, q, j)
+                        frag[:, j] = np.where(ok, (Wm[rws, kk] - hi[rws, kk].astype(np.float32)).astype(np.float16), 0)
+                    put('lo', s, frag)
             for j, (term, tt) in enumerate(L.j_order() if L.ks else []):
                 codes = np.zeros((64, 32), dtype=np.uint8)
                 for e in range(32):
@@ -400,13 +435,36 @@ def mfma6(d, a, b_agpr, scale_a, scale_b, tag=''):
     return B.mfma6('v', d, a, b_agpr, scale_a, scale_b, tag)
 
 
-def v_mov_out(k, src):
+def v_mixs(dst, high, a, scale_v, hsrc=None, hhalf=0):
+    """half `high` of dst = f16(a * v[scale_v] - h), h = 0 or the f16 half `hhalf` of v[hsrc] (v_fma_mixlo/hi_f16: f32 a, f32 scale,
+    f16 third source): the epilogue of f16p3 -- conversion to fp16, removal of the layer's weight scale and the residual in one
+    instruction per half"""
+    op = 'v_fma_mixhi_f16' if high else 'v_fma_mixlo_f16'
+    if hsrc is None:
+        text = '%s %s, %s, %s, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]' % (op, vreg(dst), vreg(a), vreg(scale_v))
+    else:
+        text = '%s %s, %s, %s, -%s op_sel:[0,0,%d] op_sel_hi:[0,0,1]' % (op, vreg(dst), vreg(a), vreg(scale_v), vreg(hsrc), hhalf)
+
+    def emu(st):
+        h = np.zeros(64) if hsrc is None else ((st.V[hsrc] >> (16 * hhalf)) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+        r = (st.f32('v', a).astype(np.float64) * st.f32('v', scale_v).astype(np.float64) - h).astype(np.float32).astype(np.float16)
+        r = r.view(np.uint16).astype(np.uint32)
+        st.V[dst] = (st.V[dst] & 0x0000ffff) | (r << 16) if high else (st.V[dst] & 0xffff0000) | r
+    return valu(text, vr(a) + vr(scale_v) + (vr(hsrc) if hsrc is not None else []), vr(dst), emu, partial=True)
+
+
+def v_mov_out(k, src, inv=None):
     """output operand k <- v[src] (the emulator keeps outputs in st.out).  f16c4e: the outputs are the stream's own registers --
     rgb straight into V_OUT (RGB's exposed epilogue: the embedding's temporaries are free by then), sigma, which FA's last row
     tile delivers while those temporaries are in use, into V_SIG"""
     if EMB:
         dst = V_SIG + k // 4 if k % 4 == 3 else V_OUT + k
         return B.v_mov_b32(dst, ('v', src))
+    if inv is not None:       # f16p3: the accumulator carries the layer's weight scale 2^k; v[inv] = 2^-k
+
+        def emu_s(st):
+            st.out[k] = (st.f32('v', src) * st.f32('v', inv)).astype(np.float32).view(np.uint32)
+        return valu('v_mul_f32 %%[o%d], %s, %s' % (k, vreg(inv), vreg(src)), vr(src) + vr(inv), [], emu_s)
 
     def emu(st):
         st.out[k] = st.V[src].copy()
@@ -460,8 +518,9 @@ def tile_anchors(L):
             for c in range(NC):
                 out.append(('x', xi, c, p))
     for s in range(L.ks):
-        for c in range(NC):
-            out.append(('m16', s, c, 0))
+        for p in range(MPASS):          # f16p3: hi(W) hi(a), hi(W) lo(a), lo(W) hi(a)
+            for c in range(NC):
+                out.append(('m16', s, c, p))
         j = s - (L.ks - L.nj)
         if j >= 0:
             out.append(('m6', j, 0, 0))
@@ -487,7 +546,9 @@ def afirst(T):
 def operand_key(T, kind, k, p):
     if kind == 'x':
         return ('xl' if p == 2 else 'xh', T, k)
-    return ('hi' if kind == 'm16' else 'a6', T, k)
+    if kind == 'm16':
+        return ('lo' if p == 2 else 'hi', T, k)
+    return ('a6', T, k)
 
 
 def hfile(name):
@@ -497,6 +558,11 @@ def hfile(name):
 
 def hset(name, s, c):
     return (A_SETH[name] if name in A_SETH else V_SET[name]) + c * 32 + s * 4
+
+
+def lset(name, s, c):
+    """lo(a) B operand of activation set `name` (f16p3: AGPR)"""
+    return A_LOSET[name] + c * 32 + s * 4
 
 
 def b6(name, term, t, c):
@@ -523,10 +589,11 @@ def epilogue_ops(T, c):
     tb = TMP(c)
     cv = tb + 4
     ops = []
+    inv = V_SC + 2 * (t.li & 1) if P3 else None
     if L.epi == 'rgb':
-        return [(v_mov_out(c * 4 + k, acc + k), None) for k in range(3)]
+        return [(v_mov_out(c * 4 + k, acc + k, inv), None) for k in range(3)]
     if L.epi == 'feat' and u == 16:
-        return [(v_mov_out(c * 4 + 3, acc), None)]
+        return [(v_mov_out(c * 4 + 3, acc, inv), None)]
     if L.epi == 'relu':
         tv = [tb + i for i in range(4)]
         for i in range(4):
@@ -535,6 +602,19 @@ def epilogue_ops(T, c):
         tv = [acc + i for i in range(4)]
     h01 = hset(L.dst, u >> 1, c) + 2 * (u & 1)
     h23 = h01 + 1
+    if P3:
+        # per value one v_fma_mix for the hi half -- f16(t 2^-k) -- and one for the lo half -- f16(t 2^-k - hi) --; the lo pairs go
+        # through two temporaries into the AGPR set.  No two consecutive instructions touch a register one of them half-writes.
+        l01, l23 = tb + 4, tb + 5
+        lo01 = lset(L.dst, u >> 1, c) + 2 * (u & 1)
+        for dst, high, src, hs, hh, cons in ((h01, 0, tv[0], None, 0, None), (h23, 0, tv[2], None, 0, None),
+                                              (h01, 1, tv[1], None, 0, ('hi', u >> 1)), (h23, 1, tv[3], None, 0, ('hi', u >> 1)),
+                                              (l01, 0, tv[0], h01, 0, None), (l23, 0, tv[2], h23, 0, None),
+                                              (l01, 1, tv[1], h01, 1, None), (l23, 1, tv[3], h23, 1, None)):
+            ops.append((v_mixs(dst, high, src, inv, hs, hh), cons))
+        ops.append((v_accw(lo01, l01), ('lo', u >> 1)))
+        ops.append((v_accw(lo01 + 1, l23), ('lo', u >> 1)))
+        return ops
     if hfile(L.dst) == 'a':       # the packed pairs go through two temporaries into the AGPR set
         p01, p23 = tb + 4, tb + 5
         ops.append((v_cvt_pk_f16(p01, tv[0], tv[1]), None))
@@ -1086,9 +1166,9 @@ def build_fillers(opts):
         ci, kc = TILE_CHUNK[T]
         pc, po = piece_of(L, kc, what, k)
         bv, off = lds_addr(ci % NSLOT, pc * 1024 + po, 16)
-        buf = V_HI + (n % 4) * 4
+        buf = V_HI + (n % N_FRAG_BUF) * 4
         bufmap[key] = buf
-        hard = last[hi_keys[n - 4]] if n >= 4 else -1
+        hard = last[hi_keys[n - N_FRAG_BUF]] if n >= N_FRAG_BUF else -1
         F.append(Filler(ds_read_b128(buf, bv, off, tag=key), max(hard, first[key] - opts.lead, certified(T)), first[key], ('rd',)))
     for n, key in enumerate(a6_keys):
         what, T, k = key
@@ -1112,6 +1192,12 @@ def build_fillers(opts):
             prev0 = TILE_OF[(t.li - 1, 0)]      # layer li-2 (same scale registers) is over once layer li-1 runs
             F.append(Filler(ds_read_b64(V_SC + 2 * (t.li & 1), V_AUX, t.li * AUX_LAYER + AUX_SCALES, tag=('scale', t.li)),
                             afirst(prev0) + 1, aidx(T, 'm6', 0, 0), ('aux',)))
+        if t.u == 0 and P3:
+            # 1 / weight scale of layer li for its epilogues (they run under the layer's tiles 1.. and under the next layer's tile 0);
+            # the registers' previous owner, layer li - 2, had its last epilogue under tile 0 of layer li - 1
+            e = afirst(TILE_OF[(t.li - 1, 0)] + 1) + 1 if t.li >= 1 else -1
+            F.append(Filler(ds_read_b64(V_SC + 2 * (t.li & 1), V_AUX, t.li * AUX_LAYER + AUX_SCALES, tag=('scale', t.li)),
+                            e, afirst(T) + 1, ('aux',)))
     # ---- epilogue of tile T-1 under tile T -------------------------------------------------------------
     for T in range(1, NT):
         tp = TILES[T - 1]
@@ -1125,6 +1211,9 @@ def build_fillers(opts):
                     if cons[0] == 'hi':
                         if cons[1] < Ln.ks:
                             dl = min(dl, aidx(T0n, 'm16', cons[1], 0) - 2)
+                    elif cons[0] == 'lo':
+                        if cons[1] < Ln.ks:
+                            dl = min(dl, aidx(T0n, 'm16', cons[1], 0, 1) - 2)
                     elif (cons[1], cons[2]) in Ln.j_order():
                         dl = min(dl, aidx(T0n, 'm6', Ln.j_order().index((cons[1], cons[2])), 0) - 2)
                 F.append(Filler(ins, e0, dl, ('epi', c)))
@@ -1246,6 +1335,8 @@ def schedule(opts):
         csrc = V_BIAS + (T & 1) * 4 if is_first else d
         if is_first:
             sch.need(('bias', T))
+        if P3 and a == ABASE[T] and T >= 1:
+            sch.need(('scale', TILES[T - 1].li))       # the epilogue of tile T - 1 (under this tile) multiplies by its layer's 1 / weight scale
         key = operand_key(T, kind, k, p)
         if kind == 'x':
             sch.need(key)
@@ -1254,7 +1345,10 @@ def schedule(opts):
                          btext=None if EMB else E_name(ek, e, c, p == 1))
         elif kind == 'm16':
             sch.need(key, [('hi', T, k + g) for g in range(1, opts.wait_group)])
-            ins = mfma16(d, bufmap[key], hfile(L.src), hset(L.src, k, c), csrc, tag=('m16', T, k, c))
+            if p == 1:        # f16p3: hi(W) x lo(a)
+                ins = mfma16(d, bufmap[key], 'a', lset(L.src, k, c), csrc, tag=('m16', T, k, c, p))
+            else:
+                ins = mfma16(d, bufmap[key], hfile(L.src), hset(L.src, k, c), csrc, tag=('m16', T, k, c) + ((p,) if p else ()))
         else:
             sch.need(key + (1,))
             term, tt = L.j_order()[k]
@@ -1301,7 +1395,7 @@ def setup_ops():
     a('v_lshrrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_LANE)))
     a('v_lshlrev_b32 %s, 4, %s' % (vreg(V_AUX), vreg(V_AUX)))
     a('v_add_u32 %s, 0x%x, %s' % (vreg(V_AUX), LDS_AUX, vreg(V_AUX)))
-    if V_SBA is not None:
+    if V_SBA is not None and not X1:
         a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBA), 0x01010101 * (127 + ACT_EXP)))
         a('v_mov_b32 %s, 0x%08x' % (vreg(V_SBL), 0x01010101 * (127 + RES_EXP)))
         a('v_mov_b32 %s, 0x%08x' % (vreg(V_CVA), f32_bits(2.0 ** ACT_EXP)))
@@ -1316,7 +1410,7 @@ def setup_ops():
         st.V[V_L8A] = lanes * 8
         st.V[V_L8B] = lanes * 8 + 65536
         st.V[V_AUX] = LDS_AUX + (lanes >> 4) * 16
-        if V_SBA is not None:
+        if V_SBA is not None and not X1:
             st.V[V_SBA] = 0x01010101 * (127 + ACT_EXP)
             st.V[V_SBL] = 0x01010101 * (127 + RES_EXP)
             st.V[V_CVA] = f32_bits(2.0 ** ACT_EXP)
@@ -1338,6 +1432,8 @@ def prologue_ops():
 def tail_ops():
     """exposed epilogue of the last row tile (RGB)"""
     ops = [s_nop(15), s_nop(15)]
+    if P3:
+        ops.append(waitcnt_lgkm(0))       # (the RGB layer's 1 / weight scale)
     for c in range(NC):
         ops += [ins for ins, _ in epilogue_ops(NT - 1, c)]
     return ops

@@ -16,8 +16,8 @@
 namespace {
 
 struct PackedNet {
-    char* d_img[3] = {nullptr, nullptr, nullptr};   // [precision mode]
-    float inv_scale[3][NERF_N_SCALES];
+    char* d_img[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [precision mode]
+    float inv_scale[5][NERF_N_SCALES];
     std::vector<std::vector<float>> host_w;  // 24 tensors, state_dict order
     bool loaded = false;
 };
@@ -31,7 +31,7 @@ const size_t kTensorNumel[24] = {
     128 * 283, 128, 256 * 256, 256, 256, 1, 3 * 128, 3};
 
 int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
-bool mode_ok(int mode) { return mode == R2L_PREC_FP16X3 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16_FP8; }
+bool mode_ok(int mode) { return mode == R2L_PREC_FP16X3 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X3_ASM; }
 
 void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
     _Float16 hi, lo;
@@ -96,6 +96,10 @@ const ChainLayer kChain[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16
 const ChainLayer kChainX[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 4, 256}, {8, 0, 16, 4, 256}, {8, 0, 16, 4, 256},
                                 {8, 0, 16, 4, 256}, {8, 2, 16, 2, 256}, {8, 0, 16, 4, 256}, {8, 0, 16, 4, 256},
                                 {8, 0, 17, 4, 257}, {8, 1, 8, 2, 128},  {4, 0, 1, 1, 3}};
+// FP16X3_ASM (gen/nerf_gen.py NERF_GEN_FMT=f16p3): per main k-step a hi AND a lo fragment of W x 2^k -- 84 chunks of <= 32 KiB
+const ChainLayer kChainP3[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
+                                 {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
+                                 {8, 0, 17, 2, 257}, {8, 1, 8, 1, 128},  {4, 0, 1, 1, 3}};
 
 struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding column), bias(row); rows < fan_out
     std::function<float(int, int)> main, emb;
@@ -103,9 +107,13 @@ struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding 
     bool is_pts;    // embedding k-steps: pts (nerf_pts_col) or view (nerf_view_col)
 };
 
-// x1: the stream of R2L_PREC_FP16X1 -- the fp16 hi fragments and the embedding fragments only (NJ = 0), no scale bytes
-int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img, bool x1 = false) {
-    const size_t stream_bytes = x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES;
+// fmt 1 (x1): the stream of R2L_PREC_FP16X1 -- the fp16 hi fragments and the embedding fragments only (NJ = 0), no scale bytes.
+// fmt 2 (p3): the stream of R2L_PREC_FP16X3_ASM -- per row tile its KS hi fragments, then its KS lo fragments, of W x 2^k with
+// max|w| 2^k in [2^12, 2^13) over the layer's main and embedding columns (lo = the fp16 rounding residual: a normal number thanks
+// to the factor); the bias x act_scale x 2^k; at the scale bytes' place 2^-k as a float for the epilogue
+int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img, int fmt = 0) {
+    const bool x1 = fmt != 0, p3 = fmt == 2;
+    const size_t stream_bytes = p3 ? NERF_CHAINP3_STREAM_BYTES : (x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
     img.assign(stream_bytes + NERF_CHAIN_AUX_BYTES, 0);
     auto mat = [&](int ti, int ncol, int col0) {
         const float* p = w[ti].data();
@@ -130,15 +138,29 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
     size_t chunk_off = 0;
     uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + stream_bytes);
     for (int li = 0; li < 11; ++li) {
-        const ChainLayer& L = (x1 ? kChainX : kChain)[li];
+        const ChainLayer& L = (p3 ? kChainP3 : (x1 ? kChainX : kChain))[li];
         const ChainSrc& S = src[li];
         const int nj = x1 ? 0 : L.ks / 2, K = L.ks * 32;
-        const int pieces = L.rpc * L.ks + L.rpc * nj + (L.rpc * nj + 1) / 2 + L.rpc * L.nx * 2;
+        const int pieces = p3 ? L.rpc * L.ks * 2 + L.rpc * L.nx * 2 : L.rpc * L.ks + L.rpc * nj + (L.rpc * nj + 1) / 2 + L.rpc * L.nx * 2;
+        float sw = 1.0f;
+        if (p3) {
+            float mx = 0.f;
+            const int n_emb = S.emb ? (S.is_pts ? 63 : 27) : 0;
+            for (int r = 0; r < L.fan_out; ++r) {
+                for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(S.main(r, k)));
+                for (int k = 0; k < n_emb; ++k) mx = fmaxf(mx, fabsf(S.emb(r, k)));
+            }
+            sw = (mx > 0.f && isfinite(mx)) ? r2l_pow2_scale(&mx, 1) : 1.0f;
+        }
         const size_t chunk_bytes = (size_t)((pieces + 3) / 4) * 4096;
         uint32_t* al = aux + (size_t)li * NERF_CHAIN_AUX_LAYER / 4;
         for (int r = 0; r < L.fan_out; ++r) {
-            const float v = (float)((double)S.bias(r) * Sa);
+            const float v = (float)((double)S.bias(r) * Sa * (double)sw);
             memcpy(&al[r], &v, 4);
+        }
+        if (p3) {
+            const float inv = 1.0f / sw;
+            for (int q = 0; q < 4; ++q) memcpy(&al[NERF_CHAIN_AUX_SCALES / 4 + 4 * q], &inv, 4);
         }
         int el = 0, ew = 0;
         if (L.ks && !x1) {
@@ -159,13 +181,18 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
         for (int u = 0; u < L.rt; ++u) {
             char* chunk = img.data() + chunk_off + (size_t)(u / L.rpc) * chunk_bytes;
             const int k = u % L.rpc;
-            const int p_b6 = L.rpc * L.ks, p_b6b = p_b6 + L.rpc * nj, p_x = p_b6b + (L.rpc * nj + 1) / 2;
+            const int p_b6 = L.rpc * L.ks, p_b6b = p_b6 + L.rpc * nj, p_x = p3 ? L.rpc * L.ks * 2 : p_b6b + (L.rpc * nj + 1) / 2;
             for (int lane = 0; lane < 64; ++lane) {
                 const int q = lane >> 4, row = 16 * u + (lane & 15);
                 if (row >= L.fan_out) continue;
-                for (int s = 0; s < L.ks; ++s) {
+                for (int s = 0; s < L.ks && !p3; ++s) {
                     _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(k * L.ks + s) * 1024 + lane * 16);
                     for (int j = 0; j < 8; ++j) ph[j] = (_Float16)S.main(row, r2l_kappa(s, q, j));
+                }
+                for (int s = 0; s < L.ks && p3; ++s) {
+                    _Float16* ph = reinterpret_cast<_Float16*>(chunk + (size_t)(k * L.ks * 2 + s) * 1024 + lane * 16);
+                    _Float16* pl = reinterpret_cast<_Float16*>(chunk + (size_t)(k * L.ks * 2 + L.ks + s) * 1024 + lane * 16);
+                    for (int j = 0; j < 8; ++j) r2l_split_f16(S.main(row, r2l_kappa(s, q, j)) * sw, &ph[j], &pl[j]);
                 }
                 for (int j = 0; j < nj; ++j) {
                     const int term = j & 1, t = j >> 1;
@@ -188,7 +215,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
                     for (int j = 0; j < 8; ++j) {
                         const int col = S.is_pts ? nerf_pts_col(x, q, j) : nerf_view_col(q, j);
                         if (col < 0) continue;
-                        r2l_split_f16(S.emb(row, col), &ph[j], &pl[j]);
+                        r2l_split_f16(S.emb(row, col) * sw, &ph[j], &pl[j]);
                     }
                 }
             }
@@ -317,7 +344,7 @@ void nerf_destroy(nerf_ctx* c) {
     if (!c) return;
     free_tmp(c);
     for (auto& n : c->net)
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < 5; ++m)
             if (n.d_img[m]) (void)hipFree(n.d_img[m]);
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_zmid) (void)hipFree(c->d_zmid);
@@ -352,9 +379,9 @@ static int upload_img(PackedNet& net, int mode, const std::vector<char>& img) {
 }
 
 static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
-    if (mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X1) {  // the layer chain's own streams (nerf_chain_kernel / nerf_chainx_kernel)
+    if (mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16X3_ASM) {  // the layer chain's own streams
         std::vector<char> img;
-        int rc = pack_chain(net.host_w, c->act_scale, img, mode == R2L_PREC_FP16X1);
+        int rc = pack_chain(net.host_w, c->act_scale, img, mode == R2L_PREC_FP16X1 ? 1 : (mode == R2L_PREC_FP16X3_ASM ? 2 : 0));
         return rc ? rc : upload_img(net, mode, img);
     }
     const int np = np_of(mode);
@@ -424,7 +451,7 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
         if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
         net.host_w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
     }
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 5; ++m)
         if (net.d_img[m]) {
             (void)hipFree(net.d_img[m]);
             net.d_img[m] = nullptr;
@@ -734,10 +761,10 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 }
 
 // run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
-static bool g_debug_chain_x1 = false;
-int nerf_debug_pack_chain_format(int fmt) {   // which stream nerf_debug_pack_chain_host packs: 0 fp16 + bf6 terms, 1 fp16 only (FP16X1)
-    if (fmt < 0 || fmt > 1) return r2l_set_error(R2L_EINVAL, "chain stream format %d", fmt);
-    g_debug_chain_x1 = fmt == 1;
+static int g_debug_chain_fmt = 0;
+int nerf_debug_pack_chain_format(int fmt) {   // which stream nerf_debug_pack_chain_host packs: 0 fp16 + bf6 terms, 1 fp16 only (FP16X1), 2 hi | lo (FP16X3_ASM)
+    if (fmt < 0 || fmt > 2) return r2l_set_error(R2L_EINVAL, "chain stream format %d", fmt);
+    g_debug_chain_fmt = fmt;
     return R2L_OK;
 }
 
@@ -749,9 +776,9 @@ long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors,
         w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
     }
     std::vector<char> img;
-    int rc = pack_chain(w, 16.0f, img, g_debug_chain_x1);
+    int rc = pack_chain(w, 16.0f, img, g_debug_chain_fmt);
     if (rc) return rc;
-    if (offs) offs[0] = g_debug_chain_x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES;
+    if (offs) offs[0] = g_debug_chain_fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (g_debug_chain_fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
 }

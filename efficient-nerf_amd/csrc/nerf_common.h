@@ -33,6 +33,9 @@
 #define NERF_CHAIN_STREAM_BYTES 2166784
 // FP16X1: the same chain without its correction terms (NERF_GEN_FMT=f16: no bf6 operand pieces, 44 chunks of up to 4 row tiles, same table)
 #define NERF_CHAINX_STREAM_BYTES 1298432
+// FP16X3_ASM: fp16x3's arithmetic on the chain (NERF_GEN_FMT=f16p3: a hi and a lo fragment of W x 2^k per k-step, 84 chunks, same table
+// with 2^-k at the scale bytes' place)
+#define NERF_CHAINP3_STREAM_BYTES 2433024
 #define NERF_CHAIN_AUX_BYTES 16384
 #define NERF_CHAIN_AUX_LAYER 1280   // per layer: 272 f32 bias | at byte 1152: 4 lane quarters x (swl, sw, 0, 0)
 #define NERF_CHAIN_AUX_SCALES 1152

@@ -307,19 +307,31 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // X1 = true is R2L_PREC_FP16X1: the same chain generated without its correction terms (NERF_GEN_FMT=f16 -> nerf_mlpx_*.inc): one fp16
 // pass on the 256-wide sources, the embedding k-steps hi(W) x (hi(E) + lo(E)); 1.30 MB of stream per tile instead of 2.17.
 // NC = 3 (X1 only, NERF_GEN_FMT=f16c3 -> nerf_mlpx3_*.inc): three column tiles of 16 points per wave, 192 points per workgroup tile.
-template <bool X1, int NC>
+// P3 = true (NC = 2) is R2L_PREC_FP16X3_ASM: fp16x3's arithmetic on the chain (NERF_GEN_FMT=f16p3 -> nerf_mlpp3_*.inc): per k-step
+// hi(W) hi(a) + hi(W) lo(a) + lo(W) hi(a) on one accumulate chain, lo(a) in a second pair of activation sets (AGPRs), 2.43 MB of
+// stream per tile; for teachers whose sharp densities need fp32-grade arithmetic -- every trained one.
+template <bool X1, int NC, bool P3 = false>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     static_assert(NC == 2 || (X1 && (NC == 3 || NC == 4)), "three / four column tiles exist for the fp16-only chain");
+    static_assert(!P3 || (!X1 && NC == 2), "the three-pass chain is a two-column-tile build");
     extern __shared__ __attribute__((aligned(16))) char nerf_chain_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     {   // resident table: per layer 272 f32 bias (act_scale domain) | E8M0 weight scales (nerf_common.h)
-        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES));
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (P3 ? NERF_CHAINP3_STREAM_BYTES : (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES)));
         uint4* dst = reinterpret_cast<uint4*>(nerf_chain_lds + NERF_CHAIN_RING_BYTES);
         for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    if constexpr (X1 && NC == 4) {
+    if constexpr (P3) {
+        asm volatile(
+#include "nerf_mlpp3_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpp3_pro_clobbers.inc"
+        );
+    } else if constexpr (X1 && NC == 4) {
         asm volatile(
 #include "nerf_mlpx4_pro_asm.inc"
             :
@@ -377,7 +389,15 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
             : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),             \
               [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),       \
               [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
-        if constexpr (X1 && NC == 4) {
+        if constexpr (P3) {
+            asm volatile(
+#include "nerf_mlpp3_asm.inc"
+                NERF_CHAIN_OUT2
+                NERF_CHAIN_IN2
+                :
+#include "nerf_mlpp3_clobbers.inc"
+            );
+        } else if constexpr (X1 && NC == 4) {
             asm volatile(
 #include "nerf_mlpx4_asm.inc"
                 NERF_CHAIN_OUT2, [o8] "=&v"(o[8]), [o9] "=&v"(o[9]), [o10] "=&v"(o[10]), [o11] "=&v"(o[11]), [o12] "=&v"(o[12]),
@@ -978,7 +998,8 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
 }
 
 hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles, bool stream_embed) {
-    static std::atomic<bool> attr_set[6][64];  // zero-initialised; the opt-in call itself is idempotent
+    static std::atomic<bool> attr_set[7][64];  // zero-initialised; the opt-in call itself is idempotent
+    if (mode == R2L_PREC_FP16X3_ASM) return launch_big_lds(&nerf_chain_kernel<false, 2, true>, attr_set[6], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X1 && x1_col_tiles == 4 && stream_embed)
         return launch_big_lds(&nerf_chain_emb_kernel, attr_set[5], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16_FP8) return launch_big_lds(&nerf_chain_kernel<false, 2>, attr_set[0], NERF_CHAIN_LDS, p, grid, stream);

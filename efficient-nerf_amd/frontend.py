@@ -415,8 +415,8 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
         eng = NeRFEngine(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance,
                          multires=args.multires, multires_views=args.multires_views, white_bkgd=args.white_bkgd,
                          precision=prec, ndc=llff_ndc, lindisp=args.lindisp)  # main.py:160-162, 525-528, 679-680
-        if args.precision in ('fp16_e4m3', 'fp16x3_asm'):
-            raise R2LError(f'--precision {args.precision} is a mode of the R2L student (the teacher has fp16x3, fp16_fp8, fp16x1)')
+        if args.precision == 'fp16_e4m3':
+            raise R2LError(f'--precision {args.precision} is a mode of the R2L student (the teacher has fp16x3, fp16x3_asm, fp16_fp8, fp16x1)')
         eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
         if auto:
             # one fp16 pass / the chain's bf6 terms under fixed activation exponents: measured against fp16x3 on rays of the job's
@@ -539,7 +539,7 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     def watched(i, ro, rd, got):
         from .teacher import get_rays
         for _ in range(3):
-            if eng.precision_name == 'fp16x3':
+            if eng.precision_name in ('fp16x3', 'fp16x3_asm'):
                 break
             if ro is None:
                 ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(render_poses[i])[:3, :4], rows=(r0, r1),

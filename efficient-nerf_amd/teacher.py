@@ -229,7 +229,7 @@ class NeRFEngine:
     #: depth_map = sum(weights * z) carries the weights' error times z: its limit is the rgb limit times max(1, far) (scene units).
     #: disp_map = 1 / max(1e-10, depth / acc) is ill-conditioned on empty rays in the reference itself and is not compared.
     WATCH_KEYS = ('rgb_map', 'acc_map', 'depth_map')
-    LADDER = ('fp16x1', 'fp16_fp8', 'fp16x3')
+    LADDER = ('fp16x1', 'fp16_fp8', 'fp16x3_asm')
     #: rays of a spot check (spot_check): < 0.5 % of a 100-pose save group, < 2 % of one 400 x 400 frame
     WATCH_RAYS = 2048
 
@@ -250,7 +250,11 @@ class NeRFEngine:
                     88-layer R2L student ends at 3.5e-4 -- for the teacher it is the fast mode (33.4-35 ms per 400 x 400 frame);
           fp16_fp8  the generated layer chain, fp16 + bf6 correction terms (1.5 pass-equivalents, ~1e-6), for weights whose
                     single-pass error is too large; its fixed exponents (|a| x 16 / 2^3 within bf6's +-28) are what is measured;
-          fp16x3    three fp16 passes, unconditional.
+          fp16x3_asm  three fp16 passes on hi / lo fragments of both operands: fp16x3's arithmetic on the generated layer chain
+                    (nerf_chain_kernel<false, 2, true>, 17 % faster than the compiler-scheduled fp16x3 it is tested against; raw within
+                    1.5e-5 of it, rgb 2e-7 on smooth teachers).  Unconditional: every TRAINED teacher ends here -- sharp densities
+                    amplify a single pass's error to 3e-3 and the fine samples follow the coarse weights discontinuously on rays
+                    that graze an object (profiles/r05_trained_like.txt).
         A candidate is kept when rgb, acc and depth agree with fp16x3 within its limits on EVERY probe set.  Returns (name, its
         largest rgb / acc difference); `auto_diffs` keeps the per-candidate maxima, `auto_detail` the per-set, per-output ones.
         The choice is not final: spot_check / step_down keep watching what is rendered afterwards (create_data per save group,
@@ -285,8 +289,9 @@ class NeRFEngine:
             self.auto_detail[name] = per_set
             if ok:
                 return name, diff
-        self.set_precision(PREC_FP16X3)
-        return 'fp16x3', diff
+        from ._lib import PREC_FP16X3_ASM
+        self.set_precision(PREC_FP16X3_ASM)
+        return 'fp16x3_asm', diff
 
     @property
     def precision_name(self):
@@ -318,7 +323,7 @@ class NeRFEngine:
         """one rung down the ladder fp16x1 -> fp16_fp8 -> fp16x3 (after a failed spot_check); returns the new mode's name"""
         from ._lib import PRECISIONS
         name = self.precision_name
-        nxt = self.LADDER[min(self.LADDER.index(name) + 1, len(self.LADDER) - 1)] if name in self.LADDER else 'fp16x3'
+        nxt = self.LADDER[min(self.LADDER.index(name) + 1, len(self.LADDER) - 1)] if name in self.LADDER else 'fp16x3_asm'
         self.set_precision(PRECISIONS[nxt])
         self.watch_fallbacks = getattr(self, 'watch_fallbacks', 0) + 1
         return nxt

@@ -83,7 +83,7 @@ def test_bench_line_round4_fields():
     # the trained-like fixture's rungs and rates in the line (CPU-oracle fields only with the CPU baseline on)
     tl = d['trained_like']
     assert tl['student']['rung'] == 'fp16x3_asm' and tl['student']['max_abs_activation'] > 10 and tl['student']['rays_per_s'] > 1e7
-    assert tl['teacher']['precision'] == 'fp16x3' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
+    assert tl['teacher']['precision'] == 'fp16x3_asm' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
     assert tl['teacher']['mlp_launches'] == 6 and 0 < tl['teacher']['mlp_kernel_ms_per_frame'] <= tl['teacher']['ms_per_frame']
     assert tl['teacher']['whole_frame_rgb_linf_from_fp16x3']['fp16x1'] > 1e-3
     assert 'value_valid_for' in d and 'trained-like' in d['value_valid_for']

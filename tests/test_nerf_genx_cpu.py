@@ -177,3 +177,65 @@ def test_emulated_wider_chain_vs_float64(G, wave, n_tiles, gain):
     for ins in G3.block_stream(G3.Opts()):
         kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
     assert kinds['mfma16'] == 1244 * G.NC and 'mfma6' not in kinds and kinds['ds'] == 1326       # the reads of two column tiles feed three / four
+
+
+# ---- f16p3: fp16x3's arithmetic on the generated chain (R2L_PREC_FP16X3_ASM of the teacher) --------------------------------------------
+GP = _load_x('f16p3')
+
+
+def cxx_pack_fmt(tensors, fmt):
+    keep, arr = _lib.host_ptrs([torch.from_numpy(np.ascontiguousarray(t)) for t in tensors])
+    offs = (C.c_longlong * 1)()
+    L = _lib.lib()
+    assert L.nerf_debug_pack_chain_format(fmt) == 0
+    try:
+        n = L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs)
+        assert n > 0, L.r2l_last_error()
+        buf = np.zeros(n, dtype=np.uint8)
+        assert L.nerf_debug_pack_chain_host(arr, len(keep), C.c_void_p(buf.ctypes.data), n, offs) == n
+    finally:
+        L.nerf_debug_pack_chain_format(0)
+    return buf, int(offs[0])
+
+
+def test_three_pass_chain_layout_packer_and_committed_text(tmp_path):
+    assert GP.P3 and GP.NC == 2 and GP.NCH == 84 and GP.NCH % GP.NSLOT == 0 and GP.XPASS == 3 and GP.MPASS == 3
+    assert GP.N_ANCH == (1100 + 72) * 3 * 2 == 7032       # 1,100 main and 72 embedding k-steps of the chain, three passes, two column tiles
+    assert GP.STREAM_BYTES == 2433024                                         # NERF_CHAINP3_STREAM_BYTES (csrc/nerf_common.h)
+    for seed, gain in ((5, 1.0), (6, 40.0), (7, 0.01)):                        # the per-layer factor 2^k follows the weights
+        t = T.make_tensors(seed=seed, gain=gain)
+        buf, aux_off = cxx_pack_fmt(t, 2)
+        img, aux = GP.pack_teacher(t)
+        assert aux_off == img.size == GP.STREAM_BYTES and buf.size == img.size + aux.size
+        assert np.array_equal(buf[:aux_off], img) and np.array_equal(buf[aux_off:], aux)
+    GP.emit(str(tmp_path), GP.Opts())
+    for name in ('nerf_mlpp3_asm.inc', 'nerf_mlpp3_pro_asm.inc', 'nerf_mlpp3_clobbers.inc', 'nerf_mlpp3_pro_clobbers.inc'):
+        built = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)
+        assert open(os.path.join(str(tmp_path), name)).read() == open(built).read(), name
+
+
+@pytest.mark.parametrize('wave,n_tiles,gain', [(0, 1, 1.0), (3, 2, 1.5), (2, 1, 2.5)])
+def test_emulated_three_pass_chain_is_fp32_grade(wave, n_tiles, gain):
+    """the exact instruction stream on the C++ packer's bytes against float64: two orders of magnitude inside what a single fp16 pass
+    gives, and no further from float64 than an fp32 evaluation of the network is"""
+    t = T.make_tensors(seed=wave, gain=gain)
+    rng = np.random.default_rng(10 + wave)
+    pts = rng.uniform(-2.5, 2.5, size=(32, 3)).astype(np.float32)
+    vd = rng.normal(size=(32, 3))
+    vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
+    ref, e, v = T.ref_mlp(t, pts, vd)
+    f16_err = np.abs(T.ref_mlp(t, pts, vd, f16_ops=True)[0] - ref).max()
+    buf, aux_off = cxx_pack_fmt(t, 2)
+    out, errs = GP.emulate_tile(GP.Opts(), buf[:aux_off], buf[aux_off:], T.make_frags(e, v, 16.0), wave=wave, n_tiles=n_tiles)
+    assert not errs, errs[:10]
+    got = np.zeros((32, 4))
+    for c in range(2):
+        for k in range(4):
+            got[c * 16:(c + 1) * 16, k] = out[c * 4 + k][:16] / 16.0
+    err = np.abs(got - ref).max()
+    print('wave %d gain %g: L_inf %.3g (single-pass fp16 operands: %.3g), |raw| max %.3g' % (wave, gain, err, f16_err, np.abs(ref).max()))
+    assert err <= 0.01 * f16_err and err < 1e-6 * max(1.0, np.abs(ref).max())
+    kinds = {}
+    for ins in GP.block_stream(GP.Opts()):
+        kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
+    assert kinds['mfma16'] == 7032 and 'mfma6' not in kinds and not any('bf6' in ins.text for ins in GP.block_stream(GP.Opts()))

@@ -226,6 +226,29 @@ def test_teacher_fp16_fp8_mode(pkg, g):
     eng.close()
 
 
+def test_teacher_fp16x3_asm_mode(pkg, g):
+    """fp16x3's arithmetic on the generated layer chain (nerf_chain_kernel<false, 2, true>, NERF_GEN_FMT=f16p3: three fp16 MFMAs per
+    k-step on hi / lo fragments of both operands, W x 2^k streamed): against the reference golden with the tolerances of the
+    compiler-scheduled fp16x3 it replaces as `auto`'s last rung -- raw 2e-4 (measured 1e-6), composited maps 1e-4 (2e-7) -- and
+    against fp16x3 itself on the same rays"""
+    from efficient_nerf_amd import NeRFEngine, PREC_FP16X3, PREC_FP16X3_ASM
+    eng = NeRFEngine(400, 400, float(g['focal']), precision=PREC_FP16X3_ASM, z_coarse=T(g['z_vals0'][0]), u=torch.linspace(0., 1., 128))
+    eng.load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    ro, rd = T(g['rays_o']).cuda(), T(g['rays_d']).cuda()
+    r0, r1 = eng.run_network(0, ro, rd, T(g['z_vals0'][0]).cuda()), eng.run_network(1, ro, rd, T(g['z_all']).cuda())
+    e0, e1 = close(r0.cpu().numpy(), g['raw0'], 2e-4), close(r1.cpu().numpy(), g['raw'], 2e-4)
+    out = eng.render_rays(ro, rd, extras=True)
+    errs = {name: close(out[key].cpu().numpy(), g[f'{name}_w'], 1e-4)
+            for key, name in (('rgb_map', 'rgb'), ('acc_map', 'acc'), ('rgb0', 'rgb0'))}
+    print(f'teacher fp16x3_asm L_inf: raw coarse {e0:.2e}, fine {e1:.2e};', {k: f'{v:.2e}' for k, v in errs.items()})
+    assert max(e0, e1) <= 2e-5 and max(errs.values()) <= 5e-6          # fp32-grade, not merely inside the contract
+    eng.set_precision(PREC_FP16X3)
+    assert (eng.run_network(1, ro, rd, T(g['z_all']).cuda()) - r1).abs().max().item() <= 5e-5
+    ref = eng.render_rays(ro, rd)
+    assert (ref['rgb_map'] - out['rgb_map']).abs().max().item() <= 2e-6
+    eng.close()
+
+
 def test_teacher_fp16x1_mode_and_errors(pkg, g):
     from efficient_nerf_amd import NeRFEngine, PREC_FP16X1, R2LError
     eng = NeRFEngine(400, 400, float(g['focal']), precision=PREC_FP16X1, z_coarse=T(g['z_vals0'][0]),
@@ -254,15 +277,15 @@ def test_teacher_auto_precision_is_measured(pkg):
     fp16x3, fastest candidate first.  The synthetic teacher takes the single fp16 pass (1-3e-5 on rgb: eleven layers and the
     compositing average the rounding errors; the 88-layer student fails with one pass) -- also with one hidden layer 64x larger
     and the next one 64x smaller (the same function); a zero limit for the single pass leaves the layer chain with its bf6
-    terms (~1e-6), zero limits for both force fp16x3.  The contract is met in every case (main.py:624-756)."""
-    from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8, PREC_FP16X1, PREC_FP16X3
+    terms (~1e-6), zero limits for both end in fp16x3_asm (three passes on the generated chain).  The contract is met in every case (main.py:624-756)."""
+    from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8, PREC_FP16X1, PREC_FP16X3_ASM
     H = 24
     focal = O.focal_from_angle(H)
     c2w = O.pose_spherical(20., -30., 4.)
     ro, rd = O.get_rays(H, H, focal, c2w)
     ro, rd = ro.reshape(-1, 3).float().contiguous().cuda(), rd.reshape(-1, 3).float().contiguous().cuda()
     for scale, limits, want in ((1.0, {}, 'fp16x1'), (64.0, {}, 'fp16x1'), (1.0, dict(max_diff_x1=0.0), 'fp16_fp8'),
-                                (64.0, dict(max_diff_x1=0.0), 'fp16_fp8'), (1.0, dict(max_diff_x1=0.0, max_diff=0.0), 'fp16x3')):
+                                (64.0, dict(max_diff_x1=0.0), 'fp16_fp8'), (1.0, dict(max_diff_x1=0.0, max_diff=0.0), 'fp16x3_asm')):
         sds = [O.make_teacher_state(1), O.make_teacher_state(2)]
         for sd in sds:      # relu is positively homogeneous: layer 2 x s, layer 3 / s leaves the network's function unchanged
             sd['pts_linears.2.weight'] = sd['pts_linears.2.weight'] * scale
@@ -273,9 +296,9 @@ def test_teacher_auto_precision_is_measured(pkg):
         print(f'hidden layer x {scale:g}, limits {limits}: differences from fp16x3 {eng.auto_diffs} -> {name}')
         # depth is part of the criterion: every candidate's per-set record carries it, under limit x far
         assert all(set(d) == {'rgb_map', 'acc_map', 'depth_map'} for per in eng.auto_detail.values() for d in per)
-        if want != 'fp16x3' and not limits:
+        if want != 'fp16x3_asm' and not limits:
             assert eng.auto_detail[name][0]['depth_map'] <= eng.AUTO_MAX_DIFF_X1 * 6.
-        assert name == want and eng.precision == {'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8, 'fp16x3': PREC_FP16X3}[want], (scale, name, diff)
+        assert name == want and eng.precision == {'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8, 'fp16x3_asm': PREC_FP16X3_ASM}[want], (scale, name, diff)
         assert 0 < eng.auto_diffs['fp16x1'] < eng.AUTO_MAX_DIFF_X1
         if 'fp16_fp8' in eng.auto_diffs:
             assert 0 < eng.auto_diffs['fp16_fp8'] < eng.AUTO_MAX_DIFF

@@ -117,7 +117,7 @@ def test_render_rays_return_set(engine, g, gr):
     assert np.abs(out['z_std'].cpu().numpy() - gr['det_z_std']).max() <= 1e-6
 
 
-@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8', 'fp16x1'])
+@pytest.mark.parametrize('prec', ['fp16x3', 'fp16_fp8', 'fp16x1', 'fp16x3_asm'])
 def test_full_teacher_frame(engine, g, prec):
     from efficient_nerf_amd import PRECISIONS
     engine.set_precision(PRECISIONS[prec])

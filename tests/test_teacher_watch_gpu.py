@@ -62,7 +62,7 @@ def test_spot_check_passes_where_the_probe_passed_and_catches_the_other_pose(pkg
         got = eng.render_rays(ro, rd)
         ok, d = eng.spot_check(ro, rd, got)
     print('after', rungs, d)
-    assert rungs and rungs[-1] in ('fp16_fp8', 'fp16x3') and eng.watch_fallbacks == len(rungs)
+    assert rungs and rungs[-1] in ('fp16_fp8', 'fp16x3_asm') and eng.watch_fallbacks == len(rungs)
     idx = torch.arange(0, H * H, 37)
     want = O.render_rays(sds[0], sds[1], ro[idx].cpu(), rd[idx].cpu(), white_bkgd=True)['rgb_map']
     assert (got['rgb_map'][idx].cpu() - want).abs().max().item() <= 1e-4

@@ -2,8 +2,8 @@
 teacher pair fitted to an analytic scene with the reference's loss, main.py:624-756 / 1355-1380; pseudo data by the HIP
 create_data path, utils/create_data.py:812-872; a W256D88 student distilled from it, README.md:79-87) through the product path.
 What nn.Linear-init weights could only predict (VERDICT r4 missing 2 / weak 1-2) is pinned here as measured:
-  * the teacher's sharp densities (sigma ~ 200, acc bimodal) make the faster modes miss by 1e-3 .. 3e-1 -- `auto` must end in fp16x3,
-    whose render is inside the 1e-4 contract of the CPU oracle;
+  * the teacher's sharp densities (sigma ~ 200, acc bimodal) make the faster modes miss by 1e-3 .. 3e-1 -- `auto` must end in three fp16 passes
+    (fp16x3_asm: the generated chain), whose render is inside the 1e-4 contract of the CPU oracle;
   * the student's residual stream grows with depth (max|a| ~ 126): `auto` must end on the last rung (fp16x3_asm), inside 1e-4."""
 import os
 
@@ -22,7 +22,7 @@ def _sd(name):
     return {k: torch.from_numpy(z[k]) for k in z.files}
 
 
-def test_trained_like_teacher_auto_ends_in_fp16x3_inside_the_contract(pkg):
+def test_trained_like_teacher_auto_ends_in_three_passes_inside_the_contract(pkg):
     from efficient_nerf_amd import NeRFEngine, PRECISIONS
     from efficient_nerf_amd import create_data as CD
     tsds = (_sd('teacher_coarse.npz'), _sd('teacher_fine.npz'))
@@ -31,7 +31,7 @@ def test_trained_like_teacher_auto_ends_in_fp16x3_inside_the_contract(pkg):
     eng = NeRFEngine(H, H, focal, precision=PRECISIONS['fp16x3']).load_state_dicts(*tsds)
     name = CD.choose_precision_for_rand(eng, H, H, focal)
     print('probe differences from fp16x3:', eng.auto_diffs)
-    assert name == 'fp16x3' and eng.precision_name == 'fp16x3'
+    assert name == 'fp16x3_asm' and eng.precision_name == 'fp16x3_asm'      # the generated three-pass chain: fp16x3's arithmetic
     assert eng.auto_diffs['fp16x1'] > 1e-3 and eng.auto_diffs['fp16_fp8'] > eng.AUTO_MAX_DIFF      # measured 1e-1 / 1e-2: not marginal
     pose = O.pose_spherical(30., -30., 4.)
     got = eng.render(pose)
@@ -42,11 +42,15 @@ def test_trained_like_teacher_auto_ends_in_fp16x3_inside_the_contract(pkg):
     want = O.render_rays(tsds[0], tsds[1], ro.reshape(-1, 3)[idx].float(), rd.reshape(-1, 3)[idx].float(), white_bkgd=True)
     for k in ('rgb_map', 'acc_map'):
         err = (got[k].cpu()[idx] - want[k]).abs().max().item()
-        print(f'trained-like teacher fp16x3 vs CPU oracle, {k}: {err:.2e}')
+        print(f'trained-like teacher fp16x3_asm vs CPU oracle, {k}: {err:.2e}')
         assert err <= 1e-4, (k, err)
     assert float(torch.relu(want['raw'][..., 3]).max()) > 100.                                       # the densities are sharp
     # why the coarse pass must be fp32-grade: with it exact, the fine pass in fp16_fp8 is within 1e-3 of fp16x3 over the whole frame;
     # the other way round the fine samples land elsewhere on rays that graze an object (sample_pdf on weights ~ 0) and whole pixels flip
+    # ... and the compiler-scheduled fp16x3 the probes compare with is as close to the oracle
+    eng.set_precision(PRECISIONS['fp16x3'])
+    got = eng.render(pose)
+    assert (got['rgb_map'].cpu()[idx] - want['rgb_map']).abs().max().item() <= 1e-4
     ref = {k: v.clone() for k, v in got.items()}
     eng.set_precision_pair(PRECISIONS['fp16x3'], PRECISIONS['fp16_fp8'])
     d_fine = (eng.render(pose)['rgb_map'] - ref['rgb_map']).abs().max().item()
@@ -93,7 +97,7 @@ def test_trained_like_pipeline_command_lines(pkg, tmp_path):
                         '--teacher_ckpt', tck, '--n_pose_kd', '2', '--datadir_kd', f'unused:{out}', '--create_data_chunk', '2',
                         '--split_size', '4096', '--H', '128', '--synthetic_poses', '1'], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert '-> fp16x3' in r.stdout and 'wrote 2 shard(s)' in r.stdout, r.stdout[-800:]
+    assert '-> fp16x3_asm' in r.stdout and 'wrote 2 shard(s)' in r.stdout, r.stdout[-800:]
     r = subprocess.run([sys.executable, os.path.join(root, 'main.py'), '--model_name', 'R2L', '--config', 'configs/lego_noview.txt',
                         '--n_sample_per_ray', '16', '--netwidth', '256', '--netdepth', '88', '--use_residual', '--trial.ON',
                         '--trial.body_arch', 'resmlp', '--pretrained_ckpt', sck, '--render_only', '--synthetic_poses', '2', '--H', '64',
