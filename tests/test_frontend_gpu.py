@@ -116,7 +116,7 @@ def test_teacher_render_only_cli(pkg, tmp_path):
     log = run_main(['--model_name', 'nerf', '--config', 'configs/lego.txt', '--pretrained_ckpt', ck, '--render_only',
                     '--render_test', '--testskip', '1', '--synthetic_poses', '1', '--H', '16', '--outdir', out])
     # the CLI default is --precision auto: for the teacher the candidates are measured against fp16x3 first, fastest first
-    assert '[precision] auto: difference from fp16x3 on' in log and log.split('[precision] auto')[1].splitlines()[0].endswith('-> fp16x1'), log
+    assert '[precision] auto: largest rgb / acc difference from fp16x3 on' in log and '[precision] watch: 1 spot check(s)' in log and log.split('[precision] auto')[1].splitlines()[0].endswith('-> fp16x1'), log
     rgbs = np.load(os.path.join(out, 'rgbs.npy'))
     H = 8
     assert rgbs.shape == (1, H, H, 3)
