@@ -9,7 +9,7 @@ mkdir -p $O
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 cd /tmp && export TMPDIR=/tmp
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $set --output-format csv -d $O/pmc_$set -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-teacher --no-create-data > $O/pmc_$set.log 2>&1 || exit 1
+  rocprofv3 --pmc $set --output-format csv -d $O/pmc_$set -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-teacher --no-create-data --no-trained-like > $O/pmc_$set.log 2>&1 || exit 1
   python $R/tools/pmc_summary.py $O/pmc_$set/*/*counter_collection.csv r2l_body > $O/pmc_$set.txt 2>&1
   python $R/tools/pmc_summary.py $O/pmc_$set/*/*counter_collection.csv 'r2l_head' >> $O/pmc_$set.txt 2>&1
 done
