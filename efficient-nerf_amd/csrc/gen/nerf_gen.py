@@ -1097,6 +1097,9 @@ class Opts:
         self.dma_gap = 4       # anchors (16-cycle MFMAs) between two LDS-DMA pieces: 4 .. 6 are 1.7 % faster than 3, 2 is slower
         self.pair = False
         self.wait_group = 2    # fp16 fragments one s_waitcnt may cover (those already issued)
+        if P3:                 # same-box sweep (gpurun_out/teacher_variants.log, round 5): cap 3 / gap 4 97.6 ms per frame, cap 2 98.2, gap 6 97.3,
+            self.cap = 2       # cap 2 + gap 6 96.6, + lead 12 97.4, + wait group 3 98.2
+            self.dma_gap = 6
         self.cap_late = 2      # f16c4e: issue slots behind an MFMA once the embedding fillers may run (anchor >= a_emb)
         if NC > 2:             # three (four) MFMAs per fragment: fewer filler slots behind each, LDS-DMA pieces further apart (same-box sweep:
             self.cap = 2       # cap 2 / 3 / 4 / 5 = 36.9 / 37.2 / 37.3 / 37.6 ms per frame, gap 3 / 4 / 6 = 37.5 / 37.2 / 36.9, both: -1.4 %)
