@@ -232,6 +232,25 @@ int main() {
         printf("%-28s power %7.1f W   sclk %6.0f MHz\n", "idle (no kernel)", p / 20, c / 20);
     }
     //   M  H  B  R  W  G  L  C  X  P  F  A [K LS]
+    if (getenv("EP_X3") != nullptr) {
+        // round 5: the mix of the kernels trained-like weights end on, in both MFMA shapes.  r2l_bodyx_kernel per
+        // block and wave: 768 fp16 MFMAs (32x32x16), 544 KiB of ds_read, 129 LDS-DMA, 128 v_fma_mix pairs, 128 v_cvt_pk, 192 v_accvgpr
+        // pairs, 385 plain VALU -> per 16 MFMAs: R 11, G 3, X 3, P 3, F 8, A 4.  In 16x16x32 shapes the same MACs are 32 MFMAs and, with
+        // the wave's 32 rays as two column tiles per A fragment, the same LDS bytes.  The teacher's three-pass chain (16x16 today): per
+        // 32 MFMAs R 11, G 3, X 6, F 5, A 1.
+        run<16, 0, 0, 11, 0, 3, 0, 0, 3, 3, 8, 4, 0, 1>("bodyx replica (32x32 shapes)");
+        run<0, 32, 0, 11, 0, 3, 0, 0, 3, 3, 8, 4, 0, 1>("bodyx replica in 16x16 shapes");
+        run<16, 0, 0, 11, 0, 0, 0, 0, 3, 3, 8, 4, 0, 1>("bodyx replica (32x32), no DMA");
+        run<0, 32, 0, 11, 0, 0, 0, 0, 3, 3, 8, 4, 0, 1>("bodyx replica (16x16), no DMA");
+        run<16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 32x32x16 f16 x16");
+        run<0, 32, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 16x16x32 f16 x32");
+        run<0, 32, 0, 11, 0, 3, 0, 0, 6, 0, 5, 1, 0, 1>("three-pass chain replica (16x16)");
+        run<16, 0, 0, 11, 0, 3, 0, 0, 6, 0, 5, 1, 0, 1>("three-pass chain replica in 32x32 shapes");
+        run<16, 0, 0, 11, 0, 3, 0, 0, 3, 3, 8, 4, 0, 1>("bodyx replica (32x32 shapes) again");
+        run<0, 32, 0, 11, 0, 3, 0, 0, 3, 3, 8, 4, 0, 1>("bodyx replica in 16x16 shapes again");
+        rsmi_shut_down();
+        return 0;
+    }
     if (getenv("EP_AB") != nullptr) {
         // A/B of the energy account's first lever (profiles/r04_energy_account.txt): the body kernel's mix with the SAME bytes,
         // VALU and MACs in 32x32 and in 16x16 MFMA shapes, loads in flight across the loop edge (power-bound, not latency-bound)
