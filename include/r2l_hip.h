@@ -40,7 +40,10 @@ extern "C" {
  *                    (compiler-scheduled kernel, kept for reference).  NeRF teacher: 0.6-1.6e-5 on rgb over whole frames
  *                    (eleven layers, compositing over 192 samples) -- its FAST mode since round 4: the generated layer chain
  *                    without correction terms (nerf_chain_kernel<true, 4>: four 16-point column tiles per wave, embedding k-steps
- *                    hi / lo on the embedding side), 0.56-0.58 of the fp16 MFMA peak; the front end's `--precision auto` measures it against FP16X3 per checkpoint.
+ *                    hi / lo on the embedding side; since round 5 one statement that also loads its rays, computes the next tile's
+ *                    embedding under the MFMAs and stores raw: nerf_chain_emb_kernel), 0.58-0.60 of the fp16 MFMA peak.  For SMOOTH
+ *                    teachers only: on a trained one (sharp densities) it is 3e-3 .. 3e-1 off; the front end's `--precision auto`
+ *                    measures it against FP16X3 on several poses per checkpoint and watches it afterwards.
  *   R2L_PREC_FP16_FP8  fp16 main pass + the two correction terms of FP16X3 on the block-scaled
  *                    low-precision MFMA (v_mfma_scale_f32_*_f8f6f4) with both operands in OCP bf6 (e3m2)
  *                    at 4x the fp16 rate: 1.5 pass-equivalents per k-step, L_inf ~3e-5 (< 1e-4).
@@ -55,11 +58,13 @@ extern "C" {
 #define R2L_PREC_FP16X1 1
 #define R2L_PREC_FP16_FP8 2
 #define R2L_PREC_FP16_E4M3 3
-/*   R2L_PREC_FP16X3_ASM (R2L student only) FP16X3's arithmetic (hi/lo split of both operands, three fp16 MFMA passes per
- *                    k-step) on the generated head and body kernels: no low-precision term anywhere, hence no operand
- *                    scales, no calibration and nothing to watch; L_inf 5-7e-7 against the reference's output, 7 % faster
- *                    than the compiler-scheduled FP16X3.  The last rung of the front end's `--precision auto` (networks
- *                    whose activations are beyond FP16_E4M3's reach). */
+/*   R2L_PREC_FP16X3_ASM FP16X3's arithmetic (hi/lo split of both operands, three fp16 MFMA passes per k-step) on the generated
+ *                    kernels: no low-precision term anywhere, hence no operand scales, no calibration and nothing to watch.
+ *                    R2L student: generated head and body kernels, L_inf 5-7e-7 against the reference's output, 7 % faster than the
+ *                    compiler-scheduled FP16X3; the last rung of the front end's `--precision auto` (networks whose activations
+ *                    are beyond FP16_E4M3's reach: e.g. the trained-like fixture, max|a| 126).  NeRF teacher (round 5): the
+ *                    generated layer chain in three passes (nerf_chain_kernel<false, 2, true>; W x 2^k streamed as hi and lo
+ *                    fragments), raw within 1.5e-5 of FP16X3, 17 % faster; `auto`'s last rung -- where every trained teacher ends. */
 #define R2L_PREC_FP16X3_ASM 4
 
 typedef struct r2l_ctx r2l_ctx;

@@ -318,6 +318,33 @@ def test_render_path_batches_frames_per_collective_two_ranks(pkg, tmp_path):
         assert os.path.getsize(os.path.join(out, f'{i:03d}.png')) > 100
 
 
+def test_main_starts_its_own_ranks_and_watches_a_teacher_path(pkg, tmp_path):
+    """`python main.py --gpus 2 ...` without torchrun: the entry script starts both ranks (launch.py; gloo between
+    them, both on this GPU).  A teacher checkpoint, five frames, `--precision auto`: probes on three poses of the path, the watch's spot
+    checks agreed between the ranks (frame 0: every rank re-renders 2,048 rays of its own rows in fp16x3), frames within 1e-4 of the oracle."""
+    from efficient_nerf_amd import frontend as fe
+    t0, t1 = O.make_teacher_state(1), O.make_teacher_state(2)
+    ck = str(tmp_path / 'nerf.tar')
+    fe.save_checkpoint(ck, t0, t1)
+    out = str(tmp_path / 'out')
+    env = dict(os.environ, R2L_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--gpus', '2', '--launch_timeout', '500', '--model_name', 'nerf',
+                        '--config', 'configs/lego.txt', '--pretrained_ckpt', ck, '--render_only', '--synthetic_poses', '5', '--H', '34',
+                        '--outdir', out], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'of each of 3 probe frame(s)' in r.stdout and '-> fp16x1' in r.stdout, r.stdout[-1500:]
+    assert 'on 2 GPU(s)' in r.stdout and '[precision] watch: 1 spot check(s)' in r.stdout and '0 fallback(s)' in r.stdout, r.stdout[-1500:]
+    rgbs = np.load(os.path.join(out, 'rgbs.npy'))
+    H = 17
+    assert rgbs.shape == (5, H, H, 3)
+    focal = O.focal_from_angle(34) / 2.
+    for i, c2w in enumerate(O.novel_poses(5)):
+        ref = O.teacher_render(t0, t1, H, H, focal, c2w, white_bkgd=True)['rgb_map'].view(H, H, 3).numpy()
+        assert np.abs(rgbs[i] - ref).max() <= 1e-4, i
+
+
 def test_cli_activation_variants(pkg, tmp_path):
     """`--act lrelu --trial.inact lrelu --trial.outact relu` (model/nerf_raybased.py:468-476, 497-522) through the command line with
     its default --precision auto: the generated modes refuse the network, auto says so and renders in fp16x3 within the contract"""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Bitwise repeatability of the teacher's modes: the same 400x400 frame rendered N times per mode (fp16x1 = the generated chain
-without correction terms, fp16_fp8 = with them), every output compared with the first render."""
+without correction terms and, since round 5, with its embedding in the stream; fp16_fp8 = with the bf6 terms; fp16x3_asm = in three passes), every output compared with the first render."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +11,7 @@ from oracle import r2l_oracle as O
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 H = 400
 poses = O.novel_poses(4)
-for name in ('fp16x1', 'fp16_fp8'):
+for name in ('fp16x1', 'fp16_fp8', 'fp16x3_asm'):
     eng = NeRFEngine(H, H, O.focal_from_angle(H), white_bkgd=True, precision=PRECISIONS[name]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
     first = [{k: v.clone() for k, v in eng.render(p[:3, :4], extras=True).items()} for p in poses]
     bad = 0
