@@ -81,8 +81,7 @@ SIGNATURES = {
     'nerf_get_rays': (C.c_int, [C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     'nerf_set_ndc': (C.c_int, [_vp, C.c_int, C.c_float]),
     'nerf_ndc_rays': (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_float, _vp, _vp, C.c_int, _vp, _vp, _vp]),
-    'nerf_debug_pack_chain_format': (C.c_int, [C.c_int]),
-    'nerf_debug_pack_chain_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, _vp, C.c_longlong, C.POINTER(C.c_longlong)]),
+    'nerf_debug_pack_chain_host': (C.c_longlong, [C.POINTER(_vp), C.c_int, C.c_int, _vp, C.c_longlong, C.POINTER(C.c_longlong)]),
     'nerf_run_network': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'nerf_sample_pdf_u': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     'nerf_render': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),

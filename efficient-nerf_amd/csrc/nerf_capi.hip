@@ -761,14 +761,8 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 }
 
 // run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
-static int g_debug_chain_fmt = 0;
-int nerf_debug_pack_chain_format(int fmt) {   // which stream nerf_debug_pack_chain_host packs: 0 fp16 + bf6 terms, 1 fp16 only (FP16X1), 2 hi | lo (FP16X3_ASM)
-    if (fmt < 0 || fmt > 2) return r2l_set_error(R2L_EINVAL, "chain stream format %d", fmt);
-    g_debug_chain_fmt = fmt;
-    return R2L_OK;
-}
-
-long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, char* out, long long cap, long long* offs) {
+long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, int fmt, char* out, long long cap, long long* offs) {
+    if (fmt < 0 || fmt > 2) return r2l_set_error(R2L_EINVAL, "chain stream format %d (0 fp16 + bf6 terms, 1 fp16 only, 2 hi | lo)", fmt);
     if (!tensors || n_tensors != 24) return r2l_set_error(R2L_EINVAL, "expected 24 tensors");
     std::vector<std::vector<float>> w;
     for (int i = 0; i < 24; ++i) {
@@ -776,9 +770,9 @@ long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors,
         w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
     }
     std::vector<char> img;
-    int rc = pack_chain(w, 16.0f, img, g_debug_chain_fmt);
+    int rc = pack_chain(w, 16.0f, img, fmt);
     if (rc) return rc;
-    if (offs) offs[0] = g_debug_chain_fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (g_debug_chain_fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
+    if (offs) offs[0] = fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
 }

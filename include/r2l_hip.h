@@ -355,9 +355,9 @@ int nerf_run_network(nerf_ctx* ctx, int which, const float* rays_o_dev, const fl
  * csrc/nerf_capi.hip pack_chain, restated by csrc/gen/nerf_gen.py pack_teacher).  tensors: the 24 state_dict
  * tensors (model/nerf_raybased.py:357-375).  Returns the image size in bytes (negative on error), copies at
  * most cap bytes to out; offs[0] receives the byte offset of the table. */
-/* which stream nerf_debug_pack_chain_host packs: 0 = fp16 + bf6 terms (R2L_PREC_FP16_FP8), 1 = fp16 only (R2L_PREC_FP16X1) */
-int nerf_debug_pack_chain_format(int fmt);
-long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, char* out, long long cap,
+/* fmt: which stream -- 0 = fp16 + bf6 terms (R2L_PREC_FP16_FP8), 1 = fp16 only (R2L_PREC_FP16X1), 2 = hi | lo fragments of W x 2^k
+ * (R2L_PREC_FP16X3_ASM) */
+long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, int fmt, char* out, long long cap,
                                      long long* offs);
 
 /* stand-alone scan kernels (all device pointers, f32):

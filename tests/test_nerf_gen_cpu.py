@@ -84,10 +84,10 @@ def make_frags(e, v, act):
 def cxx_pack(tensors):
     keep, arr = _lib.host_ptrs([torch.from_numpy(np.ascontiguousarray(t)) for t in tensors])
     offs = (C.c_longlong * 1)()
-    n = _lib.lib().nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs)
+    n = _lib.lib().nerf_debug_pack_chain_host(arr, len(keep), 0, None, 0, offs)
     assert n > 0, _lib.lib().r2l_last_error()
     buf = np.zeros(n, dtype=np.uint8)
-    assert _lib.lib().nerf_debug_pack_chain_host(arr, len(keep), C.c_void_p(buf.ctypes.data), n, offs) == n
+    assert _lib.lib().nerf_debug_pack_chain_host(arr, len(keep), 0, C.c_void_p(buf.ctypes.data), n, offs) == n
     return buf, int(offs[0])
 
 

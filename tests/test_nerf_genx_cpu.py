@@ -47,14 +47,10 @@ def cxx_pack_x(tensors):
     keep, arr = _lib.host_ptrs([torch.from_numpy(np.ascontiguousarray(t)) for t in tensors])
     offs = (C.c_longlong * 1)()
     L = _lib.lib()
-    assert L.nerf_debug_pack_chain_format(1) == 0
-    try:
-        n = L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs)
-        assert n > 0, L.r2l_last_error()
-        buf = np.zeros(n, dtype=np.uint8)
-        assert L.nerf_debug_pack_chain_host(arr, len(keep), C.c_void_p(buf.ctypes.data), n, offs) == n
-    finally:
-        L.nerf_debug_pack_chain_format(0)
+    n = L.nerf_debug_pack_chain_host(arr, len(keep), 1, None, 0, offs)
+    assert n > 0, L.r2l_last_error()
+    buf = np.zeros(n, dtype=np.uint8)
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), 1, C.c_void_p(buf.ctypes.data), n, offs) == n
     return buf, int(offs[0])
 
 
@@ -187,14 +183,11 @@ def cxx_pack_fmt(tensors, fmt):
     keep, arr = _lib.host_ptrs([torch.from_numpy(np.ascontiguousarray(t)) for t in tensors])
     offs = (C.c_longlong * 1)()
     L = _lib.lib()
-    assert L.nerf_debug_pack_chain_format(fmt) == 0
-    try:
-        n = L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs)
-        assert n > 0, L.r2l_last_error()
-        buf = np.zeros(n, dtype=np.uint8)
-        assert L.nerf_debug_pack_chain_host(arr, len(keep), C.c_void_p(buf.ctypes.data), n, offs) == n
-    finally:
-        L.nerf_debug_pack_chain_format(0)
+    n = L.nerf_debug_pack_chain_host(arr, len(keep), fmt, None, 0, offs)
+    assert n > 0, L.r2l_last_error()
+    buf = np.zeros(n, dtype=np.uint8)
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), fmt, C.c_void_p(buf.ctypes.data), n, offs) == n
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), 3, None, 0, offs) < 0          # the format is an argument, not process state
     return buf, int(offs[0])
 
 

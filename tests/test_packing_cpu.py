@@ -181,10 +181,10 @@ def test_fp16_fp8_packers_reject_weights_outside_the_split_range(pkg, built_lib)
     t = O.make_teacher_state(1)
     t['pts_linears.3.weight'] = t['pts_linears.3.weight'] * 2.0 ** -12
     keep, arr = _lib.host_ptrs([t[n] for n in NeRFEngine.STATE_NAMES])
-    assert L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs) < 0
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), 0, None, 0, offs) < 0
     assert b'teacher layer 3' in L.r2l_last_error() and b'outside the range' in L.r2l_last_error()
     keep, arr = _lib.host_ptrs([O.make_teacher_state(1)[n] for n in NeRFEngine.STATE_NAMES])
-    assert L.nerf_debug_pack_chain_host(arr, len(keep), None, 0, offs) > 0
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), 0, None, 0, offs) > 0
 
 
 def _fnv(b):
@@ -246,9 +246,9 @@ def test_host_packers_under_asan_ubsan(pkg, built_lib, tmp_path):
     L.r2l_debug_pack_body_format(0)
     tkeep, tarr = _lib.host_ptrs([tsd[n] for n in tnames])
     off = (C.c_longlong * 1)()
-    size = L.nerf_debug_pack_chain_host(tarr, 24, None, 0, off)
+    size = L.nerf_debug_pack_chain_host(tarr, 24, 0, None, 0, off)
     buf = (C.c_char * size)()
-    assert L.nerf_debug_pack_chain_host(tarr, 24, buf, size, off) == size
+    assert L.nerf_debug_pack_chain_host(tarr, 24, 0, buf, size, off) == size
     assert got[('pack_chain',)] == [str(size), _fnv(bytes(buf)), str(off[0])]
     key = (np.uint32(2654435761) * np.arange(1, 625, dtype=np.uint32)).astype(np.uint32)
     pos = C.c_int(300)

@@ -74,13 +74,13 @@ int main(int argc, char** argv) {
     r2l_debug_pack_body_format(0);
     {
         long long off = 0;
-        long long n = nerf_debug_pack_chain_host(p.data() + n_r2l, 24, nullptr, 0, &off);
+        long long n = nerf_debug_pack_chain_host(p.data() + n_r2l, 24, 0, nullptr, 0, &off);
         if (n <= 0) {
             printf("pack_chain: %s\n", r2l_last_error());
             return 1;
         }
         std::vector<char> out((size_t)n);
-        if (nerf_debug_pack_chain_host(p.data() + n_r2l, 24, out.data(), n, &off) != n) return 1;
+        if (nerf_debug_pack_chain_host(p.data() + n_r2l, 24, 0, out.data(), n, &off) != n) return 1;
         printf("pack_chain %lld %016llx %lld\n", n, (unsigned long long)fnv(out), off);
     }
     {
