@@ -30,9 +30,13 @@ def test_r2l_given_rays_ragged_counts(pkg):
     eng.close()
 
 
+@pytest.mark.parametrize('prec', ['fp16_fp8', 'fp16x1', 'fp16x3_asm'])
 @pytest.mark.parametrize('n,S', [(1, 3), (2, 64), (1, 127), (3, 43), (5, 192), (700, 64)])
-def test_teacher_chain_ragged_point_counts(pkg, n, S):
-    from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8
+def test_teacher_chain_ragged_point_counts(pkg, n, S, prec):
+    """the three generated builds of the layer chain: with bf6 terms (128-point tiles), the single pass as one statement with its ray
+    loads, embedding and raw stores in the stream (256-point tiles: nerf_chain_emb_kernel's own point -> (ray, sample) division and
+    masked stores), and in three passes (128-point tiles)"""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
     H = 32
     focal = O.focal_from_angle(H)
     sd = O.make_teacher_state(2)
@@ -41,7 +45,7 @@ def test_teacher_chain_ragged_point_counts(pkg, n, S):
     ro, rd = ro.reshape(-1, 3).float()[:n].contiguous(), rd.reshape(-1, 3).float()[:n].contiguous()
     g = torch.Generator().manual_seed(n * 1000 + S)
     z = (2. + 4. * torch.rand(n, S, generator=g)).sort(-1).values.contiguous()
-    eng = NeRFEngine(H, H, focal, precision=PREC_FP16_FP8).load_state_dicts(sd, sd)
+    eng = NeRFEngine(H, H, focal, precision=PRECISIONS[prec]).load_state_dicts(sd, sd)
     raw = eng.run_network(1, ro.cuda(), rd.cuda(), z.cuda()).cpu()
     assert raw.shape == (n, S, 4)
     pts = ro[:, None, :] + rd[:, None, :] * z[..., None]
