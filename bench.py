@@ -161,16 +161,30 @@ def trained_like_leg(torch, O, cpu):
     eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(ssd)
     rung, top = eng.choose_precision(c2w=test[0][:3, :4])
     s = {'rung': rung, 'max_act_exponent': None if top is None else int(top), 'max_abs_activation': float(eng.stream_max),
-         'ladder': 'fp16_fp8 up to %g, fp16_e4m3 up to %g, fp16x3_asm above' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)}
-    eng.render(test[1][:3, :4])
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(10):
-        eng.render_checked(lambda: eng.render(test[2 + i][:3, :4]))
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t1) / 10
+         'ladder': 'fp16_fp8 up to %g, fp16_e4m3 up to %g, above: fp16_split (head + the first `split_block` blocks in three fp16 passes, '
+                   'the rest with bf6 terms; the split bisected for rgb within %g of three passes everywhere on every ray of the probe '
+                   'frame), fp16x3_asm when less than 1/8 of the blocks would be left' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3, eng.AUTO_SPLIT_MAX_DIFF)}
+    if rung == 'fp16_split':
+        s.update(split_block=eng.split_block, n_block=eng.n_block, split_probe_diffs={str(k): v for k, v in sorted(eng.auto_split.items())})
+
+    def frames_per_s():
+        eng.render(test[1][:3, :4])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(10):
+            eng.render_checked(lambda: eng.render(test[2 + i][:3, :4]))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / 10
+    dt = frames_per_s()
     s.update(rays_per_s=H * W / dt, ms_per_frame=dt * 1e3, rung_after_10_frames=PREC_NAMES[eng.precision],
              frac_of_fp16_mfma_peak=eng.flops_per_ray * H * W / dt / 1e12 / PEAK_FP16_TFLOPS)
+    if rung == 'fp16_split':
+        from efficient_nerf_amd import get_rays
+        worst = 0.
+        for pi in (0, 67, 133):                  # what frontend.render_path's watch does every 8th batch
+            ro, rd = get_rays(H, W, focal, test[pi][:3, :4], device='cuda')
+            worst = max(worst, eng.spot_check_split(ro, rd)[1])
+        s.update(watch_worst_rgb_diff_from_three_passes=worst, watch_limit=eng.SPLIT_WATCH_MAX_DIFF, watch_rays_per_check=eng.SPLIT_WATCH_RAYS)
     if cpu:
         frames = []
         for pi in (0, 67, 133):
@@ -178,6 +192,10 @@ def trained_like_leg(torch, O, cpu):
             want = O.r2l_render(ssd, H, W, focal, test[pi][:3, :4], rows=(0, H, 8), chunk=16384)
             frames.append({'pose': pi, 'rays': int(got.shape[0]), 'linf': (got - want).abs().max().item()})
         s.update(linf_vs_cpu_oracle=max(f['linf'] for f in frames), rays_checked=sum(f['rays'] for f in frames), frames=frames)
+    if rung == 'fp16_split':                     # beside it: three passes everywhere, the rung these weights had before the split rung
+        eng.set_precision(PRECISIONS['fp16x3_asm'])
+        dt3 = frames_per_s()
+        s.update(rays_per_s_fp16x3_asm=H * W / dt3, ms_per_frame_fp16x3_asm=dt3 * 1e3)
     eng.close()
     out['student'] = s
     # ---- teacher, 400 x 400 ----
@@ -413,7 +431,7 @@ def main():
                                   'gives these weights; up to %g -> fp16_e4m3, above -> fp16x3_asm: e4m3_mode / stress_weights below; '
                                   'limits from profiles/r04_range_sweep_dists.txt).  The synthetic nn.Linear-init weights of this line sit at max|a| ~ 7; the '
                                   'trained-like fixture (trained_like.student: weights that went through teacher fit -> pseudo data -> distillation) '
-                                  'reaches max|a| ~ 126 and renders on the last rung: its rate is trained_like.student.rays_per_s' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)
+                                  'reaches max|a| ~ 126 and renders on the split rung (fp16_split): its rate is trained_like.student.rays_per_s' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)
                                   if args.precision == 'fp16_fp8' else
                                   'max|a| <= %g over all operand sets of every ray (the middle rung of --precision auto)' % eng.AUTO_MAX_ABS_E4M3)
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
@@ -499,7 +517,8 @@ def main():
             # the middle rung of `--precision auto` on the networks it is for (body weights x 1.08: largest |activation| ~ 9.5)
             out['e4m3_mode'] = middle_rung(torch, O, R2LEngine, sd, poses, focal)
             # secondary, outside the timed region: SURVEY 8(d)'s stress weights (every body weight x 1.3) through
-            # `--precision auto`: their residual stream is too large for the bf6 terms, the library must notice and take fp16x3
+            # `--precision auto`: their residual stream is too large for the bf6 terms throughout, the library must notice and measure
+            # how many leading blocks need three passes (fp16_split), or take fp16x3_asm
             ssd = {k: (v * 1.3 if k.startswith('body.') and k.endswith('weight') else v) for k, v in sd.items()}
             seng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(ssd)
             chosen, top = seng.choose_precision(c2w=poses[0])
@@ -514,7 +533,7 @@ def main():
             torch.cuda.synchronize()
             sdt = (time.perf_counter() - t1) / 3
             out['stress_weights'] = {'body_weight_gain': 1.3, 'max_act_exponent': int(top), 'max_abs_activation': float(seng.stream_max), 'auto_precision': chosen,
-                                     'linf_vs_cpu_oracle': (sg - sref).abs().max().item(), 'rays_checked': int(sg.shape[0]),
+                                     'split_block': seng.split_block, 'linf_vs_cpu_oracle': (sg - sref).abs().max().item(), 'rays_checked': int(sg.shape[0]),
                                      'value': H * W / sdt, 'unit': 'rays/s'}
             seng.close()
         if not args.no_teacher and world == 1:

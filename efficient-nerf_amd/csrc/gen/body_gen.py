@@ -1044,7 +1044,7 @@ def f16_clear_ops():
 def fused_tail_text():
     """rgb = sigmoid(W_t (x + h) + b_t) of the wave's 32 rays, straight from the residual stream in the AGPRs
     (model/nerf_raybased.py:539-544 with the global skip of :541; the standalone r2l_tail_kernel computes the same from the
-    stored images).  h, the head output, is read back from xin (the block loop consumed it); a lane sums its 128 features
+    stored images).  h, the head output, is read back from the image operand %3 points to (the block loop consumed xin); a lane sums its 128 features
     x 3 channels in fp32, ds_bpermute adds the two lane halves, lanes 0..31 store 12 bytes each.  Registers: everything
     below V_L0 is dead between the last block and the next tile's split."""
     L = []
@@ -1052,8 +1052,11 @@ def fused_tail_text():
     XA, WB, TMP, ACCS, RGBR, BIASR, TR = 0, 128, 176, 180, 186, 190, 194
     v_lane, v_rayoff, v_ray = V_LANE, V_RAYOFF, V_RAY
     NBUF = 4                                  # groups of weights in flight: 12 ds_read_b128 <= the 4-bit lgkmcnt
-    a('s_add_u32 %s, %s, %s' % (sreg(S_T0 + 4), sreg(S_XIN), sreg(S_TILEOFF)))
-    a('s_addc_u32 %s, %s, %s' % (sreg(S_T0 + 5), sreg(S_XIN + 1), sreg(S_TILEOFF + 1)))
+    # h comes through operand %3: with the fused tail nothing is written to xout, so the operand carries the HEAD image instead --
+    # the same address as xin when the launch runs all blocks, another one when it continues a residual stream that an earlier
+    # launch left in xin (R2L_PREC_FP16_SPLIT: blocks [0, split) by the bf6 kernel, the rest by this one; round 5)
+    a('s_add_u32 %s, %s, %s' % (sreg(S_T0 + 4), sreg(S_XOUT), sreg(S_TILEOFF)))
+    a('s_addc_u32 %s, %s, %s' % (sreg(S_T0 + 5), sreg(S_XOUT + 1), sreg(S_TILEOFF + 1)))
     for i in range(32):
         a('global_load_dwordx4 %s, %s, %s offset:%d' % (vreg(XA + 4 * i, 4), vreg(V_L0), sreg(S_T0 + 4, 2), (i % 4) * 1024))
         if i % 4 == 3:
@@ -1121,7 +1124,7 @@ def fused_tail_text():
 def kernel_text(opts):
     """asm text of the whole body kernel (one inline-asm statement).  Inputs (asm operands):
     %0 wimg (s64)  %1 aux (s64)  %2 xin (s64)  %3 xout (s64)  %4 n_tiles  %5 n_block  %6 wave  %7 blockIdx.x
-    %8 gridDim.x  %9 rgb (s64; 0: store the x image to xout, else the fused tail writes rgb and xout is unused)
+    %8 gridDim.x  %9 rgb (s64; 0: store the x image to xout, else the fused tail writes rgb and %3 is the head image h)
     %10 tail table (s64)  %11 n_rays  %12 number of the launch's first tile"""
     set_ring(opts)
     configure(opts.fmt)

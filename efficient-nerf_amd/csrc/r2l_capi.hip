@@ -154,11 +154,16 @@ struct r2l_ctx {
     int n_cu;
     bool loaded;
     std::vector<std::vector<float>> host_w;  // state_dict order
-    char* d_img[5];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
-    size_t img_bytes[5];
+    char* d_img[6];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
+    size_t img_bytes[6];
     char* d_body;                             // split modes: body stream v3 (r2l_body.hip) | aux blocks | tail
     int body_mode = -1;                       // ... of this mode (bf6 or e4m3 terms: chunk geometry and operand codes differ)
     size_t body_bytes, aux_off, tail_off;
+    // R2L_PREC_FP16_SPLIT: blocks [0, split_block) run on the three-pass stream d_body2, blocks [split_block, n_block) on d_body (bf6 terms)
+    char* d_body2 = nullptr;
+    size_t aux_split_off = 0;
+    size_t body2_bytes = 0, aux_off2 = 0, tail_off2 = 0;
+    int split_block = -1;                     // -1: n_block / 2 until r2l_set_split_block
     std::vector<int> act;                     // FP16_FP8: 2 n_block + 1 activation exponents (packed into the aux blocks)
     // activations as slopes (act(v) = max(v, s v): 0 relu, 0.01 LeakyReLU, 1 none): head, inside a block, behind a block.  The
     // generated kernels are built for (0, 0, 1); anything else runs in the compiler-scheduled modes only (r2l_set_activations)
@@ -194,16 +199,21 @@ struct r2l_ctx {
 
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
 enum { R2L_STREAM_BF6 = 0, R2L_STREAM_E4M3 = 1, R2L_STREAM_BF6R = 2, R2L_STREAM_F16 = 3 };   // body stream layouts (pack_body_v3)
-static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16X3_ASM; }
+static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_SPLIT; }
 // the modes with the generated head launch + generated body kernel
-static bool split_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16X3_ASM; }
+static bool split_mode(int mode) {
+    return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16X3_ASM || mode == R2L_PREC_FP16_SPLIT;
+}
 // ... of them those with low-precision correction terms in the body: calibrated operand scales, range tracking
-static bool scaled_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3; }
+static bool scaled_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16_SPLIT; }
+// the head launch in three fp16 passes (r2l_headx_kernel)?  FP16_SPLIT too: on a trained network the bf6-term head alone costs
+// 9e-5 of the 1e-4 contract (profiles/r05_split_time.txt) at 4 % of the MACs
+static bool head_x3(int mode) { return mode == R2L_PREC_FP16X3_ASM || mode == R2L_PREC_FP16_SPLIT; }
 static int stream_of(int mode) {
     return mode == R2L_PREC_FP16_E4M3 ? R2L_STREAM_E4M3 : mode == R2L_PREC_FP16X3_ASM ? R2L_STREAM_F16 :
            (R2L_BF6_CHUNK == 28672 ? R2L_STREAM_BF6 : R2L_STREAM_BF6R);
 }
-#define R2L_N_MODES 5
+#define R2L_N_MODES 6
 
 
 #ifndef R2L_SLICE_TILES
@@ -272,6 +282,7 @@ void r2l_destroy(r2l_ctx* c) {
     for (int m = 0; m < R2L_N_MODES; ++m)
         if (c->d_img[m]) (void)hipFree(c->d_img[m]);
     if (c->d_body) (void)hipFree(c->d_body);
+    if (c->d_body2) (void)hipFree(c->d_body2);
     if (c->d_xa) (void)hipFree(c->d_xa);
     if (c->d_xb) (void)hipFree(c->d_xb);
     if (c->d_wcal) (void)hipFree(c->d_wcal);
@@ -310,7 +321,7 @@ static int build_image(r2l_ctx* c, int mode) {
                                          "fp16x3 renders the others", c->act_head, c->act_in, c->act_out);
     if (split_mode(mode)) {
         // head launch: the stream of r2l_head_kernel (bf6 terms in both modes); body + tail: the v3 stream of the mode
-        int rc = pack_head_v1(c, img, mode == R2L_PREC_FP16X3_ASM);
+        int rc = pack_head_v1(c, img, head_x3(mode));
         if (rc) return rc;
         std::vector<char> body;
         rc = pack_body_v3(c, stream_of(mode), body, &c->aux_off, &c->tail_off);
@@ -325,6 +336,21 @@ static int build_image(r2l_ctx* c, int mode) {
         eb = hipMemcpy(c->d_body, body.data(), body.size(), hipMemcpyHostToDevice);
         if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "hipMemcpy body stream: %s", hipGetErrorString(eb));
         c->body_bytes = body.size();
+        if (c->d_body2) {
+            (void)hipFree(c->d_body2);
+            c->d_body2 = nullptr;
+        }
+        if (mode == R2L_PREC_FP16_SPLIT && c->n_block > 0) {     // ... and the three-pass stream for the blocks behind the split
+            std::vector<char> body2;
+            rc = pack_body_v3(c, R2L_STREAM_F16, body2, &c->aux_off2, &c->tail_off2);
+            if (rc) return rc;
+            // behind it: room for the aux blocks of a truncated bf6 launch (r2l_launch_split_aux, per slice)
+            c->aux_split_off = body2.size();
+            eb = hipMalloc((void**)&c->d_body2, body2.size() + (size_t)c->n_block * R2L_BODY_AUX_BYTES);
+            if (eb == hipSuccess) eb = hipMemcpy(c->d_body2, body2.data(), body2.size(), hipMemcpyHostToDevice);
+            if (eb != hipSuccess) return r2l_set_error(R2L_EHIP, "three-pass body stream: %s", hipGetErrorString(eb));
+            c->body2_bytes = body2.size();
+        }
         // calibration operands: per block W1^T | b1' (the folded bias, real units) | W2^T in fp32
         if (c->n_block > 0) {
             const size_t per = 2 * 65536 + 256;
@@ -815,11 +841,21 @@ int r2l_recalibrate(r2l_ctx* c, void* stream) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (!c->loaded || !c->d_gstats || c->n_block < 1)
         return r2l_set_error(R2L_ESTATE, "r2l_recalibrate needs loaded weights, R2L_PREC_FP16_FP8 and n_block >= 1");
+    if (c->mode == R2L_PREC_FP16_SPLIT)      // its guarded launches see the blocks behind the split only
+        return r2l_set_error(R2L_ESTATE, "r2l_recalibrate: R2L_PREC_FP16_SPLIT borrows the exponents of R2L_PREC_FP16_FP8 -- recalibrate there");
     if (c->n_guarded < 1) return r2l_set_error(R2L_ESTATE, "r2l_recalibrate: no guarded launch since the last reset of the range words");
     hipError_t e = r2l_launch_recalibrate(c->d_gstats, c->d_range, c->n_block, c->d_body + c->aux_off, c->d_exps, (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "recalibration launch: %s", hipGetErrorString(e));
     c->calib_pending = 0;
     c->last_stream = (hipStream_t)stream;
+    return R2L_OK;
+}
+
+int r2l_set_split_block(r2l_ctx* c, int split_block) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    if (split_block < 0 || split_block > c->n_block)
+        return r2l_set_error(R2L_EINVAL, "split block %d outside [0, %d]", split_block, c->n_block);
+    c->split_block = split_block;
     return R2L_OK;
 }
 
@@ -849,7 +885,7 @@ long long r2l_debug_pack_host(const float* const* tensors, int n_tensors, int n_
     }
     std::vector<char> img;
     if (split_mode(precision_mode)) {   // the image of this mode's head launch (r2l_head_kernel)
-        int rc = pack_head_v1(&c, img, precision_mode == R2L_PREC_FP16X3_ASM);
+        int rc = pack_head_v1(&c, img, head_x3(precision_mode));
         if (rc) return rc;
     } else {
         pack_image_host(&c, precision_mode, img);
@@ -1043,7 +1079,14 @@ static int ensure_x(r2l_ctx* c, int tiles, bool need_xb) {
 static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
     const int slice = p.n_tiles < R2L_SLICE_TILES ? p.n_tiles : R2L_SLICE_TILES;
     const bool fused_form = c->n_block > 0 && c->use_residual && c->fuse_tail;
-    int rc = ensure_x(c, slice, c->n_block > 0 && !fused_form);
+    // R2L_PREC_FP16_SPLIT: blocks [0, split) on the three-pass kernel (x image out), blocks [split, n_block) on the bf6 kernel
+    int split = -1;
+    if (c->mode == R2L_PREC_FP16_SPLIT && c->n_block > 0) {
+        split = c->split_block < 0 ? c->n_block / 2 : c->split_block;
+        if (split > c->n_block) split = c->n_block;
+    }
+    const bool two_bodies = split > 0 && split < c->n_block;
+    int rc = ensure_x(c, slice, c->n_block > 0 && (!fused_form || two_bodies));
     if (rc) return rc;
     c->last_stream = s;
     for (int t0 = 0; t0 < p.n_tiles; t0 += R2L_SLICE_TILES) {
@@ -1055,7 +1098,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
         ph.tile_begin = t0;
         ph.n_tiles = nt;
         ph.range = c->d_range;     // every ray's h0 enters the running maximum (r2l_get_range_status)
-        hipError_t e = r2l_launch_head(ph, grid, s, c->mode == R2L_PREC_FP16X3_ASM);
+        hipError_t e = r2l_launch_head(ph, grid, s, head_x3(c->mode));
         if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l head launch: %s", hipGetErrorString(e));
         const float* body_out = c->d_xa;
         bool fused = false;
@@ -1074,20 +1117,60 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             pb.wimg = c->d_body;
             pb.aux = c->d_body + c->aux_off;
             pb.xin = c->d_xa;
-            pb.xout = c->d_xb;
             pb.n_tiles = nt;
             pb.n_block = c->n_block;
-            // with the global skip the body kernel finishes the rays itself (its fused tail reads h back from xin)
+            // with the global skip the body kernel finishes the rays itself: its fused tail reads h back from the image operand
+            // xout points to (nothing is written there in that form)
             fused = c->use_residual && c->fuse_tail;
             pb.rgb = fused ? p.rgb : nullptr;
+            pb.xout = fused ? c->d_xa : c->d_xb;
             pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
             pb.n_rays = p.n_rays;
             pb.tile_begin = t0;
             pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3 ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
-            // range guard: the first launch after a weight load, then every guard_period-th (r2l_set_guard_period)
-            const bool guard = c->guard_period > 0 && scaled_mode(c->mode) && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) &&
-                               c->n_since_load % c->guard_period == 0;
-            pb.gstats = guard ? c->d_gstats : nullptr;
+            R2LBodyParams p2 = pb;
+            if (split >= 0) {
+                // blocks [0, split) in three passes (stream d_body2), blocks [split, n_block) with bf6 terms (stream d_body)
+                const int n3 = split, n6 = c->n_block - split;
+                R2LBodyParams& q6 = two_bodies ? p2 : pb;
+                if (two_bodies) {
+                    pb.rgb = nullptr;
+                    pb.xout = c->d_xb;
+                    p2.xin = c->d_xb;                               // the second launch continues the stream in place
+                }
+                if (n3 > 0) {
+                    pb.wimg = c->d_body2;
+                    pb.aux = c->d_body2 + c->aux_off2;
+                    pb.tail = reinterpret_cast<const float*>(c->d_body2 + c->tail_off2);
+                    pb.e4m3 = 2;
+                    pb.n_block = n3;
+                }
+                if (n6 > 0) {
+                    q6.wimg = c->d_body + (size_t)split * 16 * R2L_BF6_CHUNK;
+                    q6.aux = c->d_body + c->aux_off;
+                    q6.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
+                    q6.e4m3 = 0;
+                    q6.n_block = n6;
+                    if (split > 0) {
+                        // the kernel converts the NEXT ray tile's x with the exponent its last block's aux names (in the full
+                        // stream: block 0's input set): a launch that starts at `split` needs that block's there -- a patched copy
+                        // of its aux blocks, made in stream order behind whatever calibrated them
+                        q6.aux = c->d_body2 + c->aux_split_off;
+                        e = r2l_launch_split_aux(c->d_body + c->aux_off, split, n6, c->d_body2 + c->aux_split_off, s);
+                        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l split aux launch: %s", hipGetErrorString(e));
+                    }
+                }
+            }
+            // range guard: the first launch after a weight load, then every guard_period-th (r2l_set_guard_period); of a split
+            // launch pair the bf6 part, whose rows of maxima start at its first block's
+            auto guarded = [&](R2LBodyParams& q, int first) {
+                const bool guard = c->guard_period > 0 && scaled_mode(c->mode) && q.e4m3 != 2 &&
+                                   c->n_block <= r2l_body_guard_max_blocks(q.e4m3) && c->n_since_load % c->guard_period == 0;
+                q.gstats = guard ? c->d_gstats + 2 * first : nullptr;
+                return guard;
+            };
+            const bool g1 = guarded(pb, 0), g2 = two_bodies && guarded(p2, split);
+            const bool guard = g1 || g2;
             ++c->n_since_load;
             ++c->n_body;
             c->n_guarded += guard ? 1 : 0;
@@ -1098,6 +1181,7 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
                 (void)hipEventRecord(e0, s);
             }
             e = r2l_launch_body(pb, grid, s);
+            if (e == hipSuccess && two_bodies) e = r2l_launch_body(p2, grid, s);
             if (c->timing) (void)hipEventRecord(e1, s);
             if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "r2l body launch: %s", hipGetErrorString(e));
             body_out = c->d_xb;
@@ -1213,7 +1297,8 @@ long long r2l_kernel_flops_per_ray(const r2l_ctx* c) {
 }
 long long r2l_weight_image_bytes(const r2l_ctx* c) {
     if (!c) return 0;
-    return (long long)c->img_bytes[c->mode] + (split_mode(c->mode) ? (long long)c->body_bytes : 0);
+    return (long long)c->img_bytes[c->mode] + (split_mode(c->mode) ? (long long)c->body_bytes : 0) +
+           (c->mode == R2L_PREC_FP16_SPLIT ? (long long)c->body2_bytes : 0);
 }
 int r2l_rays_per_tile(const r2l_ctx*) { return R2L_TILE_RAYS; }
 

@@ -65,6 +65,8 @@ hipError_t r2l_launch_calib(const float* xa, const float* wcal, int n_block, int
 hipError_t r2l_launch_recalibrate(const unsigned* gstats, const unsigned* range, int n_block, char* aux, int* exps, hipStream_t stream);
 // r2l_set_act_exponents: exps (device, contiguous) -> the aux blocks
 hipError_t r2l_launch_spread_exponents(const int* exps, int n_block, char* aux, hipStream_t stream);
+// aux blocks [first, first + count) of the bf6 stream for a launch over just those blocks (R2L_PREC_FP16_SPLIT), made on the device
+hipError_t r2l_launch_split_aux(const char* aux, int first, int count, char* dst, hipStream_t stream);
 int r2l_body_lds_bytes();
 int r2l_body_guard_max_blocks(int e4m3);   // largest n_block whose 2 n_block maxima rows fit the LDS beside the ring
 hipError_t r2l_launch_sample_embed(const R2LParams& p, float* pts_out, float* emb_out,

@@ -74,7 +74,7 @@ FLAGS = [
     # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
     # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher measures fp16x1 (its layer chain as one
     # fp16 pass), then fp16_fp8, against fp16x3 (NeRFEngine.choose_precision); fp32 = the generic layer path for any network shape
-    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp32', 'auto'])),
+    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp16_split', 'fp32', 'auto'])),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
     # frames rendered per launch / collective / range check / host sync (0: the world size, i.e. one frame on one GPU)
@@ -386,6 +386,11 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
             elif log:
                 log(f'[precision] auto: activations of every ray of the first frame up to {eng.stream_max:.2f} (exponent {top}; '
                     f'fp16_fp8 up to {eng.AUTO_MAX_ABS:g}, fp16_e4m3 up to {eng.AUTO_MAX_ABS_E4M3:g}) -> {name}')
+                if getattr(eng, 'auto_split', None):
+                    tried = ', '.join(f'{k}: {v:.1e}' for k, v in eng.auto_split.items())
+                    log(f'[precision] auto: leading blocks in three passes (bf6 terms behind them), largest rgb difference from three passes '
+                        f'everywhere on every ray of the first frame: {tried} (limit {eng.AUTO_SPLIT_MAX_DIFF:g}) -> ' +
+                        (f'fp16_split at block {eng.split_block} of {eng.n_block}' if name == 'fp16_split' else name))
         return 'R2L', eng
     if args.model_name == 'nerf':
         # the fused teacher kernels are the 8 x 256 NeRF with view directions, L = 10 / 4 and a fine pass (configs/*.txt); every other
@@ -531,6 +536,44 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
                 got = watched(i, ro, rd, got)
             dst[f].copy_(got if kind == 'R2L' else got['rgb_map'])
 
+    # the split rung of the R2L ladder under watch: `auto` measured on the first frame how many leading blocks need three passes (the
+    # rest keep their bf6 terms); every watch_every-th batch a sample of the rank's own rays of the batch's first frame is rendered with
+    # the split and with three passes everywhere (R2LEngine.spot_check_split); a miss on any rank moves half of the bf6 part to three
+    # passes on every rank and the batch is rendered again
+    split_watching = kind == 'R2L' and watch_every > 0 and hasattr(eng, 'spot_check_split')
+    split_watch = {'checks': 0, 'fallbacks': [], 'worst': 0.0}
+
+    def watch_split(i0, nb):
+        from .teacher import get_rays
+        again = 0
+        for _ in range(6):
+            if getattr(eng, 'precision_name', None) != 'fp16_split':
+                break
+            if given_rays is not None:
+                ro = given_rays[0][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+                rd = given_rays[1][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+            else:
+                ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(render_poses[i0])[:3, :4], rows=(r0, r1), device=eng.device))
+            ok, d = eng.spot_check_split(ro, rd)
+            split_watch['checks'] += 1
+            split_watch['worst'] = max(split_watch['worst'], d)
+            bad = 0 if ok else 1
+            if world > 1:
+                t = torch.tensor([bad], dtype=torch.int32, device=eng.device if tdist.get_backend() == 'nccl' else 'cpu')
+                tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+                bad = int(t.item())
+            if not bad:
+                break
+            was = eng.split_block
+            now = eng.step_down_split()
+            split_watch['fallbacks'].append({'frame': i0, 'split': was, 'to': eng.split_block if now == 'fp16_split' else now, 'diff': d})
+            if rank == 0:
+                log(f'[precision] frame {i0}: with bf6 terms from block {was} on {d:.1e} from three passes on {eng.SPLIT_WATCH_RAYS} of its rays '
+                    f'(limit {eng.SPLIT_WATCH_MAX_DIFF:g}) -> ' + (f'split at block {eng.split_block}' if now == 'fp16_split' else now) + '; batch rendered again')
+            eng.render_checked(lambda: render_local(i0, nb), check=check)
+            again += 1
+        return again
+
     # the teacher's fast modes under watch: fp16x1 / fp16_fp8 were chosen on a probe; every watch_every-th
     # frame is checked against fp16x3 on a sample of its own rays, agreed between the ranks, with fallback + re-render
     watching = kind != 'R2L' and watch_every > 0 and hasattr(eng, 'spot_check')
@@ -587,6 +630,8 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
             # raised, or the context falls back (`auto`), and the batch is rendered again -- one check per batch
             _, again = eng.render_checked(lambda: render_local(i0, nb), check=check)
             n_again += again
+            if split_watching and n_batches % watch_every == 0:
+                n_again += watch_split(i0, nb)
         else:
             render_local(i0, nb)
         if world > 1:
@@ -621,6 +666,8 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
                      rerenders=n_again, world=world, rows_per_rank=r1 - r0)
         if watching:
             stats['watch'] = dict(watch, every=watch_every, precision=eng.precision_name)
+        if split_watching and split_watch['checks']:
+            stats['split_watch'] = dict(split_watch, every=watch_every, precision=eng.precision_name, split_block=eng.split_block)
         if host_stack is not None:
             stats['host_frames'] = host_stack          # complete: writer.close() has waited for every copy
     misc = {}
@@ -698,6 +745,10 @@ def main(argv=None):
             f'frame(s), {st["collectives"]} collective(s), {st["rerenders"]} re-render(s))')
         log(f'Rendered {len(rgbs)} view(s) {H}x{W} on {world} GPU(s) in {dt:.2f}s '
             f'({len(rgbs) * H * W / dt:.3e} rays/s incl. host I/O)')
+        if st.get('split_watch'):
+            w_ = st['split_watch']
+            log(f"[precision] split watch: {w_['checks']} spot check(s) against three passes (every {w_['every']} batches), worst {w_['worst']:.2e}, "
+                f"{len(w_['fallbacks'])} fallback(s); at the end: {w_['precision']}" + (f" at block {w_['split_block']}" if w_['precision'] == 'fp16_split' else ''))
         if st.get('watch', {}).get('checks'):
             w_ = st['watch']
             log(f"[precision] watch: {w_['checks']} spot check(s) against fp16x3 (every {w_['every']} frames, {eng.WATCH_RAYS} rays), worst "

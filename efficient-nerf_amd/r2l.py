@@ -19,11 +19,12 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, check, current_stream, dptr, lib
+from ._lib import (R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, PREC_FP16_SPLIT, check, current_stream,
+                   dptr, lib)
 
-SPLIT_MODES = (PREC_FP16_FP8, PREC_FP16_E4M3)   # generated head launch + generated body kernel, calibrated operand scales
+SPLIT_MODES = (PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16_SPLIT)   # generated head launch + generated body kernel, calibrated operand scales
 PREC_NAMES = {PREC_FP16X3: 'fp16x3', PREC_FP16X1: 'fp16x1', PREC_FP16_FP8: 'fp16_fp8', PREC_FP16_E4M3: 'fp16_e4m3',
-              PREC_FP16X3_ASM: 'fp16x3_asm'}
+              PREC_FP16X3_ASM: 'fp16x3_asm', PREC_FP16_SPLIT: 'fp16_split'}
 
 
 def _dev(device=None):
@@ -75,6 +76,7 @@ class R2LEngine:
         if self.acts != (0.0, 0.0, 1.0) or body_arch == 'mlp':
             check(lib().r2l_set_network_form(self._ctx, *self.acts, int(body_arch == 'resmlp')))
         self.precision = int(precision)
+        self.split_block = None        # R2L_PREC_FP16_SPLIT: leading blocks in three passes = first block of the bf6 part
         self._loaded = False
         # model/nerf_raybased.py:88-90, evaluated with the host's torch exactly as the
         # reference does (torch.linspace's last ulp depends on the CPU vector width)
@@ -332,11 +334,118 @@ class R2LEngine:
         top = max(self.calibrate_on(c2w=c2w, rays=rays))
         self._auto = (max_exp,)
         mode = self.LADDER[self._rung_for(self.stream_max, max_exp)]
+        self.split_block = None
+        if mode == PREC_FP16X3_ASM and max_exp is None and self.AUTO_SPLIT:
+            split, diff = self.choose_split(c2w=c2w, rays=rays)
+            if split is not None:
+                return 'fp16_split', top
         if mode != PREC_FP16_FP8:
             self.set_precision(mode)          # the exponents travel with a switch between the two split modes
             if mode in SPLIT_MODES:
                 self.range_status(reset=True)
         return PREC_NAMES[mode], top
+
+    #: the split rung (round 5, from the trained-like fixture: profiles/r05_split_time.txt).  A trained ResMLP lands beyond the activation
+    #: limits of fp16_fp8 / fp16_e4m3 (max|a| 126 where they admit 8 / 10-ish), and measured on that network the limits are right about
+    #: the whole-network modes: fp16_fp8 is 1.3-1.5e-4 from three passes (35 of 640,000 rays beyond 1e-4).  But the error is not spread
+    #: evenly: the bf6-term HEAD launch alone costs 9e-5 (its output feeds every block), and of the body blocks the early ones cost
+    #: most, because everything behind a block amplifies what it got wrong.  R2L_PREC_FP16_SPLIT therefore keeps the head launch and the
+    #: first `split` blocks in three passes and renders the rest with bf6 terms; when the limits send a network to the last rung, `auto`
+    #: MEASURES the split: every ray of the probe frame, rendered with a candidate split and with three passes everywhere
+    #: (split = n_block, bit for bit fp16x3_asm), bisecting for the smallest split within AUTO_SPLIT_MAX_DIFF.  The limit keeps a
+    #: factor of two to the contract for the poses the probe did not see (measured: up to 1.4 x the probe frame's maximum; watched:
+    #: spot_check_split against SPLIT_WATCH_MAX_DIFF) and the 4e-6 between three passes and fp32.
+    AUTO_SPLIT = True
+    AUTO_SPLIT_MAX_DIFF = 5e-5
+    SPLIT_WATCH_MAX_DIFF = 7e-5
+    SPLIT_WATCH_RAYS = 65536
+    #: a split that leaves fewer than this fraction of the blocks to the bf6 kernel is not worth two launches: fp16x3_asm
+    SPLIT_MIN_GAIN = 0.125
+
+    @property
+    def precision_name(self):
+        return PREC_NAMES[self.precision]
+
+    def set_split_block(self, split):
+        """R2L_PREC_FP16_SPLIT: the number of leading blocks in three passes = first block of the bf6 part (0 .. n_block); takes effect
+        at the next render"""
+        with torch.cuda.device(self.device):
+            check(lib().r2l_set_split_block(self._ctx, int(split)))
+        self.split_block = int(split)
+
+    def choose_split(self, c2w=None, rays=None, max_diff=None):
+        """Smallest split whose render of the probe frame is within `max_diff` (default AUTO_SPLIT_MAX_DIFF) of three passes
+        everywhere, by bisection (the difference falls with the split, up to the noise of a maximum over rays); leaves the context in
+        fp16_split with that split, or in fp16x3_asm when it would leave less than SPLIT_MIN_GAIN of the blocks to the bf6 kernel.
+        Returns (split or None, its difference).  `auto_split` keeps {split tried: difference}.  Called with the exponents of fp16_fp8
+        calibrated (choose_precision); synchronous, once per weight load, about eight frames."""
+        max_diff = self.AUTO_SPLIT_MAX_DIFF if max_diff is None else float(max_diff)
+        nb = self.n_block
+
+        def rend():
+            if rays is not None:
+                return self.render_rays(rays[0].contiguous().to(self.device, torch.float32), rays[1].contiguous().to(self.device, torch.float32))
+            return self.render(c2w)
+        try:
+            self.set_precision(PREC_FP16_SPLIT)          # the calibrated exponents travel with the switch
+        except R2LError as e:
+            self.auto_note = str(e)
+            self.set_precision(PREC_FP16X3_ASM)
+            return None, float('nan')
+        self.set_split_block(nb)
+        ref = rend().clone()
+        self.auto_split = {}
+
+        def ok(sp):
+            self.set_split_block(sp)
+            d = float((rend() - ref).abs().max())
+            self.auto_split[sp] = d
+            return d <= max_diff                 # NaN fails
+        lo, hi = 0, nb                           # invariant: hi qualifies (nb: zero difference), everything below lo does not
+        while lo < hi:
+            mid = lo if not self.auto_split else (lo + hi) // 2      # first of all: no three-pass block at all
+            if ok(mid):
+                hi = mid
+            else:
+                lo = mid + 1
+        if nb - hi < max(1, int(self.SPLIT_MIN_GAIN * nb)):
+            self.set_precision(PREC_FP16X3_ASM)
+            self.split_block = None
+            return None, 0.0
+        self.set_split_block(hi)
+        self.range_status(reset=True)
+        return hi, self.auto_split[hi]
+
+    def spot_check_split(self, rays_o, rays_d, n_rays=None):
+        """the watch of the split rung: up to `n_rays` (default SPLIT_WATCH_RAYS) of the given rays, spread over the set, rendered with
+        the split in use and with three passes everywhere; (ok, largest difference).  Other modes: (True, 0)."""
+        if self.precision != PREC_FP16_SPLIT or self.split_block is None or self.split_block >= self.n_block:
+            return True, 0.0
+        ro, rd = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        n = ro.shape[0]
+        idx = torch.arange(0, n, max(1, n // int(n_rays or self.SPLIT_WATCH_RAYS)), device=ro.device)[:int(n_rays or self.SPLIT_WATCH_RAYS)]
+        ro, rd = ro[idx].contiguous(), rd[idx].contiguous()
+        sp = self.split_block
+        got = self.render_rays(ro, rd).clone()
+        self.set_split_block(self.n_block)
+        try:
+            ref = self.render_rays(ro, rd)
+        finally:
+            self.set_split_block(sp)
+        d = float((got - ref).abs().max())
+        return d <= self.SPLIT_WATCH_MAX_DIFF, d
+
+    def step_down_split(self):
+        """after a failed spot_check_split: half of the bf6 part goes to three passes, all of it once less than SPLIT_MIN_GAIN of the
+        blocks would be left; returns the new mode's name"""
+        nb = self.n_block
+        sp = (self.split_block or 0) + max(1, (nb - (self.split_block or 0) + 1) // 2)
+        if nb - sp < max(1, int(self.SPLIT_MIN_GAIN * nb)):
+            self.set_precision(PREC_FP16X3_ASM)
+            self.split_block = None
+            return 'fp16x3_asm'
+        self.set_split_block(sp)
+        return 'fp16_split'
 
     #: check_ranges raises the exponents when the largest value of an operand set, in units of its scale (|a| act_scale / 2^E:
     #: the calibration aims at <= 16 on the frame it saw), passes 0.9 x 28 = 25.2 -- for BOTH operand formats.  bf6 clamps at
@@ -374,19 +483,29 @@ class R2LEngine:
             return None
         st = self.range_status()
         top = st['format_top']
+        split = self.precision == PREC_FP16_SPLIT
+        if split and self.split_block:           # the head output is an operand of the bf6 part only when no block runs before it
+            st['h0_fill'] = 0.0
+            st['saturated'] = st['worst_fill'] >= 1.0
         scaled = max(st['h0_fill'], st['worst_fill']) * top
         act, clamped = scaled > self.RAISE_AT, bool(st['saturated'])
         guarded = st['guarded_launches'] > 0
         auto = getattr(self, '_auto', None)
-        cur = self.LADDER.index(self.precision)
-        # the ladder's own limit applied to what THESE rays did (h0 of every ray; every set on the guarded launches)
-        want = max(cur, self._rung_for(st['stream_max'], auto[0])) if auto is not None else cur
+        if split:
+            # the bf6 part's scales are watched as in fp16_fp8; the ladder's activation limits are not applied: this rung was chosen
+            # by measured error (choose_split) and is watched by spot_check_split.  Beyond the scales it does not raise them (its
+            # guarded launches see the blocks behind the split only): three passes everywhere, nothing left to watch
+            cur = want = 0
+        else:
+            cur = self.LADDER.index(self.precision)
+            # the ladder's own limit applied to what THESE rays did (h0 of every ray; every set on the guarded launches)
+            want = max(cur, self._rung_for(st['stream_max'], auto[0])) if auto is not None else cur
         if rank_max is not None:    # the ranks launch in step, so `guarded` agrees anyway; it rides along in the one all-reduce
             act, clamped, guarded, want = rank_max([act, clamped, guarded, want])
             act, clamped, guarded = bool(act), bool(clamped), bool(guarded)
         if not (act or clamped or want > cur):
             return None
-        fmt = 'bf6' if self.precision == PREC_FP16_FP8 else 'e4m3'
+        fmt = 'e4m3' if self.precision == PREC_FP16_E4M3 else 'bf6'
         msg = ('[precision] activations reach %.1f in units of their %s scale (operand set %d; h0: %.1f; calibrated to <= 16, limit '
                '%.1f, clamped beyond %g)%s' % (st['worst_fill'] * top, fmt, st['worst_set'], st['h0_fill'] * top, self.RAISE_AT, top,
                                                  ': values were clamped' if clamped else ''))
@@ -405,6 +524,13 @@ class R2LEngine:
             if log:
                 log(msg + '; only the head output of these rays was watched: rendered again range-guarded')
             return 'measure'
+        if split:
+            self.range_status(reset=True)
+            self.set_precision(PREC_FP16X3_ASM)
+            self.split_block = None
+            if log:
+                log(msg + '; fp16_split -> fp16x3_asm, frame rendered again')
+            return 'fp16x3_asm'
         before = self.act_exponents()
         self.recalibrate()
         if agree is not None:

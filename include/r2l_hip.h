@@ -66,6 +66,17 @@ extern "C" {
  *                    generated layer chain in three passes (nerf_chain_kernel<false, 2, true>; W x 2^k streamed as hi and lo
  *                    fragments), raw within 1.5e-5 of FP16X3, 17 % faster; `auto`'s last rung -- where every trained teacher ends. */
 #define R2L_PREC_FP16X3_ASM 4
+/*   R2L_PREC_FP16_SPLIT (R2L student only, round 5) for networks the activation limits send past FP16_FP8 / FP16_E4M3 (every
+ *                    trained one so far: max|a| 126 on the trained-like fixture).  Measured on that network, rendered against three
+ *                    passes everywhere: the bf6-term head launch alone costs 9e-5 of the 1e-4 contract, and of the body blocks the
+ *                    EARLY ones cost most (their error is amplified by everything behind them).  So: head launch and blocks
+ *                    [0, split) in FP16X3_ASM's arithmetic (three fp16 passes), blocks [split, n_block) in FP16_FP8's (generated
+ *                    bf6 body kernel, 1.5 pass-equivalents, calibrated and range-guarded as in that mode); two body launches
+ *                    hand the x image over (bit-exact: both kernels keep the stream in fp32).  r2l_set_split_block sets the split
+ *                    (default n_block / 2); the front end's `--precision auto` measures the smallest split whose frame stays
+ *                    inside its limit against three passes on every ray of a probe frame, and watches it.  split = n_block:
+ *                    FP16X3_ASM's results bit for bit; split = 0: every body block with bf6 terms behind the three-pass head. */
+#define R2L_PREC_FP16_SPLIT 5
 
 typedef struct r2l_ctx r2l_ctx;
 typedef struct nerf_ctx nerf_ctx;
@@ -126,6 +137,9 @@ void r2l_destroy(r2l_ctx* ctx);
  *   tail.0.weight[3,256], tail.0.bias[3]                                            */
 int r2l_load_weights(r2l_ctx* ctx, const float* const* tensors, int n_tensors);
 int r2l_set_precision(r2l_ctx* ctx, int precision_mode);
+/* R2L_PREC_FP16_SPLIT: the number of leading blocks in three passes = first block of the bf6 part, 0 .. n_block (takes effect at
+ * the next render; no re-packing) */
+int r2l_set_split_block(r2l_ctx* ctx, int split_block);
 /* Activations of NeRF_v3_2 / ResMLP other than the README's (model/nerf_raybased.py:443-476, 497-522: args.act behind the head layer,
  * trial.inact inside a block, trial.outact behind it), as slopes s of act(v) = max(v, s v): 0 = ReLU, 0.01 = LeakyReLU (torch's
  * default negative_slope), 1 = none.  Defaults 0, 0, 1 (act=relu, inact=relu, outact=none).  Anything else renders in the

@@ -52,9 +52,10 @@ def test_bench_line_schema():
     # the middle rung of the ladder on the networks it is for
     em = d['e4m3_mode']
     assert em['auto_precision'] == 'fp16_e4m3' and em['max_act_exponent'] == 4 and 8 < em['max_abs_activation'] <= 10 and em['linf_vs_cpu_oracle'] <= 1e-4
-    # the stress weights of SURVEY 8(d) must not be rendered with the bf6 terms: the library's own range check decides
+    # the stress weights of SURVEY 8(d) must not be rendered with the bf6 terms throughout: the library's own range check decides
+    # (since round 5 the split rung: as many leading blocks in three passes as its measurement asks for, or all of them)
     sw = d['stress_weights']
-    assert sw['auto_precision'] == 'fp16x3_asm' and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
+    assert sw['auto_precision'] in ('fp16_split', 'fp16x3_asm') and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
     assert d['calibration']['max'] <= d['calibration']['auto_precision_limit']     # ... and would keep fp16_fp8 for the standard set
 
 
@@ -82,7 +83,9 @@ def test_bench_line_round4_fields():
     assert cd['tail_s'] < 1.5 and cd['extrapolated_n_pose_kd_10000_hours_one_gpu'] < 1.0 < cd['reference_quotes_hours']
     # the trained-like fixture's rungs and rates in the line (CPU-oracle fields only with the CPU baseline on)
     tl = d['trained_like']
-    assert tl['student']['rung'] == 'fp16x3_asm' and tl['student']['max_abs_activation'] > 10 and tl['student']['rays_per_s'] > 1e7
+    st = tl['student']
+    assert st['rung'] == 'fp16_split' and st['max_abs_activation'] > 10 and st['rays_per_s'] > st['rays_per_s_fp16x3_asm'] > 1e7
+    assert 0 <= st['split_block'] < st['n_block'] == 43 and st['watch_worst_rgb_diff_from_three_passes'] <= st['watch_limit']
     assert tl['teacher']['precision'] == 'fp16x3_asm' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
     assert tl['teacher']['mlp_launches'] == 6 and 0 < tl['teacher']['mlp_kernel_ms_per_frame'] <= tl['teacher']['ms_per_frame']
     assert tl['teacher']['whole_frame_rgb_linf_from_fp16x3']['fp16x1'] > 1e-3

@@ -198,7 +198,7 @@ def test_cli_rejects_unsupported(pkg, tmp_path):
 def test_cli_precision_auto(pkg, tmp_path):
     """--precision auto measures the checkpoint's activation ranges on a probe render and says what it chose; the same
     checkpoint through the poses path and the given-rays path, a stress checkpoint (body weights x 1.3, 43 blocks)
-    falls back to fp16x3_asm; every render stays within 1e-4 of the oracle"""
+    goes behind the whole-network rungs (fp16_split with the split it measured, or fp16x3_asm); every render stays within 1e-4 of the oracle"""
     from efficient_nerf_amd import frontend as fe
     H = 32
     focal = O.focal_from_angle(64) / 2.
@@ -214,7 +214,8 @@ def test_cli_precision_auto(pkg, tmp_path):
                 '--netdepth', '88', '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck,
                 '--render_only', '--synthetic_poses', '1', '--H', '64', '--precision', 'auto']
         log = run_main(base + ['--outdir', str(tmp_path / tag)])
-        assert '[precision] auto' in log and log.split('[precision] auto')[1].splitlines()[0].rstrip().endswith('-> ' + want), log
+        said = log.split('[precision] auto')[1].splitlines()[0].rstrip()
+        assert said.endswith('-> ' + want) or (want == 'fp16x3_asm' and said.endswith('-> fp16_split') and 'leading blocks in three passes' in log), log
         ref = O.r2l_render(sd, H, H, focal, poses[0]).view(H, H, 3).numpy()
         a = np.load(tmp_path / tag / 'rgbs.npy')
         assert np.abs(a[0] - ref).max() <= 1e-4

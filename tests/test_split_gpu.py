@@ -1,0 +1,152 @@
+"""GPU: R2L_PREC_FP16_SPLIT (round 5) -- the head layer and blocks [0, split) of the ResMLP in three fp16 passes, blocks [split, n_block)
+on the generated bf6 kernel, two body launches handing the x image over (model/nerf_raybased.py:443-465, 539-544) -- and how
+`--precision auto` uses it: for networks whose activations outgrow the bf6 / e4m3 rungs it measures the smallest split that stays within
+its limit of three passes on every ray of a frame, and watches it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split_endpoints_and_middle_on_a_small_network(pkg):
+    """split = n_block is fp16x3_asm bit for bit (the same head launch, the same three-pass kernel over all blocks, the same fused
+    tail); split = 0 is every block with bf6 terms behind the three-pass head: at least as close to the oracle's neighbourhood as
+    fp16_fp8; every split inside the contract; a render of part of the rows equals the rows of the whole render (a ray's result does
+    not depend on the launch it is in); the exponents of fp16_fp8 travel with the switch"""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_SPLIT, PREC_FP16X3_ASM, R2LEngine
+    H, nb = 48, 6
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=17, netdepth=2 + 2 * nb)
+    c2w = O.pose_spherical(25., -35., 4.)
+    ref = O.r2l_render(sd, H, H, focal, c2w)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    eng.calibrate_on(c2w=c2w)
+    ex = eng.act_exponents()
+    fp8 = eng.render(c2w).clone()
+    eng.set_precision(PREC_FP16X3_ASM)
+    x3 = eng.render(c2w).clone()
+    eng.set_precision(PREC_FP16_SPLIT)
+    assert eng.act_exponents() == ex                       # the calibrated exponents travel with the switch
+    outs = {}
+    for sp in (nb, 0, 3, 1, 5):
+        eng.set_split_block(sp)
+        outs[sp] = eng.render(c2w).clone()
+        err = (outs[sp].cpu() - ref).abs().max().item()
+        print(f'split {sp} of {nb}: L_inf vs CPU oracle {err:.2e}, vs fp16_fp8 {(outs[sp] - fp8).abs().max().item():.2e}, vs fp16x3_asm {(outs[sp] - x3).abs().max().item():.2e}')
+        assert err <= 1e-4
+    assert torch.equal(outs[nb], x3)
+    d = {sp: (outs[sp] - x3).abs().max().item() for sp in outs}
+    assert 0 < d[0] <= 3e-5 and d[5] <= d[0] + 2e-6       # mild i.i.d. weights: the bf6 terms cost little anywhere; fewer of them cost less
+    eng.set_split_block(3)
+    part = eng.render(c2w, rows=(7, 29))
+    assert torch.equal(part, outs[3].view(H, H, 3)[7:29].reshape(-1, 3))
+    with pytest.raises(Exception):
+        eng.set_split_block(nb + 1)
+    with pytest.raises(Exception):                         # its guarded launches see the blocks behind the split only
+        eng.recalibrate()
+    eng.close()
+
+
+def test_a_launch_over_part_of_the_blocks_converts_the_next_tile_with_its_own_first_exponent(pkg):
+    """the bf6 kernel converts the NEXT ray tile's x with the exponent its last block's aux names -- in the full stream block 0's input
+    set, for a launch that starts at block `split` that block's (r2l_split_aux_kernel patches a copy of the aux blocks).  With
+    exponents that rise with depth a wrong entry shows: a workgroup's second tile would differ from the same rays rendered as some
+    workgroup's first tile.  450 ray tiles in one launch (two per workgroup) against two launches of 225 (one each): bit for bit"""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_SPLIT, R2LEngine
+    H, nb = 240, 6                                         # 57,600 rays = 450 ray tiles of 128
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=23, netdepth=2 + 2 * nb)
+    c2w = O.pose_spherical(70., -25., 4.)
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_FP8).load_state_dict(sd)
+    ex = eng.calibrate_on(c2w=c2w)
+    ex = ex[:6] + [e + 2 for e in ex[6:12]] + ex[12:]      # as in a trained network: the exponents rise with depth (i.i.d. weights: level)
+    eng.set_act_exponents(ex)
+    eng.set_precision(PREC_FP16_SPLIT)
+    eng.set_split_block(nb)
+    ref = eng.render(c2w).clone()
+    eng.set_split_block(3)
+    whole = eng.render(c2w).clone()
+    halves = torch.cat([eng.render(c2w, rows=(0, H // 2)).clone(), eng.render(c2w, rows=(H // 2, H)).clone()], 0)
+    d = (whole - ref).abs().max().item()
+    print(f'split 3 of {nb}, exponents {ex}: {d:.2e} from three passes everywhere')
+    assert torch.equal(whole, halves)
+    assert d <= 1e-4
+    eng.close()
+
+
+def test_split_without_the_global_skip_and_in_a_graph(pkg):
+    """networks without the global skip end in r2l_tail_kernel (three launches + the tail): the second body launch then continues
+    the x image in place; and a warmed-up split render captures into a HIP graph and replays bit for bit"""
+    from efficient_nerf_amd import PREC_FP16_SPLIT, R2LEngine
+    H, nb = 32, 4
+    focal = O.focal_from_angle(H)
+    sd = O.make_r2l_state(seed=3, netdepth=2 + 2 * nb)
+    c2w = O.pose_spherical(-50., -20., 4.)
+    eng = R2LEngine(H, H, focal, n_block=nb, use_residual=False, precision=PREC_FP16_SPLIT).load_state_dict(sd)
+    eng.set_split_block(2)
+    got = eng.render(c2w).clone()
+    pts = O.sample_test(O.camera_dirs(H, H, focal), O.sampler_z_vals(16, 2., 6.), c2w[:3, :4])
+    ref = O.r2l_forward(sd, O.positional_embed(pts, 10), use_residual=False)
+    assert (got.cpu() - ref).abs().max().item() <= 1e-4
+    eng.close()
+    eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_SPLIT).load_state_dict(sd)
+    eng.set_split_block(2)
+    eng.set_guard_period(0)
+    first = eng.render(c2w).clone()
+    out = torch.empty_like(first)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        eng.render(c2w, out=out)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            eng.render(c2w, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)
+    eng.close()
+
+
+def test_auto_measures_the_split_on_the_trained_like_student(pkg):
+    """the committed trained-like student (max|a| 126: beyond the bf6 and e4m3 rungs): `auto` bisects for the fewest leading blocks
+    in three passes whose frame stays within its limit of three passes everywhere, on every ray of a frame, and the frames it then
+    renders are inside the 1e-4 contract of the CPU oracle; the watch's spot check agrees; a limit of zero ends in fp16x3_asm as
+    before"""
+    from efficient_nerf_amd import PREC_NAMES, R2LEngine
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trained_like', 'student_w256d88.npz'))
+    ssd = {k: torch.from_numpy(z[k]) for k in z.files}
+    H = 400
+    focal = O.focal_from_angle(H)
+    test = O.novel_poses(200)
+    eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(ssd)
+    rung, top = eng.choose_precision(c2w=test[0][:3, :4])
+    print(f'trained-like student: max|a| {eng.stream_max:.1f} -> {rung}, split {eng.split_block}; measured {eng.auto_split}')
+    sp = eng.split_block
+    assert rung == 'fp16_split' and 0 <= sp <= 37 and eng.auto_split[sp] <= eng.AUTO_SPLIT_MAX_DIFF
+    assert sp == 0 or any(k < sp and v > eng.AUTO_SPLIT_MAX_DIFF for k, v in eng.auto_split.items())     # a smaller one was tried, and failed
+    from efficient_nerf_amd import get_rays
+    for pi in (0, 67, 133):
+        got, again = eng.render_checked(lambda: eng.render(test[pi][:3, :4]))
+        assert PREC_NAMES[eng.precision] == 'fp16_split'
+        g = got.cpu().view(H, H, 3)[::8].reshape(-1, 3)
+        want = O.r2l_render(ssd, H, H, focal, test[pi][:3, :4], rows=(0, H, 8), chunk=16384)
+        err = (g - want).abs().max().item()
+        ro, rd = get_rays(H, H, focal, test[pi][:3, :4], device='cuda')
+        ok, d = eng.spot_check_split(ro, rd)
+        print(f'pose {pi}: L_inf vs CPU oracle on {g.shape[0]} rays {err:.2e}; spot check {d:.2e}')
+        assert err <= 1e-4 and ok
+    # the step-down of the watch: half of the bf6 part to three passes; and the old behaviour when no split qualifies
+    assert eng.step_down_split() == 'fp16_split' and eng.split_block == sp + (43 - sp + 1) // 2
+    while eng.step_down_split() == 'fp16_split':
+        assert eng.split_block < 43
+    assert PREC_NAMES[eng.precision] == 'fp16x3_asm' and eng.split_block is None
+    eng.close()
+    eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(ssd)
+    eng.AUTO_SPLIT_MAX_DIFF = 0.0
+    assert eng.choose_precision(c2w=test[0][:3, :4])[0] == 'fp16x3_asm' and eng.split_block is None
+    eng.close()

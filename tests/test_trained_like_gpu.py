@@ -4,7 +4,8 @@ create_data path, utils/create_data.py:812-872; a W256D88 student distilled from
 What nn.Linear-init weights could only predict (VERDICT r4 missing 2 / weak 1-2) is pinned here as measured:
   * the teacher's sharp densities (sigma ~ 200, acc bimodal) make the faster modes miss by 1e-3 .. 3e-1 -- `auto` must end in three fp16 passes
     (fp16x3_asm: the generated chain), whose render is inside the 1e-4 contract of the CPU oracle;
-  * the student's residual stream grows with depth (max|a| ~ 126): `auto` must end on the last rung (fp16x3_asm), inside 1e-4."""
+  * the student's residual stream grows with depth (max|a| ~ 126): beyond the whole-network bf6 / e4m3 rungs; `auto` must end on the
+    split rung (fp16_split: head and leading blocks in three passes, tests/test_split_gpu.py) or the last one, inside 1e-4."""
 import os
 
 import numpy as np
@@ -61,7 +62,7 @@ def test_trained_like_teacher_auto_ends_in_three_passes_inside_the_contract(pkg)
     eng.close()
 
 
-def test_trained_like_student_auto_ends_on_the_last_rung_inside_the_contract(pkg):
+def test_trained_like_student_auto_ends_behind_the_whole_network_rungs_inside_the_contract(pkg):
     from efficient_nerf_amd import PREC_NAMES, R2LEngine
     ssd = _sd('student_w256d88.npz')
     H = 400
@@ -70,10 +71,10 @@ def test_trained_like_student_auto_ends_on_the_last_rung_inside_the_contract(pkg
     test = O.novel_poses(200)
     rung, top = eng.choose_precision(c2w=test[0][:3, :4])
     print(f'trained-like student: max|a| {eng.stream_max:.1f}, exponent {top} -> {rung}')
-    assert rung == 'fp16x3_asm' and eng.stream_max > eng.AUTO_MAX_ABS_E4M3
+    assert rung == 'fp16_split' and eng.split_block > 0 and eng.stream_max > eng.AUTO_MAX_ABS_E4M3
     for pi in (0, 67, 133):
         got, again = eng.render_checked(lambda: eng.render(test[pi][:3, :4]))
-        assert again == 0 and PREC_NAMES[eng.precision] == 'fp16x3_asm'
+        assert again == 0 and PREC_NAMES[eng.precision] == 'fp16_split'
         g = got.cpu().view(H, H, 3)[::8].reshape(-1, 3)
         want = O.r2l_render(ssd, H, H, focal, test[pi][:3, :4], rows=(0, H, 8), chunk=16384)
         err = (g - want).abs().max().item()
@@ -84,7 +85,7 @@ def test_trained_like_student_auto_ends_on_the_last_rung_inside_the_contract(pkg
 
 def test_trained_like_pipeline_command_lines(pkg, tmp_path):
     """the fixture through the reference's command lines: `create_data.py --create_data rand` on the teacher .tar (auto -> fp16x3,
-    said in the log), `main.py --render_only` on the student .tar (auto -> fp16x3_asm)"""
+    said in the log), `main.py --render_only` on the student .tar (auto -> fp16_split or, should the small frame ask for it, fp16x3_asm)"""
     import subprocess
     import sys
     from efficient_nerf_amd import frontend as fe
@@ -103,4 +104,4 @@ def test_trained_like_pipeline_command_lines(pkg, tmp_path):
                         '--trial.body_arch', 'resmlp', '--pretrained_ckpt', sck, '--render_only', '--synthetic_poses', '2', '--H', '64',
                         '--outdir', str(tmp_path / 'img')], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert '-> fp16x3_asm' in r.stdout, r.stdout[-1200:]
+    assert '-> fp16_split at block' in r.stdout or '-> fp16x3_asm' in r.stdout, r.stdout[-1200:]
