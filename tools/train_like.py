@@ -34,6 +34,21 @@ LIGHT = torch.tensor([0.4, 0.3, 0.85]) / torch.tensor([0.4, 0.3, 0.85]).norm()
 SPHERES = [((-0.55, 0.15, 0.10), 0.50, (0.85, 0.15, 0.12), 0.0), ((0.50, -0.45, 0.25), 0.38, (0.15, 0.65, 0.20), 0.5),
            ((0.05, -0.10, -0.55), 0.30, (0.90, 0.80, 0.15), 0.0)]        # centre, radius, colour, specular weight
 BOX = ((0.25, 0.60, -0.20), (0.35, 0.28, 0.30), (0.15, 0.25, 0.85))      # centre, half size, colour
+SEEDS = {'teacher': (11, 12), 'teacher_rs': 7, 'student': 21, 'student_rs': 9}
+
+
+def use_variant(v):
+    """--variant 1: a second scene (two large overlapping spheres, one shiny, a flat slab, a small bright sphere) and other seeds for
+    every network and sampler -- is what the committed fixture shows a property of trained weights or of that one run?"""
+    global SPHERES, BOX, LIGHT
+    if v == 0:
+        return
+    assert v == 1, v
+    SPHERES = [((-0.20, -0.30, 0.00), 0.62, (0.20, 0.35, 0.85), 0.6), ((0.45, 0.35, 0.15), 0.45, (0.90, 0.55, 0.10), 0.0),
+               ((-0.55, 0.55, -0.35), 0.22, (0.95, 0.95, 0.30), 0.0)]
+    BOX = ((0.00, 0.00, -0.75), (0.85, 0.85, 0.08), (0.55, 0.50, 0.45))
+    LIGHT = torch.tensor([-0.5, 0.2, 0.8]) / torch.tensor([-0.5, 0.2, 0.8]).norm()
+    SEEDS.update(teacher=(31, 32), teacher_rs=17, student=41, student_rs=19)
 
 
 def scene_rgb(ro, rd):
@@ -82,11 +97,11 @@ def rand_pose(rs):
 def fit_teacher(steps, n_rand, dev, log):
     """main.py:1355-1380 for the nerf branch on the analytic scene; returns the two state dicts (CPU, fp32)"""
     focal = O.focal_from_angle(H_T)
-    sds = [{k: v.clone().to(dev).requires_grad_(True) for k, v in O.make_teacher_state(s, sigma_bias_shift=0.).items()} for s in (11, 12)]    # nn.Linear's own init
+    sds = [{k: v.clone().to(dev).requires_grad_(True) for k, v in O.make_teacher_state(s, sigma_bias_shift=0.).items()} for s in SEEDS['teacher']]    # nn.Linear's own init
     params = [p for sd in sds for p in sd.values()]
     opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
-    rs = np.random.RandomState(7)
-    torch.manual_seed(7)
+    rs = np.random.RandomState(SEEDS['teacher_rs'])
+    torch.manual_seed(SEEDS['teacher_rs'])
     dirs = O.camera_dirs(H_T, H_T, focal).reshape(H_T, H_T, 3)
     t0 = time.time()
     for it in range(1, steps + 1):
@@ -135,11 +150,11 @@ def distil(data_dir, steps, files, dev, log):
     """step 3 of the README: the W256D88 student on the shards (main.py:1369-1380), returns its state dict (CPU, fp32)"""
     from efficient_nerf_amd.create_data import BlenderDataset_v2
     ds = BlenderDataset_v2(data_dir, pseudo_ratio=-1)
-    sd = {k: v.clone().to(dev).requires_grad_(True) for k, v in O.make_r2l_state(seed=21).items()}
+    sd = {k: v.clone().to(dev).requires_grad_(True) for k, v in O.make_r2l_state(seed=SEEDS['student']).items()}
     opt = torch.optim.Adam(list(sd.values()), lr=5e-4, betas=(0.9, 0.999))
     z = O.sampler_z_vals(16, 2., 6.).to(dev)
-    rs = np.random.RandomState(9)
-    torch.manual_seed(9)
+    rs = np.random.RandomState(SEEDS['student_rs'])
+    torch.manual_seed(SEEDS['student_rs'])
     t0 = time.time()
     for it in range(1, steps + 1):
         lr = 1e-4 + (5e-4 - 1e-4) * it / 200 if it < 200 else 5e-4 * 0.1 ** ((it - 200) / (1.5 * steps))   # --warmup_lr 0.0001,200
@@ -216,6 +231,8 @@ def measure(tsds, ssd, log, cpu_rows=8):
     seng = R2LEngine(Hs, Hs, fs, 2., 6., n_block=43, use_residual=True).load_state_dict(ssd)
     rung, top = seng.choose_precision(c2w=test[0][:3, :4])
     s = {'rung': rung, 'max_act_exponent': None if top is None else int(top), 'max_abs_activation': float(seng.stream_max), 'frames': []}
+    if rung == 'fp16_split':
+        s.update(split_block=seng.split_block, split_probe_diffs={str(k): v for k, v in sorted(seng.auto_split.items())})
     teng = NeRFEngine(Hs, Hs, fs, precision=PRECISIONS[name]).load_state_dicts(*tsds)
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     for pi in (0, 67, 133):
@@ -240,6 +257,17 @@ def measure(tsds, ssd, log, cpu_rows=8):
     torch.cuda.synchronize()
     s['ms_per_frame'] = (time.perf_counter() - t0) / 10 * 1e3
     s['rays_per_s'] = Hs * Hs / (s['ms_per_frame'] * 1e-3)
+    if rung == 'fp16_split':                      # the watch's view of three more poses, and three passes everywhere beside it
+        from efficient_nerf_amd import get_rays
+        s['watch'] = [seng.spot_check_split(*get_rays(Hs, Hs, fs, test[pi][:3, :4], device='cuda'))[1] for pi in (20, 100, 180)]
+        seng.set_precision(PRECISIONS['fp16x3_asm'])
+        seng.render(test[1][:3, :4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10):
+            seng.render(test[2 + i][:3, :4])
+        torch.cuda.synchronize()
+        s['ms_per_frame_fp16x3_asm'] = (time.perf_counter() - t0) / 10 * 1e3
     rep['student'] = s
     log(f'[measure] student: {json.dumps(s)}')
     seng.close()
@@ -256,7 +284,9 @@ def main():
     ap.add_argument('--student-steps', type=int, default=6000)
     ap.add_argument('--files', type=int, default=4, help='shards of 4,096 rays per student batch (the reference: --N_rand 20)')
     ap.add_argument('--measure-only', action='store_true', help='load the three .npz from --out and measure')
+    ap.add_argument('--variant', type=int, default=0, help='0: the committed fixture\'s scene and seeds; 1: a second scene, other seeds')
     args = ap.parse_args()
+    use_variant(args.variant)
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device('cuda')
     logf = open(os.path.join(args.out, 'train_like.log'), 'a')
@@ -282,7 +312,7 @@ def main():
         log(f'[train_like] fitted in {time.time() - t0:.0f} s')
     with torch.no_grad():
         rep = measure(tsds, ssd, log)
-    rep['recipe'] = {k: getattr(args, k) for k in ('teacher_steps', 'teacher_rays', 'poses', 'student_steps', 'files')}
+    rep['recipe'] = {k: getattr(args, k) for k in ('teacher_steps', 'teacher_rays', 'poses', 'student_steps', 'files', 'variant')}
     json.dump(rep, open(os.path.join(args.out, 'report.json'), 'w'), indent=1)
 
 
