@@ -105,3 +105,6 @@ def test_trained_like_pipeline_command_lines(pkg, tmp_path):
                         '--outdir', str(tmp_path / 'img')], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert '-> fp16_split at block' in r.stdout or '-> fp16x3_asm' in r.stdout, r.stdout[-1200:]
+    if '-> fp16_split at block' in r.stdout:       # ... and render_path watched it: the first batch's rays against three passes everywhere
+        assert 'split watch: 1 spot check(s) against three passes' in r.stdout and ' 0 fallback(s)' in r.stdout, r.stdout[-1200:]
+    print(r.stdout[-1500:])
