@@ -112,6 +112,39 @@ def test_split_without_the_global_skip_and_in_a_graph(pkg):
     eng.close()
 
 
+def test_random_networks_frames_and_splits(pkg):
+    """randomised: depth, ragged frame shapes (ray counts that are no multiple of the 128-ray tile), pose, global skip on / off, every
+    split of the depth: split = n_block reproduces fp16x3_asm bit for bit, split = 0 differs from fp16_fp8 by the head launch only,
+    everything in between stays as close to three passes as fp16_fp8 does on these i.i.d. weights"""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_SPLIT, PREC_FP16X3_ASM, R2LEngine
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for it in range(8):
+        H, W = int(rng.integers(3, 70)), int(rng.integers(3, 70))
+        nb = int(rng.integers(1, 30))
+        res = bool(rng.integers(0, 2))
+        sd = O.make_r2l_state(seed=int(rng.integers(1 << 30)), netdepth=2 + 2 * nb, body_gain=float(rng.choice([0.7, 1.0])))
+        c2w = O.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-80, -5)), float(rng.uniform(3, 5)))
+        focal = O.focal_from_angle(W)
+        eng = R2LEngine(H, W, focal, n_block=nb, use_residual=res, precision=PREC_FP16_FP8).load_state_dict(sd)
+        eng.calibrate_on(c2w=c2w)
+        fp8 = eng.render(c2w).clone()
+        eng.set_precision(PREC_FP16X3_ASM)
+        x3 = eng.render(c2w).clone()
+        eng.set_precision(PREC_FP16_SPLIT)
+        limit = max(6e-5, 2.0 * (fp8 - x3).abs().max().item())
+        for sp in sorted({0, nb, int(rng.integers(0, nb + 1)), int(rng.integers(0, nb + 1))}):
+            eng.set_split_block(sp)
+            got = eng.render(c2w)
+            d = (got - x3).abs().max().item()
+            assert torch.isfinite(got).all() and d <= limit, (it, H, W, nb, res, sp, d, limit)
+            if sp == nb:
+                assert torch.equal(got, x3), (it, H, W, nb, res)
+            worst = max(worst, d)
+        eng.close()
+    print(f'8 random networks x up to 4 splits: worst {worst:.2e} from three passes everywhere')
+
+
 def test_auto_measures_the_split_on_the_trained_like_student(pkg):
     """the committed trained-like student (max|a| 126: beyond the bf6 and e4m3 rungs): `auto` bisects for the fewest leading blocks
     in three passes whose frame stays within its limit of three passes everywhere, on every ray of a frame, and the frames it then
