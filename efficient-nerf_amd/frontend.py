@@ -75,6 +75,8 @@ FLAGS = [
     # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher measures fp16x1 (its layer chain as one
     # fp16 pass), then fp16_fp8, against fp16x3 (NeRFEngine.choose_precision); fp32 = the generic layer path for any network shape
     ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp16_split', 'fp32', 'auto'])),
+    # --precision fp16_split taken literally: how many leading ResMLP blocks run in three fp16 passes (-1: half of them; `auto` measures it)
+    ('--split_block', dict(type=int, default=-1)),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
     # frames rendered per launch / collective / range check / host sync (0: the world size, i.e. one frame on one GPU)
@@ -377,6 +379,10 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
                         width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec,
                         res_scale=float(args.trial.res_scale), act=acts[0], inact=acts[1], outact=acts[2], body_arch=arch)
         eng.load_state_dict(ckpt['network_fn_state_dict'])
+        if args.precision == 'fp16_split' and getattr(args, 'split_block', -1) >= 0:
+            eng.set_split_block(args.split_block)
+            if log:
+                log(f'[precision] fp16_split: blocks [0, {eng.split_block}) in three fp16 passes, blocks [{eng.split_block}, {eng.n_block}) with bf6 terms (--split_block)')
         if auto:
             if probe_pose is None and probe_rays is None:
                 raise R2LError('--precision auto needs a pose or rays to measure the activation ranges with')
@@ -547,8 +553,8 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
         from .teacher import get_rays
         again = 0
         for _ in range(6):
-            if getattr(eng, 'precision_name', None) != 'fp16_split':
-                break
+            if getattr(eng, 'precision_name', None) != 'fp16_split' or getattr(eng, '_auto', None) is None:
+                break          # an explicit --precision fp16_split keeps its split, as every explicit mode keeps itself
             if given_rays is not None:
                 ro = given_rays[0][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
                 rd = given_rays[1][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)

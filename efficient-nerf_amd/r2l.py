@@ -76,7 +76,8 @@ class R2LEngine:
         if self.acts != (0.0, 0.0, 1.0) or body_arch == 'mlp':
             check(lib().r2l_set_network_form(self._ctx, *self.acts, int(body_arch == 'resmlp')))
         self.precision = int(precision)
-        self.split_block = None        # R2L_PREC_FP16_SPLIT: leading blocks in three passes = first block of the bf6 part
+        # R2L_PREC_FP16_SPLIT: leading blocks in three passes = first block of the bf6 part (the library's default: half)
+        self.split_block = self.n_block // 2 if self.precision == PREC_FP16_SPLIT else None
         self._loaded = False
         # model/nerf_raybased.py:88-90, evaluated with the host's torch exactly as the
         # reference does (torch.linspace's last ulp depends on the CPU vector width)
@@ -163,6 +164,8 @@ class R2LEngine:
         with torch.cuda.device(self.device):
             check(lib().r2l_set_precision(self._ctx, int(precision)))
         self.precision = int(precision)
+        if self.precision == PREC_FP16_SPLIT and self.split_block is None:
+            self.set_split_block(self.n_block // 2)       # the library's default, said explicitly so that both sides agree
 
     # -- rendering ------------------------------------------------------------------
     def _rows(self, rows):

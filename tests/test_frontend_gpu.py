@@ -189,6 +189,28 @@ def test_checkpoint_saved_from_cuda_dataparallel(pkg, tmp_path):
         assert np.abs(rgbs[i] - ref).max() <= 1e-4
 
 
+def test_cli_explicit_split(pkg, tmp_path):
+    """--precision fp16_split --split_block k taken literally (no probe, no watch: an explicit mode keeps itself); k = n_block renders
+    what --precision fp16x3_asm renders, bit for bit; both inside the contract"""
+    from efficient_nerf_amd import frontend as fe
+    nb, H = 4, 32
+    sd = O.make_r2l_state(seed=8, netdepth=2 + 2 * nb)
+    ck = str(tmp_path / 'r2l.tar')
+    fe.save_checkpoint(ck, sd)
+    base = ['--model_name', 'R2L', '--config', 'configs/lego_noview.txt', '--n_sample_per_ray', '16', '--netwidth', '256', '--netdepth', str(2 + 2 * nb),
+            '--use_residual', '--trial.ON', '--trial.body_arch', 'resmlp', '--pretrained_ckpt', ck, '--render_only', '--synthetic_poses', '1', '--H', '64']
+    outs = {}
+    for tag, extra in (('s1', ['--precision', 'fp16_split', '--split_block', '1']), ('s4', ['--precision', 'fp16_split', '--split_block', str(nb)]),
+                       ('x3', ['--precision', 'fp16x3_asm'])):
+        log = run_main(base + extra + ['--outdir', str(tmp_path / tag)])
+        outs[tag] = np.load(tmp_path / tag / 'rgbs.npy')
+        if tag != 'x3':
+            assert f'[precision] fp16_split: blocks [0, {extra[-1]}) in three fp16 passes' in log and 'split watch' not in log, log
+    ref = O.r2l_render(sd, H, H, O.focal_from_angle(64) / 2., O.novel_poses(1)[0]).view(H, H, 3).numpy()
+    assert np.array_equal(outs['s4'], outs['x3'])
+    assert np.abs(outs['s1'][0] - ref).max() <= 1e-4 and 0 < np.abs(outs['s1'] - outs['x3']).max() <= 5e-5
+
+
 def test_cli_rejects_unsupported(pkg, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--model_name', 'R2L'], cwd=ROOT,
                        capture_output=True, text=True)

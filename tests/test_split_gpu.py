@@ -95,7 +95,10 @@ def test_split_without_the_global_skip_and_in_a_graph(pkg):
     assert (got.cpu() - ref).abs().max().item() <= 1e-4
     eng.close()
     eng = R2LEngine(H, H, focal, n_block=nb, precision=PREC_FP16_SPLIT).load_state_dict(sd)
+    assert eng.split_block == nb // 2                      # the default, on both sides of the C-ABI
+    half = eng.render(c2w).clone()
     eng.set_split_block(2)
+    assert torch.equal(eng.render(c2w), half)
     eng.set_guard_period(0)
     first = eng.render(c2w).clone()
     out = torch.empty_like(first)
