@@ -161,11 +161,12 @@ def trained_like_leg(torch, O, cpu):
     eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(ssd)
     rung, top = eng.choose_precision(c2w=test[0][:3, :4])
     s = {'rung': rung, 'max_act_exponent': None if top is None else int(top), 'max_abs_activation': float(eng.stream_max),
-         'ladder': 'fp16_fp8 up to %g, fp16_e4m3 up to %g, above: fp16_split (head + the first `split_block` blocks in three fp16 passes, '
-                   'the rest with bf6 terms; the split bisected for rgb within %g of three passes everywhere on every ray of the probe '
-                   'frame), fp16x3_asm when less than 1/8 of the blocks would be left' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3, eng.AUTO_SPLIT_MAX_DIFF)}
-    if rung == 'fp16_split':
-        s.update(split_block=eng.split_block, n_block=eng.n_block, split_probe_diffs={str(k): v for k, v in sorted(eng.auto_split.items())})
+         'ladder': 'fp16_fp8 up to %g, fp16_e4m3 up to %g, above: fp16_split / fp16_split8 (head + the first `split_block` blocks in three fp16 passes, '
+                   'the rest with bf6 / e4m3 terms; per format the split bisected for rgb within %g of three passes everywhere on every ray of the '
+                   'probe frame, the cheaper of the two taken), fp16x3_asm when that would save less than 5 %% of its body time' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3, eng.AUTO_SPLIT_MAX_DIFF)}
+    if rung.startswith('fp16_split'):
+        s.update(split_block=eng.split_block, n_block=eng.n_block, terms_behind_the_split='e4m3' if rung.endswith('8') else 'bf6',
+                 split_probe_diffs={m: {str(k): v for k, v in sorted(t.items())} for m, t in eng.auto_split.items()})
 
     def frames_per_s():
         eng.render(test[1][:3, :4])
@@ -178,7 +179,7 @@ def trained_like_leg(torch, O, cpu):
     dt = frames_per_s()
     s.update(rays_per_s=H * W / dt, ms_per_frame=dt * 1e3, rung_after_10_frames=PREC_NAMES[eng.precision],
              frac_of_fp16_mfma_peak=eng.flops_per_ray * H * W / dt / 1e12 / PEAK_FP16_TFLOPS)
-    if rung == 'fp16_split':
+    if rung.startswith('fp16_split'):
         from efficient_nerf_amd import get_rays
         worst = 0.
         for pi in (0, 67, 133):                  # what frontend.render_path's watch does every 8th batch
@@ -192,7 +193,7 @@ def trained_like_leg(torch, O, cpu):
             want = O.r2l_render(ssd, H, W, focal, test[pi][:3, :4], rows=(0, H, 8), chunk=16384)
             frames.append({'pose': pi, 'rays': int(got.shape[0]), 'linf': (got - want).abs().max().item()})
         s.update(linf_vs_cpu_oracle=max(f['linf'] for f in frames), rays_checked=sum(f['rays'] for f in frames), frames=frames)
-    if rung == 'fp16_split':                     # beside it: three passes everywhere, the rung these weights had before the split rung
+    if rung.startswith('fp16_split'):            # beside it: three passes everywhere, the rung these weights had before the split rung
         eng.set_precision(PRECISIONS['fp16x3_asm'])
         dt3 = frames_per_s()
         s.update(rays_per_s_fp16x3_asm=H * W / dt3, ms_per_frame_fp16x3_asm=dt3 * 1e3)

@@ -10,6 +10,6 @@ path (same names, argument meaning, error behaviour) and is plumbing only: it ha
 PyTorch-ROCm device pointers and the current HIP stream to the library.  There is no CPU
 or eager fallback: if the library is missing or no gfx950 device is visible, calls raise.
 """
-from ._lib import lib, R2LError, PREC_FP16X3, PREC_FP16X1, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, PREC_FP16_SPLIT, PRECISIONS  # noqa: F401
+from ._lib import lib, R2LError, PREC_FP16X3, PREC_FP16X1, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, PREC_FP16_SPLIT, PREC_FP16_SPLIT8, PRECISIONS  # noqa: F401
 from .r2l import PointSampler, PositionalEmbedder, R2LEngine, NeRF_v3_2, render_func, PREC_NAMES  # noqa: F401
 from .teacher import NeRFEngine, get_rays, ndc_rays, raw2outputs, sample_pdf, merge_sorted, render  # noqa: F401

@@ -154,12 +154,13 @@ struct r2l_ctx {
     int n_cu;
     bool loaded;
     std::vector<std::vector<float>> host_w;  // state_dict order
-    char* d_img[6];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
-    size_t img_bytes[6];
+    char* d_img[7];                           // [mode] packed image (FP16_FP8: the 32 head chunks, hi|lo layout)
+    size_t img_bytes[7];
     char* d_body;                             // split modes: body stream v3 (r2l_body.hip) | aux blocks | tail
     int body_mode = -1;                       // ... of this mode (bf6 or e4m3 terms: chunk geometry and operand codes differ)
     size_t body_bytes, aux_off, tail_off;
-    // R2L_PREC_FP16_SPLIT: blocks [0, split_block) run on the three-pass stream d_body2, blocks [split_block, n_block) on d_body (bf6 terms)
+    // R2L_PREC_FP16_SPLIT / _SPLIT8: blocks [0, split_block) run on the three-pass stream d_body2, blocks [split_block, n_block) on d_body
+    // (bf6 / e4m3 terms)
     char* d_body2 = nullptr;
     size_t aux_split_off = 0;
     size_t body2_bytes = 0, aux_off2 = 0, tail_off2 = 0;
@@ -199,21 +200,25 @@ struct r2l_ctx {
 
 static int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
 enum { R2L_STREAM_BF6 = 0, R2L_STREAM_E4M3 = 1, R2L_STREAM_BF6R = 2, R2L_STREAM_F16 = 3 };   // body stream layouts (pack_body_v3)
-static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_SPLIT; }
+static bool mode_ok(int mode) { return mode >= R2L_PREC_FP16X3 && mode <= R2L_PREC_FP16_SPLIT8; }
+// the split rungs: head + leading blocks in three passes, the rest with bf6 (SPLIT) or e4m3 (SPLIT8) terms
+static bool two_part(int mode) { return mode == R2L_PREC_FP16_SPLIT || mode == R2L_PREC_FP16_SPLIT8; }
+// ... the modes whose correction terms are e4m3 (operand top 448, 32 KiB chunks)
+static bool e4m3_terms(int mode) { return mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16_SPLIT8; }
 // the modes with the generated head launch + generated body kernel
 static bool split_mode(int mode) {
-    return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16X3_ASM || mode == R2L_PREC_FP16_SPLIT;
+    return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16X3_ASM || two_part(mode);
 }
 // ... of them those with low-precision correction terms in the body: calibrated operand scales, range tracking
-static bool scaled_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || mode == R2L_PREC_FP16_SPLIT; }
+static bool scaled_mode(int mode) { return mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16_E4M3 || two_part(mode); }
 // the head launch in three fp16 passes (r2l_headx_kernel)?  FP16_SPLIT too: on a trained network the bf6-term head alone costs
 // 9e-5 of the 1e-4 contract (profiles/r05_split_time.txt) at 4 % of the MACs
-static bool head_x3(int mode) { return mode == R2L_PREC_FP16X3_ASM || mode == R2L_PREC_FP16_SPLIT; }
+static bool head_x3(int mode) { return mode == R2L_PREC_FP16X3_ASM || two_part(mode); }
 static int stream_of(int mode) {
-    return mode == R2L_PREC_FP16_E4M3 ? R2L_STREAM_E4M3 : mode == R2L_PREC_FP16X3_ASM ? R2L_STREAM_F16 :
+    return e4m3_terms(mode) ? R2L_STREAM_E4M3 : mode == R2L_PREC_FP16X3_ASM ? R2L_STREAM_F16 :
            (R2L_BF6_CHUNK == 28672 ? R2L_STREAM_BF6 : R2L_STREAM_BF6R);
 }
-#define R2L_N_MODES 6
+#define R2L_N_MODES 7
 
 
 #ifndef R2L_SLICE_TILES
@@ -340,7 +345,7 @@ static int build_image(r2l_ctx* c, int mode) {
             (void)hipFree(c->d_body2);
             c->d_body2 = nullptr;
         }
-        if (mode == R2L_PREC_FP16_SPLIT && c->n_block > 0) {     // ... and the three-pass stream for the blocks behind the split
+        if (two_part(mode) && c->n_block > 0) {     // ... and the three-pass stream for the blocks in front of the split
             std::vector<char> body2;
             rc = pack_body_v3(c, R2L_STREAM_F16, body2, &c->aux_off2, &c->tail_off2);
             if (rc) return rc;
@@ -811,7 +816,7 @@ int r2l_get_range_status(r2l_ctx* c, r2l_range_status* out, int reset) {
     const int* ex = reinterpret_cast<const int*>(g + nset + 1);
     auto f = [](unsigned u) { float v; memcpy(&v, &u, 4); return v; };
     // largest magnitude of the operand format: bf6 (e3m2) 28, e4m3 448; the calibration aims at <= 16 in both
-    const float top = c->mode == R2L_PREC_FP16_E4M3 ? 448.0f : 28.0f;
+    const float top = e4m3_terms(c->mode) ? 448.0f : 28.0f;
     out->h0_max = f(r[0]) / c->act_scale;
     out->h0_fill = c->n_block > 0 ? ldexpf(f(r[0]), -ex[0]) / top : 0.0f;
     out->stream_max = out->h0_max;
@@ -841,8 +846,8 @@ int r2l_recalibrate(r2l_ctx* c, void* stream) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     if (!c->loaded || !c->d_gstats || c->n_block < 1)
         return r2l_set_error(R2L_ESTATE, "r2l_recalibrate needs loaded weights, R2L_PREC_FP16_FP8 and n_block >= 1");
-    if (c->mode == R2L_PREC_FP16_SPLIT)      // its guarded launches see the blocks behind the split only
-        return r2l_set_error(R2L_ESTATE, "r2l_recalibrate: R2L_PREC_FP16_SPLIT borrows the exponents of R2L_PREC_FP16_FP8 -- recalibrate there");
+    if (two_part(c->mode))      // its guarded launches see the blocks behind the split only
+        return r2l_set_error(R2L_ESTATE, "r2l_recalibrate: R2L_PREC_FP16_SPLIT / _SPLIT8 borrow the exponents of R2L_PREC_FP16_FP8 -- recalibrate there");
     if (c->n_guarded < 1) return r2l_set_error(R2L_ESTATE, "r2l_recalibrate: no guarded launch since the last reset of the range words");
     hipError_t e = r2l_launch_recalibrate(c->d_gstats, c->d_range, c->n_block, c->d_body + c->aux_off, c->d_exps, (hipStream_t)stream);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "recalibration launch: %s", hipGetErrorString(e));
@@ -953,7 +958,7 @@ int r2l_debug_body(r2l_ctx* c, const float* x_in_dev, float* x_out_dev, int n_ti
     pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
     pb.n_rays = 0;
     pb.tile_begin = 0;
-    pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3 ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
+    pb.e4m3 = e4m3_terms(c->mode) ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
     pb.gstats = c->guard_period == 1 && scaled_mode(c->mode) && c->n_block <= r2l_body_guard_max_blocks(pb.e4m3) ? c->d_gstats : nullptr;
     c->last_stream = (hipStream_t)stream;
     hipError_t e = r2l_launch_body(pb, balanced_grid(n_tiles, c->n_cu), (hipStream_t)stream);
@@ -1079,9 +1084,9 @@ static int ensure_x(r2l_ctx* c, int tiles, bool need_xb) {
 static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
     const int slice = p.n_tiles < R2L_SLICE_TILES ? p.n_tiles : R2L_SLICE_TILES;
     const bool fused_form = c->n_block > 0 && c->use_residual && c->fuse_tail;
-    // R2L_PREC_FP16_SPLIT: blocks [0, split) on the three-pass kernel (x image out), blocks [split, n_block) on the bf6 kernel
+    // R2L_PREC_FP16_SPLIT / _SPLIT8: blocks [0, split) on the three-pass kernel (x image out), blocks [split, n_block) on the bf6 / e4m3 kernel
     int split = -1;
-    if (c->mode == R2L_PREC_FP16_SPLIT && c->n_block > 0) {
+    if (two_part(c->mode) && c->n_block > 0) {
         split = c->split_block < 0 ? c->n_block / 2 : c->split_block;
         if (split > c->n_block) split = c->n_block;
     }
@@ -1127,10 +1132,10 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
             pb.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
             pb.n_rays = p.n_rays;
             pb.tile_begin = t0;
-            pb.e4m3 = c->mode == R2L_PREC_FP16_E4M3 ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
+            pb.e4m3 = e4m3_terms(c->mode) ? 1 : c->mode == R2L_PREC_FP16X3_ASM ? 2 : 0;
             R2LBodyParams p2 = pb;
             if (split >= 0) {
-                // blocks [0, split) in three passes (stream d_body2), blocks [split, n_block) with bf6 terms (stream d_body)
+                // blocks [0, split) in three passes (stream d_body2), blocks [split, n_block) with bf6 / e4m3 terms (stream d_body)
                 const int n3 = split, n6 = c->n_block - split;
                 R2LBodyParams& q6 = two_bodies ? p2 : pb;
                 if (two_bodies) {
@@ -1146,10 +1151,10 @@ static int launch_split(r2l_ctx* c, const R2LParams& p, hipStream_t s) {
                     pb.n_block = n3;
                 }
                 if (n6 > 0) {
-                    q6.wimg = c->d_body + (size_t)split * 16 * R2L_BF6_CHUNK;
+                    q6.wimg = c->d_body + (size_t)split * 16 * (e4m3_terms(c->mode) ? R2L_BODY8_CHUNK : R2L_BF6_CHUNK);
                     q6.aux = c->d_body + c->aux_off;
                     q6.tail = reinterpret_cast<const float*>(c->d_body + c->tail_off);
-                    q6.e4m3 = 0;
+                    q6.e4m3 = e4m3_terms(c->mode) ? 1 : 0;
                     q6.n_block = n6;
                     if (split > 0) {
                         // the kernel converts the NEXT ray tile's x with the exponent its last block's aux names (in the full
@@ -1298,7 +1303,7 @@ long long r2l_kernel_flops_per_ray(const r2l_ctx* c) {
 long long r2l_weight_image_bytes(const r2l_ctx* c) {
     if (!c) return 0;
     return (long long)c->img_bytes[c->mode] + (split_mode(c->mode) ? (long long)c->body_bytes : 0) +
-           (c->mode == R2L_PREC_FP16_SPLIT ? (long long)c->body2_bytes : 0);
+           (two_part(c->mode) ? (long long)c->body2_bytes : 0);
 }
 int r2l_rays_per_tile(const r2l_ctx*) { return R2L_TILE_RAYS; }
 

@@ -74,8 +74,9 @@ FLAGS = [
     # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
     # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher measures fp16x1 (its layer chain as one
     # fp16 pass), then fp16_fp8, against fp16x3 (NeRFEngine.choose_precision); fp32 = the generic layer path for any network shape
-    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp16_split', 'fp32', 'auto'])),
-    # --precision fp16_split taken literally: how many leading ResMLP blocks run in three fp16 passes (-1: half of them; `auto` measures it)
+    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp16_split', 'fp16_split8', 'fp32', 'auto'])),
+    # --precision fp16_split / fp16_split8 taken literally: how many leading ResMLP blocks run in three fp16 passes (-1: half of them; `auto`
+    # measures it, and which of the two formats behind the split is cheaper)
     ('--split_block', dict(type=int, default=-1)),
     ('--synthetic_poses', dict(type=int, default=0)), ('--outdir', dict(type=str, default='')),
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
@@ -379,10 +380,11 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
                         width=args.netwidth, n_block=n_block, use_residual=args.use_residual, precision=prec,
                         res_scale=float(args.trial.res_scale), act=acts[0], inact=acts[1], outact=acts[2], body_arch=arch)
         eng.load_state_dict(ckpt['network_fn_state_dict'])
-        if args.precision == 'fp16_split' and getattr(args, 'split_block', -1) >= 0:
+        if args.precision in ('fp16_split', 'fp16_split8') and getattr(args, 'split_block', -1) >= 0:
             eng.set_split_block(args.split_block)
             if log:
-                log(f'[precision] fp16_split: blocks [0, {eng.split_block}) in three fp16 passes, blocks [{eng.split_block}, {eng.n_block}) with bf6 terms (--split_block)')
+                log(f'[precision] {args.precision}: blocks [0, {eng.split_block}) in three fp16 passes, blocks [{eng.split_block}, {eng.n_block}) with '
+                    f'{"e4m3" if args.precision.endswith("8") else "bf6"} terms (--split_block)')
         if auto:
             if probe_pose is None and probe_rays is None:
                 raise R2LError('--precision auto needs a pose or rays to measure the activation ranges with')
@@ -393,10 +395,11 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
                 log(f'[precision] auto: activations of every ray of the first frame up to {eng.stream_max:.2f} (exponent {top}; '
                     f'fp16_fp8 up to {eng.AUTO_MAX_ABS:g}, fp16_e4m3 up to {eng.AUTO_MAX_ABS_E4M3:g}) -> {name}')
                 if getattr(eng, 'auto_split', None):
-                    tried = ', '.join(f'{k}: {v:.1e}' for k, v in eng.auto_split.items())
-                    log(f'[precision] auto: leading blocks in three passes (bf6 terms behind them), largest rgb difference from three passes '
-                        f'everywhere on every ray of the first frame: {tried} (limit {eng.AUTO_SPLIT_MAX_DIFF:g}) -> ' +
-                        (f'fp16_split at block {eng.split_block} of {eng.n_block}' if name == 'fp16_split' else name))
+                    tried = '; '.join(f"{'e4m3' if m.endswith('8') else 'bf6'} terms behind them: " + ', '.join(f'{k}: {v:.1e}' for k, v in t.items())
+                                      for m, t in eng.auto_split.items())
+                    log(f'[precision] auto: leading blocks in three passes, largest rgb difference from three passes everywhere on every ray of '
+                        f'the first frame -- {tried} (limit {eng.AUTO_SPLIT_MAX_DIFF:g}) -> ' +
+                        (f'{name} at block {eng.split_block} of {eng.n_block}' if name.startswith('fp16_split') else name))
         return 'R2L', eng
     if args.model_name == 'nerf':
         # the fused teacher kernels are the 8 x 256 NeRF with view directions, L = 10 / 4 and a fine pass (configs/*.txt); every other
@@ -553,7 +556,7 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
         from .teacher import get_rays
         again = 0
         for _ in range(6):
-            if getattr(eng, 'precision_name', None) != 'fp16_split' or getattr(eng, '_auto', None) is None:
+            if not str(getattr(eng, 'precision_name', '')).startswith('fp16_split') or getattr(eng, '_auto', None) is None:
                 break          # an explicit --precision fp16_split keeps its split, as every explicit mode keeps itself
             if given_rays is not None:
                 ro = given_rays[0][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
@@ -572,10 +575,10 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
                 break
             was = eng.split_block
             now = eng.step_down_split()
-            split_watch['fallbacks'].append({'frame': i0, 'split': was, 'to': eng.split_block if now == 'fp16_split' else now, 'diff': d})
+            split_watch['fallbacks'].append({'frame': i0, 'split': was, 'to': eng.split_block if now.startswith('fp16_split') else now, 'diff': d})
             if rank == 0:
-                log(f'[precision] frame {i0}: with bf6 terms from block {was} on {d:.1e} from three passes on {eng.SPLIT_WATCH_RAYS} of its rays '
-                    f'(limit {eng.SPLIT_WATCH_MAX_DIFF:g}) -> ' + (f'split at block {eng.split_block}' if now == 'fp16_split' else now) + '; batch rendered again')
+                log(f'[precision] frame {i0}: with low-precision terms from block {was} on {d:.1e} from three passes on {eng.SPLIT_WATCH_RAYS} of its rays '
+                    f'(limit {eng.SPLIT_WATCH_MAX_DIFF:g}) -> ' + (f'split at block {eng.split_block}' if now.startswith('fp16_split') else now) + '; batch rendered again')
             eng.render_checked(lambda: render_local(i0, nb), check=check)
             again += 1
         return again
@@ -754,7 +757,7 @@ def main(argv=None):
         if st.get('split_watch'):
             w_ = st['split_watch']
             log(f"[precision] split watch: {w_['checks']} spot check(s) against three passes (every {w_['every']} batches), worst {w_['worst']:.2e}, "
-                f"{len(w_['fallbacks'])} fallback(s); at the end: {w_['precision']}" + (f" at block {w_['split_block']}" if w_['precision'] == 'fp16_split' else ''))
+                f"{len(w_['fallbacks'])} fallback(s); at the end: {w_['precision']}" + (f" at block {w_['split_block']}" if w_['precision'].startswith('fp16_split') else ''))
         if st.get('watch', {}).get('checks'):
             w_ = st['watch']
             log(f"[precision] watch: {w_['checks']} spot check(s) against fp16x3 (every {w_['every']} frames, {eng.WATCH_RAYS} rays), worst "

@@ -15,16 +15,18 @@ that writes [N,3].  Calling ``.materialize()`` (or torch ops via ``.tensor``) on
 handles runs the stand-alone HIP kernels instead, which is what the parity tests do.
 """
 import ctypes as C
+import math
 
 import torch
 
 from . import _lib
-from ._lib import (R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, PREC_FP16_SPLIT, check, current_stream,
+from ._lib import (R2LError, PREC_FP16X1, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, PREC_FP16_SPLIT, PREC_FP16_SPLIT8, check, current_stream,
                    dptr, lib)
 
-SPLIT_MODES = (PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16_SPLIT)   # generated head launch + generated body kernel, calibrated operand scales
+SPLIT_MODES = (PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16_SPLIT, PREC_FP16_SPLIT8)   # generated head launch + generated body kernel, calibrated operand scales
+TWO_PART = (PREC_FP16_SPLIT, PREC_FP16_SPLIT8)   # head + leading blocks in three passes, the rest with bf6 / e4m3 terms
 PREC_NAMES = {PREC_FP16X3: 'fp16x3', PREC_FP16X1: 'fp16x1', PREC_FP16_FP8: 'fp16_fp8', PREC_FP16_E4M3: 'fp16_e4m3',
-              PREC_FP16X3_ASM: 'fp16x3_asm', PREC_FP16_SPLIT: 'fp16_split'}
+              PREC_FP16X3_ASM: 'fp16x3_asm', PREC_FP16_SPLIT: 'fp16_split', PREC_FP16_SPLIT8: 'fp16_split8'}
 
 
 def _dev(device=None):
@@ -77,7 +79,7 @@ class R2LEngine:
             check(lib().r2l_set_network_form(self._ctx, *self.acts, int(body_arch == 'resmlp')))
         self.precision = int(precision)
         # R2L_PREC_FP16_SPLIT: leading blocks in three passes = first block of the bf6 part (the library's default: half)
-        self.split_block = self.n_block // 2 if self.precision == PREC_FP16_SPLIT else None
+        self.split_block = self.n_block // 2 if self.precision in TWO_PART else None
         self._loaded = False
         # model/nerf_raybased.py:88-90, evaluated with the host's torch exactly as the
         # reference does (torch.linspace's last ulp depends on the CPU vector width)
@@ -164,7 +166,7 @@ class R2LEngine:
         with torch.cuda.device(self.device):
             check(lib().r2l_set_precision(self._ctx, int(precision)))
         self.precision = int(precision)
-        if self.precision == PREC_FP16_SPLIT and self.split_block is None:
+        if self.precision in TWO_PART and self.split_block is None:
             self.set_split_block(self.n_block // 2)       # the library's default, said explicitly so that both sides agree
 
     # -- rendering ------------------------------------------------------------------
@@ -341,47 +343,56 @@ class R2LEngine:
         if mode == PREC_FP16X3_ASM and max_exp is None and self.AUTO_SPLIT:
             split, diff = self.choose_split(c2w=c2w, rays=rays)
             if split is not None:
-                return 'fp16_split', top
+                return PREC_NAMES[self.precision], top
         if mode != PREC_FP16_FP8:
             self.set_precision(mode)          # the exponents travel with a switch between the two split modes
             if mode in SPLIT_MODES:
                 self.range_status(reset=True)
         return PREC_NAMES[mode], top
 
-    #: the split rung (round 5, from the trained-like fixture: profiles/r05_split_time.txt).  A trained ResMLP lands beyond the activation
+    #: the split rungs (round 5, from the trained-like fixture: profiles/r05_split_time.txt).  A trained ResMLP lands beyond the activation
     #: limits of fp16_fp8 / fp16_e4m3 (max|a| 126 where they admit 8 / 10-ish), and measured on that network the limits are right about
     #: the whole-network modes: fp16_fp8 is 1.3-1.5e-4 from three passes (35 of 640,000 rays beyond 1e-4).  But the error is not spread
     #: evenly: the bf6-term HEAD launch alone costs 9e-5 (its output feeds every block), and of the body blocks the early ones cost
-    #: most, because everything behind a block amplifies what it got wrong.  R2L_PREC_FP16_SPLIT therefore keeps the head launch and the
-    #: first `split` blocks in three passes and renders the rest with bf6 terms; when the limits send a network to the last rung, `auto`
-    #: MEASURES the split: every ray of the probe frame, rendered with a candidate split and with three passes everywhere
-    #: (split = n_block, bit for bit fp16x3_asm), bisecting for the smallest split within AUTO_SPLIT_MAX_DIFF.  The limit keeps a
-    #: factor of two to the contract for the poses the probe did not see (measured: up to 1.4 x the probe frame's maximum; watched:
-    #: spot_check_split against SPLIT_WATCH_MAX_DIFF) and the 4e-6 between three passes and fp32.
+    #: most, because everything behind a block amplifies what it got wrong.  R2L_PREC_FP16_SPLIT / _SPLIT8 therefore keep the head launch
+    #: and the first `split` blocks in three passes and render the rest with bf6 / e4m3 terms; when the limits send a network to the last
+    #: rung, `auto` MEASURES: every ray of the probe frame, rendered with a candidate split and with three passes everywhere
+    #: (split = n_block, bit for bit fp16x3_asm), bisecting for the smallest split within AUTO_SPLIT_MAX_DIFF -- for both formats, and
+    #: takes the cheaper of the two results by BLOCK_COST (the fixture: e4m3 terms from block 0 on, 11.3 ms per 800 x 800 frame, against
+    #: bf6 terms from block 21 on, 12.5 ms; its second variant: bf6 from block 9, 10.9 ms).  The limit keeps a factor of two to the
+    #: contract for the poses the probe did not see (measured: up to 1.4 x the probe frame's maximum; watched: spot_check_split against
+    #: SPLIT_WATCH_MAX_DIFF) and the 4e-6 between three passes and fp32.
     AUTO_SPLIT = True
     AUTO_SPLIT_MAX_DIFF = 5e-5
     SPLIT_WATCH_MAX_DIFF = 7e-5
     SPLIT_WATCH_RAYS = 65536
-    #: a split that leaves fewer than this fraction of the blocks to the bf6 kernel is not worth two launches: fp16x3_asm
-    SPLIT_MIN_GAIN = 0.125
+    #: a split that would save less than this fraction of the three-pass body's time is not worth two launches and a watch: fp16x3_asm
+    SPLIT_MIN_GAIN = 0.05
+    #: measured time of one ResMLP block at 800 x 800 in units of the bf6 kernel's (0.215 ms): e4m3 terms 0.256, three passes 0.352
+    BLOCK_COST = {PREC_FP16_SPLIT: 1.0, PREC_FP16_SPLIT8: 1.19, PREC_FP16X3_ASM: 1.63}
 
     @property
     def precision_name(self):
         return PREC_NAMES[self.precision]
 
     def set_split_block(self, split):
-        """R2L_PREC_FP16_SPLIT: the number of leading blocks in three passes = first block of the bf6 part (0 .. n_block); takes effect
-        at the next render"""
+        """R2L_PREC_FP16_SPLIT / _SPLIT8: the number of leading blocks in three passes = first block of the bf6 / e4m3 part
+        (0 .. n_block); takes effect at the next render"""
         with torch.cuda.device(self.device):
             check(lib().r2l_set_split_block(self._ctx, int(split)))
         self.split_block = int(split)
 
-    def choose_split(self, c2w=None, rays=None, max_diff=None):
-        """Smallest split whose render of the probe frame is within `max_diff` (default AUTO_SPLIT_MAX_DIFF) of three passes
-        everywhere, by bisection (the difference falls with the split, up to the noise of a maximum over rays); leaves the context in
-        fp16_split with that split, or in fp16x3_asm when it would leave less than SPLIT_MIN_GAIN of the blocks to the bf6 kernel.
-        Returns (split or None, its difference).  `auto_split` keeps {split tried: difference}.  Called with the exponents of fp16_fp8
-        calibrated (choose_precision); synchronous, once per weight load, about eight frames."""
+    def split_cost(self, mode, split):
+        """body time of a two-part render in units of one bf6 block (BLOCK_COST)"""
+        return self.BLOCK_COST[PREC_FP16X3_ASM] * split + self.BLOCK_COST[mode] * (self.n_block - split)
+
+    def choose_split(self, c2w=None, rays=None, max_diff=None, modes=TWO_PART):
+        """Per format of `modes` (bf6 terms, e4m3 terms) the smallest split whose render of the probe frame is within `max_diff`
+        (default AUTO_SPLIT_MAX_DIFF) of three passes everywhere, by bisection (the difference falls with the split, up to the noise of
+        a maximum over rays); leaves the context in the cheaper of the two (split_cost) with its split, or in fp16x3_asm when that
+        would save less than SPLIT_MIN_GAIN of the three-pass body.  Returns (split or None, its difference).  `auto_split` keeps
+        {mode name: {split tried: difference}}.  Called with the exponents of fp16_fp8 calibrated (choose_precision); synchronous,
+        once per weight load, about a dozen frames."""
         max_diff = self.AUTO_SPLIT_MAX_DIFF if max_diff is None else float(max_diff)
         nb = self.n_block
 
@@ -389,40 +400,56 @@ class R2LEngine:
             if rays is not None:
                 return self.render_rays(rays[0].contiguous().to(self.device, torch.float32), rays[1].contiguous().to(self.device, torch.float32))
             return self.render(c2w)
-        try:
-            self.set_precision(PREC_FP16_SPLIT)          # the calibrated exponents travel with the switch
-        except R2LError as e:
-            self.auto_note = str(e)
-            self.set_precision(PREC_FP16X3_ASM)
-            return None, float('nan')
-        self.set_split_block(nb)
-        ref = rend().clone()
-        self.auto_split = {}
+        self.auto_split, best, ref = {}, None, None
+        for mode in modes:
+            try:
+                self.set_precision(mode)             # the calibrated exponents travel with the switch
+            except R2LError as e:
+                self.auto_note = str(e)
+                continue
+            if ref is None:
+                self.set_split_block(nb)
+                ref = rend().clone()
+            tried = self.auto_split[PREC_NAMES[mode]] = {}
 
-        def ok(sp):
-            self.set_split_block(sp)
-            d = float((rend() - ref).abs().max())
-            self.auto_split[sp] = d
-            return d <= max_diff                 # NaN fails
-        lo, hi = 0, nb                           # invariant: hi qualifies (nb: zero difference), everything below lo does not
-        while lo < hi:
-            mid = lo if not self.auto_split else (lo + hi) // 2      # first of all: no three-pass block at all
-            if ok(mid):
-                hi = mid
-            else:
-                lo = mid + 1
-        if nb - hi < max(1, int(self.SPLIT_MIN_GAIN * nb)):
+            def ok(sp):
+                self.set_split_block(sp)
+                d = float((rend() - ref).abs().max())
+                tried[sp] = d
+                return d <= max_diff                 # NaN fails
+            # everything at or above `hi` qualifies (nb: zero difference), everything below `lo` does not; no use looking above what
+            # the format found so far already beats
+            lo, hi = 0, nb
+            if best is not None:
+                x = (best[0] - self.BLOCK_COST[mode] * nb) / (self.BLOCK_COST[PREC_FP16X3_ASM] - self.BLOCK_COST[mode])
+                if x <= 0:
+                    continue                         # this format with no three-pass block at all costs more already
+                hi = min(nb, int(math.ceil(x)) - 1)  # the largest split that would still be cheaper
+                if hi < nb and not ok(hi):
+                    continue
+            while lo < hi:
+                mid = lo if not tried else (lo + hi) // 2          # first of all: no three-pass block at all
+                if ok(mid):
+                    hi = mid
+                else:
+                    lo = mid + 1
+            cost = self.split_cost(mode, hi)
+            if hi < nb and (best is None or cost < best[0]):
+                best = (cost, mode, hi, tried[hi])
+        if best is None or best[0] > (1.0 - self.SPLIT_MIN_GAIN) * self.split_cost(PREC_FP16X3_ASM, nb):
             self.set_precision(PREC_FP16X3_ASM)
             self.split_block = None
             return None, 0.0
-        self.set_split_block(hi)
+        _, mode, sp, d = best
+        self.set_precision(mode)
+        self.set_split_block(sp)
         self.range_status(reset=True)
-        return hi, self.auto_split[hi]
+        return sp, d
 
     def spot_check_split(self, rays_o, rays_d, n_rays=None):
         """the watch of the split rung: up to `n_rays` (default SPLIT_WATCH_RAYS) of the given rays, spread over the set, rendered with
         the split in use and with three passes everywhere; (ok, largest difference).  Other modes: (True, 0)."""
-        if self.precision != PREC_FP16_SPLIT or self.split_block is None or self.split_block >= self.n_block:
+        if self.precision not in TWO_PART or self.split_block is None or self.split_block >= self.n_block:
             return True, 0.0
         ro, rd = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
         n = ro.shape[0]
@@ -439,16 +466,16 @@ class R2LEngine:
         return d <= self.SPLIT_WATCH_MAX_DIFF, d
 
     def step_down_split(self):
-        """after a failed spot_check_split: half of the bf6 part goes to three passes, all of it once less than SPLIT_MIN_GAIN of the
-        blocks would be left; returns the new mode's name"""
+        """after a failed spot_check_split: half of the low-precision part goes to three passes, all of it once that would save less than
+        SPLIT_MIN_GAIN of the three-pass body; returns the new mode's name"""
         nb = self.n_block
         sp = (self.split_block or 0) + max(1, (nb - (self.split_block or 0) + 1) // 2)
-        if nb - sp < max(1, int(self.SPLIT_MIN_GAIN * nb)):
+        if sp >= nb or self.split_cost(self.precision, sp) > (1.0 - self.SPLIT_MIN_GAIN) * self.split_cost(PREC_FP16X3_ASM, nb):
             self.set_precision(PREC_FP16X3_ASM)
             self.split_block = None
             return 'fp16x3_asm'
         self.set_split_block(sp)
-        return 'fp16_split'
+        return PREC_NAMES[self.precision]
 
     #: check_ranges raises the exponents when the largest value of an operand set, in units of its scale (|a| act_scale / 2^E:
     #: the calibration aims at <= 16 on the frame it saw), passes 0.9 x 28 = 25.2 -- for BOTH operand formats.  bf6 clamps at
@@ -486,7 +513,7 @@ class R2LEngine:
             return None
         st = self.range_status()
         top = st['format_top']
-        split = self.precision == PREC_FP16_SPLIT
+        split = self.precision in TWO_PART
         if split and self.split_block:           # the head output is an operand of the bf6 part only when no block runs before it
             st['h0_fill'] = 0.0
             st['saturated'] = st['worst_fill'] >= 1.0

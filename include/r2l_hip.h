@@ -77,6 +77,12 @@ extern "C" {
  *                    inside its limit against three passes on every ray of a probe frame, and watches it.  split = n_block:
  *                    FP16X3_ASM's results bit for bit; split = 0: every body block with bf6 terms behind the three-pass head. */
 #define R2L_PREC_FP16_SPLIT 5
+/*   R2L_PREC_FP16_SPLIT8 the same two-part form with FP16_E4M3's arithmetic behind the split (e4m3 correction terms: 2.0
+ *                    pass-equivalents, 0.44 x the error of the bf6 terms on the trained-like student).  Which of the two is cheaper at
+ *                    the same error depends on the network -- the trained-like fixture: SPLIT8 at split 0 (11.3 ms per 800 x 800
+ *                    frame) against SPLIT at split 21 (12.5 ms); its second variant: SPLIT at split 9 (10.9 ms) -- so `auto` bisects
+ *                    both and takes the cheaper. */
+#define R2L_PREC_FP16_SPLIT8 6
 
 typedef struct r2l_ctx r2l_ctx;
 typedef struct nerf_ctx nerf_ctx;
@@ -137,8 +143,8 @@ void r2l_destroy(r2l_ctx* ctx);
  *   tail.0.weight[3,256], tail.0.bias[3]                                            */
 int r2l_load_weights(r2l_ctx* ctx, const float* const* tensors, int n_tensors);
 int r2l_set_precision(r2l_ctx* ctx, int precision_mode);
-/* R2L_PREC_FP16_SPLIT: the number of leading blocks in three passes = first block of the bf6 part, 0 .. n_block (takes effect at
- * the next render; no re-packing) */
+/* R2L_PREC_FP16_SPLIT / _SPLIT8: the number of leading blocks in three passes = first block of the bf6 / e4m3 part, 0 .. n_block (takes
+ * effect at the next render; no re-packing) */
 int r2l_set_split_block(r2l_ctx* ctx, int split_block);
 /* Activations of NeRF_v3_2 / ResMLP other than the README's (model/nerf_raybased.py:443-476, 497-522: args.act behind the head layer,
  * trial.inact inside a block, trial.outact behind it), as slopes s of act(v) = max(v, s v): 0 = ReLU, 0.01 = LeakyReLU (torch's

@@ -55,7 +55,7 @@ def test_bench_line_schema():
     # the stress weights of SURVEY 8(d) must not be rendered with the bf6 terms throughout: the library's own range check decides
     # (since round 5 the split rung: as many leading blocks in three passes as its measurement asks for, or all of them)
     sw = d['stress_weights']
-    assert sw['auto_precision'] in ('fp16_split', 'fp16x3_asm') and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
+    assert sw['auto_precision'] in ('fp16_split', 'fp16_split8', 'fp16x3_asm') and sw['max_act_exponent'] > 3 and sw['linf_vs_cpu_oracle'] <= 1e-4
     assert d['calibration']['max'] <= d['calibration']['auto_precision_limit']     # ... and would keep fp16_fp8 for the standard set
 
 
@@ -84,7 +84,7 @@ def test_bench_line_round4_fields():
     # the trained-like fixture's rungs and rates in the line (CPU-oracle fields only with the CPU baseline on)
     tl = d['trained_like']
     st = tl['student']
-    assert st['rung'] == 'fp16_split' and st['max_abs_activation'] > 10 and st['rays_per_s'] > st['rays_per_s_fp16x3_asm'] > 1e7
+    assert st['rung'] in ('fp16_split', 'fp16_split8') and st['max_abs_activation'] > 10 and st['rays_per_s'] > st['rays_per_s_fp16x3_asm'] > 1e7
     assert 0 <= st['split_block'] < st['n_block'] == 43 and st['watch_worst_rgb_diff_from_three_passes'] <= st['watch_limit']
     assert tl['teacher']['precision'] == 'fp16x3_asm' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
     assert tl['teacher']['mlp_launches'] == 6 and 0 < tl['teacher']['mlp_kernel_ms_per_frame'] <= tl['teacher']['ms_per_frame']

@@ -129,7 +129,7 @@ def test_edge_rays_beyond_the_centre_probe_are_caught(pkg):
     assert full == raised, (full, raised)
     # what `--precision auto` makes of it: the border rays put the exponents past fp16_fp8's limit
     name, top = eng.choose_precision(c2w=c2w)
-    assert name in ('fp16_split', 'fp16x3_asm') and top == max(full) > eng.AUTO_MAX_EXP      # behind the whole-network rungs: the split, measured
+    assert name in ('fp16_split', 'fp16_split8', 'fp16x3_asm') and top == max(full) > eng.AUTO_MAX_EXP      # behind the whole-network rungs: the split, measured
     ref = O.r2l_render(sd, H, H, focal, c2w, rows=(0, 8))
     assert (eng.render(c2w, rows=(0, 8)).cpu() - ref).abs().max().item() <= 1e-4
     eng.close()

@@ -13,12 +13,14 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def test_split_endpoints_and_middle_on_a_small_network(pkg):
+@pytest.mark.parametrize('mode', ['fp16_split', 'fp16_split8'])
+def test_split_endpoints_and_middle_on_a_small_network(pkg, mode):
     """split = n_block is fp16x3_asm bit for bit (the same head launch, the same three-pass kernel over all blocks, the same fused
     tail); split = 0 is every block with bf6 terms behind the three-pass head: at least as close to the oracle's neighbourhood as
     fp16_fp8; every split inside the contract; a render of part of the rows equals the rows of the whole render (a ray's result does
     not depend on the launch it is in); the exponents of fp16_fp8 travel with the switch"""
-    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_SPLIT, PREC_FP16X3_ASM, R2LEngine
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3_ASM, PRECISIONS, R2LEngine
+    PREC_FP16_SPLIT = PRECISIONS[mode]
     H, nb = 48, 6
     focal = O.focal_from_angle(H)
     sd = O.make_r2l_state(seed=17, netdepth=2 + 2 * nb)
@@ -52,12 +54,14 @@ def test_split_endpoints_and_middle_on_a_small_network(pkg):
     eng.close()
 
 
-def test_a_launch_over_part_of_the_blocks_converts_the_next_tile_with_its_own_first_exponent(pkg):
+@pytest.mark.parametrize('mode', ['fp16_split', 'fp16_split8'])
+def test_a_launch_over_part_of_the_blocks_converts_the_next_tile_with_its_own_first_exponent(pkg, mode):
     """the bf6 kernel converts the NEXT ray tile's x with the exponent its last block's aux names -- in the full stream block 0's input
     set, for a launch that starts at block `split` that block's (r2l_split_aux_kernel patches a copy of the aux blocks).  With
     exponents that rise with depth a wrong entry shows: a workgroup's second tile would differ from the same rays rendered as some
     workgroup's first tile.  450 ray tiles in one launch (two per workgroup) against two launches of 225 (one each): bit for bit"""
-    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_SPLIT, R2LEngine
+    from efficient_nerf_amd import PREC_FP16_FP8, PRECISIONS, R2LEngine
+    PREC_FP16_SPLIT = PRECISIONS[mode]
     H, nb = 240, 6                                         # 57,600 rays = 450 ray tiles of 128
     focal = O.focal_from_angle(H)
     sd = O.make_r2l_state(seed=23, netdepth=2 + 2 * nb)
@@ -115,11 +119,13 @@ def test_split_without_the_global_skip_and_in_a_graph(pkg):
     eng.close()
 
 
-def test_random_networks_frames_and_splits(pkg):
+@pytest.mark.parametrize('mode', ['fp16_split', 'fp16_split8'])
+def test_random_networks_frames_and_splits(pkg, mode):
     """randomised: depth, ragged frame shapes (ray counts that are no multiple of the 128-ray tile), pose, global skip on / off, every
     split of the depth: split = n_block reproduces fp16x3_asm bit for bit, split = 0 differs from fp16_fp8 by the head launch only,
     everything in between stays as close to three passes as fp16_fp8 does on these i.i.d. weights"""
-    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16_SPLIT, PREC_FP16X3_ASM, R2LEngine
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3_ASM, PRECISIONS, R2LEngine
+    PREC_FP16_SPLIT = PRECISIONS[mode]
     rng = np.random.default_rng(5)
     worst = 0.0
     for it in range(8):
@@ -149,11 +155,11 @@ def test_random_networks_frames_and_splits(pkg):
 
 
 def test_auto_measures_the_split_on_the_trained_like_student(pkg):
-    """the committed trained-like student (max|a| 126: beyond the bf6 and e4m3 rungs): `auto` bisects for the fewest leading blocks
-    in three passes whose frame stays within its limit of three passes everywhere, on every ray of a frame, and the frames it then
-    renders are inside the 1e-4 contract of the CPU oracle; the watch's spot check agrees; a limit of zero ends in fp16x3_asm as
-    before"""
-    from efficient_nerf_amd import PREC_NAMES, R2LEngine
+    """the committed trained-like student (max|a| 126: beyond the whole-network bf6 and e4m3 rungs): per format behind the split (bf6
+    terms, e4m3 terms) `auto` bisects for the fewest leading blocks in three passes whose frame stays within its limit of three passes
+    everywhere, on every ray of a frame, and takes the cheaper of the two; the frames it then renders are inside the 1e-4 contract of
+    the CPU oracle; the watch's spot check agrees; the step-down ends in fp16x3_asm; a limit of zero ends there at once, as before"""
+    from efficient_nerf_amd import PREC_FP16_SPLIT, PREC_FP16_SPLIT8, PREC_NAMES, R2LEngine
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trained_like', 'student_w256d88.npz'))
     ssd = {k: torch.from_numpy(z[k]) for k in z.files}
     H = 400
@@ -163,12 +169,16 @@ def test_auto_measures_the_split_on_the_trained_like_student(pkg):
     rung, top = eng.choose_precision(c2w=test[0][:3, :4])
     print(f'trained-like student: max|a| {eng.stream_max:.1f} -> {rung}, split {eng.split_block}; measured {eng.auto_split}')
     sp = eng.split_block
-    assert rung == 'fp16_split' and 0 <= sp <= 37 and eng.auto_split[sp] <= eng.AUTO_SPLIT_MAX_DIFF
-    assert sp == 0 or any(k < sp and v > eng.AUTO_SPLIT_MAX_DIFF for k, v in eng.auto_split.items())     # a smaller one was tried, and failed
+    assert rung in ('fp16_split', 'fp16_split8') and 0 <= sp <= 37 and eng.auto_split[rung][sp] <= eng.AUTO_SPLIT_MAX_DIFF
+    assert sp == 0 or any(k < sp and v > eng.AUTO_SPLIT_MAX_DIFF for k, v in eng.auto_split[rung].items())     # a smaller one was tried, and failed
+    # the other format was measured too (bf6 first), and what was taken is the cheaper by the measured block times
+    assert set(eng.auto_split) == {'fp16_split', 'fp16_split8'}
+    ok6 = [k for k, v in eng.auto_split['fp16_split'].items() if v <= eng.AUTO_SPLIT_MAX_DIFF]
+    assert ok6 and eng.split_cost(eng.precision, sp) <= eng.split_cost(PREC_FP16_SPLIT, min(ok6))
     from efficient_nerf_amd import get_rays
     for pi in (0, 67, 133):
         got, again = eng.render_checked(lambda: eng.render(test[pi][:3, :4]))
-        assert PREC_NAMES[eng.precision] == 'fp16_split'
+        assert PREC_NAMES[eng.precision] == rung
         g = got.cpu().view(H, H, 3)[::8].reshape(-1, 3)
         want = O.r2l_render(ssd, H, H, focal, test[pi][:3, :4], rows=(0, H, 8), chunk=16384)
         err = (g - want).abs().max().item()
@@ -176,9 +186,9 @@ def test_auto_measures_the_split_on_the_trained_like_student(pkg):
         ok, d = eng.spot_check_split(ro, rd)
         print(f'pose {pi}: L_inf vs CPU oracle on {g.shape[0]} rays {err:.2e}; spot check {d:.2e}')
         assert err <= 1e-4 and ok
-    # the step-down of the watch: half of the bf6 part to three passes; and the old behaviour when no split qualifies
-    assert eng.step_down_split() == 'fp16_split' and eng.split_block == sp + (43 - sp + 1) // 2
-    while eng.step_down_split() == 'fp16_split':
+    # the step-down of the watch: half of the low-precision part to three passes, until too little would be saved
+    assert eng.step_down_split() == rung and eng.split_block == sp + (43 - sp + 1) // 2
+    while eng.step_down_split() == rung:
         assert eng.split_block < 43
     assert PREC_NAMES[eng.precision] == 'fp16x3_asm' and eng.split_block is None
     eng.close()

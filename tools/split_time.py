@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """R2L_PREC_FP16_SPLIT on the trained-like student at 800 x 800: per split (head + blocks [0, split) in three passes, blocks
-[split, 43) with bf6 terms) the frame time and the L_inf / rms against three passes everywhere (fp16x3_asm) and against the CPU oracle
+[split, 43) with bf6 terms -- fp16_split -- or e4m3 terms -- fp16_split8) the frame time and the L_inf / rms against three passes everywhere (fp16x3_asm) and against the CPU oracle
 on every 8th row, then what `--precision auto` picks.  Beside it the whole-network modes (bf6-term head launch)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,11 +40,13 @@ def row(name):
 
 eng.set_precision(PRECISIONS['fp16_fp8']); eng.calibrate_on(c2w=poses[0])
 row('fp16_fp8 ')
-eng.set_precision(PRECISIONS['fp16_split'])
-for sp in (0, 2, 5, 8, 12, 16, 20, 24, 28, 32, 38, 43):
-    eng.set_split_block(sp)
-    row(f'split {sp:2d} ')
+for mode, splits in (('fp16_split', (0, 2, 5, 8, 12, 16, 20, 24, 28, 32, 38, 43)), ('fp16_split8', (0, 1, 2, 5, 8, 12, 16, 24, 32))):
+    eng.set_precision(PRECISIONS[mode])
+    print(mode + ': head + blocks [0, split) in three passes, blocks [split, 43) with ' + ('e4m3' if mode.endswith('8') else 'bf6') + ' terms')
+    for sp in splits:
+        eng.set_split_block(sp)
+        row(f'split {sp:2d} ')
 eng.close()
 eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(sd)
 t0 = time.perf_counter(); rung, top = eng.choose_precision(c2w=poses[0]); dt = time.perf_counter() - t0
-print(f'auto: {rung} split {eng.split_block} (measured {eng.auto_split}) in {dt:.2f} s; {timed():.2f} ms per frame = {H * H / timed() * 1e3:.3e} rays/s')
+print(f'auto: {rung} split {eng.split_block} (measured {eng.auto_split}; costs in bf6 blocks: ' + ', '.join(f'{m} {eng.split_cost(PRECISIONS[m], min(k for k, v in t.items() if v <= eng.AUTO_SPLIT_MAX_DIFF)):.1f}' for m, t in eng.auto_split.items() if any(v <= eng.AUTO_SPLIT_MAX_DIFF for v in t.values())) + f') in {dt:.2f} s; {timed():.2f} ms per frame = {H * H / timed() * 1e3:.3e} rays/s')

@@ -231,8 +231,8 @@ def measure(tsds, ssd, log, cpu_rows=8):
     seng = R2LEngine(Hs, Hs, fs, 2., 6., n_block=43, use_residual=True).load_state_dict(ssd)
     rung, top = seng.choose_precision(c2w=test[0][:3, :4])
     s = {'rung': rung, 'max_act_exponent': None if top is None else int(top), 'max_abs_activation': float(seng.stream_max), 'frames': []}
-    if rung == 'fp16_split':
-        s.update(split_block=seng.split_block, split_probe_diffs={str(k): v for k, v in sorted(seng.auto_split.items())})
+    if rung.startswith('fp16_split'):
+        s.update(split_block=seng.split_block, split_probe_diffs={m: {str(k): v for k, v in sorted(t.items())} for m, t in seng.auto_split.items()})
     teng = NeRFEngine(Hs, Hs, fs, precision=PRECISIONS[name]).load_state_dicts(*tsds)
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     for pi in (0, 67, 133):
@@ -257,7 +257,7 @@ def measure(tsds, ssd, log, cpu_rows=8):
     torch.cuda.synchronize()
     s['ms_per_frame'] = (time.perf_counter() - t0) / 10 * 1e3
     s['rays_per_s'] = Hs * Hs / (s['ms_per_frame'] * 1e-3)
-    if rung == 'fp16_split':                      # the watch's view of three more poses, and three passes everywhere beside it
+    if rung.startswith('fp16_split'):             # the watch's view of three more poses, and three passes everywhere beside it
         from efficient_nerf_amd import get_rays
         s['watch'] = [seng.spot_check_split(*get_rays(Hs, Hs, fs, test[pi][:3, :4], device='cuda'))[1] for pi in (20, 100, 180)]
         seng.set_precision(PRECISIONS['fp16x3_asm'])
