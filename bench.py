@@ -429,10 +429,10 @@ def main():
         st = eng.range_status()
         # the rate is that of ONE rung of `--precision auto`'s ladder; which rung a checkpoint gets depends on its own activations
         out['value_valid_for'] = ('activation exponent <= 3 (max|a| <= %g over all operand sets of every ray: the rung --precision auto '
-                                  'gives these weights; up to %g -> fp16_e4m3, above -> fp16x3_asm: e4m3_mode / stress_weights below; '
+                                  'gives these weights; up to %g -> fp16_e4m3, above -> a measured split rung or fp16x3_asm: e4m3_mode / stress_weights / trained_like below; '
                                   'limits from profiles/r04_range_sweep_dists.txt).  The synthetic nn.Linear-init weights of this line sit at max|a| ~ 7; the '
                                   'trained-like fixture (trained_like.student: weights that went through teacher fit -> pseudo data -> distillation) '
-                                  'reaches max|a| ~ 126 and renders on the split rung (fp16_split): its rate is trained_like.student.rays_per_s' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)
+                                  'reaches max|a| ~ 126 and renders on a split rung (fp16_split / fp16_split8, measured per checkpoint): its rate is trained_like.student.rays_per_s' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3)
                                   if args.precision == 'fp16_fp8' else
                                   'max|a| <= %g over all operand sets of every ray (the middle rung of --precision auto)' % eng.AUTO_MAX_ABS_E4M3)
         out['calibration'] = {'act_exponents': ex, 'min': min(ex), 'max': max(ex),
