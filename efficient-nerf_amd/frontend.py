@@ -394,6 +394,9 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
             elif log:
                 log(f'[precision] auto: activations of every ray of the first frame up to {eng.stream_max:.2f} (exponent {top}; '
                     f'fp16_fp8 up to {eng.AUTO_MAX_ABS:g}, fp16_e4m3 up to {eng.AUTO_MAX_ABS_E4M3:g}) -> {name}')
+                if getattr(eng, 'auto_verify', None) is not None:
+                    log(f'[precision] auto: the rung those limits name is {eng.auto_verify:.1e} from three passes on every ray of the first frame '
+                        f'(limit {eng.AUTO_VERIFY_MAX_DIFF:g})' + ('' if eng.auto_verify <= eng.AUTO_VERIFY_MAX_DIFF else ': measured rungs instead'))
                 if getattr(eng, 'auto_split', None):
                     tried = '; '.join(f"{'e4m3' if m.endswith('8') else 'bf6'} terms behind them: " + ', '.join(f'{k}: {v:.1e}' for k, v in t.items())
                                       for m, t in eng.auto_split.items())

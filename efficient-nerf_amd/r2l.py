@@ -320,7 +320,9 @@ class R2LEngine:
         up to max|a| = 8, fp16_e4m3 up to 10, fp16x3_asm above.  The error of the low-precision terms is relative to the residual
         stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so the choice needs the ranges of THESE weights:
         `calibrate_on` measures them on every ray of the frame of pose `c2w` (or of the given `rays` = (rays_o, rays_d)).
-        `max_exp` overrides fp16_fp8's limit and disables the middle step (tests).  What is rendered afterwards stays
+        The rung the limits name is then verified against three passes on the probe frame (AUTO_VERIFY), and networks beyond the limits
+        -- or failing that check -- get a measured split rung (choose_split).
+        `max_exp` overrides fp16_fp8's limit and disables the middle step and both measurements (tests).  What is rendered afterwards stays
         watched (range_status / `check_ranges`, which applies the same limits to what it sees).  Synchronous, once per weight load.
         Weights the generated kernels cannot pack (a layer with max|w| outside 2^-12 .. 2^6) get fp16x3, the compiler-scheduled
         mode with per-layer scales: ('fp16x3', None), the library's message in `auto_note`.
@@ -340,6 +342,21 @@ class R2LEngine:
         self._auto = (max_exp,)
         mode = self.LADDER[self._rung_for(self.stream_max, max_exp)]
         self.split_block = None
+        self.auto_verify = self.auto_split = None
+        if mode != PREC_FP16X3_ASM and max_exp is None and self.AUTO_VERIFY:
+            # the limits come from i.i.d. weight families; a trained network amplifies what its early layers get wrong (the trained-like
+            # student scaled to max|a| = 4 -- a ReLU network is positively homogeneous, the function and its rgb error are the same -- is
+            # 1.3e-4 off in fp16_fp8): the rung the limits name is rendered against three passes on every ray of the probe frame
+            if mode != PREC_FP16_FP8:
+                self.set_precision(mode)
+            got = self._probe_render(c2w, rays).clone()
+            self.set_precision(PREC_FP16X3_ASM)
+            self.auto_verify = float((got - self._probe_render(c2w, rays)).abs().max())
+            if self.auto_verify <= self.AUTO_VERIFY_MAX_DIFF:
+                self.set_precision(mode)
+                self.range_status(reset=True)
+                return PREC_NAMES[mode], top
+            mode = PREC_FP16X3_ASM               # ... a miss (or NaN): the measured rungs
         if mode == PREC_FP16X3_ASM and max_exp is None and self.AUTO_SPLIT:
             split, diff = self.choose_split(c2w=c2w, rays=rays)
             if split is not None:
@@ -363,6 +380,10 @@ class R2LEngine:
     #: contract for the poses the probe did not see (measured: up to 1.4 x the probe frame's maximum; watched: spot_check_split against
     #: SPLIT_WATCH_MAX_DIFF) and the 4e-6 between three passes and fp32.
     AUTO_SPLIT = True
+    #: the whole-network rungs the activation limits name are verified once per weight load: rgb of the probe frame against three passes
+    #: everywhere (fp16x3_asm); beyond AUTO_VERIFY_MAX_DIFF the network goes to the measured split rungs whatever its activations are
+    AUTO_VERIFY = True
+    AUTO_VERIFY_MAX_DIFF = 7e-5
     AUTO_SPLIT_MAX_DIFF = 5e-5
     SPLIT_WATCH_MAX_DIFF = 7e-5
     SPLIT_WATCH_RAYS = 65536
@@ -382,6 +403,11 @@ class R2LEngine:
             check(lib().r2l_set_split_block(self._ctx, int(split)))
         self.split_block = int(split)
 
+    def _probe_render(self, c2w, rays):
+        if rays is not None:
+            return self.render_rays(rays[0].contiguous().to(self.device, torch.float32), rays[1].contiguous().to(self.device, torch.float32))
+        return self.render(c2w)
+
     def split_cost(self, mode, split):
         """body time of a two-part render in units of one bf6 block (BLOCK_COST)"""
         return self.BLOCK_COST[PREC_FP16X3_ASM] * split + self.BLOCK_COST[mode] * (self.n_block - split)
@@ -395,11 +421,7 @@ class R2LEngine:
         once per weight load, about a dozen frames."""
         max_diff = self.AUTO_SPLIT_MAX_DIFF if max_diff is None else float(max_diff)
         nb = self.n_block
-
-        def rend():
-            if rays is not None:
-                return self.render_rays(rays[0].contiguous().to(self.device, torch.float32), rays[1].contiguous().to(self.device, torch.float32))
-            return self.render(c2w)
+        rend = lambda: self._probe_render(c2w, rays)
         self.auto_split, best, ref = {}, None, None
         for mode in modes:
             try:

@@ -196,3 +196,41 @@ def test_auto_measures_the_split_on_the_trained_like_student(pkg):
     eng.AUTO_SPLIT_MAX_DIFF = 0.0
     assert eng.choose_precision(c2w=test[0][:3, :4])[0] == 'fp16x3_asm' and eng.split_block is None
     eng.close()
+
+
+def test_auto_verifies_the_rung_the_activation_limits_name(pkg):
+    """a ReLU ResMLP is positively homogeneous: head and biases x 1/32, tail weight x 32 is the same function with activations 32 times
+    smaller.  The trained-like student scaled that way has max|a| = 3.9 -- inside fp16_fp8's activation limit (8), which was derived from
+    i.i.d. weight families -- and the same 1.3e-4 error in fp16_fp8, because what makes the error is what the network does with it, not
+    the size of its stream.  `auto` renders the rung the limits name against three passes on every ray of the probe frame, sees it, and
+    takes the measured rungs; the synthetic W256D88 weights pass the same check and keep fp16_fp8"""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_NAMES, R2LEngine
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trained_like', 'student_w256d88.npz'))
+    ssd = {k: torch.from_numpy(z[k]).clone() for k in z.files}
+    a = 1. / 32.
+    for k in ssd:
+        if k.startswith('head.') or (k.startswith('body.') and k.endswith('bias')):
+            ssd[k] = ssd[k] * a
+        elif k == 'tail.0.weight':
+            ssd[k] = ssd[k] / a
+    H = 400
+    focal = O.focal_from_angle(H)
+    test = O.novel_poses(200)
+    eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(ssd)
+    rung, top = eng.choose_precision(c2w=test[0][:3, :4])
+    print(f'scaled trained-like student: max|a| {eng.stream_max:.2f} (exponent {top}); fp16_fp8 is {eng.auto_verify:.2e} from three passes -> {rung}, split {eng.split_block}')
+    assert eng.stream_max <= eng.AUTO_MAX_ABS and eng.auto_verify > eng.AUTO_VERIFY_MAX_DIFF
+    assert rung in ('fp16_split', 'fp16_split8', 'fp16x3_asm') and PREC_NAMES[eng.precision] == rung
+    got = eng.render(test[67][:3, :4]).cpu().view(H, H, 3)[::8].reshape(-1, 3)
+    want = O.r2l_render(ssd, H, H, focal, test[67][:3, :4], rows=(0, H, 8), chunk=16384)
+    assert (got - want).abs().max().item() <= 1e-4
+    eng.set_precision(PREC_FP16_FP8)         # what the limits alone would have rendered it with
+    bad = (eng.render(test[67][:3, :4]).cpu().view(H, H, 3)[::8].reshape(-1, 3) - want).abs().max().item()
+    print(f'pose 67 against the CPU oracle: {rung} {(got - want).abs().max().item():.2e}, fp16_fp8 {bad:.2e}')
+    eng.close()
+    sd = O.make_r2l_state(seed=0)
+    eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(sd)
+    rung, top = eng.choose_precision(c2w=test[0][:3, :4])
+    print(f'synthetic weights: max|a| {eng.stream_max:.2f}; fp16_fp8 is {eng.auto_verify:.2e} from three passes -> {rung}')
+    assert rung == 'fp16_fp8' and eng.auto_verify <= eng.AUTO_VERIFY_MAX_DIFF and eng.auto_split is None
+    eng.close()
