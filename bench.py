@@ -161,6 +161,7 @@ def trained_like_leg(torch, O, cpu):
     eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(ssd)
     rung, top = eng.choose_precision(c2w=test[0][:3, :4])
     s = {'rung': rung, 'max_act_exponent': None if top is None else int(top), 'max_abs_activation': float(eng.stream_max),
+         'rgb_diff_from_three_passes_of_the_rung_the_limits_name': eng.auto_verify,
          'ladder': 'fp16_fp8 up to %g, fp16_e4m3 up to %g, above: fp16_split / fp16_split8 (head + the first `split_block` blocks in three fp16 passes, '
                    'the rest with bf6 / e4m3 terms; per format the split bisected for rgb within %g of three passes everywhere on every ray of the '
                    'probe frame, the cheaper of the two taken), fp16x3_asm when that would save less than 5 %% of its body time' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3, eng.AUTO_SPLIT_MAX_DIFF)}
@@ -271,7 +272,7 @@ def middle_rung(torch, O, R2LEngine, sd, poses, focal):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / 5
     out = {'body_weight_gain': GAIN, 'max_act_exponent': int(top), 'max_abs_activation': float(eng.stream_max), 'auto_precision': chosen,
-           'linf_vs_cpu_oracle': (got - ref).abs().max().item(), 'rays_checked': int(got.shape[0]), 'value': H * W / dt,
+           'rgb_diff_from_three_passes_on_the_probe_frame': eng.auto_verify, 'linf_vs_cpu_oracle': (got - ref).abs().max().item(), 'rays_checked': int(got.shape[0]), 'value': H * W / dt,
            'unit': 'rays/s', 'ms_per_frame': dt * 1e3}
     if chosen in ('fp16_fp8', 'fp16_e4m3'):
         out['worst_fill'] = eng.range_status()['worst_fill']
@@ -515,6 +516,13 @@ def main():
             out['alt_precision'] = alt
             eng.set_precision(prec)
         if world == 1 and not args.no_cpu_baseline and args.precision == 'fp16_fp8':
+            # what `--precision auto` does with the weights of the headline: the rung the activation limits name, verified against three
+            # passes on every ray of a frame (R2LEngine.choose_precision)
+            aeng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(sd)
+            aname, atop = aeng.choose_precision(c2w=poses[0])
+            out['auto_on_these_weights'] = {'precision': aname, 'max_abs_activation': float(aeng.stream_max),
+                                            'rgb_diff_from_three_passes_on_the_probe_frame': aeng.auto_verify, 'limit': aeng.AUTO_VERIFY_MAX_DIFF}
+            aeng.close()
             # the middle rung of `--precision auto` on the networks it is for (body weights x 1.08: largest |activation| ~ 9.5)
             out['e4m3_mode'] = middle_rung(torch, O, R2LEngine, sd, poses, focal)
             # secondary, outside the timed region: SURVEY 8(d)'s stress weights (every body weight x 1.3) through
@@ -534,7 +542,7 @@ def main():
             torch.cuda.synchronize()
             sdt = (time.perf_counter() - t1) / 3
             out['stress_weights'] = {'body_weight_gain': 1.3, 'max_act_exponent': int(top), 'max_abs_activation': float(seng.stream_max), 'auto_precision': chosen,
-                                     'split_block': seng.split_block, 'linf_vs_cpu_oracle': (sg - sref).abs().max().item(), 'rays_checked': int(sg.shape[0]),
+                                     'split_block': seng.split_block, 'split_probe_diffs': seng.auto_split, 'linf_vs_cpu_oracle': (sg - sref).abs().max().item(), 'rays_checked': int(sg.shape[0]),
                                      'value': H * W / sdt, 'unit': 'rays/s'}
             seng.close()
         if not args.no_teacher and world == 1:

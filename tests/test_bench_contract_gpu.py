@@ -49,6 +49,9 @@ def test_bench_line_schema():
     rw = d['range_watch']
     assert rw['saturated'] == 0 and rw['launches'] == 2 and 0 < rw['h0_fill'] < 1 and rw['worst_fill'] < 1
     assert d['calibration']['measured_on'].startswith('every ray')
+    # `auto` on the headline's own weights: the rung the limits name, verified against three passes
+    aw = d['auto_on_these_weights']
+    assert aw['precision'] == 'fp16_fp8' and 0 < aw['rgb_diff_from_three_passes_on_the_probe_frame'] <= aw['limit'] <= 1e-4
     # the middle rung of the ladder on the networks it is for
     em = d['e4m3_mode']
     assert em['auto_precision'] == 'fp16_e4m3' and em['max_act_exponent'] == 4 and 8 < em['max_abs_activation'] <= 10 and em['linf_vs_cpu_oracle'] <= 1e-4
