@@ -14,6 +14,8 @@
 //   P   v_cvt_pk_f16_f32
 //   F   v_fma_f32
 //   A   v_accvgpr_write_b32 + v_accvgpr_read_b32 (one pair)
+//   E   v_mfma_scale_f32_32x32x64_f8f6f4   e4m3 x e4m3 (64 pipe cycles), random bytes            (round 5: r2l_body8_kernel's terms)
+//   Q   v_cvt_scalef32_pk_fp8_f16          (2 values per lane)
 // For every configuration: iterations / s (-> events / s per class), socket power and sclk through rocm_smi over a
 // ~2.5 s steady-state window.  tools/energy_fit.py turns the table into joules per event and prices the two kernels'
 // instruction mixes at their measured rates (profiles/r04_energy_account.txt).
@@ -31,6 +33,7 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,7 +48,7 @@ struct Cfg {
 // slot s of 16 holds floor((s + 1) n / 16) - floor(s n / 16) instructions of a class with n per iteration
 #define SLOTS(n, text) ".rept ((eps_s + 1) * %c[" #n "]) / 16 - (eps_s * %c[" #n "]) / 16\n" text ".endr\n"
 
-template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A, int K, int LS>
+template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A, int K, int LS, int E8, int Q8>
 __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, const char* __restrict__ stream, int iters, float* sink) {
     i32x4* l = reinterpret_cast<i32x4*>(smem);
     for (int i = threadIdx.x; i < 4096; i += 256) l[i] = data[i];
@@ -58,6 +61,9 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
         a[j] = i32x6{p[0], p[1], p[2], p[3], r[0], r[1]};     // weights: N(0, 1)
         b[j] = i32x6{q[0], q[1], q[2], q[3], r[2], r[3]};     // activations: relu(N(0, 1))
     }
+    const i32x8 a8 = {a[0][0], a[0][1], a[0][2], a[0][3], a[1][0], a[1][1], a[1][2], a[1][3]};     // 32 random bytes per lane as e4m3 operands
+    const i32x8 b8 = {b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], b[1][2], b[1][3]};
+    unsigned q8 = 0;
     f32x16 c0 = {0}, c1 = {0};
     f32x4 h0 = {0, 0, 0, 0}, h1 = h0;
     int sc = 127;
@@ -102,6 +108,9 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
             SLOTS(nX, "v_fma_mixlo_f16 %[x1], %[x0], %[scale], %[v0] op_sel_hi:[1,0,0]\n v_fma_mixhi_f16 %[x1], %[x0], %[scale], %[v1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
             SLOTS(nC, ".if (eps_s & 1)\n v_cvt_scalef32_pk32_bf6_f16 %[cv], %[src2], %[scale]\n .else\n v_cvt_scalef32_pk32_bf6_f16 %[cv], %[src], %[scale]\n .endif\n")
             SLOTS(nA, "v_accvgpr_write_b32 a0, %[v0]\n s_nop 0\n v_accvgpr_read_b32 %[acct], a0\n")
+            SLOTS(nE, ".if (eps_s & 1)\n v_mfma_scale_f32_32x32x64_f8f6f4 %[c1], %[a8], %[b8], %[c1], %[sc], %[sc] op_sel_hi:[0,0,0]\n .else\n"
+                      " v_mfma_scale_f32_32x32x64_f8f6f4 %[c0], %[b8], %[a8], %[c0], %[sc], %[sc] op_sel_hi:[0,0,0]\n .endif\n")
+            SLOTS(nQ, "v_cvt_scalef32_pk_fp8_f16 %[q8], %[x0], %[scale]\n")
             ".set eps_s, eps_s + 1\n"
             ".endr\n"
             // wrap the stream offset (scalar compare on lane 0's value is not needed: every lane adds the same steps)
@@ -113,19 +122,19 @@ __global__ __launch_bounds__(256, 1) void probe(const i32x4* __restrict__ data, 
             // the previous iteration's are waited for
             "s_waitcnt vmcnt(%c[nG] + %c[nL]) lgkmcnt(0)\n"
             : [c0] "+v"(c0), [c1] "+v"(c1), [h0] "+v"(h0), [h1] "+v"(h1), [v2] "+v"(v2), [d0] "+v"(d0), [g0] "+v"(g0), [goff] "+v"(goff),
-              [x0] "+v"(x0), [x1] "+v"(x1), [cv] "+v"(cv), [acct] "+v"(acc_t)
+              [x0] "+v"(x0), [x1] "+v"(x1), [cv] "+v"(cv), [acct] "+v"(acc_t), [q8] "+v"(q8)
             : [a0] "v"(__builtin_shufflevector(a[0], a[0], 0, 1, 2, 3)), [a1] "v"(__builtin_shufflevector(a[1], a[1], 0, 1, 2, 3)),
               [a2] "v"(__builtin_shufflevector(a[2], a[2], 0, 1, 2, 3)), [a3] "v"(__builtin_shufflevector(a[3], a[3], 0, 1, 2, 3)),
               [b0] "v"(__builtin_shufflevector(b[0], b[0], 0, 1, 2, 3)), [b1] "v"(__builtin_shufflevector(b[1], b[1], 0, 1, 2, 3)),
               [b2] "v"(__builtin_shufflevector(b[2], b[2], 0, 1, 2, 3)), [b3] "v"(__builtin_shufflevector(b[3], b[3], 0, 1, 2, 3)),
-              [a0x] "v"(a[0]), [a1x] "v"(a[1]), [b0x] "v"(b[0]), [b1x] "v"(b[1]), [sc] "v"(sc), [v0] "v"(v0), [v1] "v"(v1),
+              [a0x] "v"(a[0]), [a1x] "v"(a[1]), [b0x] "v"(b[0]), [b1x] "v"(b[1]), [a8] "v"(a8), [b8] "v"(b8), [sc] "v"(sc), [v0] "v"(v0), [v1] "v"(v1),
               [addr] "v"(addr), [waddr] "v"(waddr), [d1] "v"(d1), [gbase] "s"(gbase), [src] "v"(src), [src2] "v"(src2), [scale] "v"(scale),
               [m0v] "s"(lds_dma_base), [wrap] "v"(STREAM_BYTES - (2u << 20)), [start] "v"(LS ? (unsigned)(wave * 1024 + lane * 16) : (unsigned)lane * 16), [gstep] "v"(LS ? 4096u : 1024u), [nK] "i"(K),
               [nM] "i"(M), [nH] "i"(H), [nB] "i"(B), [nR] "i"(R), [nW] "i"(W), [nG] "i"(G), [nL] "i"(L), [nC] "i"(C), [nX] "i"(X),
-              [nP] "i"(P), [nF] "i"(F), [nA] "i"(A)
+              [nP] "i"(P), [nF] "i"(F), [nA] "i"(A), [nE] "i"(E8), [nQ] "i"(Q8)
             : "a0", "vcc", "memory");
     }
-    float s = c0[0] + c1[1] + h0[2] + h1[3] + v2 + v3 + d0[0] + g0[1] + __int_as_float(x0 ^ x1 ^ acc_t ^ cv[0] ^ cv[5]);
+    float s = c0[0] + c1[1] + h0[2] + h1[3] + v2 + v3 + d0[0] + g0[1] + __int_as_float(x0 ^ x1 ^ acc_t ^ cv[0] ^ cv[5] ^ q8);
     if (s == 12345.678f) sink[0] = s;
 }
 
@@ -147,9 +156,9 @@ static const i32x4* g_data;
 static const char* g_stream;
 static float* g_sink;
 
-template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A, int K = 0, int LS = 0>
+template <int M, int H, int B, int R, int W, int G, int L, int C, int X, int P, int F, int A, int K = 0, int LS = 0, int E8 = 0, int Q8 = 0>
 void run(const char* tag) {
-    auto kern = probe<M, H, B, R, W, G, L, C, X, P, F, A, K, LS>;
+    auto kern = probe<M, H, B, R, W, G, L, C, X, P, F, A, K, LS, E8, Q8>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     // calibrate the iteration count to ~2.5 ms per launch
     hipEvent_t e0, e1;
@@ -183,8 +192,8 @@ void run(const char* tag) {
     hipError_t err = hipGetLastError();
     hipEventElapsedTime(&ms, e0, e1);
     const double it_per_s = (double)iters * window / (ms * 1e-3);        // per wave; x 1024 waves on the chip
-    printf("%-34s M %2d H %2d B %2d K %2d R %2d W %2d G %2d L %2d%s C %2d X %2d P %2d F %2d A %2d   iter/s/wave %.4e   power %7.1f W   sclk %6.0f MHz   (%d samples)%s\n",
-           tag, M, H, B, K, R, W, G, L, LS ? " lockstep" : "         ", C, X, P, F, A, it_per_s, n ? pw_sum / n : 0.0, n ? ck_sum / n : 0.0, n,
+    printf("%-34s M %2d H %2d B %2d K %2d E %2d Q %2d R %2d W %2d G %2d L %2d%s C %2d X %2d P %2d F %2d A %2d   iter/s/wave %.4e   power %7.1f W   sclk %6.0f MHz   (%d samples)%s\n",
+           tag, M, H, B, K, E8, Q8, R, W, G, L, LS ? " lockstep" : "         ", C, X, P, F, A, it_per_s, n ? pw_sum / n : 0.0, n ? ck_sum / n : 0.0, n,
            err == hipSuccess ? "" : hipGetErrorString(err));
     fflush(stdout);
 }
@@ -232,6 +241,26 @@ int main() {
         printf("%-28s power %7.1f W   sclk %6.0f MHz\n", "idle (no kernel)", p / 20, c / 20);
     }
     //   M  H  B  R  W  G  L  C  X  P  F  A [K LS]
+    if (getenv("EP_E4M3") != nullptr) {
+        // round 5, second part: the kernel the trained-like student lands on since the split rungs, r2l_body8_kernel
+        // (e4m3 terms).  Per block and wave: 256 fp16 MFMAs (32x32x16) + 128 e4m3 MFMAs (32x32x64, 64 pipe cycles each), 544 KiB of ds_read,
+        // 129 LDS-DMA, 256 v_cvt_scalef32_pk_fp8_f16, 128 v_fma_mix pairs, 128 v_cvt_pk, 128 v_accvgpr pairs, ~130 plain VALU
+        // -> per 16 MFMAs: M 11, E 5, R 23, G 5, Q 11, X 5, P 5, F 5, A 5
+        run<0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 16, 0>("mfma 32x32x64 e4m3 x16");
+        run<0, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 32x32x64 bf6 x16");
+        run<16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 32x32x16 f16 x16");
+        run<0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64>("v_cvt_scalef32_pk_fp8_f16 x64");
+        run<11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 5, 0>("mfma 32x32 f16:e4m3 2:1");
+        run<11, 0, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0>("mfma 32x32 f16:bf6 2:1");
+        run<11, 0, 0, 23, 0, 5, 0, 0, 5, 5, 5, 5, 0, 1, 5, 11>("body8 replica (e4m3 terms)");
+        run<11, 0, 5, 22, 0, 5, 0, 1, 5, 5, 8, 4, 0, 1>("body replica (bf6 terms)");
+        run<11, 0, 0, 23, 0, 0, 0, 0, 5, 5, 5, 5, 0, 1, 5, 11>("body8 replica, no DMA");
+        run<11, 0, 0, 0, 0, 5, 0, 0, 5, 5, 5, 5, 0, 1, 5, 11>("body8 replica, no ds_read");
+        run<11, 0, 0, 23, 0, 5, 0, 0, 0, 0, 0, 0, 0, 1, 5, 0>("body8 replica, no VALU");
+        run<11, 0, 0, 23, 0, 5, 0, 0, 5, 5, 5, 5, 0, 1, 5, 11>("body8 replica (e4m3 terms) again");
+        rsmi_shut_down();
+        return 0;
+    }
     if (getenv("EP_X3") != nullptr) {
         // round 5: the mix of the kernels trained-like weights end on, in both MFMA shapes.  r2l_bodyx_kernel per
         // block and wave: 768 fp16 MFMAs (32x32x16), 544 KiB of ds_read, 129 LDS-DMA, 128 v_fma_mix pairs, 128 v_cvt_pk, 192 v_accvgpr
