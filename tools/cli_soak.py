@@ -2,7 +2,8 @@
 """The reference's command line over its whole test path, twice: `main.py --render_only` on 200 synthetic 800x800 poses (PNG writing
 on: 200 x 1.9 MB through the writer threads), the two `rgbs.npy` stacks compared bit for bit, 8 frames spread over the path compared
 with the CPU oracle on 2,500 strided rays each, the PNGs decoded back and compared with to8b of the stack.
-    python tools/cli_soak.py [n_frames]          (through gpurun; ~1.5 minutes)"""
+    python tools/cli_soak.py [n_frames]          (through gpurun; ~1.5 minutes; SOAK_WEIGHTS=trained_like: the trained-like student, i.e. the
+    split rungs of `--precision auto` and their watch over the whole path)"""
 import os
 import subprocess
 import sys
@@ -23,7 +24,11 @@ from oracle import r2l_oracle as O  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 H = 800
 d = tempfile.mkdtemp(prefix='r2l_soak_')
-sd = O.make_r2l_state(seed=0)
+if os.environ.get('SOAK_WEIGHTS') == 'trained_like':      # the committed trained-like student instead of the synthetic weights
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'trained_like', 'student_w256d88.npz'))
+    sd = {k: torch.from_numpy(z[k]) for k in z.files}
+else:
+    sd = O.make_r2l_state(seed=0)
 ck = os.path.join(d, 'r2l.tar')
 fe.save_checkpoint(ck, sd)
 stacks = []
