@@ -91,21 +91,22 @@ def measured_traffic(precision):
     return e.get('bytes_per_launch'), rel + ' (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources; not measured in this run)'
 
 
-def create_data_leg(torch, O, precision):
+def create_data_leg(torch, O, precision, sds=None, n_pose=200):
     """secondary, outside the timed region: BASELINE config 5's unit of work at the reference's own size -- save groups of
     `utils/create_data.py --create_data rand` (:812-872): 100 random poses (random focal) at 400x400 through the teacher,
     i_save = 100, split_size = 4096 -> 3,906 shards of 147 KB per group -- with the wall-clock split and the extrapolation to
     --n_pose_kd 10000 (100 groups), for which the reference quotes "around 24 hrs" (README.md:87).  TWO groups are run: the
     first group's shuffle, copy and file writes overlap the second group's renders (the steady state of the 100-group job), the
-    second group's are the exposed tail, which the job pays once."""
+    second group's are the exposed tail, which the job pays once.  `sds`: another teacher pair than the synthetic one (the
+    trained-like leg: one group)."""
     import shutil
     import tempfile
     from efficient_nerf_amd import NeRFEngine, PRECISIONS
     from efficient_nerf_amd import create_data as CD
-    th, n_pose = 400, 200
+    th = 400
     focal = O.focal_from_angle(th)
     auto = precision == 'auto'
-    eng = NeRFEngine(th, th, focal, precision=PRECISIONS['fp16x3' if auto else precision]).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    eng = NeRFEngine(th, th, focal, precision=PRECISIONS['fp16x3' if auto else precision]).load_state_dicts(*(sds or (O.make_teacher_state(1), O.make_teacher_state(2))))
     if auto:       # what `python create_data.py` does by default: the fastest mode whose measured difference from fp16x3 is inside its
         precision = CD.choose_precision_for_rand(eng, th, th, focal)      # limits on every probe pose; watched per save group
     eng.render(O.novel_poses(1)[0][:3, :4])          # buffers allocated, kernels loaded
@@ -122,7 +123,7 @@ def create_data_leg(torch, O, precision):
         shutil.rmtree(out, ignore_errors=True)
     eng.close()
     mlp_s = tm.get('mlp_kernel_ms', 0.0) / 1e3
-    return {'workload': 'create_data rand: 2 save groups of 100 random poses (random focal) 400x400, NeRF teacher 64 + 128 samples, '
+    return {'workload': 'create_data rand: %d save group(s) of 100 random poses (random focal) 400x400,' % (n_pose // 100) + ' NeRF teacher 64 + 128 samples, '
                         'i_save 100, split_size 4096 (utils/create_data.py:812-872)', 'precision': precision, 'groups': tm.get('groups'),
             'poses': n_pose, 'shards': n, 'shard_bytes_total': nbytes, 'wall_s': wall, 'poses_per_s': n_pose / wall,
             'rays_per_s': n_pose * th * th / wall,
@@ -242,6 +243,10 @@ def trained_like_leg(torch, O, cpu):
                  sigma_max=float(torch.relu(want['raw'][..., 3]).max()))
     teng.close()
     out['teacher'] = t
+    # ... and BASELINE config 5's unit of work with this teacher: one save group of 100 poses through `create_data rand`
+    cd = create_data_leg(torch, O, 'auto', sds=tsds, n_pose=100)
+    out['create_data'] = {k: cd[k] for k in ('workload', 'precision', 'poses', 'shards', 'wall_s', 'poses_per_s', 'mlp_kernel_share_of_wall', 'watch',
+                                             'extrapolated_n_pose_kd_10000_hours_one_gpu')}
     return out
 
 

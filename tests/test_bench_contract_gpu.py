@@ -90,6 +90,7 @@ def test_bench_line_round4_fields():
     assert st['rung'] in ('fp16_split', 'fp16_split8') and st['max_abs_activation'] > 10 and st['rays_per_s'] > st['rays_per_s_fp16x3_asm'] > 1e7
     assert 0 <= st['split_block'] < st['n_block'] == 43 and st['watch_worst_rgb_diff_from_three_passes'] <= st['watch_limit']
     assert tl['teacher']['precision'] == 'fp16x3_asm' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
+    assert tl['create_data']['precision'] == 'fp16x3_asm' and tl['create_data']['poses'] == 100 and tl['create_data']['shards'] == 3906 and tl['create_data']['poses_per_s'] > 5
     assert tl['teacher']['mlp_launches'] == 6 and 0 < tl['teacher']['mlp_kernel_ms_per_frame'] <= tl['teacher']['ms_per_frame']
     assert tl['teacher']['whole_frame_rgb_linf_from_fp16x3']['fp16x1'] > 1e-3
     assert 'value_valid_for' in d and 'trained-like' in d['value_valid_for']
