@@ -1,0 +1,117 @@
+"""CPU: the decision logic of the split rungs (R2LEngine.choose_split / step_down_split / choose_precision's verification; the
+reference has no counterpart: model/nerf_raybased.py:443-465, 539-544 compute in fp32) on a stand-in engine whose "renders" are numbers
+from an error model -- the bisection per format, the cost comparison between the formats, the bound on the second format's search,
+the fallback to fp16x3_asm, and the verification of the rung the activation limits name.  No GPU, no library call."""
+import pytest
+import torch
+
+
+def _fake(pkg, nb, err, stream_max=100.0):
+    """an R2LEngine without a context: err(mode, split) -> the L_inf the probe frame would show against three passes"""
+    from efficient_nerf_amd import r2l as R
+
+    class Fake(R.R2LEngine):
+        def __init__(self):
+            self.n_block, self.device, self.split_block, self.precision = nb, 'cpu', None, R.PREC_FP16X3
+            self.renders = self.repacks = 0
+            self.stream_max = stream_max
+
+        def set_precision(self, p):
+            self.repacks += 1
+            self.precision = int(p)
+            if self.precision in R.TWO_PART and self.split_block is None:
+                self.split_block = nb // 2
+
+        def set_split_block(self, sp):
+            assert 0 <= sp <= nb
+            self.split_block = int(sp)
+
+        def _probe_render(self, c2w, rays):
+            self.renders += 1
+            if self.precision in R.TWO_PART:
+                e = err(self.precision, self.split_block)
+            elif self.precision == R.PREC_FP16X3_ASM:
+                e = 0.0
+            else:
+                e = err(self.precision, None)
+            return torch.tensor([[0.5 + e, 0.5, 0.5]])
+
+        def range_status(self, reset=False):
+            return {}
+
+        def calibrate_on(self, c2w=None, rays=None):
+            return [3] * (2 * nb + 1)
+    return Fake(), R
+
+
+def test_bisection_takes_the_cheaper_format(pkg):
+    """a network like the committed fixture: bf6 terms need 21 blocks in front, e4m3 terms none -> fp16_split8 at block 0 (51.2 against
+    56.2 bf6-block times); the e4m3 search starts below the split that would cost as much as the bf6 result"""
+    nb = 43
+    err = lambda mode, sp: (9.8e-5 if mode == 5 else 4.8e-5) * (1.0 - sp / nb) ** 0.35     # falls with the split, steeply at the end
+    eng, R = _fake(pkg, nb, err)
+    sp, d = eng.choose_split(c2w=None)
+    assert eng.precision == R.PREC_FP16_SPLIT8 and sp == 0 and d == pytest.approx(4.8e-5, rel=2e-3)
+    six = eng.auto_split['fp16_split']
+    best6 = min(k for k, v in six.items() if v <= eng.AUTO_SPLIT_MAX_DIFF)
+    assert six[best6] <= 5e-5 and all(err(5, k) > 5e-5 for k in range(best6)) and 0 in six      # the smallest qualifying split, found by bisection
+    eight = eng.auto_split['fp16_split8']
+    bound = (eng.split_cost(R.PREC_FP16_SPLIT, best6) - 1.19 * nb) / (1.63 - 1.19)
+    assert max(eight) < bound and 0 in eight
+    assert eng.renders <= 16
+
+
+def test_bf6_stays_when_it_is_cheaper_and_e4m3_is_not_even_measured(pkg):
+    """the second trained network: bf6 terms from block 9 on cost 48.7 bf6-block times, e4m3 terms from block 0 on 51.2"""
+    nb = 43
+    err = lambda mode, sp: 7.9e-5 * (1.0 - sp / 40.0) ** 2 if mode == 5 else 1e-6
+    eng, R = _fake(pkg, nb, err)
+    sp, d = eng.choose_split(c2w=None)
+    assert eng.precision == R.PREC_FP16_SPLIT and err(5, sp) <= 5e-5 < err(5, sp - 1)
+    assert eng.split_cost(R.PREC_FP16_SPLIT, sp) < eng.split_cost(R.PREC_FP16_SPLIT8, 0)
+    assert eng.auto_split['fp16_split8'] == {}       # tried nothing: no split of it could be cheaper
+
+
+def test_nothing_qualifies_or_too_little_is_saved(pkg):
+    nb = 43
+    eng, R = _fake(pkg, nb, lambda mode, sp: 3e-4 * (nb - sp) / nb + (1e-4 if sp < nb else 0.0))     # i.i.d.-like: every block counts, a floor on top
+    assert eng.choose_split(c2w=None) == (None, 0.0) and eng.precision == R.PREC_FP16X3_ASM and eng.split_block is None
+    # qualifying only with 41 of 43 blocks in three passes: 43 x 1.63 = 70.1 against 41 x 1.63 + 2 = 68.8 -> 1.8 % saved: not worth it
+    eng, R = _fake(pkg, nb, lambda mode, sp: 0.0 if sp >= 41 else 1e-3)
+    assert eng.choose_split(c2w=None)[0] is None and eng.precision == R.PREC_FP16X3_ASM
+    # NaN fails every comparison
+    eng, R = _fake(pkg, nb, lambda mode, sp: float('nan') if sp < nb else 0.0)
+    assert eng.choose_split(c2w=None)[0] is None
+
+
+def test_step_down_moves_half_of_the_rest_and_ends_in_three_passes(pkg):
+    nb = 43
+    eng, R = _fake(pkg, nb, lambda mode, sp: 0.0)
+    eng.set_precision(R.PREC_FP16_SPLIT8)
+    eng.set_split_block(0)
+    seen = []
+    while True:
+        name = eng.step_down_split()
+        seen.append((name, eng.split_block))
+        if name == 'fp16x3_asm':
+            break
+    assert seen[0] == ('fp16_split8', 22) and seen[1] == ('fp16_split8', 33) and seen[-1] == ('fp16x3_asm', None) and len(seen) <= 5
+    assert all(eng.split_cost(R.PREC_FP16_SPLIT8, s) <= 0.95 * 1.63 * nb for n, s in seen[:-1])
+
+
+def test_the_rung_the_limits_name_is_verified(pkg):
+    """activations inside fp16_fp8's limit: the rung is rendered against three passes; inside the limit it stays (two probe renders,
+    three re-packs), beyond it the measured rungs take over -- whatever the activations say"""
+    nb = 43
+    eng, R = _fake(pkg, nb, lambda mode, sp: 3.2e-5 if sp is None else 1e-5, stream_max=6.2)
+    name, top = eng.choose_precision(c2w=None)
+    assert name == 'fp16_fp8' and eng.auto_verify == pytest.approx(3.2e-5, rel=2e-3) and eng.auto_split is None and eng.renders == 2
+    eng, R = _fake(pkg, nb, lambda mode, sp: 1.35e-4 if sp is None else (8e-5 if mode == 5 else 3e-5) * (1 - sp / nb), stream_max=3.9)
+    name, top = eng.choose_precision(c2w=None)
+    assert eng.auto_verify == pytest.approx(1.35e-4, rel=2e-3) and name == 'fp16_split8' and eng.split_block == 0
+    # the middle rung is verified as itself
+    eng, R = _fake(pkg, nb, lambda mode, sp: {2: 9e-5, 3: 3e-5}.get(mode, 0.0) if sp is None else 0.0, stream_max=9.5)
+    assert eng.choose_precision(c2w=None)[0] == 'fp16_e4m3' and eng.auto_verify == pytest.approx(3e-5, rel=2e-3)
+    # `max_exp` (tests) switches both measurements off
+    eng, R = _fake(pkg, nb, lambda mode, sp: 1.0, stream_max=3.9)
+    assert eng.choose_precision(c2w=None, max_exp=3)[0] == 'fp16_fp8' and eng.auto_verify is None and eng.renders == 0
