@@ -1,4 +1,4 @@
-"""Randomised differential check on the GPU box: the generated kernels' modes (fp16_fp8, fp16_e4m3, fp16x3_asm) against fp16x3
+"""Randomised differential check on the GPU box: the generated kernels' modes (fp16_fp8, fp16_e4m3, fp16x3_asm, the two split modes) against fp16x3
 (compiler-scheduled kernels) on random networks, frame sizes, poses and weight gains; prints the worst difference per mode."""
 import os
 import sys
@@ -9,11 +9,12 @@ import numpy as np
 import torch
 import _pkg
 _pkg.load()
-from efficient_nerf_amd import NeRFEngine, R2LEngine, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM
+from efficient_nerf_amd import NeRFEngine, R2LEngine, PREC_FP16X3, PREC_FP16_FP8, PREC_FP16_E4M3, PREC_FP16X3_ASM, PREC_FP16_SPLIT, PREC_FP16_SPLIT8
 from oracle import r2l_oracle as O
 
 rng = np.random.default_rng(int(os.environ.get('SEED', 1)))
-MODES = (('fp16_fp8', PREC_FP16_FP8, 2e-4), ('fp16_e4m3', PREC_FP16_E4M3, 1e-4), ('fp16x3_asm', PREC_FP16X3_ASM, 1e-5))
+MODES = (('fp16_fp8', PREC_FP16_FP8, 2e-4), ('fp16_e4m3', PREC_FP16_E4M3, 1e-4), ('fp16x3_asm', PREC_FP16X3_ASM, 1e-5),
+         ('fp16_split', PREC_FP16_SPLIT, 2e-4), ('fp16_split8', PREC_FP16_SPLIT8, 1e-4))      # round 5: at a random split, with or without the global skip
 worst = {m[0]: 0.0 for m in MODES}
 for it in range(int(os.environ.get('N_R2L', 12))):
     H, W = int(rng.integers(3, 70)), int(rng.integers(3, 70))
@@ -31,6 +32,8 @@ for it in range(int(os.environ.get('N_R2L', 12))):
     e3.close()
     for name, prec, tol in MODES:
         e8 = R2LEngine(H, W, focal, n_block=nb, precision=prec).load_state_dict(sd)
+        if name.startswith('fp16_split'):
+            e8.set_split_block(int(rng.integers(0, nb + 1)))
         b = e8.render(c2w).cpu()
         d = (a - b).abs().max().item()
         assert torch.isfinite(b).all() and d < tol, (name, H, W, nb, gain, d)

@@ -12,8 +12,13 @@ rows = int(os.environ.get('S_ROWS', H))
 sd = O.make_r2l_state(seed=0, netdepth=2 + 2 * nb)
 eng = R2LEngine(H, H, O.focal_from_angle(H), n_block=nb, precision=PRECISIONS[name]).load_state_dict(sd)
 poses = O.novel_poses(8)[:, :3, :4].contiguous().cuda()
-if name in ('fp16_fp8', 'fp16_e4m3'):
+if name in ('fp16_fp8', 'fp16_e4m3', 'fp16_split', 'fp16_split8'):
+    if name.startswith('fp16_split'):          # the two-part modes borrow fp16_fp8's exponents; S_SPLIT: blocks in three passes in front
+        eng.set_precision(PRECISIONS['fp16_fp8'])
     eng.calibrate_on(c2w=O.novel_poses(8)[0])
+    if name.startswith('fp16_split'):
+        eng.set_precision(PRECISIONS[name])
+        eng.set_split_block(int(os.environ.get('S_SPLIT', nb // 2)))
     eng.set_guard_period(int(os.environ.get('S_GUARD', 8)))
 ref = None
 bad = 0
