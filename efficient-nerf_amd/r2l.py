@@ -375,7 +375,7 @@ class R2LEngine:
     #: and the first `split` blocks in three passes and render the rest with bf6 / e4m3 terms; when the limits send a network to the last
     #: rung, `auto` MEASURES: every ray of the probe frame, rendered with a candidate split and with three passes everywhere
     #: (split = n_block, bit for bit fp16x3_asm), bisecting for the smallest split within AUTO_SPLIT_MAX_DIFF -- for both formats, and
-    #: takes the cheaper of the two results by BLOCK_COST (the fixture: e4m3 terms from block 0 on, 11.3 ms per 800 x 800 frame, against
+    #: takes the cheaper of the two results by BLOCK_COST (the fixture: e4m3 terms from block 0 on, 11.1 ms per 800 x 800 frame, against
     #: bf6 terms from block 21 on, 12.5 ms; its second variant: bf6 from block 9, 10.9 ms).  The limit keeps a factor of two to the
     #: contract for the poses the probe did not see (measured: up to 1.4 x the probe frame's maximum; watched: spot_check_split against
     #: SPLIT_WATCH_MAX_DIFF) and the 4e-6 between three passes and fp32.
@@ -389,8 +389,9 @@ class R2LEngine:
     SPLIT_WATCH_RAYS = 65536
     #: a split that would save less than this fraction of the three-pass body's time is not worth two launches and a watch: fp16x3_asm
     SPLIT_MIN_GAIN = 0.05
-    #: measured time of one ResMLP block at 800 x 800 in units of the bf6 kernel's (0.215 ms): e4m3 terms 0.256, three passes 0.352
-    BLOCK_COST = {PREC_FP16_SPLIT: 1.0, PREC_FP16_SPLIT8: 1.19, PREC_FP16X3_ASM: 1.63}
+    #: measured time of one ResMLP block at 800 x 800 in units of the bf6 kernel's (profiles/r05_split_time.txt: frame time over the split,
+    #: 0.129 ms per block moved from bf6 terms to three passes, 0.099 from e4m3 terms; bf6 0.205 ms, e4m3 0.235, three passes 0.334)
+    BLOCK_COST = {PREC_FP16_SPLIT: 1.0, PREC_FP16_SPLIT8: 1.15, PREC_FP16X3_ASM: 1.63}
 
     @property
     def precision_name(self):

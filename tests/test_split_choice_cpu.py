@@ -45,7 +45,7 @@ def _fake(pkg, nb, err, stream_max=100.0):
 
 
 def test_bisection_takes_the_cheaper_format(pkg):
-    """a network like the committed fixture: bf6 terms need 21 blocks in front, e4m3 terms none -> fp16_split8 at block 0 (51.2 against
+    """a network like the committed fixture: bf6 terms need 21 blocks in front, e4m3 terms none -> fp16_split8 at block 0 (49.5 against
     56.2 bf6-block times); the e4m3 search starts below the split that would cost as much as the bf6 result"""
     nb = 43
     err = lambda mode, sp: (9.8e-5 if mode == 5 else 4.8e-5) * (1.0 - sp / nb) ** 0.35     # falls with the split, steeply at the end
@@ -56,13 +56,14 @@ def test_bisection_takes_the_cheaper_format(pkg):
     best6 = min(k for k, v in six.items() if v <= eng.AUTO_SPLIT_MAX_DIFF)
     assert six[best6] <= 5e-5 and all(err(5, k) > 5e-5 for k in range(best6)) and 0 in six      # the smallest qualifying split, found by bisection
     eight = eng.auto_split['fp16_split8']
-    bound = (eng.split_cost(R.PREC_FP16_SPLIT, best6) - 1.19 * nb) / (1.63 - 1.19)
+    c8, c3 = eng.BLOCK_COST[R.PREC_FP16_SPLIT8], eng.BLOCK_COST[R.PREC_FP16X3_ASM]
+    bound = (eng.split_cost(R.PREC_FP16_SPLIT, best6) - c8 * nb) / (c3 - c8)
     assert max(eight) < bound and 0 in eight
     assert eng.renders <= 16
 
 
 def test_bf6_stays_when_it_is_cheaper_and_e4m3_is_not_even_measured(pkg):
-    """the second trained network: bf6 terms from block 9 on cost 48.7 bf6-block times, e4m3 terms from block 0 on 51.2"""
+    """the second trained network: bf6 terms from block 9 on cost 48.7 bf6-block times, e4m3 terms from block 0 on 49.5"""
     nb = 43
     err = lambda mode, sp: 7.9e-5 * (1.0 - sp / 40.0) ** 2 if mode == 5 else 1e-6
     eng, R = _fake(pkg, nb, err)
