@@ -42,14 +42,16 @@ for kind in ('uniform', 'laplace', 'sparse', 'outlier'):
             ea = R2LEngine(H, H, focal).load_state_dict(sd)
             pick, ptop = ea.choose_precision(c2w=poses[0])
             err = max((ea.render(c) - r).abs().max().item() for c, r in zip(poses, ref))
+            # round 5: how auto got there -- the rung the limits name against three passes on the probe frame, the measured split
+            how = ('' if ea.auto_verify is None else ' verify %.1e' % ea.auto_verify) + ('' if ea.split_block is None else ' split %d' % ea.split_block)
             ea.close()
             key = pick
             worst_by_rung[key] = max(worst_by_rung.get(key, 0.0), err)
             print('%-8s seed %d gain %.2f: exponent x %2d h %2d  max|a| %6.2f   L_inf vs fp16x3: fp16_fp8 %.2e (%.1e x max|a|)  fp16_e4m3 %.2e '
-                  '(%.1e x max|a|)   auto -> %-10s %.2e  %s'
+                  '(%.1e x max|a|)   auto -> %-11s %.2e  %s%s'
                   % (kind, seed, gain, top[0], top[1], top[2], worst['fp16_fp8'], worst['fp16_fp8'] / top[2], worst['fp16_e4m3'],
-                     worst['fp16_e4m3'] / top[2], pick, err, 'OK' if err <= 7e-5 else ('tight' if err <= 1e-4 else 'OVER')), flush=True)
+                     worst['fp16_e4m3'] / top[2], pick, err, 'OK' if err <= 7e-5 else ('tight' if err <= 1e-4 else 'OVER'), how), flush=True)
 print()
 for pick, e in sorted(worst_by_rung.items()):
-    print('worst L_inf of what auto rendered with, by rung (fp16_fp8: max|a| <= %g, fp16_e4m3: <= %g, fp16x3_asm above): %-10s %.2e'
+    print('worst L_inf of what auto rendered with, by rung (fp16_fp8: max|a| <= %g, fp16_e4m3: <= %g, both verified; measured split rungs or fp16x3_asm above): %-11s %.2e'
           % (R2LEngine.AUTO_MAX_ABS, R2LEngine.AUTO_MAX_ABS_E4M3, pick, e))
