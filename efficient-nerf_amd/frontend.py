@@ -388,20 +388,22 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
         if auto:
             if probe_pose is None and probe_rays is None:
                 raise R2LError('--precision auto needs a pose or rays to measure the activation ranges with')
-            name, top = eng.choose_precision(c2w=probe_pose, rays=probe_rays)
+            # ranges from the first pose; the verification of the rung and the split measurement on up to three poses spanning the path
+            plist = [p for p in (probe_poses or []) if p is not None]
+            name, top = eng.choose_precision(c2w=plist if (probe_rays is None and len(plist) > 1) else probe_pose, rays=probe_rays)
             if log and top is None:
                 log(f'[precision] auto: {eng.auto_note} -> {name}')
             elif log:
                 log(f'[precision] auto: activations of every ray of the first frame up to {eng.stream_max:.2f} (exponent {top}; '
                     f'fp16_fp8 up to {eng.AUTO_MAX_ABS:g}, fp16_e4m3 up to {eng.AUTO_MAX_ABS_E4M3:g}) -> {name}')
                 if getattr(eng, 'auto_verify', None) is not None:
-                    log(f'[precision] auto: the rung those limits name is {eng.auto_verify:.1e} from three passes on every ray of the first frame '
+                    log(f'[precision] auto: the rung those limits name is {eng.auto_verify:.1e} from three passes on every ray of {max(1, len(plist))} probe frame(s) '
                         f'(limit {eng.AUTO_VERIFY_MAX_DIFF:g})' + ('' if eng.auto_verify <= eng.AUTO_VERIFY_MAX_DIFF else ': measured rungs instead'))
                 if getattr(eng, 'auto_split', None):
                     tried = '; '.join(f"{'e4m3' if m.endswith('8') else 'bf6'} terms behind them: " + ', '.join(f'{k}: {v:.1e}' for k, v in t.items())
                                       for m, t in eng.auto_split.items())
                     log(f'[precision] auto: leading blocks in three passes, largest rgb difference from three passes everywhere on every ray of '
-                        f'the first frame -- {tried} (limit {eng.AUTO_SPLIT_MAX_DIFF:g}) -> ' +
+                        f'{max(1, len(plist))} probe frame(s) -- {tried} (limit {eng.AUTO_SPLIT_MAX_DIFF:g}) -> ' +
                         (f'{name} at block {eng.split_block} of {eng.n_block}' if name.startswith('fp16_split') else name))
         return 'R2L', eng
     if args.model_name == 'nerf':

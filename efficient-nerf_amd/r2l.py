@@ -319,7 +319,8 @@ class R2LEngine:
         """`--precision auto`: the fastest mode the network's own activation ranges allow: fp16_fp8 (bf6 correction terms)
         up to max|a| = 8, fp16_e4m3 up to 10, fp16x3_asm above.  The error of the low-precision terms is relative to the residual
         stream, the contract (L_inf <= 1e-4 on rgb) is absolute, so the choice needs the ranges of THESE weights:
-        `calibrate_on` measures them on every ray of the frame of pose `c2w` (or of the given `rays` = (rays_o, rays_d)).
+        `calibrate_on` measures them on every ray of the frame of pose `c2w` (or of the given `rays` = (rays_o, rays_d); `c2w` may be a
+        list of poses: ranges from the first, the two measurements below over all).
         The rung the limits name is then verified against three passes on the probe frame (AUTO_VERIFY), and networks beyond the limits
         -- or failing that check -- get a measured split rung (choose_split).
         `max_exp` overrides fp16_fp8's limit and disables the middle step and both measurements (tests).  What is rendered afterwards stays
@@ -338,7 +339,9 @@ class R2LEngine:
             return 'fp16x3', None
         if self.n_block == 0:
             return 'fp16_fp8', 0
-        top = max(self.calibrate_on(c2w=c2w, rays=rays))
+        # a list of poses (frontend.render_path: first, middle, last of the path): ranges from the first, as every first render does;
+        # the verification and the split measurement below on all of them
+        top = max(self.calibrate_on(c2w=c2w[0] if isinstance(c2w, (list, tuple)) else c2w, rays=rays))
         self._auto = (max_exp,)
         mode = self.LADDER[self._rung_for(self.stream_max, max_exp)]
         self.split_block = None
@@ -405,8 +408,12 @@ class R2LEngine:
         self.split_block = int(split)
 
     def _probe_render(self, c2w, rays):
+        """the probe frame(s) of choose_precision / choose_split: the given rays, one pose, or a list of poses (rendered one after the
+        other: the decisions are taken on the largest difference over all of them)"""
         if rays is not None:
             return self.render_rays(rays[0].contiguous().to(self.device, torch.float32), rays[1].contiguous().to(self.device, torch.float32))
+        if isinstance(c2w, (list, tuple)):
+            return torch.cat([self.render(p).clone() for p in c2w], 0)
         return self.render(c2w)
 
     def split_cost(self, mode, split):
