@@ -160,12 +160,13 @@ def trained_like_leg(torch, O, cpu):
     focal = O.focal_from_angle(W)
     test = O.novel_poses(200)
     eng = R2LEngine(H, W, focal, 2., 6., n_block=N_BLOCK, use_residual=True).load_state_dict(ssd)
-    rung, top = eng.choose_precision(c2w=test[0][:3, :4])
+    # as the command line does for a render path: ranges from the first pose, verification / split measurement on the first, middle, last
+    rung, top = eng.choose_precision(c2w=[test[k][:3, :4] for k in (0, 100, 199)])
     s = {'rung': rung, 'max_act_exponent': None if top is None else int(top), 'max_abs_activation': float(eng.stream_max),
          'rgb_diff_from_three_passes_of_the_rung_the_limits_name': eng.auto_verify,
          'ladder': 'fp16_fp8 up to %g, fp16_e4m3 up to %g, above: fp16_split / fp16_split8 (head + the first `split_block` blocks in three fp16 passes, '
-                   'the rest with bf6 / e4m3 terms; per format the split bisected for rgb within %g of three passes everywhere on every ray of the '
-                   'probe frame, the cheaper of the two taken), fp16x3_asm when that would save less than 5 %% of its body time' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3, eng.AUTO_SPLIT_MAX_DIFF)}
+                   'the rest with bf6 / e4m3 terms; per format the split bisected for rgb within %g of three passes everywhere on every ray of three '
+                   'probe frames (first, middle, last test pose), the cheaper of the two taken), fp16x3_asm when that would save less than 5 %% of its body time' % (eng.AUTO_MAX_ABS, eng.AUTO_MAX_ABS_E4M3, eng.AUTO_SPLIT_MAX_DIFF)}
     if rung.startswith('fp16_split'):
         s.update(split_block=eng.split_block, n_block=eng.n_block, terms_behind_the_split='e4m3' if rung.endswith('8') else 'bf6',
                  split_probe_diffs={m: {str(k): v for k, v in sorted(t.items())} for m, t in eng.auto_split.items()})
