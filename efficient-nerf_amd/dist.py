@@ -213,11 +213,12 @@ def agree_act_exponents(eng, group=None):
     """R2L_PREC_FP16_FP8 measures its bf6 activation exponents on the first render's own rays (include/r2l_hip.h) -- under
     row sharding every rank sees other rays and would end with its own set, and the rows of one assembled frame would come
     from slightly different arithmetic.  Call once after the first render of every rank: the ranks take the element-wise
-    maximum (what one GPU would have measured on all their samples together).  Synchronous; no-op for one rank or for
-    the other precisions."""
-    from ._lib import PREC_FP16_FP8, PREC_FP16_E4M3
-    if not dist.is_initialized() or dist.get_world_size(group) == 1 or eng.precision not in (PREC_FP16_FP8, PREC_FP16_E4M3) \
-            or eng.n_block == 0:
+    maximum (what one GPU would have measured on all their samples together).  Every mode with calibrated operand scales takes
+    part: fp16_fp8, fp16_e4m3 and the two-part modes fp16_split / fp16_split8, whose low-precision blocks read the same exponents
+    (an explicit `--precision fp16_split` on several ranks kept per-rank exponents).  Synchronous; no-op for one rank or
+    for the modes without scales."""
+    from .r2l import SPLIT_MODES
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or eng.precision not in SPLIT_MODES or eng.n_block == 0:
         return None
     ex = torch.tensor(eng.act_exponents(), dtype=torch.int32)
     if dist.get_backend(group) == 'nccl':
@@ -226,6 +227,29 @@ def agree_act_exponents(eng, group=None):
     ex = [int(v) for v in ex.cpu()]
     eng.set_act_exponents(ex)
     return ex
+
+
+def agree_precision(eng, group=None):
+    """`--precision auto` measures its rung on every rank (R2LEngine.choose_precision / choose_split: a bisection over maxima that are
+    noisy at the 1e-5 level).  The ranks render rows of the SAME frames, so they must run the same arithmetic and enter the same watch
+    collectives: rank 0's (mode, split_block) is broadcast and every rank adopts it; the activation exponents follow
+    (agree_act_exponents).  Returns (mode, split_block) in use.  No-op for one rank."""
+    mode, split = int(eng.precision), -1 if getattr(eng, 'split_block', None) is None else int(eng.split_block)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return mode, split
+    t = torch.tensor([mode, split], dtype=torch.int32)
+    if dist.get_backend(group) == 'nccl':
+        t = t.to(eng.device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    m0, s0 = (int(v) for v in t.cpu())
+    if m0 != mode:
+        eng.set_precision(m0)
+    if s0 >= 0 and (m0 != mode or s0 != split):
+        eng.set_split_block(s0)
+    elif s0 < 0:
+        eng.split_block = None
+    agree_act_exponents(eng, group)
+    return m0, s0
 
 
 def check_ranges(eng, log=None, group=None):

@@ -391,6 +391,9 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
             # ranges from the first pose; the verification of the rung and the split measurement on up to three poses spanning the path
             plist = [p for p in (probe_poses or []) if p is not None]
             name, top = eng.choose_precision(c2w=plist if (probe_rays is None and len(plist) > 1) else probe_pose, rays=probe_rays)
+            from . import dist as D
+            D.agree_precision(eng)        # several ranks: rank 0's rung and split on every rank (each measured its own; they must not differ)
+            name = eng.precision_name
             if log and top is None:
                 log(f'[precision] auto: {eng.auto_note} -> {name}')
             elif log:
@@ -431,11 +434,11 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
             return 'nerf', eng
         if 'network_fine_state_dict' not in ckpt:
             raise KeyError("checkpoint lacks 'network_fine_state_dict'")
+        if args.precision in ('fp16_e4m3', 'fp16_split', 'fp16_split8'):
+            raise R2LError(f'--precision {args.precision} is a mode of the R2L student (the teacher has fp16x3, fp16x3_asm, fp16_fp8, fp16x1)')
         eng = NeRFEngine(H, W, focal, near, far, N_samples=args.N_samples, N_importance=args.N_importance,
                          multires=args.multires, multires_views=args.multires_views, white_bkgd=args.white_bkgd,
                          precision=prec, ndc=llff_ndc, lindisp=args.lindisp)  # main.py:160-162, 525-528, 679-680
-        if args.precision == 'fp16_e4m3':
-            raise R2LError(f'--precision {args.precision} is a mode of the R2L student (the teacher has fp16x3, fp16x3_asm, fp16_fp8, fp16x1)')
         eng.load_state_dicts(ckpt['network_fn_state_dict'], ckpt['network_fine_state_dict'])
         if auto:
             # one fp16 pass / the chain's bf6 terms under fixed activation exponents: measured against fp16x3 on rays of the job's
@@ -550,27 +553,37 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
                 got = watched(i, ro, rd, got)
             dst[f].copy_(got if kind == 'R2L' else got['rgb_map'])
 
-    # the split rung of the R2L ladder under watch: `auto` measured on the first frame how many leading blocks need three passes (the
-    # rest keep their bf6 terms); every watch_every-th batch a sample of the rank's own rays of the batch's first frame is rendered with
-    # the split and with three passes everywhere (R2LEngine.spot_check_split); a miss on any rank moves half of the bf6 part to three
-    # passes on every rank and the batch is rendered again
-    split_watching = kind == 'R2L' and watch_every > 0 and hasattr(eng, 'spot_check_split')
+    # every rung `auto` can choose for the R2L student under an rgb watch (R2LEngine.spot_check_rgb): the split rungs -- `auto` measured on
+    # the probe frames how many leading blocks need three passes -- every watch_every-th batch (a sample of the rank's own rays of the
+    # batch's first frame with the split and with three passes everywhere; a miss on any rank moves half of the low-precision part to
+    # three passes on every rank); the whole-network rungs fp16_fp8 / fp16_e4m3 (round 6) every WHOLE_WATCH_EVERY-th batch against a second
+    # context holding the weights in three passes (a miss sends the network to the measured split rungs: rank 0's choice on every
+    # rank, then checked on every rank's rays by the same loop).  The batch is rendered again after every change.
+    split_watching = kind == 'R2L' and watch_every > 0 and hasattr(eng, 'spot_check_rgb')
     split_watch = {'checks': 0, 'fallbacks': [], 'worst': 0.0}
+    whole_every = max(1, int(getattr(eng, 'WHOLE_WATCH_EVERY', 16) * watch_every / 8)) if watch_every > 0 else 0
+
+    def watch_due(n_batches):
+        mode = eng.watched_mode() if split_watching else None
+        return (mode == 'split' and n_batches % watch_every == 0) or (mode == 'whole' and n_batches % whole_every == 0)
 
     def watch_split(i0, nb):
         from .teacher import get_rays
         again = 0
         for _ in range(6):
-            if not str(getattr(eng, 'precision_name', '')).startswith('fp16_split') or getattr(eng, '_auto', None) is None:
-                break          # an explicit --precision fp16_split keeps its split, as every explicit mode keeps itself
-            if given_rays is not None:
-                ro = given_rays[0][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
-                rd = given_rays[1][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
-            else:
-                ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(render_poses[i0])[:3, :4], rows=(r0, r1), device=eng.device))
-            ok, d = eng.spot_check_split(ro, rd)
-            split_watch['checks'] += 1
-            split_watch['worst'] = max(split_watch['worst'], d)
+            # every rank enters the collective whatever its local mode is (a rank that had left the rung would otherwise
+            # miss the all-reduce its peers are in); a rank with nothing to watch reports "good"
+            mode = eng.watched_mode()
+            ok, d = True, 0.0
+            if mode is not None:
+                if given_rays is not None:
+                    ro = given_rays[0][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+                    rd = given_rays[1][i0].reshape(H, W, 3)[r0:r1].reshape(-1, 3).contiguous().to(eng.device, torch.float32)
+                else:
+                    ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(render_poses[i0])[:3, :4], rows=(r0, r1), device=eng.device))
+                ok, d = eng.spot_check_rgb(ro, rd)
+                split_watch['checks'] += 1
+                split_watch['worst'] = max(split_watch['worst'], d)
             bad = 0 if ok else 1
             if world > 1:
                 t = torch.tensor([bad], dtype=torch.int32, device=eng.device if tdist.get_backend() == 'nccl' else 'cpu')
@@ -578,12 +591,23 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
                 bad = int(t.item())
             if not bad:
                 break
-            was = eng.split_block
-            now = eng.step_down_split()
-            split_watch['fallbacks'].append({'frame': i0, 'split': was, 'to': eng.split_block if now.startswith('fp16_split') else now, 'diff': d})
+            was_mode, was = eng.precision_name, eng.split_block
+            if mode == 'whole':
+                now = eng.step_down_whole(ro, rd)
+                D.agree_precision(eng)                 # rank 0's measured rung on every rank; the loop checks it on every rank's rays next
+                now = eng.precision_name
+                limit, n_w = eng.WHOLE_WATCH_MAX_DIFF, eng.WHOLE_WATCH_RAYS
+            elif mode == 'split':
+                now = eng.step_down_split()
+                limit, n_w = eng.SPLIT_WATCH_MAX_DIFF, eng.SPLIT_WATCH_RAYS
+            else:                                      # a peer missed: follow its rung (it steps down deterministically from the shared state)
+                now = eng.precision_name
+                limit, n_w = eng.SPLIT_WATCH_MAX_DIFF, eng.SPLIT_WATCH_RAYS
+            split_watch['fallbacks'].append({'frame': i0, 'from': was_mode, 'split': was, 'to': eng.split_block if now.startswith('fp16_split') else now, 'diff': d})
             if rank == 0:
-                log(f'[precision] frame {i0}: with low-precision terms from block {was} on {d:.1e} from three passes on {eng.SPLIT_WATCH_RAYS} of its rays '
-                    f'(limit {eng.SPLIT_WATCH_MAX_DIFF:g}) -> ' + (f'split at block {eng.split_block}' if now.startswith('fp16_split') else now) + '; batch rendered again')
+                what = f'with low-precision terms from block {was} on' if mode == 'split' else f'{was_mode} is'
+                log(f'[precision] frame {i0}: {what} {d:.1e} from three passes on {n_w} of its rays (limit {limit:g}) -> ' +
+                    (f'{now} at block {eng.split_block}' if now.startswith('fp16_split') else now) + '; batch rendered again')
             eng.render_checked(lambda: render_local(i0, nb), check=check)
             again += 1
         return again
@@ -644,7 +668,7 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
             # raised, or the context falls back (`auto`), and the batch is rendered again -- one check per batch
             _, again = eng.render_checked(lambda: render_local(i0, nb), check=check)
             n_again += again
-            if split_watching and n_batches % watch_every == 0:
+            if watch_due(n_batches):
                 n_again += watch_split(i0, nb)
         else:
             render_local(i0, nb)
@@ -681,7 +705,7 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
         if watching:
             stats['watch'] = dict(watch, every=watch_every, precision=eng.precision_name)
         if split_watching and split_watch['checks']:
-            stats['split_watch'] = dict(split_watch, every=watch_every, precision=eng.precision_name, split_block=eng.split_block)
+            stats['split_watch'] = dict(split_watch, every=watch_every, whole_every=whole_every, precision=eng.precision_name, split_block=eng.split_block)
         if host_stack is not None:
             stats['host_frames'] = host_stack          # complete: writer.close() has waited for every copy
     misc = {}

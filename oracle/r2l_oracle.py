@@ -541,6 +541,38 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, near=2., far=6., N_samples=6
                 raw0=raw0, raw=raw, z_std=torch.std(z_samples, dim=-1, unbiased=False))
 
 
+def render_rays_taps(sd_coarse, sd_fine, rays_o, rays_d, dtype=torch.float32, near=2., far=6., N_samples=64, N_importance=128,
+                     white_bkgd=True, z_samples=None):
+    """render_rays (perturb = 0) with EVERY step evaluated in `dtype` and the sample_pdf taps returned: float32 = render_rays'
+    arithmetic; float64 = the same functions on the same float32 inputs (rays, the host's float32 linspace values of t and u) with
+    ~1e-16 rounding, the stand-in for exact arithmetic the whole-frame classification measures both the fp32 reference and the HIP
+    path against (tools/teacher_whole_frame.py).  `z_samples` (optional, [n, N_importance]) replaces sample_pdf's output: the fine
+    pass at GIVEN sample positions.  main.py:624-756, helpers:283-330."""
+    ro, rd = rays_o.to(dtype), rays_d.to(dtype)
+    viewdirs = rd / torch.norm(rd, dim=-1, keepdim=True)
+    t_vals = torch.linspace(0., 1., steps=N_samples).to(rd.device, dtype)
+    z_vals = (near * torch.ones_like(rd[..., :1])) * (1. - t_vals) + (far * torch.ones_like(rd[..., :1])) * t_vals
+
+    def net(sd, pts):
+        e = torch.cat([nerf_embed(pts.reshape(-1, 3), 10), nerf_embed(viewdirs[:, None].expand(pts.shape).reshape(-1, 3), 4)], -1)
+        return teacher_forward(sd, e, dtype=dtype).reshape(list(pts.shape[:-1]) + [4])
+
+    raw0 = net(sd_coarse, ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None])
+    rgb0, disp0, acc0, weights0, depth0 = raw2outputs(raw0, z_vals, rd, white_bkgd)
+    z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    u = torch.linspace(0., 1., steps=N_importance).to(rd.device, dtype).expand(ro.shape[0], N_importance)
+    zs, cdf, inds = sample_pdf(z_mid, weights0[..., 1:-1], N_importance, u=u, taps=True)
+    below, above = (inds - 1).clamp(min=0), inds.clamp(max=cdf.shape[-1] - 1)
+    denom = torch.gather(cdf, 1, above) - torch.gather(cdf, 1, below)
+    if z_samples is not None:
+        zs = z_samples.to(dtype)
+    z_all = merge_z(z_vals, zs)
+    raw = net(sd_fine, ro[..., None, :] + rd[..., None, :] * z_all[..., :, None])
+    rgb, disp, acc, weights, depth = raw2outputs(raw, z_all, rd, white_bkgd)
+    return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, rgb0=rgb0, acc0=acc0, weights0=weights0, cdf=cdf, inds=inds,
+                denom=denom, u=u, z_samples=zs, z_vals=z_all, raw0=raw0, raw=raw)
+
+
 def teacher_render(sd_coarse, sd_fine, H, W, focal, c2w, rows=None, chunk=4096, ndc=False, **kw):
     """main.py:107-186 (render, c2w given, use_viewdirs=True) over a row range; ndc=True projects the
     rays with ndc_rays(H, W, focal, 1., ...) after the view directions were taken (main.py:148-162)."""

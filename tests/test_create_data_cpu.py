@@ -62,7 +62,9 @@ def _digest(d):
     return out
 
 
-@pytest.mark.parametrize('world,i_save,n_pose', [(2, 5, 11), (3, 5, 11), (3, 4, 9)])
+# (8, 8, 17): the target machine's world size -- 8 poses per save group (one per rank), two groups + a remainder pose;
+# (8, 5, 11): fewer poses per group than ranks
+@pytest.mark.parametrize('world,i_save,n_pose', [(2, 5, 11), (3, 5, 11), (3, 4, 9), (8, 8, 17), (8, 5, 11)])
 def test_multi_rank_directory_is_identical_to_single_rank(tmp_path, world, i_save, n_pose):
     H, W = 6, 8
     d1, dn = str(tmp_path / 'w1'), str(tmp_path / f'w{world}')

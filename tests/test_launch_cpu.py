@@ -57,6 +57,25 @@ def test_ranks_get_the_torchrun_environment_and_rank0_owns_stdout(tmp_path):
         assert e['argv'] == ['--x', '1'] and e['MASTER_PORT'] == out[0]['MASTER_PORT'] and int(e['MASTER_PORT']) > 0
 
 
+def test_eight_ranks(tmp_path):
+    """the driver's N = 8: eight children, ranks 0..7 each exactly once, one port, rank 0's line alone on stdout"""
+    script = _script(tmp_path, '''
+        import json, os
+        print(json.dumps({k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}), flush=True)
+    ''')
+    code = ('import importlib.util, sys\n'
+            'spec = importlib.util.spec_from_file_location("l", %r)\n'
+            'm = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n'
+            'sys.exit(m.spawn_ranks(%r, [], 8, timeout=60))\n') % (os.path.join(ROOT, 'efficient-nerf_amd', 'launch.py'), script)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    err = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{')]
+    assert [e['RANK'] for e in out] == ['0'] and sorted(int(e['RANK']) for e in err) == list(range(1, 8))
+    assert {e['WORLD_SIZE'] for e in out + err} == {'8'} and len({e['MASTER_PORT'] for e in out + err}) == 1
+    assert all(e['LOCAL_RANK'] == e['RANK'] for e in out + err)
+
+
 def test_json_only_keeps_library_chatter_off_stdout(tmp_path):
     """bench.py's launcher: the driver parses ONE JSON line from stdout; what gloo / RCCL print there while connecting
     ('[Gloo] Rank 0 is connected to ...' on the GPU box) is relayed to stderr"""

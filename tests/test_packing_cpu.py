@@ -227,11 +227,11 @@ def test_host_packers_under_asan_ubsan(pkg, built_lib, tmp_path):
     got = {}
     for ln in r.stdout.splitlines():
         t = ln.split()
-        got[(t[0], t[1]) if t[0] != 'pack_chain' else (t[0],)] = t[1:] if t[0] == 'pack_chain' else t[2:]
+        got[(t[0], t[1])] = t[2:]
     # the product library on the same tensors
     L = _lib.lib()
     keep, arr = _lib.host_ptrs([sd[n] for n in names])
-    for mode in range(5):
+    for mode in range(7):         # ... incl. the two-part modes fp16_split / fp16_split8
         size = L.r2l_debug_pack_host(arr, len(keep), n_block, mode, None, 0)
         buf = (C.c_char * size)()
         assert L.r2l_debug_pack_host(arr, len(keep), n_block, mode, buf, size) == size
@@ -245,11 +245,12 @@ def test_host_packers_under_asan_ubsan(pkg, built_lib, tmp_path):
         assert got[('pack_body', str(fmt))] == [str(size), _fnv(bytes(buf)), str(offs[0]), str(offs[1])], fmt
     L.r2l_debug_pack_body_format(0)
     tkeep, tarr = _lib.host_ptrs([tsd[n] for n in tnames])
-    off = (C.c_longlong * 1)()
-    size = L.nerf_debug_pack_chain_host(tarr, 24, 0, None, 0, off)
-    buf = (C.c_char * size)()
-    assert L.nerf_debug_pack_chain_host(tarr, 24, 0, buf, size, off) == size
-    assert got[('pack_chain',)] == [str(size), _fnv(bytes(buf)), str(off[0])]
+    for fmt in (0, 1, 2):         # the chain streams: bf6 terms, one fp16 pass, three passes (the p3 hi | lo layout: ADVICE r5)
+        off = (C.c_longlong * 1)()
+        size = L.nerf_debug_pack_chain_host(tarr, 24, fmt, None, 0, off)
+        buf = (C.c_char * size)()
+        assert L.nerf_debug_pack_chain_host(tarr, 24, fmt, buf, size, off) == size
+        assert got[('pack_chain', str(fmt))] == [str(size), _fnv(bytes(buf)), str(off[0])], fmt
     key = (np.uint32(2654435761) * np.arange(1, 625, dtype=np.uint32)).astype(np.uint32)
     pos = C.c_int(300)
     for n in (0, 1, 2, 63, 64, 65, 100000):

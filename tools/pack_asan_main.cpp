@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     fclose(f);
     std::vector<const float*> p;
     for (auto& v : w) p.push_back(v.data());
-    for (int mode = 0; mode <= 4; ++mode) {       // R2L_PREC_FP16X3, FP16X1, FP16_FP8, FP16_E4M3, FP16X3_ASM: chunk streams / head streams
+    for (int mode = 0; mode <= 6; ++mode) {       // R2L_PREC_FP16X3, FP16X1, FP16_FP8, FP16_E4M3, FP16X3_ASM, FP16_SPLIT, FP16_SPLIT8: chunk / head streams
         long long n = r2l_debug_pack_host(p.data(), n_r2l, n_block, mode, nullptr, 0);
         if (n <= 0) {
             printf("pack_host mode %d: %s\n", mode, r2l_last_error());
@@ -72,16 +72,16 @@ int main(int argc, char** argv) {
         printf("pack_body %d %lld %016llx %lld %lld\n", fmt, n, (unsigned long long)fnv(out), offs[0], offs[1]);
     }
     r2l_debug_pack_body_format(0);
-    {
+    for (int fmt : {0, 1, 2}) {                    // the teacher's chain streams: bf6 terms, one fp16 pass, three fp16 passes (hi | lo pieces)
         long long off = 0;
-        long long n = nerf_debug_pack_chain_host(p.data() + n_r2l, 24, 0, nullptr, 0, &off);
+        long long n = nerf_debug_pack_chain_host(p.data() + n_r2l, 24, fmt, nullptr, 0, &off);
         if (n <= 0) {
-            printf("pack_chain: %s\n", r2l_last_error());
+            printf("pack_chain fmt %d: %s\n", fmt, r2l_last_error());
             return 1;
         }
         std::vector<char> out((size_t)n);
-        if (nerf_debug_pack_chain_host(p.data() + n_r2l, 24, 0, out.data(), n, &off) != n) return 1;
-        printf("pack_chain %lld %016llx %lld\n", n, (unsigned long long)fnv(out), off);
+        if (nerf_debug_pack_chain_host(p.data() + n_r2l, 24, fmt, out.data(), n, &off) != n) return 1;
+        printf("pack_chain %d %lld %016llx %lld\n", fmt, n, (unsigned long long)fnv(out), off);
     }
     {
         std::vector<unsigned> key(624);
