@@ -171,17 +171,37 @@ def trained_like_leg(torch, O, cpu):
         s.update(split_block=eng.split_block, n_block=eng.n_block, terms_behind_the_split='e4m3' if rung.endswith('8') else 'bf6',
                  split_probe_diffs={m: {str(k): v for k, v in sorted(t.items())} for m, t in eng.auto_split.items()})
 
-    def frames_per_s():
+    def frames_per_s(n=10):
+        """(wall seconds per frame, HIP-event milliseconds of the body launch(es) per frame, launches timed): the events bracket the
+        body launch -- in a two-part mode the pair of launches (three-pass part, low-precision part) -- on its stream"""
         eng.render(test[1][:3, :4])
+        eng.timing(True)
+        eng.kernel_time_ms(reset=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(10):
-            eng.render_checked(lambda: eng.render(test[2 + i][:3, :4]))
+        extra = 0
+        for i in range(n):
+            extra += eng.render_checked(lambda: eng.render(test[2 + i][:3, :4]))[1]
         torch.cuda.synchronize()
-        return (time.perf_counter() - t1) / 10
-    dt = frames_per_s()
+        wall = (time.perf_counter() - t1) / n
+        kms, kn = eng.kernel_time_ms(reset=True)
+        eng.timing(False)
+        return wall, kms / max(1, kn), kn, extra
+    dt, kms, kn, extra = frames_per_s()
+    kern = {'fp16_split': ['r2l_bodyx_kernel (blocks in front of the split)', 'r2l_body_kernel (behind it)'],
+            'fp16_split8': ['r2l_bodyx_kernel (blocks in front of the split)', 'r2l_body8_kernel (behind it)'],
+            'fp16_fp8': ['r2l_body_kernel'], 'fp16_e4m3': ['r2l_body8_kernel'], 'fp16x3_asm': ['r2l_bodyx_kernel']}.get(rung, [rung])
+    if rung.startswith('fp16_split') and eng.split_block == 0:
+        kern = kern[1:]
     s.update(rays_per_s=H * W / dt, ms_per_frame=dt * 1e3, rung_after_10_frames=PREC_NAMES[eng.precision],
-             frac_of_fp16_mfma_peak=eng.flops_per_ray * H * W / dt / 1e12 / PEAK_FP16_TFLOPS)
+             frac_of_fp16_mfma_peak=eng.flops_per_ray * H * W / dt / 1e12 / PEAK_FP16_TFLOPS,
+             # as the headline's roofline object, for the kernel(s) these weights render on (VERDICT r5 weak 6): algorithmic flops of the
+             # body + fused tail per launch over the HIP-event time of the body launch(es); profiles/r06_trained_kernel_stats.csv is the
+             # rocprofv3 trace of the same leg (the head launch, r2l_head_kernel<true> in a two-part mode, is outside the bracket)
+             roofline={'bound': 'mfma', 'kernels': kern, 'avg_kernel_ms': kms, 'launches': kn, 'rerenders': extra,
+                       'algorithmic_flops_per_ray': eng.kernel_flops_per_ray,
+                       'achieved': eng.kernel_flops_per_ray * H * W / (kms * 1e-3) / 1e12, 'peak': PEAK_FP16_TFLOPS, 'unit': 'TFLOP/s',
+                       'frac': eng.kernel_flops_per_ray * H * W / (kms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS})
     if rung.startswith('fp16_split'):
         from efficient_nerf_amd import get_rays
         worst = 0.
@@ -198,7 +218,7 @@ def trained_like_leg(torch, O, cpu):
         s.update(linf_vs_cpu_oracle=max(f['linf'] for f in frames), rays_checked=sum(f['rays'] for f in frames), frames=frames)
     if rung.startswith('fp16_split'):            # beside it: three passes everywhere, the rung these weights had before the split rung
         eng.set_precision(PRECISIONS['fp16x3_asm'])
-        dt3 = frames_per_s()
+        dt3 = frames_per_s()[0]
         s.update(rays_per_s_fp16x3_asm=H * W / dt3, ms_per_frame_fp16x3_asm=dt3 * 1e3)
     eng.close()
     out['student'] = s
@@ -235,6 +255,28 @@ def trained_like_leg(torch, O, cpu):
     whole['coarse fp16x3 + fine fp16_fp8'] = (teng.render(poses[0])['rgb_map'] - ref).abs().max().item()
     t['whole_frame_rgb_linf_from_fp16x3'] = whole
     teng.set_precision(PRECISIONS[name])
+    # every ray of three frames against the fp32 CPU oracle's whole frames (committed: tests/golden/trained_like/teacher_whole_frame.npz,
+    # made by tools/teacher_whole_frame.py --oracle); the rays that differ by more than 5e-5 taken apart against a float64 evaluation
+    # (oracle/whole_frame.py: VERDICT r5 next 1).  The checker runs here; nothing of it is in the product path.
+    from oracle import whole_frame as WF
+    if cpu and os.path.exists(WF.FIXTURE) and th == WF.H:
+        fx = WF.load_fixture()
+        wf = {'rays': 0, 'n_gt_1e-4_vs_fp32_oracle': 0, 'n_explained_by_f64': 0, 'worst_unexplained': 0.0, 'linf_vs_fp32_oracle': 0.0,
+              'classes': {}, 'fp32_oracle_itself_vs_f64_n_gt_1e-4': 0, 'mode': name}
+        for pi in range(len(WF.POSES)):
+            r = WF.classify_frame(teng, tsds, fx, pi, detail=False)
+            wf['rays'] += r['rays']
+            for k in ('n_gt_1e-4_vs_fp32_oracle', 'n_explained_by_f64'):
+                wf[k] += r[k]
+            wf['fp32_oracle_itself_vs_f64_n_gt_1e-4'] += r['ref_vs_f64_n_gt_1e-4']
+            wf['worst_unexplained'] = max(wf['worst_unexplained'], r['worst_unexplained'])
+            wf['linf_vs_fp32_oracle'] = max(wf['linf_vs_fp32_oracle'], r['linf_vs_fp32_oracle'])
+            for k, v in r['classes'].items():
+                wf['classes'][k] = wf['classes'].get(k, 0) + v
+        wf['note'] = ('classes of the rays that differ from the fp32 oracle by more than 5e-5: ref = the fp32 oracle itself is > 1e-4 from float64 or '
+                      'takes a sample_pdf decision differently from float64 there; tie = the HIP path does, at a cdf comparison closer than 1e-6; cond = no '
+                      'decision differs, (u - cdf) / denom with denom ~ 1e-5 amplifies float32-grade differences; hip = unexplained (a shortfall of the HIP path)')
+        t['whole_frame'] = wf
     if cpu:
         idx = torch.arange(0, th * th, 10)[:16384]                     # 16,000 rays spread over the frame
         ro, rd = O.get_rays(th, th, tf, poses[0][:3, :4])
@@ -242,6 +284,10 @@ def trained_like_leg(torch, O, cpu):
         got = teng.render(poses[0])
         t.update(linf_vs_cpu_oracle=(got['rgb_map'].cpu()[idx] - want['rgb_map']).abs().max().item(), rays_checked=int(idx.numel()),
                  sigma_max=float(torch.relu(want['raw'][..., 3]).max()))
+        if name != 'fp16x3':           # the compiler-scheduled fp16x3 on the same rays, so that the figure above can be attributed
+            teng.set_precision(PRECISIONS['fp16x3'])
+            t['linf_vs_cpu_oracle_fp16x3_same_rays'] = (teng.render(poses[0])['rgb_map'].cpu()[idx] - want['rgb_map']).abs().max().item()
+            teng.set_precision(PRECISIONS[name])
     teng.close()
     out['teacher'] = t
     # ... and BASELINE config 5's unit of work with this teacher: one save group of 100 poses through `create_data rand`

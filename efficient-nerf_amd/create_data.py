@@ -387,11 +387,11 @@ def create_rand(engine, H, W, focal, n_pose_kd, datadir_new, use_rand_focal=True
             j = (i - 1) % i_save                            # index inside the save group
             if j % world != rank:
                 continue
-            check = watching and first and engine.precision_name not in ('fp16x3', 'fp16x3_asm')
+            check = watching and first and engine.precision_name != 'fp16x3'
             m = render_pose(i, pose, focal_, j, check)
             while world == 1 and m is not None:             # one rank: act at once, only this pose is rendered again
                 step_down(i, m)
-                m = render_pose(i, pose, focal_, j, engine.precision_name not in ('fp16x3', 'fp16x3_asm'))
+                m = render_pose(i, pose, focal_, j, engine.precision_name != 'fp16x3')
             miss = miss or m
             first = False
         return miss

@@ -620,7 +620,7 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
     def watched(i, ro, rd, got):
         from .teacher import get_rays
         for _ in range(3):
-            if eng.precision_name in ('fp16x3', 'fp16x3_asm'):
+            if eng.precision_name == 'fp16x3':          # the mode the watch compares with (fp16x3_asm is watched too since round 6)
                 break
             if ro is None:
                 ro, rd = (t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(render_poses[i])[:3, :4], rows=(r0, r1),

@@ -144,6 +144,7 @@ class NeRFEngine:
         self.H, self.W, self.focal = int(H), int(W), float(focal)
         self.N_samples, self.N_importance = int(N_samples), int(N_importance)
         self.near, self.far = float(near), float(far)
+        self.white_bkgd = bool(white_bkgd)
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             check(lib().nerf_create(C.byref(self._ctx), self.H, self.W, self.focal, float(near), float(far),
@@ -229,7 +230,15 @@ class NeRFEngine:
     #: depth_map = sum(weights * z) carries the weights' error times z: its limit is the rgb limit times max(1, far) (scene units).
     #: disp_map = 1 / max(1e-10, depth / acc) is ill-conditioned on empty rays in the reference itself and is not compared.
     WATCH_KEYS = ('rgb_map', 'acc_map', 'depth_map')
-    LADDER = ('fp16x1', 'fp16_fp8', 'fp16x3_asm')
+    LADDER = ('fp16x1', 'fp16_fp8', 'fp16x3_asm', 'fp16x3')
+    #: fp16x3_asm (the generated three-pass chain) against fp16x3 (the compiler-scheduled kernel every probe compares with), round 6
+    #:: both are fp32-grade, and on a TRAINED teacher two fp32-grade evaluations differ by more than any tight limit on the
+    #: rays where sample_pdf is discontinuous -- a coarse weight that differs in its last float32 bits moves a fine sample by up to a
+    #: coarse bin (helpers:312-326; the fp32 reference itself is > 1e-4 from float64 there: profiles/r06_teacher_whole_frame.txt).  The
+    #: comparison is therefore made stage by stage: the COARSE maps (rgb0 / acc0: continuous in the weights; measured 7.8e-7 apart over
+    #: whole frames of the trained-like teacher) on every ray, and the fine network + compositing AT THE SAME SAMPLE POSITIONS (run_network on
+    #: the reference's z_vals: measured 5.4e-7 apart): even samples that move by 2e-5 change a pixel by 2e-4 where sigma ~ 200.  Tight limit: both are fp32-grade.
+    AUTO_MAX_DIFF_X3ASM = 5e-6
     #: rays of a spot check (spot_check): < 0.5 % of a 100-pose save group, < 2 % of one 400 x 400 frame
     WATCH_RAYS = 2048
 
@@ -290,8 +299,35 @@ class NeRFEngine:
             if ok:
                 return name, diff
         from ._lib import PREC_FP16X3_ASM
+        self.set_precision(PREC_FP16X3)
+        refs_x = [self.render_rays(ro, rd, extras=True) for ro, rd in probes]
+        refs_x = [{k: v.clone() for k, v in r.items() if k in self.WATCH_KEYS + ('rgb0', 'acc0', 'z_vals')} for r in refs_x]
         self.set_precision(PREC_FP16X3_ASM)
-        return 'fp16x3_asm', diff
+        per_set, ok = [], True
+        for (ro, rd), ref in zip(probes, refs_x):
+            d, good = self._x3_pair(ro, rd, ref)
+            per_set.append(d)
+            ok = ok and good
+        self.auto_diffs['fp16x3_asm'] = max(max(d['rgb_map'], d['acc_map'], d['rgb0'], d['acc0']) for d in per_set)
+        self.auto_detail['fp16x3_asm'] = per_set
+        if ok:
+            return 'fp16x3_asm', self.auto_diffs['fp16x3_asm']
+        self.set_precision(PREC_FP16X3)          # the generated chain disagrees with the mode everything is measured against: that mode
+        return 'fp16x3', self.auto_diffs['fp16x3_asm']
+
+    def _x3_pair(self, ro, rd, ref):
+        """fp16x3_asm (the current mode) against `ref` = what fp16x3 rendered for these rays with extras: ({output: largest difference},
+        ok) -- stage by stage, see AUTO_MAX_DIFF_X3ASM: the coarse maps of a full render, then the FINE network and its compositing at
+        the reference's own sample positions (run_network + raw2outputs on ref['z_vals'])"""
+        lim = self._limits(self.AUTO_MAX_DIFF_X3ASM)
+        lim['rgb0'] = lim['acc0'] = self.AUTO_MAX_DIFF_X3ASM
+        got = self.render_rays(ro, rd, extras=True)
+        d = {k: float((got[k] - ref[k]).abs().max()) for k in ('rgb0', 'acc0')}
+        raw = self.run_network(1, ro, rd, ref['z_vals'])
+        rgb, _, acc, _, depth = raw2outputs(raw, ref['z_vals'], rd, white_bkgd=self.white_bkgd)
+        for k, v in (('rgb_map', rgb), ('acc_map', acc), ('depth_map', depth)):
+            d[k] = float((v - ref[k]).abs().max())
+        return d, all(d[k] <= lim[k] for k in d)       # NaN fails
 
     @property
     def precision_name(self):
@@ -303,12 +339,22 @@ class NeRFEngine:
         its current fast mode; up to `n_rays` (default WATCH_RAYS) of those rays, spread over the set, are rendered again in
         fp16x3 and rgb / acc / depth compared under the mode's limits (a ray's result does not depend on the batch it is in).
         Returns (ok, {output: largest difference}).  fp16x3 itself: (True, {}).  Synchronous (one small render + three maxima)."""
-        from ._lib import PREC_FP16_FP8
+        from ._lib import PREC_FP16_FP8, PREC_FP16X3_ASM
         cur = self.precision
-        if cur not in (PREC_FP16X1, PREC_FP16_FP8):
+        if cur not in (PREC_FP16X1, PREC_FP16_FP8, PREC_FP16X3_ASM):
             return True, {}
         ro, rd = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
         idx = self._strided(ro.shape[0], int(n_rays or self.WATCH_RAYS), ro.device)
+        if cur == PREC_FP16X3_ASM:        # two fp32-grade modes: coarse maps, then the fine pass at the same sample positions (_x3_pair)
+            ro_s, rd_s = ro[idx].contiguous(), rd[idx].contiguous()
+            self.set_precision(PREC_FP16X3)
+            try:
+                ref = {k: v.clone() for k, v in self.render_rays(ro_s, rd_s, extras=True).items()}
+            finally:
+                self.set_precision(cur)
+            d, good = self._x3_pair(ro_s, rd_s, ref)
+            self.watch_checks = getattr(self, 'watch_checks', 0) + 1
+            return good, d
         lim = self._limits(self.AUTO_MAX_DIFF_X1 if cur == PREC_FP16X1 else self.AUTO_MAX_DIFF)
         self.set_precision(PREC_FP16X3)
         try:
@@ -320,10 +366,10 @@ class NeRFEngine:
         return all(d[k] <= lim[k] for k in d), d
 
     def step_down(self):
-        """one rung down the ladder fp16x1 -> fp16_fp8 -> fp16x3 (after a failed spot_check); returns the new mode's name"""
+        """one rung down the ladder fp16x1 -> fp16_fp8 -> fp16x3_asm -> fp16x3 (after a failed spot_check); returns the new mode's name"""
         from ._lib import PRECISIONS
         name = self.precision_name
-        nxt = self.LADDER[min(self.LADDER.index(name) + 1, len(self.LADDER) - 1)] if name in self.LADDER else 'fp16x3_asm'
+        nxt = self.LADDER[min(self.LADDER.index(name) + 1, len(self.LADDER) - 1)] if name in self.LADDER else 'fp16x3'
         self.set_precision(PRECISIONS[nxt])
         self.watch_fallbacks = getattr(self, 'watch_fallbacks', 0) + 1
         return nxt

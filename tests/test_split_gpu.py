@@ -234,3 +234,79 @@ def test_auto_verifies_the_rung_the_activation_limits_name(pkg):
     print(f'synthetic weights: max|a| {eng.stream_max:.2f}; fp16_fp8 is {eng.auto_verify:.2e} from three passes -> {rung}')
     assert rung == 'fp16_fp8' and eng.auto_verify <= eng.AUTO_VERIFY_MAX_DIFF and eng.auto_split is None
     eng.close()
+
+
+def test_whole_network_rung_is_watched_and_falls_back_to_the_measured_rungs(pkg):
+    """fp16_fp8 chosen by `auto` used to be watched for activation RANGE only.  The scaled trained-like student
+    (max|a| 3.9: inside fp16_fp8's activation limit, 1.3e-4 off in it on whole frames) is probed on the rays of a frame where fp16_fp8 happens
+    to be good (<= 2e-5 from three passes): `auto` verifies inside its limit there and keeps fp16_fp8 -- what a probe pose that does not see
+    the hard rays would do.  The rgb watch (spot_check_rgb: a sample of the rendered rays against a second context in three passes) must
+    see the other rays of the frame miss, step down to the measured split rungs, and what is rendered afterwards must be inside the 1e-4
+    contract of the CPU oracle; render_path must do all of that by itself on its first batch.  Synthetic weights: the watch passes."""
+    from efficient_nerf_amd import PREC_FP16_FP8, PREC_FP16X3_ASM, PREC_NAMES, R2LEngine, get_rays
+    from efficient_nerf_amd import frontend as fe
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trained_like', 'student_w256d88.npz'))
+    ssd = {k: torch.from_numpy(z[k]).clone() for k in z.files}
+    a = 1. / 32.
+    for k in ssd:
+        if k.startswith('head.') or (k.startswith('body.') and k.endswith('bias')):
+            ssd[k] = ssd[k] * a
+        elif k == 'tail.0.weight':
+            ssd[k] = ssd[k] / a
+    H = 400
+    focal = O.focal_from_angle(H)
+    test = O.novel_poses(200)
+    pose = test[0][:3, :4]
+    ro, rd = (t.reshape(-1, 3) for t in get_rays(H, H, focal, pose, device='cuda'))
+    eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(ssd)
+    eng.set_precision(PREC_FP16_FP8)
+    eng.calibrate_on(c2w=pose)
+    got8 = eng.render(pose).clone()
+    eng.set_precision(PREC_FP16X3_ASM)
+    d = (got8 - eng.render(pose)).abs().max(-1)[0]
+    easy = torch.nonzero(d <= 2e-5).flatten()[:65536]
+    print(f'scaled trained-like student: fp16_fp8 is {d.max().item():.2e} from three passes on the frame; {int((d <= 2e-5).sum())} rays within 2e-5')
+    assert d.max().item() > eng.WHOLE_WATCH_MAX_DIFF and easy.numel() >= 16384
+    rung, top = eng.choose_precision(rays=(ro[easy].contiguous(), rd[easy].contiguous()))
+    print(f'probed on {easy.numel()} easy rays: verify {eng.auto_verify:.2e} -> {rung}')
+    assert rung == 'fp16_fp8' and eng.auto_verify <= eng.AUTO_VERIFY_MAX_DIFF and eng.watched_mode() == 'whole'
+    # the engine-level watch: the frame's rays miss, the step-down lands on a measured rung that passes
+    ok, dd = eng.spot_check_rgb(ro, rd)
+    print(f'spot_check_rgb on the whole frame: ok {ok}, {dd:.2e} (limit {eng.WHOLE_WATCH_MAX_DIFF:g})')
+    assert not ok and dd > eng.WHOLE_WATCH_MAX_DIFF
+    now = eng.step_down_whole(ro, rd)
+    print(f'step_down_whole -> {now}, split {eng.split_block}; measured {eng.auto_split}')
+    assert now in ('fp16_split', 'fp16_split8', 'fp16x3_asm') and PREC_NAMES[eng.precision] == now
+    ok, dd = eng.spot_check_rgb(ro, rd)
+    assert ok, dd
+    got = eng.render(test[67][:3, :4]).cpu().view(H, H, 3)[::8].reshape(-1, 3)
+    want = O.r2l_render(ssd, H, H, focal, test[67][:3, :4], rows=(0, H, 8), chunk=16384)
+    print(f'pose 67 in {now}: {(got - want).abs().max().item():.2e} from the CPU oracle')
+    assert (got - want).abs().max().item() <= 1e-4
+    eng.close()
+    # render_path by itself: same probe, then three frames; the first batch's watch trips and the frames it returns are the re-rendered ones
+    eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(ssd)
+    assert eng.choose_precision(rays=(ro[easy].contiguous(), rd[easy].contiguous()))[0] == 'fp16_fp8'
+    lines, stats = [], {}
+    rgbs, _ = fe.render_path([test[i] for i in (0, 67, 133)], (H, H, focal), 'R2L', eng, log=lines.append, stats=stats)
+    w = stats['split_watch']
+    print('\n'.join(ln for ln in lines if 'precision' in ln))
+    print({k: v for k, v in w.items()})
+    assert len(w['fallbacks']) >= 1 and w['fallbacks'][0]['from'] == 'fp16_fp8' and w['fallbacks'][0]['frame'] == 0
+    assert eng.precision_name in ('fp16_split', 'fp16_split8', 'fp16x3_asm') and stats['rerenders'] >= 1
+    for j, pi in enumerate((0, 67, 133)):
+        want = O.r2l_render(ssd, H, H, focal, test[pi][:3, :4], rows=(0, H, 8), chunk=16384)
+        err = (rgbs[j].cpu()[::8].reshape(-1, 3) - want).abs().max().item()
+        print(f'render_path frame {j} (pose {pi}) after the fallback: {err:.2e} from the CPU oracle')
+        assert err <= 1e-4
+    eng.close()
+    # synthetic weights: fp16_fp8 stays, the watch runs and passes
+    sd = O.make_r2l_state(seed=0)
+    eng = R2LEngine(H, H, focal, 2., 6., n_block=43, use_residual=True).load_state_dict(sd)
+    assert eng.choose_precision(c2w=pose)[0] == 'fp16_fp8' and eng.watched_mode() == 'whole'
+    stats = {}
+    fe.render_path([test[i] for i in range(0, 200, 10)], (H, H, focal), 'R2L', eng, log=lambda s: None, stats=stats)
+    w = stats['split_watch']
+    print(f'synthetic weights, 20 frames: {w}')
+    assert w['checks'] == 2 and not w['fallbacks'] and w['worst'] <= eng.WHOLE_WATCH_MAX_DIFF and eng.precision_name == 'fp16_fp8'
+    eng.close()

@@ -110,6 +110,8 @@ def main():
     for k in (2, 3, 5):
         cands.append((f'split {k} + bf6 cal', make_lin_terms(q_bf6, 28., True), k))
         cands.append((f'split {k} + e4m3 cal', make_lin_terms(q_e4m3, 448., True), k))
+    for k in (3, 4):          # what a hybrid chain WITHOUT calibrated exponents would do (isa.py ACT_EXP / RES_EXP as shipped)
+        cands.append((f'split {k} + bf6 fixed', make_lin_terms(q_bf6, 28., False), k))
     for pi in range(3):
         ro_all, rd_all = WF.frame_rays(pi)
         idx = torch.arange(0, H * H, max(1, H * H // n))[:n]

@@ -69,6 +69,21 @@ def main():
         summary[mode] = tot
         say(f'== {mode}: {tot["rays"]} rays, L_inf vs fp32 oracle {tot["worst_all"]:.2e}; > 1e-4: {tot["n_gt"]}, of which explained by the float64 '
             f'evaluation {tot["n_expl"]}; classes of the rays examined {tot["classes"]}; worst unexplained {tot["worst_unexpl"]:.2e}')
+    # the two fp32-grade modes against each other (NeRFEngine._x3_pair: what `auto` and the watch compare): coarse maps on every ray,
+    # fine maps on the rays whose fine samples did not move
+    if 'fp16x3_asm' in a.modes and 'fp16x3' in a.modes:
+        from efficient_nerf_amd.teacher import get_rays
+        for pi in poses:
+            ro, rd = (t.reshape(-1, 3) for t in get_rays(H, H, WF.focal(), WF.pose(pi)[:3, :4], device=eng.device))
+            eng.set_precision(PRECISIONS['fp16x3'])
+            ref = {k: v.clone() for k, v in eng.render_rays(ro, rd, extras=True).items()}
+            eng.set_precision(PRECISIONS['fp16x3_asm'])
+            d, good = eng._x3_pair(ro, rd, ref)
+            allr = (eng.render_rays(ro, rd)['rgb_map'] - ref['rgb_map']).abs().max(-1)[0]
+            say(f'pose {pi}: fp16x3_asm against fp16x3 over the whole frame, stage by stage (coarse maps; fine pass at fp16x3\'s sample positions): '
+                f'{json.dumps({k: float("%.3g" % v) for k, v in d.items()})} (limit {eng.AUTO_MAX_DIFF_X3ASM:g}: {"ok" if good else "MISS"}); the two full '
+                f'renders: rgb {float(allr.max()):.2e}, rays > 1e-4: {int((allr > 1e-4).sum())}')
+            summary.setdefault('x3_pair', {})[pi] = d
     eng.close()
     with open(a.out + '.txt', 'w') as f:
         f.write('\n'.join(lines) + '\n')

@@ -94,19 +94,22 @@ def rand_pose(rs):
     return O.pose_spherical(-180 + rs.rand() * 360, -90 + rs.rand() * 90, 4.)      # dataset/load_blender.py:359-368
 
 
+LR_SCALE = 1.0      # --lr-scale: both fits' peak learning rate x this (round 6: is the rung a property of the recipe's learning rate?)
+
+
 def fit_teacher(steps, n_rand, dev, log):
     """main.py:1355-1380 for the nerf branch on the analytic scene; returns the two state dicts (CPU, fp32)"""
     focal = O.focal_from_angle(H_T)
     sds = [{k: v.clone().to(dev).requires_grad_(True) for k, v in O.make_teacher_state(s, sigma_bias_shift=0.).items()} for s in SEEDS['teacher']]    # nn.Linear's own init
     params = [p for sd in sds for p in sd.values()]
-    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    opt = torch.optim.Adam(params, lr=5e-4 * LR_SCALE, betas=(0.9, 0.999))
     rs = np.random.RandomState(SEEDS['teacher_rs'])
     torch.manual_seed(SEEDS['teacher_rs'])
     dirs = O.camera_dirs(H_T, H_T, focal).reshape(H_T, H_T, 3)
     t0 = time.time()
     for it in range(1, steps + 1):
         for g in opt.param_groups:
-            g['lr'] = 5e-4 * 0.1 ** (it / (2. * steps))        # main.py:1181-1195, decay compressed to this run's length
+            g['lr'] = 5e-4 * LR_SCALE * 0.1 ** (it / (2. * steps))        # main.py:1181-1195, decay compressed to this run's length
         c2w = rand_pose(rs)[:3, :4]
         if it <= steps // 8:                                    # precrop_iters / precrop_frac = 0.5 (main.py:1300-1318)
             lo, hi = H_T // 4, 3 * H_T // 4
@@ -151,13 +154,13 @@ def distil(data_dir, steps, files, dev, log):
     from efficient_nerf_amd.create_data import BlenderDataset_v2
     ds = BlenderDataset_v2(data_dir, pseudo_ratio=-1)
     sd = {k: v.clone().to(dev).requires_grad_(True) for k, v in O.make_r2l_state(seed=SEEDS['student']).items()}
-    opt = torch.optim.Adam(list(sd.values()), lr=5e-4, betas=(0.9, 0.999))
+    opt = torch.optim.Adam(list(sd.values()), lr=5e-4 * LR_SCALE, betas=(0.9, 0.999))
     z = O.sampler_z_vals(16, 2., 6.).to(dev)
     rs = np.random.RandomState(SEEDS['student_rs'])
     torch.manual_seed(SEEDS['student_rs'])
     t0 = time.time()
     for it in range(1, steps + 1):
-        lr = 1e-4 + (5e-4 - 1e-4) * it / 200 if it < 200 else 5e-4 * 0.1 ** ((it - 200) / (1.5 * steps))   # --warmup_lr 0.0001,200
+        lr = (1e-4 + (5e-4 - 1e-4) * it / 200 if it < 200 else 5e-4 * 0.1 ** ((it - 200) / (1.5 * steps))) * LR_SCALE   # --warmup_lr 0.0001,200
         for g in opt.param_groups:
             g['lr'] = lr
         batch = [ds[int(k)] for k in rs.randint(0, len(ds), files)]
@@ -257,9 +260,11 @@ def measure(tsds, ssd, log, cpu_rows=8):
     torch.cuda.synchronize()
     s['ms_per_frame'] = (time.perf_counter() - t0) / 10 * 1e3
     s['rays_per_s'] = Hs * Hs / (s['ms_per_frame'] * 1e-3)
-    if rung.startswith('fp16_split'):             # the watch's view of three more poses, and three passes everywhere beside it
+    if seng.watched_mode() is not None:           # the watch's view of three more poses (split rungs and, since round 6, the whole-network rungs)
         from efficient_nerf_amd import get_rays
-        s['watch'] = [seng.spot_check_split(*get_rays(Hs, Hs, fs, test[pi][:3, :4], device='cuda'))[1] for pi in (20, 100, 180)]
+        s['watch'] = [seng.spot_check_rgb(*get_rays(Hs, Hs, fs, test[pi][:3, :4], device='cuda'))[1] for pi in (20, 100, 180)]
+        s['auto_verify'] = seng.auto_verify
+    if rung.startswith('fp16_split'):             # ... and three passes everywhere beside it
         seng.set_precision(PRECISIONS['fp16x3_asm'])
         seng.render(test[1][:3, :4])
         torch.cuda.synchronize()
@@ -285,8 +290,12 @@ def main():
     ap.add_argument('--files', type=int, default=4, help='shards of 4,096 rays per student batch (the reference: --N_rand 20)')
     ap.add_argument('--measure-only', action='store_true', help='load the three .npz from --out and measure')
     ap.add_argument('--variant', type=int, default=0, help='0: the committed fixture\'s scene and seeds; 1: a second scene, other seeds')
+    ap.add_argument('--lr-scale', type=float, default=1.0, help='peak learning rate of both fits x this')
+    ap.add_argument('--teacher-from', default='', help='directory with teacher_coarse.npz / teacher_fine.npz to distil from (skips the teacher fit)')
     args = ap.parse_args()
     use_variant(args.variant)
+    global LR_SCALE
+    LR_SCALE = args.lr_scale
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device('cuda')
     logf = open(os.path.join(args.out, 'train_like.log'), 'a')
@@ -301,7 +310,11 @@ def main():
         ssd = load_sd(os.path.join(args.out, 'student_w256d88.npz'))
     else:
         t0 = time.time()
-        tsds = fit_teacher(args.teacher_steps, args.teacher_rays, dev, log)
+        if args.teacher_from:
+            tsds = [load_sd(os.path.join(args.teacher_from, f'teacher_{n}.npz')) for n in ('coarse', 'fine')]
+            log(f'[train_like] teacher from {args.teacher_from}')
+        else:
+            tsds = fit_teacher(args.teacher_steps, args.teacher_rays, dev, log)
         save_sd(os.path.join(args.out, 'teacher_coarse.npz'), tsds[0])
         save_sd(os.path.join(args.out, 'teacher_fine.npz'), tsds[1])
         import tempfile
@@ -312,7 +325,7 @@ def main():
         log(f'[train_like] fitted in {time.time() - t0:.0f} s')
     with torch.no_grad():
         rep = measure(tsds, ssd, log)
-    rep['recipe'] = {k: getattr(args, k) for k in ('teacher_steps', 'teacher_rays', 'poses', 'student_steps', 'files', 'variant')}
+    rep['recipe'] = {k: getattr(args, k) for k in ('teacher_steps', 'teacher_rays', 'poses', 'student_steps', 'files', 'variant', 'lr_scale', 'teacher_from')}
     json.dump(rep, open(os.path.join(args.out, 'report.json'), 'w'), indent=1)
 
 
