@@ -10,8 +10,9 @@ PREC_FP16_E4M3 = 3  # R2L only: the same with both correction terms in OCP e4m3 
 PREC_FP16X3_ASM = 4  # R2L only: fp16x3's three fp16 passes on the generated body kernel's machine (no scales, nothing to calibrate)
 PREC_FP16_SPLIT = 5  # R2L only: head + blocks [0, split) in three passes, blocks [split, n_block) with bf6 terms (r2l_set_split_block)
 PREC_FP16_SPLIT8 = 6  # ... with e4m3 terms behind the split (2.0 pass-equivalents, 0.44 x the bf6 terms' error)
+PREC_FP16_MIX = 7  # teacher only: fp16_fp8's layer chain with its first two trunk layers in three fp16 passes (the fine pass of trained teachers)
 PRECISIONS = {'fp16x3': PREC_FP16X3, 'fp16x1': PREC_FP16X1, 'fp16_fp8': PREC_FP16_FP8, 'fp16_e4m3': PREC_FP16_E4M3,
-              'fp16x3_asm': PREC_FP16X3_ASM, 'fp16_split': PREC_FP16_SPLIT, 'fp16_split8': PREC_FP16_SPLIT8}
+              'fp16x3_asm': PREC_FP16X3_ASM, 'fp16_split': PREC_FP16_SPLIT, 'fp16_split8': PREC_FP16_SPLIT8, 'fp16_mix': PREC_FP16_MIX}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('R2L_LIB_PATH', os.path.join(_HERE, 'libr2l_hip.so'))  # override: ablation builds (tools/)

@@ -87,8 +87,19 @@ ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # that computed the embedding between two blocks while the matrix pipe idled (2.3 ms of a 33.4 ms frame, -DNERF_SKIP_EMBED) is gone.
 # The arithmetic per point is that of nerf_tile_embed (csrc/nerf_kernels.hip), operation for operation: bitwise-equal results.
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
-assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3'), FMT
-X1 = FMT != 'bf6'
+assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3', 'mix'), FMT
+# NERF_GEN_FMT=mix (round 6): the bf6 chain with its FIRST trunk layers in three fp16 passes -- layers L1 .. L<MIXK> as in f16p3 (hi / lo
+# fragments of both operands, W x 2^k in the stream), everything behind them with bf6 terms.  For the FINE pass of trained teachers: the
+# early layers' error is what the sharp tail of such a network amplifies (tools/teacher_mixed_study.py on whole frames of the trained-like
+# teacher, fine pass at fixed sample positions, L_inf from three passes everywhere: bf6 terms in every layer 1.2-1.6e-4, L1 in three
+# passes 3.5-8.8e-5, L1 + L2 2.3-3.2e-5; profiles/r06_teacher_mixed_study.txt); the coarse pass, which steers sample_pdf, stays in f16p3.
+# Per layer: Layer.p3.  L0 (embedding k-steps only: three passes in every format) hands L1 hi + lo fp16 sets, L<MIXK> hands the first
+# bf6 layer hi + bf6 sets (its accumulators carry the 2^k of its stream: one v_mul more per value).  Registers: the bf6 map; the lo(a)
+# sets of the three-pass layers live in AGPRs the bf6 chain does not use (lset).
+MIX = FMT == 'mix'
+MIXK = int(os.environ.get('NERF_GEN_MIX_K', '2')) if MIX else 0
+assert 0 <= MIXK <= 7
+X1 = FMT not in ('bf6', 'mix')
 EMB = FMT == 'f16c4e'
 # NERF_GEN_FMT=f16p3 (round 5): fp16x3's arithmetic on the generated chain -- per k-step three fp16 MFMAs on one accumulate chain,
 # hi(W) hi(a) + hi(W) lo(a) + lo(W) hi(a), lo = the fp16 rounding residual -- for teachers that need fp32-grade arithmetic: every
@@ -98,13 +109,13 @@ EMB = FMT == 'f16c4e'
 # a normal fp16 number, the epilogue takes the factor out (one v_fma_mix per value does it together with the conversion to fp16).
 P3 = FMT == 'f16p3'
 NC = {'f16c3': 3, 'f16c4': 4, 'f16c4e': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
-SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e', 'f16p3': 'p3'}[FMT]     # nerf_mlpx_asm.inc ...
+SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e', 'f16p3': 'p3', 'mix': 'm'}[FMT]     # nerf_mlpx_asm.inc ...
 # passes of an embedding k-step: hi(W) hi(E), hi(W) lo(E), lo(W) hi(E).  The fp16-only chains drop the third (their 256-wide layers
 # carry no lo(W) term either; measured over whole frames, three seed pairs x three poses: rgb 6.5e-6 .. 1.9e-5 from fp16x3 with two
 # passes against 6.4e-6 .. 1.6e-5 with three, -4.4 % time; ONE pass -- no lo(E), i.e. fp16-rounded coordinates -- reads 1.3 .. 2.8e-5
 # for another -4 % and is not taken).  The stream keeps the lo(W) fragments (unread: 72 of 1,298 KiB).  NERF_GEN_XPASS overrides.
 XPASS = int(os.environ.get('NERF_GEN_XPASS', '2' if (X1 and not P3) else '3'))
-MPASS = 3 if P3 else 1          # MFMAs per main k-step and column tile
+MPASS = 3 if P3 else 1          # MFMAs per main k-step and column tile (per layer: Layer.mpass)
 if NC > 2:
     V_SET = {'P': 0}              # fp16 B operands of set P (VGPR): + c*32 + s*4
     A_SETH = {'Q': 0}             # ... of set Q (AGPR)
@@ -129,6 +140,9 @@ if P3:
     N_FRAG_BUF = 6                # rotating weight-fragment buffers from V_HI (hi and lo fragments alike): into V_A6's registers, unused here
 else:
     N_FRAG_BUF = 4
+# mix: AGPRs above the bf6 sets (0..95) that the block owns besides them: the last 16 registers of lo(Q) and of lo(P) (lset).  The
+# compiler keeps the 48 input registers and what it carries across the block (the next tile's rays) out of both.
+A_EXTRA_CLOBBER = (224, 256) if MIX else None
 if EMB:
     V_OUT = N_VGPR_CLOBBER        # 16: (rgb, sigma) of the four column tiles -- and the embedding's temporaries until the RGB epilogue
     V_SIG = V_OUT + 16            # 4: sigma of the column tiles (FA's last row tile), moved into V_OUT at the tail
@@ -152,18 +166,27 @@ class Layer:
         self.name, self.src, self.dst, self.ks, self.extra, self.rt, self.epi = name, src, dst, ks, extra, rt, epi
         self.rt_per_chunk = rt_per_chunk
         self.fan_out = fan_out           # real output rows
+        self.p3 = P3                     # main k-steps as three fp16 passes (mix: set per layer by chain())
         self.nj = 0 if X1 else ks // 2   # K=128 MFMAs per row tile and column tile (2 terms x ks/4)
         self.nx = len(extra)
 
+    def set_p3(self, on):
+        self.p3 = bool(on)
+        self.nj = 0 if (X1 or self.p3) else self.ks // 2
+
+    @property
+    def mpass(self):
+        return 3 if self.p3 else 1
+
     def j_order(self):
         """(term, t) of the K=128 MFMAs in issue order: term 0 = (w - hi) x bf6(a), 1 = w x bf6(a - hi)"""
-        if X1:
+        if X1 or self.p3:
             return []
         return [(0, 0), (1, 0), (0, 1), (1, 1)] if self.ks == 8 else [(0, 0), (1, 0)]
 
     def chunk_pieces(self):
         r = self.rt_per_chunk
-        if P3:
+        if self.p3:
             return r * self.ks * 2 + r * self.nx * 2
         return r * self.ks + r * self.nj + (r * self.nj + 1) // 2 + r * self.nx * 2
 
@@ -183,6 +206,18 @@ def chain():
     L.append(Layer('FA', 'P', 'Q', 8, [], 17, 'feat', r_std, 257))
     L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', r_v, 128))
     L.append(Layer('RGB', 'P', None, 4, [], 1, 'rgb', 1, 3))
+    for li, l in enumerate(L):
+        l.li = li
+        if MIX:
+            l.set_p3(1 <= li <= MIXK)
+            if l.p3:
+                l.rt_per_chunk = {'L5': 1}.get(l.name, 2)
+    for li, l in enumerate(L):
+        # lo_out: the epilogue hands its consumer hi + lo fp16 sets (the consumer runs three passes); scaled: its accumulators carry the
+        # 2^k of a three-pass stream; uses_inv: its epilogue multiplies by the f32 in the layer's scale registers (1 / 2^k; L0 of mix: 1.0)
+        l.lo_out = li + 1 < len(L) and L[li + 1].p3
+        l.scaled = l.p3
+        l.uses_inv = l.p3 or (MIX and l.lo_out)
     return L
 
 
@@ -231,7 +266,7 @@ def piece_of(L, k, what, idx):
     (fp16 fragment of main k-step idx), 'b6' / 'b6b' (first 16 / last 8 bytes per lane of bf6 operand idx), 'xh' / 'xl'
     (hi / lo fragment of embedding k-step idx)"""
     r = L.rt_per_chunk
-    if P3:      # per row tile: its ks hi fragments, then its ks lo fragments; behind all row tiles the embedding k-steps (hi, lo)
+    if L.p3:    # per row tile: its ks hi fragments, then its ks lo fragments; behind all row tiles the embedding k-steps (hi, lo)
         if what in ('hi', 'lo'):
             return k * L.ks * 2 + (L.ks if what == 'lo' else 0) + idx, 0
         return r * L.ks * 2 + (k * L.nx + idx) * 2 + (1 if what == 'xl' else 0), 0
@@ -305,7 +340,10 @@ def pack_teacher(tensors, act_scale=16.0):
         a0 = li * AUX_LAYER // 4
         aux[a0:a0 + len(bias)] = (bias.astype(np.float64) * act_scale).astype(np.float32).view(np.uint32)
         el = ew = 0
-        if P3:      # W x 2^k with max|w| 2^k in [2^12, 2^13) over everything that accumulates into this layer's rows (r2l_pow2_scale)
+        if L.uses_inv and not L.p3:     # mix, L0: its epilogue is the three-pass one (hi + lo sets for L1) with factor 1
+            for qq in range(4):
+                aux[a0 + AUX_SCALES // 4 + 4 * qq] = np.array([1.0], dtype=np.float32).view(np.uint32)[0]
+        if L.p3:    # W x 2^k with max|w| 2^k in [2^12, 2^13) over everything that accumulates into this layer's rows (r2l_pow2_scale)
             mx = max(float(np.abs(m).max()) for m in (Wm, We) if m is not None)
             sw = np.float32(2.0 ** (12 - int(np.floor(np.log2(mx)))) if mx > 0 and np.isfinite(mx) else 1.0)
             aux[a0:a0 + len(bias)] = (bias.astype(np.float64) * act_scale * float(sw)).astype(np.float32).view(np.uint32)
@@ -315,7 +353,7 @@ def pack_teacher(tensors, act_scale=16.0):
             We = None if We is None else (We * sw).astype(np.float32)
         if Wm is not None:
             hi = Wm.astype(np.float16)
-        if Wm is not None and not X1:       # the E8M0 scale bytes of the bf6 terms
+        if Wm is not None and not X1 and not L.p3:       # the E8M0 scale bytes of the bf6 terms
             el, ew = weight_exps(layer_exponent(Wm))
             for qq in range(4):
                 aux[a0 + AUX_SCALES // 4 + 4 * qq] = 0x01010101 * (127 + el)
@@ -337,7 +375,7 @@ def pack_teacher(tensors, act_scale=16.0):
                 for j in range(8):
                     frag[:, j] = np.where(ok, hi[rws, kappa(s, q, j)], 0)
                 put('hi', s, frag)
-                if P3:
+                if L.p3:
                     frag = np.zeros((64, 8), dtype=np.float16)
                     for j in range(8):
                         kk = kappa(s, q, j)
@@ -518,7 +556,7 @@ def tile_anchors(L):
             for c in range(NC):
                 out.append(('x', xi, c, p))
     for s in range(L.ks):
-        for p in range(MPASS):          # f16p3: hi(W) hi(a), hi(W) lo(a), lo(W) hi(a)
+        for p in range(L.mpass):        # three passes: hi(W) hi(a), hi(W) lo(a), lo(W) hi(a)
             for c in range(NC):
                 out.append(('m16', s, c, p))
         j = s - (L.ks - L.nj)
@@ -562,6 +600,14 @@ def hset(name, s, c):
 
 def lset(name, s, c):
     """lo(a) B operand of activation set `name` (f16p3: AGPR)"""
+    if MIX:
+        # during L1 lo(Q) (read) and lo(P) (written) are both live and no bf6 set is: each takes one bf6 set's 48 registers (lo(Q) those of
+        # bf6(Q), which L2's epilogues write first, when L1 is over; lo(P) those of bf6(P), written first by L3's epilogues) and 16 above
+        # the inputs
+        i = c * 8 + s
+        if name == 'Q':
+            return 48 + i * 4 if i < 12 else 224 + (i - 12) * 4
+        return i * 4 if i < 12 else 240 + (i - 12) * 4
     return A_LOSET[name] + c * 32 + s * 4
 
 
@@ -589,7 +635,7 @@ def epilogue_ops(T, c):
     tb = TMP(c)
     cv = tb + 4
     ops = []
-    inv = V_SC + 2 * (t.li & 1) if P3 else None
+    inv = V_SC + 2 * (t.li & 1) if L.uses_inv else None
     if L.epi == 'rgb':
         return [(v_mov_out(c * 4 + k, acc + k, inv), None) for k in range(3)]
     if L.epi == 'feat' and u == 16:
@@ -598,11 +644,15 @@ def epilogue_ops(T, c):
         tv = [tb + i for i in range(4)]
         for i in range(4):
             ops.append((v_max0(tv[i], acc + i), None))
+        if L.scaled and not L.lo_out:       # mix, the last three-pass layer: the bf6-style epilogue below on values that carry 2^k
+            for i in range(4):
+                ops.append((v_mul(tv[i], tv[i], inv), None))
     else:
+        assert not (L.scaled and not L.lo_out)
         tv = [acc + i for i in range(4)]
     h01 = hset(L.dst, u >> 1, c) + 2 * (u & 1)
     h23 = h01 + 1
-    if P3:
+    if L.lo_out if MIX else P3:
         # per value one v_fma_mix for the hi half -- f16(t 2^-k) -- and one for the lo half -- f16(t 2^-k - hi) --; the lo pairs go
         # through two temporaries into the AGPR set.  No two consecutive instructions touch a register one of them half-writes.
         l01, l23 = tb + 4, tb + 5
@@ -1191,11 +1241,14 @@ def build_fillers(opts):
     for T, t in enumerate(TILES):
         F.append(Filler(ds_read_b128(V_BIAS + (T & 1) * 4, V_AUX, t.li * AUX_LAYER + 64 * t.u, tag=('bias', T)),
                         afirst(T - 1) + 1 if T >= 1 else -1, afirst(T), ('aux',)))
-        if t.u == 0 and t.layer.ks and not X1:
+        if t.u == 0 and t.layer.nj:
             prev0 = TILE_OF[(t.li - 1, 0)]      # layer li-2 (same scale registers) is over once layer li-1 runs
+            e = afirst(prev0) + 1
+            if t.li >= 2 and CHAIN[t.li - 2].uses_inv:      # ... unless it multiplies by them in its epilogues: those end under tile 0 of layer li-1
+                e = afirst(prev0 + 1) + 1
             F.append(Filler(ds_read_b64(V_SC + 2 * (t.li & 1), V_AUX, t.li * AUX_LAYER + AUX_SCALES, tag=('scale', t.li)),
-                            afirst(prev0) + 1, aidx(T, 'm6', 0, 0), ('aux',)))
-        if t.u == 0 and P3:
+                            e, aidx(T, 'm6', 0, 0), ('aux',)))
+        if t.u == 0 and t.layer.uses_inv:
             # 1 / weight scale of layer li for its epilogues (they run under the layer's tiles 1.. and under the next layer's tile 0);
             # the registers' previous owner, layer li - 2, had its last epilogue under tile 0 of layer li - 1
             e = afirst(TILE_OF[(t.li - 1, 0)] + 1) + 1 if t.li >= 1 else -1
@@ -1338,7 +1391,7 @@ def schedule(opts):
         csrc = V_BIAS + (T & 1) * 4 if is_first else d
         if is_first:
             sch.need(('bias', T))
-        if P3 and a == ABASE[T] and T >= 1:
+        if a == ABASE[T] and T >= 1 and TILES[T - 1].layer.uses_inv:
             sch.need(('scale', TILES[T - 1].li))       # the epilogue of tile T - 1 (under this tile) multiplies by its layer's 1 / weight scale
         key = operand_key(T, kind, k, p)
         if kind == 'x':
@@ -1435,7 +1488,7 @@ def prologue_ops():
 def tail_ops():
     """exposed epilogue of the last row tile (RGB)"""
     ops = [s_nop(15), s_nop(15)]
-    if P3:
+    if CHAIN[-1].uses_inv:
         ops.append(waitcnt_lgkm(0))       # (the RGB layer's 1 / weight scale)
     for c in range(NC):
         ops += [ins for ins, _ in epilogue_ops(NT - 1, c)]
@@ -1614,6 +1667,8 @@ def emit(dirname, opts):
             f.write('"%s\\n\\t"\n' % line)
     def clob(nv0, nv1, na):
         regs = ['v%d' % i for i in range(nv0, nv1)] + ['a%d' % i for i in range(na)]
+        if na and A_EXTRA_CLOBBER:
+            regs += ['a%d' % i for i in range(*A_EXTRA_CLOBBER)]
         regs += ['s%d' % i for i in range(N_SGPR_LO, N_SGPR_HI)] + ['vcc', 'scc', 'memory']
         return ', '.join('"%s"' % r for r in regs) + '\n'
 

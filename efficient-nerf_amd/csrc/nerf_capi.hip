@@ -16,8 +16,8 @@
 namespace {
 
 struct PackedNet {
-    char* d_img[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [precision mode]
-    float inv_scale[5][NERF_N_SCALES];
+    char* d_img[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [precision mode]
+    float inv_scale[8][NERF_N_SCALES];
     std::vector<std::vector<float>> host_w;  // 24 tensors, state_dict order
     bool loaded = false;
 };
@@ -31,7 +31,9 @@ const size_t kTensorNumel[24] = {
     128 * 283, 128, 256 * 256, 256, 256, 1, 3 * 128, 3};
 
 int np_of(int mode) { return mode == R2L_PREC_FP16X1 ? 1 : 2; }
-bool mode_ok(int mode) { return mode == R2L_PREC_FP16X3 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X3_ASM; }
+bool mode_ok(int mode) {
+    return mode == R2L_PREC_FP16X3 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X3_ASM || mode == R2L_PREC_FP16_MIX;
+}
 
 void put_frag(char* chunk, int np, int frag, int lane, int j, float v) {
     _Float16 hi, lo;
@@ -111,9 +113,12 @@ struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding 
 // fmt 2 (p3): the stream of R2L_PREC_FP16X3_ASM -- per row tile its KS hi fragments, then its KS lo fragments, of W x 2^k with
 // max|w| 2^k in [2^12, 2^13) over the layer's main and embedding columns (lo = the fp16 rounding residual: a normal number thanks
 // to the factor); the bias x act_scale x 2^k; at the scale bytes' place 2^-k as a float for the epilogue
+// fmt 3 (mix): the stream of R2L_PREC_FP16_MIX -- fmt 0 with layers L1 .. L<NERF_MIX_K> packed as in fmt 2 (hi | lo fragments of
+// W x 2^k, 2^-k at the scale bytes' place) and 1.0f there for L0, whose epilogue hands L1 hi + lo sets with the three-pass form
 int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img, int fmt = 0) {
-    const bool x1 = fmt != 0, p3 = fmt == 2;
-    const size_t stream_bytes = p3 ? NERF_CHAINP3_STREAM_BYTES : (x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
+    const bool mix = fmt == 3;
+    const bool x1 = fmt != 0 && !mix, all_p3 = fmt == 2;
+    const size_t stream_bytes = mix ? NERF_CHAINM_STREAM_BYTES : all_p3 ? NERF_CHAINP3_STREAM_BYTES : (x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
     img.assign(stream_bytes + NERF_CHAIN_AUX_BYTES, 0);
     auto mat = [&](int ti, int ncol, int col0) {
         const float* p = w[ti].data();
@@ -138,9 +143,10 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
     size_t chunk_off = 0;
     uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + stream_bytes);
     for (int li = 0; li < 11; ++li) {
-        const ChainLayer& L = (p3 ? kChainP3 : (x1 ? kChainX : kChain))[li];
+        const ChainLayer& L = (all_p3 ? kChainP3 : (x1 ? kChainX : kChain))[li];
         const ChainSrc& S = src[li];
-        const int nj = x1 ? 0 : L.ks / 2, K = L.ks * 32;
+        const bool p3 = all_p3 || (mix && li >= 1 && li <= NERF_MIX_K);      // this layer's main k-steps run three fp16 passes
+        const int nj = (x1 || p3) ? 0 : L.ks / 2, K = L.ks * 32;
         const int pieces = p3 ? L.rpc * L.ks * 2 + L.rpc * L.nx * 2 : L.rpc * L.ks + L.rpc * nj + (L.rpc * nj + 1) / 2 + L.rpc * L.nx * 2;
         float sw = 1.0f;
         if (p3) {
@@ -158,12 +164,12 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
             const float v = (float)((double)S.bias(r) * Sa * (double)sw);
             memcpy(&al[r], &v, 4);
         }
-        if (p3) {
+        if (p3 || (mix && li == 0)) {
             const float inv = 1.0f / sw;
             for (int q = 0; q < 4; ++q) memcpy(&al[NERF_CHAIN_AUX_SCALES / 4 + 4 * q], &inv, 4);
         }
         int el = 0, ew = 0;
-        if (L.ks && !x1) {
+        if (L.ks && !x1 && !p3) {
             std::vector<float> all((size_t)L.fan_out * K);
             for (int r = 0; r < L.fan_out; ++r)
                 for (int k = 0; k < K; ++k) all[(size_t)r * K + k] = S.main(r, k);
@@ -344,7 +350,7 @@ void nerf_destroy(nerf_ctx* c) {
     if (!c) return;
     free_tmp(c);
     for (auto& n : c->net)
-        for (int m = 0; m < 5; ++m)
+        for (int m = 0; m < 8; ++m)
             if (n.d_img[m]) (void)hipFree(n.d_img[m]);
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_zmid) (void)hipFree(c->d_zmid);
@@ -379,9 +385,9 @@ static int upload_img(PackedNet& net, int mode, const std::vector<char>& img) {
 }
 
 static int build_net(nerf_ctx* c, PackedNet& net, int mode) {
-    if (mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16X3_ASM) {  // the layer chain's own streams
+    if (mode == R2L_PREC_FP16_FP8 || mode == R2L_PREC_FP16X1 || mode == R2L_PREC_FP16X3_ASM || mode == R2L_PREC_FP16_MIX) {  // the layer chain's own streams
         std::vector<char> img;
-        int rc = pack_chain(net.host_w, c->act_scale, img, mode == R2L_PREC_FP16X1 ? 1 : (mode == R2L_PREC_FP16X3_ASM ? 2 : 0));
+        int rc = pack_chain(net.host_w, c->act_scale, img, mode == R2L_PREC_FP16X1 ? 1 : (mode == R2L_PREC_FP16X3_ASM ? 2 : (mode == R2L_PREC_FP16_MIX ? 3 : 0)));
         return rc ? rc : upload_img(net, mode, img);
     }
     const int np = np_of(mode);
@@ -451,7 +457,7 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
         if (!tensors[i]) return r2l_set_error(R2L_EINVAL, "tensor %d is NULL", i);
         net.host_w.emplace_back(tensors[i], tensors[i] + kTensorNumel[i]);
     }
-    for (int m = 0; m < 5; ++m)
+    for (int m = 0; m < 8; ++m)
         if (net.d_img[m]) {
             (void)hipFree(net.d_img[m]);
             net.d_img[m] = nullptr;
@@ -762,7 +768,7 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 
 // run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
 long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, int fmt, char* out, long long cap, long long* offs) {
-    if (fmt < 0 || fmt > 2) return r2l_set_error(R2L_EINVAL, "chain stream format %d (0 fp16 + bf6 terms, 1 fp16 only, 2 hi | lo)", fmt);
+    if (fmt < 0 || fmt > 3) return r2l_set_error(R2L_EINVAL, "chain stream format %d (0 fp16 + bf6 terms, 1 fp16 only, 2 hi | lo, 3 mix)", fmt);
     if (!tensors || n_tensors != 24) return r2l_set_error(R2L_EINVAL, "expected 24 tensors");
     std::vector<std::vector<float>> w;
     for (int i = 0; i < 24; ++i) {
@@ -772,7 +778,7 @@ long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors,
     std::vector<char> img;
     int rc = pack_chain(w, 16.0f, img, fmt);
     if (rc) return rc;
-    if (offs) offs[0] = fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
+    if (offs) offs[0] = fmt == 3 ? NERF_CHAINM_STREAM_BYTES : fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
 }

@@ -36,6 +36,10 @@
 // FP16X3_ASM: fp16x3's arithmetic on the chain (NERF_GEN_FMT=f16p3: a hi and a lo fragment of W x 2^k per k-step, 84 chunks, same table
 // with 2^-k at the scale bytes' place)
 #define NERF_CHAINP3_STREAM_BYTES 2433024
+// R2L_PREC_FP16_MIX (gen/nerf_gen.py NERF_GEN_FMT=mix): the bf6 chain with trunk layers L1 .. L<NERF_MIX_K> in three fp16 passes (their
+// chunks in the hi | lo layout of the p3 stream, W x 2^k): 80 chunks as the bf6 stream, 2 x 8 of them 32 KiB instead of 28
+#define NERF_MIX_K 2
+#define NERF_CHAINM_STREAM_BYTES 2232320
 #define NERF_CHAIN_AUX_BYTES 16384
 #define NERF_CHAIN_AUX_LAYER 1280   // per layer: 272 f32 bias | at byte 1152: 4 lane quarters x (swl, sw, 0, 0)
 #define NERF_CHAIN_AUX_SCALES 1152

@@ -310,20 +310,32 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // P3 = true (NC = 2) is R2L_PREC_FP16X3_ASM: fp16x3's arithmetic on the chain (NERF_GEN_FMT=f16p3 -> nerf_mlpp3_*.inc): per k-step
 // hi(W) hi(a) + hi(W) lo(a) + lo(W) hi(a) on one accumulate chain, lo(a) in a second pair of activation sets (AGPRs), 2.43 MB of
 // stream per tile; for teachers whose sharp densities need fp32-grade arithmetic -- every trained one.
-template <bool X1, int NC, bool P3 = false>
+// MIX = true (NC = 2) is R2L_PREC_FP16_MIX (round 6): the bf6 chain with trunk layers L1 .. L<NERF_MIX_K> in three fp16 passes
+// (NERF_GEN_FMT=mix -> nerf_mlpm_*.inc): for the FINE pass of trained teachers, whose sharp tail amplifies what the early layers get wrong
+// (profiles/r06_teacher_mixed_study.txt); lo(a) of those layers' sources in AGPRs the bf6 chain leaves free (a176-a255).
+template <bool X1, int NC, bool P3 = false, bool MIX = false>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     static_assert(NC == 2 || (X1 && (NC == 3 || NC == 4)), "three / four column tiles exist for the fp16-only chain");
     static_assert(!P3 || (!X1 && NC == 2), "the three-pass chain is a two-column-tile build");
+    static_assert(!MIX || (!X1 && !P3 && NC == 2), "the mixed chain is a two-column-tile build of the bf6 chain");
     extern __shared__ __attribute__((aligned(16))) char nerf_chain_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     {   // resident table: per layer 272 f32 bias (act_scale domain) | E8M0 weight scales (nerf_common.h)
-        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (P3 ? NERF_CHAINP3_STREAM_BYTES : (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES)));
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (MIX ? NERF_CHAINM_STREAM_BYTES : P3 ? NERF_CHAINP3_STREAM_BYTES : (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES)));
         uint4* dst = reinterpret_cast<uint4*>(nerf_chain_lds + NERF_CHAIN_RING_BYTES);
         for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    if constexpr (P3) {
+    if constexpr (MIX) {
+        asm volatile(
+#include "nerf_mlpm_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpm_pro_clobbers.inc"
+        );
+    } else if constexpr (P3) {
         asm volatile(
 #include "nerf_mlpp3_pro_asm.inc"
             :
@@ -389,7 +401,15 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
             : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),             \
               [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),       \
               [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
-        if constexpr (P3) {
+        if constexpr (MIX) {
+            asm volatile(
+#include "nerf_mlpm_asm.inc"
+                NERF_CHAIN_OUT2
+                NERF_CHAIN_IN2
+                :
+#include "nerf_mlpm_clobbers.inc"
+            );
+        } else if constexpr (P3) {
             asm volatile(
 #include "nerf_mlpp3_asm.inc"
                 NERF_CHAIN_OUT2
@@ -998,7 +1018,8 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
 }
 
 hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles, bool stream_embed) {
-    static std::atomic<bool> attr_set[7][64];  // zero-initialised; the opt-in call itself is idempotent
+    static std::atomic<bool> attr_set[8][64];  // zero-initialised; the opt-in call itself is idempotent
+    if (mode == R2L_PREC_FP16_MIX) return launch_big_lds(&nerf_chain_kernel<false, 2, false, true>, attr_set[7], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X3_ASM) return launch_big_lds(&nerf_chain_kernel<false, 2, true>, attr_set[6], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X1 && x1_col_tiles == 4 && stream_embed)
         return launch_big_lds(&nerf_chain_emb_kernel, attr_set[5], NERF_CHAIN_LDS, p, grid, stream);

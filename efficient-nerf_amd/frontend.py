@@ -74,7 +74,7 @@ FLAGS = [
     # ranges, measured on every ray of the first frame and watched on every frame after it, keep it inside the 1e-4 rgb
     # contract, fp16x3_asm otherwise (R2LEngine.choose_precision / check_ranges); the teacher measures fp16x1 (its layer chain as one
     # fp16 pass), then fp16_fp8, against fp16x3 (NeRFEngine.choose_precision); fp32 = the generic layer path for any network shape
-    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp16_split', 'fp16_split8', 'fp32', 'auto'])),
+    ('--precision', dict(type=str, default='auto', choices=['fp16x3', 'fp16x1', 'fp16_fp8', 'fp16_e4m3', 'fp16x3_asm', 'fp16_split', 'fp16_split8', 'fp16_mix', 'fp32', 'auto'])),
     # --precision fp16_split / fp16_split8 taken literally: how many leading ResMLP blocks run in three fp16 passes (-1: half of them; `auto`
     # measures it, and which of the two formats behind the split is cheaper)
     ('--split_block', dict(type=int, default=-1)),
@@ -363,6 +363,8 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
                 log(f'[precision] {args.precision}: this network is outside the fused kernels\' shapes -> generic fp32 layer path '
                     f'({len(eng.plan)} Linear launches per chunk, {eng.flops_per_ray / 1e6:.2f} MFLOP/ray)')
             return 'R2L', eng
+        if args.precision == 'fp16_mix':
+            raise R2LError('--precision fp16_mix is a mode of the NeRF teacher\'s fine network (the R2L student has fp16_split / fp16_split8)')
         acts = (args.act.lower(), args.trial.inact.lower(), args.trial.outact.lower())
         for a in acts:
             if a not in R2LEngine.ACT_SLOPES:
@@ -451,9 +453,11 @@ def build_engine(args, hwf, ckpt, probe_pose=None, probe_rays=None, log=None, pr
                 sets = [tuple(t.reshape(-1, 3) for t in get_rays(H, W, focal, torch.as_tensor(p)[:3, :4], device=eng.device)) for p in plist]
             name, diff = eng.choose_precision(sets)
             if log:
-                tried = ', '.join(f'{k} {v:.1e} (limit {eng.AUTO_MAX_DIFF_X1 if k == "fp16x1" else eng.AUTO_MAX_DIFF:.0e})' for k, v in eng.auto_diffs.items())
-                log(f'[precision] auto: largest rgb / acc difference from fp16x3 on {min(4096, sets[0][0].shape[0])} rays of each of '
-                    f'{len(sets)} probe frame(s): {tried} -> {name}')
+                lims = {'fp16x1': eng.AUTO_MAX_DIFF_X1, 'fp16_fp8': eng.AUTO_MAX_DIFF, 'fp16_mix': eng.AUTO_MAX_DIFF_MIX, 'fp16x3_asm': eng.AUTO_MAX_DIFF_X3ASM}
+                tried = ', '.join(f'{k} {v:.1e} (limit {lims.get(k, 0):.0e})' for k, v in eng.auto_diffs.items())
+                log(f'[precision] auto: largest rgb / acc difference from fp16x3 on {min(4096, sets[0][0].shape[0])} rays of each of {len(sets)} probe '
+                    f'frame(s) (fp16_mix = coarse fp16x3_asm + fine bf6 chain with two three-pass layers: from fp16x3_asm for both, up to '
+                    f'{eng.MIX_PROBE_RAYS} rays; fp16x3_asm: stage by stage): {tried} -> {name}')
         return 'nerf', eng
     raise R2LError(f'model_name={args.model_name} is not a render path of this build')
 

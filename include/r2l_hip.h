@@ -83,6 +83,13 @@ extern "C" {
  *                    frame) against SPLIT at split 21 (12.5 ms); its second variant: SPLIT at split 9 (10.9 ms) -- so `auto` bisects
  *                    both and takes the cheaper. */
 #define R2L_PREC_FP16_SPLIT8 6
+/*   R2L_PREC_FP16_MIX (NeRF teacher only, round 6) R2L_PREC_FP16_FP8's layer chain with its first two 256 x 256 trunk layers
+ *                    (pts_linears.1, .2: model/nerf_raybased.py:379-386) in FP16X3_ASM's three fp16 passes and everything behind them
+ *                    with bf6 correction terms: ~2.0 pass-equivalents.  For the FINE network of trained teachers (nerf_set_precision_pair
+ *                    (FP16X3_ASM, FP16_MIX)): the sharp density tail of such a network amplifies the early layers' error, and with them
+ *                    exact the fine pass stays within 3-4e-5 of three passes everywhere at fixed sample positions; the coarse network,
+ *                    which steers sample_pdf, keeps FP16X3_ASM.  `--precision auto` measures it per checkpoint and watches it. */
+#define R2L_PREC_FP16_MIX 7
 
 typedef struct r2l_ctx r2l_ctx;
 typedef struct nerf_ctx nerf_ctx;

@@ -187,7 +187,7 @@ def cxx_pack_fmt(tensors, fmt):
     assert n > 0, L.r2l_last_error()
     buf = np.zeros(n, dtype=np.uint8)
     assert L.nerf_debug_pack_chain_host(arr, len(keep), fmt, C.c_void_p(buf.ctypes.data), n, offs) == n
-    assert L.nerf_debug_pack_chain_host(arr, len(keep), 3, None, 0, offs) < 0          # the format is an argument, not process state
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), 4, None, 0, offs) < 0          # the format is an argument, not process state
     return buf, int(offs[0])
 
 
@@ -232,3 +232,91 @@ def test_emulated_three_pass_chain_is_fp32_grade(wave, n_tiles, gain):
     for ins in GP.block_stream(GP.Opts()):
         kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
     assert kinds['mfma16'] == 7032 and 'mfma6' not in kinds and not any('bf6' in ins.text for ins in GP.block_stream(GP.Opts()))
+
+
+# ---- mix: the bf6 chain with its first two trunk layers in three passes (R2L_PREC_FP16_MIX: the fine pass of trained teachers, round 6) ----
+GM = _load_x('mix')
+
+
+def test_mixed_chain_layout_packer_and_committed_text(tmp_path):
+    assert GM.MIX and GM.MIXK == 2 and not GM.X1 and not GM.P3 and GM.NC == 2 and GM.NCH == 80 and GM.NCH % GM.NSLOT == 0
+    assert [l.p3 for l in GM.CHAIN] == [False, True, True] + [False] * 8 and [l.lo_out for l in GM.CHAIN] == [True, True] + [False] * 9
+    assert [l.uses_inv for l in GM.CHAIN] == [True, True, True] + [False] * 8 and [l.nj for l in GM.CHAIN] == [0, 0, 0, 4, 4, 4, 4, 4, 4, 4, 2]
+    # L1, L2: 16 row tiles x 8 k-steps x 3 passes x 2 column tiles instead of (8 + 4) x 2: 768 more MFMAs per layer than the bf6 chain
+    assert GM.N_ANCH == T.G.N_ANCH + 2 * 16 * (8 * 3 * 2 - (8 + 4) * 2) == 4500
+    assert GM.STREAM_BYTES == 2232320                                          # NERF_CHAINM_STREAM_BYTES (csrc/nerf_common.h)
+    # the lo(a) sets of the three-pass layers: inside the bf6 sets' registers while those are dead, 16 each above the inputs
+    regs = {n: sorted({GM.lset(n, s_, c) + i for s_ in range(8) for c in range(2) for i in range(4)}) for n in 'PQ'}
+    assert len(regs['P']) == len(regs['Q']) == 64 and not set(regs['P']) & set(regs['Q'])
+    assert set(regs['P']) <= set(range(0, 48)) | set(range(240, 256)) and set(regs['Q']) <= set(range(48, 96)) | set(range(224, 240))
+    for seed, gain in ((5, 1.0), (6, 40.0), (7, 0.01)):
+        t = T.make_tensors(seed=seed, gain=gain)
+        buf, aux_off = cxx_pack_fmt(t, 3)
+        img, aux = GM.pack_teacher(t)
+        assert aux_off == img.size == GM.STREAM_BYTES and buf.size == img.size + aux.size
+        assert np.array_equal(buf[:aux_off], img) and np.array_equal(buf[aux_off:], aux)
+    GM.emit(str(tmp_path), GM.Opts())
+    for name in ('nerf_mlpm_asm.inc', 'nerf_mlpm_pro_asm.inc', 'nerf_mlpm_clobbers.inc', 'nerf_mlpm_pro_clobbers.inc'):
+        built = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)
+        assert open(os.path.join(str(tmp_path), name)).read() == open(built).read(), name
+    assert '"a224"' in open(os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', 'nerf_mlpm_clobbers.inc')).read()        # the block owns a224-a255 too
+
+
+def _run_tile(G, buf, aux_off, e, v, wave=0, n_tiles=1):
+    out, errs = G.emulate_tile(G.Opts(), buf[:aux_off], buf[aux_off:], T.make_frags(e, v, 16.0), wave=wave, n_tiles=n_tiles)
+    assert not errs, errs[:10]
+    got = np.zeros((32, 4))
+    for c in range(2):
+        for k in range(4):
+            got[c * 16:(c + 1) * 16, k] = out[c * 4 + k][:16] / 16.0
+    return got
+
+
+@pytest.mark.parametrize('wave,n_tiles,gain', [(0, 1, 1.0), (3, 2, 1.5)])
+def test_emulated_mixed_chain_on_synthetic_weights(wave, n_tiles, gain):
+    """the exact instruction stream (no hazard, every LDS read waited for) on the C++ packer's bytes against float64: on smooth synthetic
+    weights the bf6 layers behind the split set the error -- that of the bf6 chain, an order of magnitude inside a single fp16 pass"""
+    t = T.make_tensors(seed=wave, gain=gain)
+    rng = np.random.default_rng(10 + wave)
+    pts = rng.uniform(-2.5, 2.5, size=(32, 3)).astype(np.float32)
+    vd = rng.normal(size=(32, 3))
+    vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
+    ref, e, v = T.ref_mlp(t, pts, vd)
+    f16_err = np.abs(T.ref_mlp(t, pts, vd, f16_ops=True)[0] - ref).max()
+    buf, aux_off = cxx_pack_fmt(t, 3)
+    err = np.abs(_run_tile(GM, buf, aux_off, e, v, wave, n_tiles) - ref).max()
+    print('wave %d gain %g: mixed chain L_inf %.3g (single-pass fp16 operands: %.3g)' % (wave, gain, err, f16_err))
+    assert err <= 0.15 * f16_err
+    kinds = {}
+    for ins in GM.block_stream(GM.Opts()):
+        kinds[ins.kind] = kinds.get(ins.kind, 0) + 1
+    assert kinds['mfma16'] == 3656 and kinds['mfma6'] == 844       # the bf6 chain: 2,504 + 1,228
+
+
+def test_emulated_mixed_chain_on_the_trained_like_fine_network():
+    """what the format is for: the committed trained-like FINE network at the 32 densest sample points of four hard rays (sigma up to 31
+    there).  Against float64 the bf6 chain's density is 6e-4 (relative) off, the mixed chain's 9e-5, three passes everywhere 5e-6: the
+    two exact layers buy a factor of five and more, as the float study on whole frames says (profiles/r06_teacher_mixed_study.txt)"""
+    from oracle import r2l_oracle as O
+    from oracle import whole_frame as WF
+    sds = WF.load_teacher()
+    t = [sds[1][n].numpy() for n in O.teacher_state_names()]
+    ro, rd = WF.frame_rays(0)
+    idx = torch.tensor([44697, 74345, 75007, 45332])
+    with torch.no_grad():
+        o = O.render_rays_taps(sds[0], sds[1], ro[idx], rd[idx])
+    pts, vd = [], []
+    for j in range(4):
+        z = o['z_vals'][j][torch.topk(o['raw'][j, :, 3], 8).indices]
+        pts.append(ro[idx[j]][None] + rd[idx[j]][None] * z[:, None])
+        vd.append((rd[idx[j]] / rd[idx[j]].norm())[None].expand(8, 3))
+    pts, vd = torch.cat(pts).numpy().astype(np.float32), torch.cat(vd).numpy().astype(np.float32)
+    ref, e, v = T.ref_mlp(t, pts, vd)
+    assert ref[:, 3].max() > 20.
+    rel = {}
+    for name, G, fmt in (('bf6', T.G, 0), ('mix', GM, 3), ('p3', GP, 2)):
+        buf, aux_off = cxx_pack_fmt(t, fmt)
+        d = np.abs(_run_tile(G, buf, aux_off, e, v) - ref)
+        rel[name] = (d[:, 3] / np.maximum(1., np.abs(ref[:, 3])))[ref[:, 3] > 1].max()
+        print('%-4s raw L_inf rgb %.3g sigma %.3g; sigma relative (sigma > 1) %.3g' % (name, d[:, :3].max(), d[:, 3].max(), rel[name]))
+    assert rel['mix'] <= 0.3 * rel['bf6'] and rel['p3'] <= 0.3 * rel['mix'] and rel['mix'] < 2e-4

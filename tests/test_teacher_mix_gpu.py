@@ -1,0 +1,104 @@
+"""GPU: R2L_PREC_FP16_MIX (round 6) -- the teacher's fine network on the bf6 layer chain with its first two trunk layers in three fp16
+passes (csrc/gen/nerf_gen.py NERF_GEN_FMT=mix, emulated on the CPU by tests/test_nerf_genx_cpu.py), the coarse network in fp16x3_asm.
+The rung `--precision auto` gives TRAINED teachers instead of three passes everywhere: the reference's teacher is
+always a trained network (model/nerf_raybased.py:337-401 through main.py:624-756; create_data: utils/create_data.py:812-872)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mix_raw_against_fp16x3_on_synthetic_weights(pkg):
+    """run_network in the mixed chain (both networks) against the compiler-scheduled fp16x3: raw within the bf6 chain's tolerance"""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    H = 40
+    focal = O.focal_from_angle(H)
+    sds = (O.make_teacher_state(1), O.make_teacher_state(2))
+    eng = NeRFEngine(H, H, focal, precision=PRECISIONS['fp16x3']).load_state_dicts(*sds)
+    ro, rd = O.get_rays(H, H, focal, O.pose_spherical(30., -30., 4.)[:3, :4])
+    ro, rd = ro.reshape(-1, 3).float().cuda(), rd.reshape(-1, 3).float().cuda()
+    z = eng.z_coarse.cuda()
+    ref = [eng.run_network(w, ro, rd, z).clone() for w in (0, 1)]
+    eng.set_precision_pair(PRECISIONS['fp16_mix'], PRECISIONS['fp16_mix'])
+    for w in (0, 1):
+        d = (eng.run_network(w, ro, rd, z) - ref[w]).abs().max().item()
+        print(f'network {w}: raw of the mixed chain within {d:.2e} of fp16x3')
+        assert d <= 2e-4
+    # a render with the pair the rung uses: coarse fp16x3_asm, fine fp16_mix
+    eng.set_precision(PRECISIONS['fp16_mix'])
+    assert eng.precision_name == 'fp16_mix' and eng.precision_coarse == PRECISIONS['fp16x3_asm']
+    got = eng.render(O.pose_spherical(30., -30., 4.))
+    eng.set_precision(PRECISIONS['fp16x3'])
+    want = eng.render(O.pose_spherical(30., -30., 4.))
+    for k in ('rgb_map', 'acc_map'):
+        assert (got[k] - want[k]).abs().max().item() <= 2e-5, k
+    eng.close()
+    e2 = NeRFEngine(H, H, focal, precision=PRECISIONS['fp16_mix']).load_state_dicts(*sds)       # constructed in the rung: the same pair
+    assert e2.precision_name == 'fp16_mix' and e2.precision_coarse == PRECISIONS['fp16x3_asm']
+    assert torch.equal(e2.render(O.pose_spherical(30., -30., 4.))['rgb_map'], got['rgb_map'])
+    e2.close()
+
+
+def test_trained_like_teacher_gets_the_mixed_rung_and_it_holds_on_whole_frames(pkg):
+    """the committed trained-like teacher: `auto` (create_data's probes) ends on fp16_mix; against three passes for both networks on the
+    same generated chain -- the same coarse pass, so z_samples are bitwise the same and the maps compare directly -- every ray of three
+    whole 400 x 400 frames is within 5e-5 on rgb; the frame is faster than three passes everywhere; the watch passes; one rung down is
+    fp16x3_asm"""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    from efficient_nerf_amd import create_data as CD
+    from oracle import whole_frame as WF
+    sds = WF.load_teacher()
+    H = WF.H
+    eng = NeRFEngine(H, H, WF.focal(), precision=PRECISIONS['fp16x3']).load_state_dicts(*sds)
+    name = CD.choose_precision_for_rand(eng, H, H, WF.focal())
+    print('auto:', name, eng.auto_diffs)
+    assert name == 'fp16_mix' and eng.precision_name == 'fp16_mix'
+    assert eng.auto_diffs['fp16_mix'] <= eng.AUTO_MAX_DIFF_MIX and eng.auto_diffs['fp16x3_asm'] <= eng.AUTO_MAX_DIFF_X3ASM
+    assert eng.auto_diffs['fp16_fp8'] > eng.AUTO_MAX_DIFF
+    times = {}
+    outs = {}
+    for mode in ('fp16x3_asm', 'fp16_mix'):
+        eng.set_precision(PRECISIONS[mode])
+        eng.render(WF.pose(0))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs[mode] = [{k: v.clone() for k, v in eng.render(WF.pose(pi), extras=True).items()} for pi in range(3)]
+        torch.cuda.synchronize()
+        times[mode] = (time.perf_counter() - t0) / 3
+    worst = 0.
+    for pi in range(3):
+        a, b = outs['fp16_mix'][pi], outs['fp16x3_asm'][pi]
+        assert torch.equal(a['z_samples'], b['z_samples']) and torch.equal(a['rgb0'], b['rgb0'])       # the coarse pass is the same launch
+        d = {k: (a[k] - b[k]).abs().max().item() for k in ('rgb_map', 'acc_map', 'depth_map')}
+        n5 = int(((a['rgb_map'] - b['rgb_map']).abs().max(-1)[0] > 3e-5).sum())
+        print(f'pose {pi}: fp16_mix from fp16x3_asm over {H * H} rays: {d}; rays beyond 3e-5: {n5}')
+        worst = max(worst, d['rgb_map'])
+        assert d['rgb_map'] <= 5e-5 and d['acc_map'] <= 1e-4 and d['depth_map'] <= 6e-4
+    print(f'per frame (extras copied): fp16x3_asm {times["fp16x3_asm"] * 1e3:.1f} ms, fp16_mix {times["fp16_mix"] * 1e3:.1f} ms; worst rgb {worst:.2e}')
+    assert times['fp16_mix'] < 0.92 * times['fp16x3_asm']
+    # the watch: a sample of a rendered frame against three passes on the same chain
+    eng.set_precision(PRECISIONS['fp16_mix'])
+    from efficient_nerf_amd.teacher import get_rays
+    ro, rd = (t.reshape(-1, 3) for t in get_rays(H, H, WF.focal(), WF.pose(1)[:3, :4], device=eng.device))
+    ok, d = eng.spot_check(ro, rd, eng.render_rays(ro, rd))
+    print('spot check:', ok, d)
+    assert ok and d['rgb_map'] <= eng.AUTO_MAX_DIFF_MIX
+    assert eng.step_down() == 'fp16x3_asm' and eng.precision_coarse == PRECISIONS['fp16x3_asm'] == eng.precision
+    eng.close()
+
+
+def test_synthetic_teacher_keeps_its_single_pass(pkg):
+    """the smooth synthetic teacher is not affected: `auto` still takes fp16x1, the first rung"""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    from efficient_nerf_amd import create_data as CD
+    H = 200
+    focal = O.focal_from_angle(H)
+    eng = NeRFEngine(H, H, focal, precision=PRECISIONS['fp16x3']).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    assert CD.choose_precision_for_rand(eng, H, H, focal) == 'fp16x1'
+    eng.close()

@@ -2,8 +2,10 @@
 teacher pair fitted to an analytic scene with the reference's loss, main.py:624-756 / 1355-1380; pseudo data by the HIP
 create_data path, utils/create_data.py:812-872; a W256D88 student distilled from it, README.md:79-87) through the product path.
 What nn.Linear-init weights could only predict (VERDICT r4 missing 2 / weak 1-2) is pinned here as measured:
-  * the teacher's sharp densities (sigma ~ 200, acc bimodal) make the faster modes miss by 1e-3 .. 3e-1 -- `auto` must end in three fp16 passes
-    (fp16x3_asm: the generated chain), whose render is inside the 1e-4 contract of the CPU oracle;
+  * the teacher's sharp densities (sigma ~ 200, acc bimodal) make the whole-network fast modes miss by 1e-3 .. 3e-1 -- `auto` must end on the
+    measured rung behind them (round 6: fp16_mix = coarse pass in three fp16 passes on the generated chain, fine pass with its first two
+    trunk layers in three passes; fp16x3_asm for both before), whose render is inside the 1e-4 contract of the CPU oracle on the sampled rays
+    (whole frames: the test at the end of this file);
   * the student's residual stream grows with depth (max|a| ~ 126): beyond the whole-network bf6 / e4m3 rungs; `auto` must end on the
     split rung (fp16_split: head and leading blocks in three passes, tests/test_split_gpu.py) or the last one, inside 1e-4."""
 import os
@@ -32,7 +34,7 @@ def test_trained_like_teacher_auto_ends_in_three_passes_inside_the_contract(pkg)
     eng = NeRFEngine(H, H, focal, precision=PRECISIONS['fp16x3']).load_state_dicts(*tsds)
     name = CD.choose_precision_for_rand(eng, H, H, focal)
     print('probe differences from fp16x3:', eng.auto_diffs)
-    assert name == 'fp16x3_asm' and eng.precision_name == 'fp16x3_asm'      # the generated three-pass chain: fp16x3's arithmetic
+    assert name == 'fp16_mix' and eng.precision_name == 'fp16_mix'      # round 6: coarse on the generated three-pass chain, fine with its first two layers in three passes
     assert eng.auto_diffs['fp16x1'] > 1e-3 and eng.auto_diffs['fp16_fp8'] > eng.AUTO_MAX_DIFF      # measured 1e-1 / 1e-2: not marginal
     pose = O.pose_spherical(30., -30., 4.)
     got = eng.render(pose)
@@ -43,7 +45,7 @@ def test_trained_like_teacher_auto_ends_in_three_passes_inside_the_contract(pkg)
     want = O.render_rays(tsds[0], tsds[1], ro.reshape(-1, 3)[idx].float(), rd.reshape(-1, 3)[idx].float(), white_bkgd=True)
     for k in ('rgb_map', 'acc_map'):
         err = (got[k].cpu()[idx] - want[k]).abs().max().item()
-        print(f'trained-like teacher fp16x3_asm vs CPU oracle, {k}: {err:.2e}')
+        print(f'trained-like teacher {name} vs CPU oracle, {k}: {err:.2e}')
         assert err <= 1e-4, (k, err)
     assert float(torch.relu(want['raw'][..., 3]).max()) > 100.                                       # the densities are sharp
     # why the coarse pass must be fp32-grade: with it exact, the fine pass in fp16_fp8 is within 1e-3 of fp16x3 over the whole frame;
@@ -98,7 +100,7 @@ def test_trained_like_pipeline_command_lines(pkg, tmp_path):
                         '--teacher_ckpt', tck, '--n_pose_kd', '2', '--datadir_kd', f'unused:{out}', '--create_data_chunk', '2',
                         '--split_size', '4096', '--H', '128', '--synthetic_poses', '1'], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert '-> fp16x3_asm' in r.stdout and 'wrote 2 shard(s)' in r.stdout, r.stdout[-800:]
+    assert ('-> fp16_mix' in r.stdout or '-> fp16x3_asm' in r.stdout) and 'wrote 2 shard(s)' in r.stdout, r.stdout[-800:]
     r = subprocess.run([sys.executable, os.path.join(root, 'main.py'), '--model_name', 'R2L', '--config', 'configs/lego_noview.txt',
                         '--n_sample_per_ray', '16', '--netwidth', '256', '--netdepth', '88', '--use_residual', '--trial.ON',
                         '--trial.body_arch', 'resmlp', '--pretrained_ckpt', sck, '--render_only', '--synthetic_poses', '2', '--H', '64',
@@ -111,7 +113,7 @@ def test_trained_like_pipeline_command_lines(pkg, tmp_path):
     print(r.stdout[-1500:])
 
 
-@pytest.mark.parametrize('mode', ['fp16x3_asm', 'fp16x3'])
+@pytest.mark.parametrize('mode', ['fp16x3_asm', 'fp16x3', 'fp16_mix'])
 def test_trained_like_teacher_whole_rows_against_the_fp32_oracle_and_float64(pkg, mode):
     """EVERY ray of 200 contiguous rows (80,000 rays) of the top-down pose of the trained-like teacher, not a
     strided sample -- the block holds the rays on which the two fp32-grade HIP modes were known to differ by 1e-4 ... 4.7e-2 (rows 128-175,

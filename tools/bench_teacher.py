@@ -18,7 +18,7 @@ H = W = int(os.environ.get('T_H', 400))
 REP = int(os.environ.get('T_REP', 3))
 FLOP_PER_RAY = 2 * 593408 * 256
 ONLY = os.environ.get('T_PREC')  # e.g. fp16_fp8: that mode only (profiling runs)
-for prec, name in ((PREC_FP16X3, 'fp16x3'), (2, 'fp16_fp8'), (PREC_FP16X1, 'fp16x1'), (4, 'fp16x3_asm')):
+for prec, name in ((PREC_FP16X3, 'fp16x3'), (2, 'fp16_fp8'), (PREC_FP16X1, 'fp16x1'), (4, 'fp16x3_asm'), (7, 'fp16_mix')):
     if ONLY and name != ONLY:
         continue
     eng = NeRFEngine(H, W, O.focal_from_angle(W), precision=prec).load_state_dicts(O.make_teacher_state(1),
@@ -31,7 +31,7 @@ for prec, name in ((PREC_FP16X3, 'fp16x3'), (2, 'fp16_fp8'), (PREC_FP16X1, 'fp16
         out = eng.render(poses[i % 4])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / REP
-    passes = {'fp16x3': 3, 'fp16_fp8': 1.5, 'fp16x1': 1, 'fp16x3_asm': 3}[name]
+    passes = {'fp16x3': 3, 'fp16_fp8': 1.5, 'fp16x1': 1, 'fp16x3_asm': 3, 'fp16_mix': 0.25 * 3 + 0.75 * 1.96}[name]   # mix: coarse three passes, fine 2 of ~8.6 layers
     print(f'teacher {name} {H}x{W}: {dt*1e3:.1f} ms/frame, {H*W/dt:.3e} rays/s, algorithmic {FLOP_PER_RAY*H*W/dt/1e12:.0f} TFLOP/s '
           f'(executed {FLOP_PER_RAY*H*W*passes/dt/1e12:.0f})', flush=True)
     eng.close()
