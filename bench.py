@@ -228,7 +228,10 @@ def trained_like_leg(torch, O, cpu):
     teng = NeRFEngine(th, th, tf, precision=PRECISIONS['fp16x3']).load_state_dicts(*tsds)
     name = CD.choose_precision_for_rand(teng, th, th, tf)
     t = {'precision': name, 'probe_diffs_from_fp16x3': dict(teng.auto_diffs),
-         'limits': {'fp16x1': teng.AUTO_MAX_DIFF_X1, 'fp16_fp8': teng.AUTO_MAX_DIFF}}
+         'limits': {'fp16x1': teng.AUTO_MAX_DIFF_X1, 'fp16_fp8': teng.AUTO_MAX_DIFF, 'fp16_mix': teng.AUTO_MAX_DIFF_MIX, 'fp16x3_asm': teng.AUTO_MAX_DIFF_X3ASM},
+         'rungs': 'fp16x1, fp16_fp8: both networks, against fp16x3 on 4,096 rays of each probe set; fp16_mix (round 6): coarse network fp16x3_asm, fine network '
+                  'on the bf6 chain with its first two trunk layers in three passes, against fp16x3_asm for both on up to 65,536 rays per set (same coarse pass: '
+                  'same sample positions); fp16x3_asm: against fp16x3 stage by stage (coarse maps; fine pass at the same sample positions); last: fp16x3'}
     poses = [O.pose_spherical(30., -30., 4.), O.pose_spherical(150., -85., 4.), O.pose_spherical(-100., -5., 4.)]
     teng.render(poses[0])
     teng.timing(True)

@@ -128,6 +128,42 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
     return oo.view(rays_o.shape), dd.view(rays_d.shape)
 
 
+def rebalanced_state(sd, maxima, keep=2, target=8.0):
+    """An exact reparametrisation of NeRF(D=8, W=256, use_viewdirs) (model/nerf_raybased.py:377-401) that brings the inputs of its layers
+    into the range the bf6 layer chain converts them with (fixed exponents: |a| <= 14 for the values, <= 8 for their fp16 residuals;
+    csrc/gen/isa.py ACT_EXP / RES_EXP): relu is positively homogeneous and feature_linear is linear, so the output of trunk layer i
+    divided by 2^s_i, feature by 2^s_f and the view layer's output by 2^s_v -- with the consumers' weight columns multiplied back -- is the
+    same function, and every factor a power of two makes it the same function in float32 arithmetic too (no rounding: each weight and
+    bias is scaled exactly).  `maxima`: {'h0' .. 'h7', 'feature', 'views': largest |value| measured on the job's own points
+    (NeRFEngine.fine_activation_maxima)}; s = ceil(log2(max / target)) so that max / 2^s lies in (target / 2, target]; the outputs of the
+    first `keep` trunk layers stay as they are (R2L_PREC_FP16_MIX runs the layers that read them in three fp16 passes).  Returns (new
+    state dict, {name: s})."""
+    import math
+    sd = {(k[7:] if k.startswith('module.') else k): v.detach().to('cpu', torch.float32).clone() for k, v in sd.items()}
+    sh = lambda m: 0 if not (m > 0 and math.isfinite(m)) else int(math.ceil(math.log2(m / target)))
+    s = {f'h{i}': (0 if i < keep else sh(float(maxima[f'h{i}']))) for i in range(8)}
+    s['feature'], s['views'] = sh(float(maxima['feature'])), sh(float(maxima['views']))
+    for i in range(8):
+        prev = s[f'h{i - 1}'] if i else 0
+        W = sd[f'pts_linears.{i}.weight']
+        if i == 5:          # cat([input_pts, h]) (:385): the first 63 columns read the embedding
+            W[:, :63] *= 2.0 ** (-s['h5'])
+            W[:, 63:] *= 2.0 ** (prev - s['h5'])
+        elif i == 0:
+            W *= 2.0 ** (-s['h0'])
+        else:
+            W *= 2.0 ** (prev - s[f'h{i}'])
+        sd[f'pts_linears.{i}.bias'] *= 2.0 ** (-s[f'h{i}'])
+    sd['alpha_linear.weight'] *= 2.0 ** s['h7']
+    sd['feature_linear.weight'] *= 2.0 ** (s['h7'] - s['feature'])
+    sd['feature_linear.bias'] *= 2.0 ** (-s['feature'])
+    sd['views_linears.0.weight'][:, :256] *= 2.0 ** (s['feature'] - s['views'])
+    sd['views_linears.0.weight'][:, 256:] *= 2.0 ** (-s['views'])
+    sd['views_linears.0.bias'] *= 2.0 ** (-s['views'])
+    sd['rgb_linear.weight'] *= 2.0 ** s['views']
+    return sd, s
+
+
 class NeRFEngine:
     """One nerf_ctx: coarse + fine NeRF(D=8, W=256, use_viewdirs) and the render_rays
     pipeline (include/r2l_hip.h)."""
@@ -209,7 +245,68 @@ class NeRFEngine:
         """The `.tar`'s 'network_fn_state_dict' / 'network_fine_state_dict' (main.py:1516-1542)."""
         self._load(0, network_fn_state_dict)
         self._load(1, network_fine_state_dict)
+        self._fine_state = network_fine_state_dict        # a reference: rebalance_fine re-packs the fine network from it
+        self.fine_shifts = None
         return self
+
+    def fine_activation_maxima(self, rays_o, rays_d, z_vals, max_points=1 << 18):
+        """largest |value| of every hidden activation of the FINE network (outputs of pts_linears.0-7, feature_linear, views_linears.0)
+        on up to `max_points` of the points rays_o + rays_d z_vals ([n, S]: the sample positions a render of these rays used), evaluated
+        layer by layer with the library's fp32 layer kernels (generic.Linear = r2l_linear_forward; the embedding by nerf_embed): what
+        rebalanced_state needs.  Synchronous; once per weight load."""
+        from .generic import Linear, _view
+        sd = {(k[7:] if k.startswith('module.') else k): v for k, v in self._fine_state.items()}
+        dev = self.device
+        n, S = z_vals.shape
+        step = max(1, (n * S) // int(max_points))
+        ro, rd, z = rays_o.reshape(-1, 3)[::step].contiguous(), rays_d.reshape(-1, 3)[::step].contiguous(), z_vals[::step].contiguous()
+        n = ro.shape[0]
+        m = n * S
+        pts = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        cat = torch.empty((m, 63 + 256), dtype=torch.float32, device=dev)
+        views = torch.empty((m, 256 + 27), dtype=torch.float32, device=dev)
+        work = [torch.empty((m, 256), dtype=torch.float32, device=dev) for _ in range(2)]
+        lin = {k: Linear(sd[k + '.weight'], sd[k + '.bias'], dev) for k in [f'pts_linears.{i}' for i in range(8)] + ['feature_linear', 'views_linears.0']}
+        mx = {}
+        with torch.cuda.device(dev):
+            check(lib().r2l_sample_points(dptr(ro), dptr(rd), n, dptr(z), S, 1, dptr(pts), current_stream()))
+            op, ldo = _view(cat[:, :63])
+            check(lib().nerf_embed(dptr(pts), 3, m, 3, 10, op, ldo, current_stream()))
+            dirs = (rd / torch.norm(rd, dim=-1, keepdim=True))[:, None, :].expand(n, S, 3).reshape(m, 3).contiguous()      # main.py:148-157, 76-77
+            op, ldo = _view(views[:, 256:])
+            check(lib().nerf_embed(dptr(dirs), 3, m, 3, 4, op, ldo, current_stream()))
+            x, pp = cat[:, :63], 0
+            for i in range(8):
+                y = cat[:, 63:] if i == 4 else work[pp]         # h = cat([input_pts, h]) behind layer 4 (model/nerf_raybased.py:385)
+                if i != 4:
+                    pp ^= 1
+                lin[f'pts_linears.{i}'](x, y, act='relu')
+                mx[f'h{i}'] = float(y.abs().max())
+                x = cat if i == 4 else y
+            lin['feature_linear'](x, views[:, :256])
+            mx['feature'] = float(views[:, :256].abs().max())
+            hv = work[pp][:, :128]
+            lin['views_linears.0'](views, hv, act='relu')
+            mx['views'] = float(hv.abs().max())
+        for l in lin.values():
+            l.close()
+        return mx
+
+    def rebalance_fine(self, rays_o, rays_d, z_vals):
+        """Re-pack the fine network from an exact power-of-two reparametrisation whose hidden activations fit the bf6 chain's fixed
+        conversion exponents on these points (rebalanced_state): the calibration of R2L_PREC_FP16_MIX / _FP16_FP8 without a kernel
+        change.  The function the network computes is unchanged bit for bit in float32; three passes render the same image.  Returns
+        the shifts {activation: s} (also kept in `fine_shifts`)."""
+        mx = self.fine_activation_maxima(rays_o, rays_d, z_vals)
+        sd, sh = rebalanced_state(self._fine_state, mx)
+        try:
+            self._load(1, sd)
+        except R2LError as e:          # a rescaled layer outside what the chain's weight split packs (max|w| beyond 2^-12 .. 2^6): as loaded
+            self._load(1, self._fine_state)
+            self.fine_shifts, self.fine_maxima, self.rebalance_note = None, mx, str(e)
+            return None
+        self.fine_shifts, self.fine_maxima = sh, mx
+        return sh
 
     def set_precision(self, precision):
         from ._lib import PREC_FP16_MIX, PREC_FP16X3_ASM
@@ -247,6 +344,7 @@ class NeRFEngine:
     AUTO_MAX_DIFF_MIX = 5e-5
     MIX_PROBE_RAYS = 65536
     AUTO_MIX = True
+    AUTO_REBALANCE = True
     #: fp16x3_asm (the generated three-pass chain) against fp16x3 (the compiler-scheduled kernel every probe compares with), round 6
     #:: both are fp32-grade, and on a TRAINED teacher two fp32-grade evaluations differ by more than any tight limit on the
     #: rays where sample_pdf is discontinuous -- a coarse weight that differs in its last float32 bits moves a fine sample by up to a
@@ -323,6 +421,13 @@ class NeRFEngine:
                 idx = self._strided(ro.shape[0], self.MIX_PROBE_RAYS, ro.device)
                 big.append((ro[idx].contiguous(), rd[idx].contiguous()))
             self.set_precision(PREC_FP16X3_ASM)
+            if self.AUTO_REBALANCE:
+                # the fine network's activations on the probes' own fine sample positions -> exact rescaling into the bf6 chain's range
+                # (measured on the trained-like teacher: worst rgb difference over whole frames 4.3e-5 -> 3.0e-5)
+                zs, rs = [], []
+                for ro, rd in probes:
+                    zs.append(self.render_rays(ro, rd, extras=True)['z_vals'].clone())
+                self.rebalance_fine(torch.cat([p[0] for p in probes]), torch.cat([p[1] for p in probes]), torch.cat(zs))
             refs_m = [{k: v.clone() for k, v in self.render_rays(ro, rd).items() if k in self.WATCH_KEYS} for ro, rd in big]
             self.set_precision(PREC_FP16_MIX)
             lim = self._limits(self.AUTO_MAX_DIFF_MIX)

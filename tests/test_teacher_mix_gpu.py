@@ -102,3 +102,57 @@ def test_synthetic_teacher_keeps_its_single_pass(pkg):
     eng = NeRFEngine(H, H, focal, precision=PRECISIONS['fp16x3']).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
     assert CD.choose_precision_for_rand(eng, H, H, focal) == 'fp16x1'
     eng.close()
+
+
+def test_rebalanced_fine_network_is_the_same_function_and_fits_the_bf6_range(pkg):
+    """NeRFEngine.rebalance_fine: the activation maxima of the fine network measured with the library's fp32 layer kernels agree with the
+    CPU oracle's, the power-of-two reparametrisation renders the same image in three passes (the same function in float32), every
+    rescaled activation lies in (4, 8], and the mixed chain is closer to three passes on the rebalanced network than on the original"""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    from efficient_nerf_amd.teacher import get_rays, rebalanced_state
+    from oracle import whole_frame as WF
+    import torch.nn.functional as F
+    sds = WF.load_teacher()
+    H = WF.H
+    eng = NeRFEngine(H, H, WF.focal(), precision=PRECISIONS['fp16x3_asm']).load_state_dicts(*sds)
+    ro, rd = (t.reshape(-1, 3) for t in get_rays(H, H, WF.focal(), WF.pose(0)[:3, :4], device=eng.device))
+    idx = torch.arange(0, H * H, 40, device=ro.device)
+    ros, rds = ro[idx].contiguous(), rd[idx].contiguous()
+    ref = {k: v.clone() for k, v in eng.render_rays(ros, rds, extras=True).items()}
+    mx = eng.fine_activation_maxima(ros, rds, ref['z_vals'], max_points=1 << 20)
+    # the oracle's activations on the same points (CPU fp32)
+    pts = (ros[:, None, :] + rds[:, None, :] * ref['z_vals'][:, :, None]).reshape(-1, 3).cpu()
+    vd = (rds / rds.norm(dim=-1, keepdim=True))[:, None, :].expand(-1, ref['z_vals'].shape[1], 3).reshape(-1, 3).cpu()
+    sd = sds[1]
+    e, ev = O.nerf_embed(pts, 10), O.nerf_embed(vd, 4)
+    h, want = e, {}
+    with torch.no_grad():
+        for i in range(8):
+            h = F.relu(F.linear(h, sd[f'pts_linears.{i}.weight'], sd[f'pts_linears.{i}.bias']))
+            want[f'h{i}'] = float(h.abs().max())
+            if i == 4:
+                h = torch.cat([e, h], -1)
+        feat = F.linear(h, sd['feature_linear.weight'], sd['feature_linear.bias'])
+        want['feature'] = float(feat.abs().max())
+        want['views'] = float(F.relu(F.linear(torch.cat([feat, ev], -1), sd['views_linears.0.weight'], sd['views_linears.0.bias'])).abs().max())
+    print('maxima (HIP fp32 layers):', {k: round(v, 2) for k, v in mx.items()})
+    for k in want:
+        assert abs(mx[k] - want[k]) <= 1e-3 * want[k], (k, mx[k], want[k])
+    assert mx['views'] > 50 and mx['h7'] > 14            # beyond the chain's fixed range: what the rebalancing is for
+    eng.set_precision(PRECISIONS['fp16_mix'])
+    before = (eng.render_rays(ros, rds)['rgb_map'] - ref['rgb_map']).abs().max().item()
+    sh = eng.rebalance_fine(ros, rds, ref['z_vals'])
+    print('shifts:', sh)
+    assert sh is not None and sh['h0'] == sh['h1'] == 0 and sh['views'] >= 3 and sh['h7'] >= 1
+    for k, v in eng.fine_maxima.items():
+        if k not in ('h0', 'h1'):
+            assert 4.0 < v / 2.0 ** sh[k] <= 8.0, (k, v, sh[k])
+    after = (eng.render_rays(ros, rds)['rgb_map'] - ref['rgb_map']).abs().max().item()
+    eng.set_precision(PRECISIONS['fp16x3_asm'])
+    same = eng.render_rays(ros, rds, extras=True)
+    d3 = (same['rgb_map'] - ref['rgb_map']).abs().max().item()
+    print(f'three passes on the rebalanced network vs the original: rgb {d3:.1e}, raw {(same["raw"] - ref["raw"]).abs().max().item():.1e}; '
+          f'fp16_mix from three passes on {idx.numel()} rays: {before:.2e} as loaded, {after:.2e} rebalanced')
+    assert d3 <= 2e-6 and torch.equal(same['z_samples'], ref['z_samples'])
+    assert after <= max(before, 3e-5) and after <= 5e-5
+    eng.close()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""profiles/r06_trained_family.txt from the reports of tools/r06_family.sh (gpurun_out/r06_family/*.json): per point of the trained-like
+family (tools/train_like.py with other student lengths, learning rates, the second scene, a longer teacher fit) which rung `--precision auto`
+gives the teacher and the student, the measured differences behind the choice, L_inf against the CPU oracle, the watch, the rates."""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'r06_family')
+out = ['# the trained-like family through `--precision auto` (round 6, VERDICT r5 next 4): tools/train_like.py at other points of its recipe;',
+       '# reports only (weights not committed).  Contract: L_inf <= 1e-4 on rgb against the CPU oracle (teacher: 1,020 strided rays per frame x 3 poses;',
+       '# student: 80,000 rays per frame x 3 poses at 800 x 800).  Committed fixture for comparison: v0, teacher 4,000 steps, student 6,000 steps, lr x 1:',
+       '# teacher sigma <= 200 -> fp16_mix (fp16x3_asm before round 6), student max|a| 126 -> fp16_split8 at block 0-2.', '']
+worst_t = worst_s = 0.
+for f in sorted(glob.glob(os.path.join(src, '*.json'))):
+    r = json.load(open(f))
+    rc, t, s = r['recipe'], r['teacher'], r['student']
+    name = os.path.basename(f)[:-5]
+    out.append(f'## {name}: scene variant {rc["variant"]}, teacher {"from the committed fixture" if rc.get("teacher_from") else "%d steps" % rc["teacher_steps"]}, '
+               f'student {rc["student_steps"]} steps, learning rates x {rc.get("lr_scale", 1.0):g}')
+    tl = max(fr['auto_mode_linf_vs_cpu_oracle'] for fr in t['frames'])
+    worst_t = max(worst_t, tl)
+    out.append(f'teacher: PSNR vs scene {min(fr["psnr_vs_scene_db"] for fr in t["frames"]):.1f}-{max(fr["psnr_vs_scene_db"] for fr in t["frames"]):.1f} dB, sigma max '
+               f'{max(fr["sigma_max"] for fr in t["frames"]):.0f}, acc < 0.05 on {t["frames"][0]["acc_lt_0.05"]:.2f} / > 0.95 on {t["frames"][0]["acc_gt_0.95"]:.2f} of the rays | auto -> '
+               f'{t["auto_precision"]}; probe differences ' + ', '.join(f'{k} {v:.1e}' for k, v in t['probe_diffs'].items()) +
+               f' | L_inf vs CPU oracle {tl:.1e} | {t["ms_per_frame"]:.1f} ms per 400 x 400 frame = {t["rays_per_s"]:.2e} rays/s = '
+               f'{303824896 * t["rays_per_s"] / 2.5e15:.3f} of the fp16 peak')
+    worst_s = max(worst_s, s['linf_vs_cpu_oracle'])
+    line = (f'student: PSNR vs teacher {min(fr["psnr_student_vs_teacher_db"] for fr in s["frames"]):.1f}-{max(fr["psnr_student_vs_teacher_db"] for fr in s["frames"]):.1f} dB, '
+            f'max|a| {s["max_abs_activation"]:.0f} | auto -> {s["rung"]}' + (f' at block {s["split_block"]} of 43' if 'split_block' in s else ''))
+    if s.get('auto_verify') is not None:
+        line += f' (the rung the activation limits name: {s["auto_verify"]:.1e} from three passes)'
+    line += f' | L_inf vs CPU oracle {s["linf_vs_cpu_oracle"]:.1e} on {sum(fr["rays_checked"] for fr in s["frames"])} rays'
+    if s.get('watch'):
+        line += ' | watch on three more poses ' + ', '.join(f'{w:.1e}' for w in s['watch'])
+    line += f' | {s["ms_per_frame"]:.2f} ms per 800 x 800 frame = {s["rays_per_s"]:.2e} rays/s'
+    if 'ms_per_frame_fp16x3_asm' in s:
+        line += f' (three passes everywhere: {s["ms_per_frame_fp16x3_asm"]:.2f} ms)'
+    out.append(line)
+    out.append('')
+out.append(f'== worst L_inf against the CPU oracle over the family: teacher {worst_t:.1e}, student {worst_s:.1e} (contract 1e-4)')
+text = '\n'.join(out) + '\n'
+open(os.path.join(ROOT, 'profiles', 'r06_trained_family.txt'), 'w').write(text)
+print(text)
