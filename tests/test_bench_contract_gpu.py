@@ -89,8 +89,15 @@ def test_bench_line_round4_fields():
     st = tl['student']
     assert st['rung'] in ('fp16_split', 'fp16_split8') and st['max_abs_activation'] > 10 and st['rays_per_s'] > st['rays_per_s_fp16x3_asm'] > 1e7
     assert 0 <= st['split_block'] < st['n_block'] == 43 and st['watch_worst_rgb_diff_from_three_passes'] <= st['watch_limit']
-    assert tl['teacher']['precision'] == 'fp16x3_asm' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
-    assert tl['create_data']['precision'] == 'fp16x3_asm' and tl['create_data']['poses'] == 100 and tl['create_data']['shards'] == 3906 and tl['create_data']['poses_per_s'] > 5
+    # round 6: the trained-like teacher gets fp16_mix (coarse three passes, fine with its first two layers in three passes), measured and watched
+    assert tl['teacher']['precision'] == 'fp16_mix' and tl['teacher']['probe_diffs_from_fp16x3']['fp16x1'] > 1e-3
+    assert tl['teacher']['probe_diffs_from_fp16x3']['fp16_mix'] <= tl['teacher']['limits']['fp16_mix'] == 5e-5
+    assert tl['teacher']['probe_diffs_from_fp16x3']['fp16x3_asm'] <= tl['teacher']['limits']['fp16x3_asm']
+    assert tl['teacher']['frac_of_fp16_mfma_peak'] > 0.22
+    assert tl['create_data']['precision'] == 'fp16_mix' and tl['create_data']['poses'] == 100 and tl['create_data']['shards'] == 3906 and tl['create_data']['poses_per_s'] > 8
+    assert tl['create_data']['watch']['checks'] >= 1 and tl['create_data']['watch']['fallbacks'] == []
+    ro = st['roofline']          # the student's kernels timed with HIP events, as the headline's
+    assert ro['launches'] == 10 + ro['rerenders'] and 0 < ro['avg_kernel_ms'] < st['ms_per_frame'] and 0.2 < ro['frac'] < 0.4
     assert tl['teacher']['mlp_launches'] == 6 and 0 < tl['teacher']['mlp_kernel_ms_per_frame'] <= tl['teacher']['ms_per_frame']
     assert tl['teacher']['whole_frame_rgb_linf_from_fp16x3']['fp16x1'] > 1e-3
     assert 'value_valid_for' in d and 'trained-like' in d['value_valid_for']

@@ -59,7 +59,7 @@ def test_bisection_takes_the_cheaper_format(pkg):
     c8, c3 = eng.BLOCK_COST[R.PREC_FP16_SPLIT8], eng.BLOCK_COST[R.PREC_FP16X3_ASM]
     bound = (eng.split_cost(R.PREC_FP16_SPLIT, best6) - c8 * nb) / (c3 - c8)
     assert max(eight) < bound and 0 in eight
-    assert eng.renders <= 16
+    assert eng.renders <= 20        # (round 6: a split that passes inside the last 20 % of the limit costs one more render, of split + 1)
 
 
 def test_bf6_stays_when_it_is_cheaper_and_e4m3_is_not_even_measured(pkg):
@@ -116,3 +116,31 @@ def test_the_rung_the_limits_name_is_verified(pkg):
     # `max_exp` (tests) switches both measurements off
     eng, R = _fake(pkg, nb, lambda mode, sp: 1.0, stream_max=3.9)
     assert eng.choose_precision(c2w=None, max_exp=3)[0] == 'fp16_fp8' and eng.auto_verify is None and eng.renders == 0
+
+
+def test_a_split_inside_the_last_fifth_of_the_limit_needs_its_neighbour(pkg):
+    """the difference is a maximum over rays and not monotone in the split at the 1e-5 level (the committed fixture: 5.75e-5 at
+    17, 7.9e-5 at 20, 6.5e-5 at 21, 4.99e-5 at 22 against a limit of 5e-5).  A split is taken when it passes within SPLIT_MARGIN x the
+    limit, or when the next split passes as well: with that record 22 is taken only because 23 passes too; with 23 above the limit
+    the bisection moves on"""
+    nb = 43
+    noisy = {17: 5.75e-5, 20: 7.9e-5, 21: 6.5e-5, 22: 4.99e-5}
+
+    def err(after22):
+        def f(mode, sp):
+            if mode != 5:
+                return 1.0                       # e4m3 terms never qualify here
+            if sp in noisy:
+                return noisy[sp]
+            if sp == 23:
+                return after22
+            return 9e-5 * (1.0 - sp / nb) if sp < 22 else 3.5e-5 * (1.0 - (sp - 22) / 21.)
+        return f
+    eng, R = _fake(pkg, nb, err(4.2e-5))
+    sp, d = eng.choose_split(c2w=None)
+    assert eng.precision == R.PREC_FP16_SPLIT and sp == 22 and d == pytest.approx(4.99e-5, rel=1e-3) and eng.auto_split['fp16_split'][23] == pytest.approx(4.2e-5, rel=1e-3)
+    eng, R = _fake(pkg, nb, err(5.4e-5))            # ... the neighbour misses: 22 passed by 1e-7 of a noisy maximum and is not trusted
+    sp, d = eng.choose_split(c2w=None)
+    assert sp is None or sp > 23
+    tried = eng.auto_split['fp16_split']
+    assert tried.get(22, 1.0) <= eng.AUTO_SPLIT_MAX_DIFF < tried.get(23, 0.0)          # 22 was measured, passed on its own, and was not taken

@@ -25,6 +25,9 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv r2l_body_kernel > $O/pmc_$name.txt 2>&1
   python $R/tools/pmc_summary.py $O/pmc_$name/*/*counter_collection.csv 'r2l_head' >> $O/pmc_$name.txt 2>&1
 done
+# round 6: the kernel trace of the TRAINED-LIKE legs (student on its split rung: r2l_head_kernel<true>, r2l_bodyx_kernel,
+# r2l_body8_kernel; teacher: coarse nerf_chain_kernel<false, 2, true>, fine nerf_chain_kernel<false, 2, false, true>), the program directly after `--`
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_trained -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-teacher --no-create-data > $O/trace_trained.log 2>&1 || exit 1
 python $R/tools/traffic_json.py $O/pmc_FETCH_SIZE/*/*counter_collection.csv $O/pmc_WRITE_SIZE/*/*counter_collection.csv r2l_body_kernel fp16_fp8 $O/traffic.json
 cat $O/bench_n1_fp16_fp8.json
 fi

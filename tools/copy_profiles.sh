@@ -11,6 +11,7 @@ for n in SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; do [ -f $O/pmc8_$n.txt ] && cp $O/pmc8_
 cp $(ls -t $O/trace/*/*kernel_stats.csv | head -1) profiles/${TAG}_kernel_stats.csv      # the newest: gpurun merges runs into one directory
 for n in FETCH_SIZE GRBM_GUI_ACTIVE SQ_WAVE_CYCLES TCC_HIT_sum WRITE_SIZE; do cp $O/pmc_$n.txt profiles/${TAG}_pmc_$n.txt; done
 cp $O/traffic.json profiles/${TAG}_traffic.json
+ls $O/trace_trained/*/*kernel_stats.csv > /dev/null 2>&1 && cp $(ls -t $O/trace_trained/*/*kernel_stats.csv | head -1) profiles/${TAG}_trained_kernel_stats.csv
 grep -h "^stress\|MISMATCH" $O/pmc_stress.log > profiles/${TAG}_pmc_stress.txt
 cp $(ls -t $O/teacher_trace/*/*kernel_stats.csv | head -1) profiles/${TAG}_teacher_kernel_stats.csv
 grep teacher $O/teacher_time.txt > profiles/${TAG}_teacher_time.txt
