@@ -789,7 +789,8 @@ def main(argv=None):
             f'({len(rgbs) * H * W / dt:.3e} rays/s incl. host I/O)')
         if st.get('split_watch'):
             w_ = st['split_watch']
-            log(f"[precision] split watch: {w_['checks']} spot check(s) against three passes (every {w_['every']} batches), worst {w_['worst']:.2e}, "
+            every = w_['every'] if str(w_['precision']).startswith('fp16_split') else w_.get('whole_every', w_['every'])
+            log(f"[precision] rgb watch: {w_['checks']} spot check(s) against three passes (every {every} batches), worst {w_['worst']:.2e}, "
                 f"{len(w_['fallbacks'])} fallback(s); at the end: {w_['precision']}" + (f" at block {w_['split_block']}" if w_['precision'].startswith('fp16_split') else ''))
         if st.get('watch', {}).get('checks'):
             w_ = st['watch']

@@ -363,7 +363,7 @@ class NeRFEngine:
     def _strided(n, k, device):
         return torch.arange(0, n, max(1, n // k), device=device)[:k]
 
-    def choose_precision(self, rays_o, rays_d=None, max_diff=None, max_diff_x1=None):
+    def choose_precision(self, rays_o, rays_d=None, max_diff=None, max_diff_x1=None, max_diff_mix=None):
         """`--precision auto` for the teacher, measured on THESE weights and rays.  `rays_o, rays_d`: one ray set, or a list of
         (rays_o, rays_d) probe sets spanning what the job will render (create_data: top-down to horizontal poses, focal x 1 ... x 2;
         render_path: the first, middle and last pose); up to 4,096 rays of every set, spread over it, are rendered coarse + fine in
@@ -430,7 +430,7 @@ class NeRFEngine:
                 self.rebalance_fine(torch.cat([p[0] for p in probes]), torch.cat([p[1] for p in probes]), torch.cat(zs))
             refs_m = [{k: v.clone() for k, v in self.render_rays(ro, rd).items() if k in self.WATCH_KEYS} for ro, rd in big]
             self.set_precision(PREC_FP16_MIX)
-            lim = self._limits(self.AUTO_MAX_DIFF_MIX)
+            lim = self._limits(self.AUTO_MAX_DIFF_MIX if max_diff_mix is None else float(max_diff_mix))
             per_set, ok = [], True
             for (ro, rd), ref in zip(big, refs_m):
                 got = self.render_rays(ro, rd)

@@ -205,7 +205,7 @@ def test_cli_explicit_split(pkg, tmp_path):
         log = run_main(base + extra + ['--outdir', str(tmp_path / tag)])
         outs[tag] = np.load(tmp_path / tag / 'rgbs.npy')
         if tag != 'x3':
-            assert f'[precision] fp16_split: blocks [0, {extra[-1]}) in three fp16 passes' in log and 'split watch' not in log, log
+            assert f'[precision] fp16_split: blocks [0, {extra[-1]}) in three fp16 passes' in log and 'rgb watch' not in log, log
     ref = O.r2l_render(sd, H, H, O.focal_from_angle(64) / 2., O.novel_poses(1)[0]).view(H, H, 3).numpy()
     assert np.array_equal(outs['s4'], outs['x3'])
     assert np.abs(outs['s1'][0] - ref).max() <= 1e-4 and 0 < np.abs(outs['s1'] - outs['x3']).max() <= 5e-5

@@ -109,7 +109,7 @@ def test_trained_like_pipeline_command_lines(pkg, tmp_path):
     split = '-> fp16_split at block' in r.stdout or '-> fp16_split8 at block' in r.stdout
     assert split or '-> fp16x3_asm' in r.stdout, r.stdout[-1200:]
     if split:       # ... and render_path watched it: the first batch's rays against three passes everywhere
-        assert 'split watch: 1 spot check(s) against three passes' in r.stdout and ' 0 fallback(s)' in r.stdout, r.stdout[-1200:]
+        assert 'rgb watch: 1 spot check(s) against three passes' in r.stdout and ' 0 fallback(s)' in r.stdout, r.stdout[-1200:]
     print(r.stdout[-1500:])
 
 
