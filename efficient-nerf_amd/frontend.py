@@ -82,6 +82,9 @@ FLAGS = [
     ('--H', dict(type=int, default=0)), ('--W', dict(type=int, default=0)),
     # frames rendered per launch / collective / range check / host sync (0: the world size, i.e. one frame on one GPU)
     ('--frames_per_batch', dict(type=int, default=0)),
+    # the watches behind `--precision auto` (render_path): the split rungs / the teacher's fast modes every watch_every-th batch / frame, the
+    # whole-network rungs every 2 x watch_every-th batch; 0 switches them off (A/B of their cost: tools/cli_soak.py)
+    ('--watch_every', dict(type=int, default=8)),
     # N > 1 without torchrun: main.py / create_data.py start the N ranks themselves before importing torch (launch.py)
     ('--gpus', dict(type=int, default=0)), ('--launch_timeout', dict(type=float, default=0.)),
 ]
@@ -776,7 +779,7 @@ def main(argv=None):
     st = {}
     with torch.no_grad():
         rgbs, misc = render_path(poses, hwf, kind, eng, gt_imgs=gt, savedir=outdir, log=log, given_rays=given, stats=st,
-                                 frames_per_batch=args.frames_per_batch or None)
+                                 frames_per_batch=args.frames_per_batch or None, watch_every=args.watch_every)
     dt = time.time() - t_
     if rank == 0:
         np.save(os.path.join(outdir, 'rgbs.npy'), st['host_frames'].numpy() if 'host_frames' in st else rgbs.cpu().numpy())

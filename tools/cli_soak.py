@@ -36,7 +36,8 @@ for rep in range(2):
     out = os.path.join(d, 'out%d' % rep)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '--model_name', 'R2L', '--config', 'configs/lego_noview_800x800.txt',
                         '--n_sample_per_ray', '16', '--netwidth', '256', '--netdepth', '88', '--use_residual', '--trial.ON', '--trial.body_arch',
-                        'resmlp', '--pretrained_ckpt', ck, '--render_only', '--synthetic_poses', str(n), '--H', str(H), '--outdir', out],
+                        'resmlp', '--pretrained_ckpt', ck, '--render_only', '--synthetic_poses', str(n), '--H', str(H), '--outdir', out] +
+                       (['--watch_every', os.environ['SOAK_WATCH_EVERY']] if 'SOAK_WATCH_EVERY' in os.environ else []),
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     print('\n'.join(ln for ln in r.stdout.splitlines() if ln.startswith(('[precision]', 'Render loop', 'Rendered'))), flush=True)
