@@ -81,6 +81,7 @@ SIGNATURES = {
     'nerf_load_weights': (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.c_int]),
     'nerf_set_precision': (C.c_int, [_vp, C.c_int]),
     'nerf_set_precision_pair': (C.c_int, [_vp, C.c_int, C.c_int]),
+    'nerf_set_skip_rgb0': (C.c_int, [_vp, C.c_int]),
     'nerf_set_sampling': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
     'nerf_get_rays': (C.c_int, [C.c_int, C.c_int, C.c_double, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     'nerf_set_ndc': (C.c_int, [_vp, C.c_int, C.c_float]),

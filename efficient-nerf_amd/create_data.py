@@ -361,6 +361,10 @@ def create_rand(engine, H, W, focal, n_pose_kd, datadir_new, use_rand_focal=True
     # ladder and the group is rendered again.
     watching = bool(watch) and hasattr(engine, 'spot_check')
     wstat = {'checks': 0, 'fallbacks': [], 'worst': {}}
+    if hasattr(engine, 'set_skip_rgb0'):
+        # the shards hold [rays_o, rays_d, rgb] (utils/create_data.py:832-836; `rgb, disp, acc, _ = render(...)` :824-831): nobody takes rgb0,
+        # so the coarse pass runs without its view branch where its mode has that build (fp16x3_asm): the same rgb bit for bit
+        engine.set_skip_rgb0(True)
 
     def render_pose(i, pose, focal_, j, check):
         rays_o, rays_d = get_rays_fn(H, W, focal_, pose[:3, :4], device=dev)  # get_rays1 (:819)

@@ -87,7 +87,7 @@ ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # that computed the embedding between two blocks while the matrix pipe idled (2.3 ms of a 33.4 ms frame, -DNERF_SKIP_EMBED) is gone.
 # The arithmetic per point is that of nerf_tile_embed (csrc/nerf_kernels.hip), operation for operation: bitwise-equal results.
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
-assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3', 'mix'), FMT
+assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3', 'f16p3a', 'mix'), FMT
 # NERF_GEN_FMT=mix (round 6): the bf6 chain with its FIRST trunk layers in three fp16 passes -- layers L1 .. L<MIXK> as in f16p3 (hi / lo
 # fragments of both operands, W x 2^k in the stream), everything behind them with bf6 terms.  For the FINE pass of trained teachers: the
 # early layers' error is what the sharp tail of such a network amplifies (tools/teacher_mixed_study.py on whole frames of the trained-like
@@ -96,6 +96,14 @@ assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3', 'mix'), FMT
 # Per layer: Layer.p3.  L0 (embedding k-steps only: three passes in every format) hands L1 hi + lo fp16 sets, L<MIXK> hands the first
 # bf6 layer hi + bf6 sets (its accumulators carry the 2^k of its stream: one v_mul more per value).  Registers: the bf6 map; the lo(a)
 # sets of the three-pass layers live in AGPRs the bf6 chain does not use (lset).
+# NERF_GEN_FMT=f16p3a (round 6): f16p3 WITHOUT the view branch -- trunk, then the alpha row of the feature | alpha layer alone, no views /
+# rgb layers: raw = (0, 0, 0, sigma).  For the COARSE pass of a render whose caller does not ask for rgb0: sample_pdf and every map of the
+# fine pass depend on the coarse network through its densities only (main.py:716-733), and the reference's call sites drop rgb0
+# (main.py:277-282, utils/create_data.py:824-831: `rgb, disp, acc, _ = render(...)`).  17 % of the network's MACs; the alpha row gets its
+# own weight scale 2^k.  A second, all-zero row tile keeps the chunk count a multiple of the ring's four slots (68).
+ALPHA = FMT == 'f16p3a'
+if ALPHA:
+    FMT = 'f16p3'
 MIX = FMT == 'mix'
 MIXK = int(os.environ.get('NERF_GEN_MIX_K', '2')) if MIX else 0
 assert 0 <= MIXK <= 7
@@ -109,7 +117,7 @@ EMB = FMT == 'f16c4e'
 # a normal fp16 number, the epilogue takes the factor out (one v_fma_mix per value does it together with the conversion to fp16).
 P3 = FMT == 'f16p3'
 NC = {'f16c3': 3, 'f16c4': 4, 'f16c4e': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
-SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e', 'f16p3': 'p3', 'mix': 'm'}[FMT]     # nerf_mlpx_asm.inc ...
+SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e', 'f16p3': 'p3', 'mix': 'm'}[FMT] + ('a' if ALPHA else '')     # nerf_mlpx_asm.inc ...
 # passes of an embedding k-step: hi(W) hi(E), hi(W) lo(E), lo(W) hi(E).  The fp16-only chains drop the third (their 256-wide layers
 # carry no lo(W) term either; measured over whole frames, three seed pairs x three poses: rgb 6.5e-6 .. 1.9e-5 from fp16x3 with two
 # passes against 6.4e-6 .. 1.6e-5 with three, -4.4 % time; ONE pass -- no lo(E), i.e. fp16-rounded coordinates -- reads 1.3 .. 2.8e-5
@@ -203,9 +211,12 @@ def chain():
     L.append(Layer('L5', 'Q', 'P', 8, E2, 16, 'relu', r_l5, 256))
     L.append(Layer('L6', 'P', 'Q', 8, [], 16, 'relu', r_std, 256))
     L.append(Layer('L7', 'Q', 'P', 8, [], 16, 'relu', r_std, 256))
-    L.append(Layer('FA', 'P', 'Q', 8, [], 17, 'feat', r_std, 257))
-    L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', r_v, 128))
-    L.append(Layer('RGB', 'P', None, 4, [], 1, 'rgb', 1, 3))
+    if ALPHA:       # the alpha row alone (row tile 0, row 0) + an all-zero row tile (chunk count = 0 mod 4); no view branch
+        L.append(Layer('FA', 'P', None, 8, [], 2, 'alpha', 1, 1))
+    else:
+        L.append(Layer('FA', 'P', 'Q', 8, [], 17, 'feat', r_std, 257))
+        L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', r_v, 128))
+        L.append(Layer('RGB', 'P', None, 4, [], 1, 'rgb', 1, 3))
     for li, l in enumerate(L):
         l.li = li
         if MIX:
@@ -320,6 +331,9 @@ def layer_matrices(t):
     out.append((np.ascontiguousarray(w5[:, 63:]), np.ascontiguousarray(w5[:, :63]), t[11]))
     for i in (6, 7):
         out.append((W(2 * i, 256, 256), None, t[2 * i + 1]))
+    if ALPHA:
+        out.append((W(20, 1, 256), None, t[21].reshape(-1)))
+        return out
     out.append((np.concatenate([W(18, 256, 256), W(20, 1, 256)], 0), None, np.concatenate([t[19].reshape(-1), t[21].reshape(-1)])))
     wv = W(16, 128, 283)                                                   # cat([feature, input_views]) (:390)
     out.append((np.ascontiguousarray(wv[:, :256]), np.ascontiguousarray(wv[:, 256:]), t[17]))
@@ -509,6 +523,13 @@ def v_mov_out(k, src, inv=None):
     return valu('v_mov_b32 %%[o%d], %s' % (k, vreg(src)), vr(src), [], emu)
 
 
+def v_zero_out(k):
+    """output operand k <- 0.0"""
+    def emu(st):
+        st.out[k] = np.zeros(64, dtype=np.uint32)
+    return valu('v_mov_b32 %%[o%d], 0' % k, [], [], emu)
+
+
 def dma_piece(i, pw, tag=''):
     """piece i of this wave's pw KiB of a chunk: global_load_lds_dwordx4 v_off, s[S_G:S_G+1] offset:imm with LDS
     destination M0 + imm + lane*16; pieces 4.. use the +4096 offset register and M0 + 4096"""
@@ -636,6 +657,10 @@ def epilogue_ops(T, c):
     cv = tb + 4
     ops = []
     inv = V_SC + 2 * (t.li & 1) if L.uses_inv else None
+    if L.epi == 'alpha':     # f16p3a: sigma from row 0 of row tile 0, zeros for the colours nobody computed; the padding row tile: nothing
+        if u != 0:
+            return []
+        return [(v_mov_out(c * 4 + 3, acc, inv), None)] + [(v_zero_out(c * 4 + k), None) for k in range(3)]
     if L.epi == 'rgb':
         return [(v_mov_out(c * 4 + k, acc + k, inv), None) for k in range(3)]
     if L.epi == 'feat' and u == 16:

@@ -18,6 +18,7 @@ namespace {
 struct PackedNet {
     char* d_img[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [precision mode]
     float inv_scale[8][NERF_N_SCALES];
+    char* d_img_alpha = nullptr;             // the three-pass stream without the view branch (coarse network, nerf_set_skip_rgb0)
     std::vector<std::vector<float>> host_w;  // 24 tensors, state_dict order
     bool loaded = false;
 };
@@ -103,6 +104,11 @@ const ChainLayer kChainP3[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 
                                  {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
                                  {8, 0, 17, 2, 257}, {8, 1, 8, 1, 128},  {4, 0, 1, 1, 3}};
 
+// FP16X3_ASM without the view branch (NERF_GEN_FMT=f16p3a): the trunk of kChainP3, then the alpha row alone (row tile 0; row tile 1 is
+// padding: 68 chunks = 0 mod 4) -- for the coarse pass of renders whose caller does not take rgb0 (nerf_set_skip_rgb0)
+const ChainLayer kChainP3A[9] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
+                                 {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 2, 1, 1}};
+
 struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding column), bias(row); rows < fan_out
     std::function<float(int, int)> main, emb;
     std::function<float(int)> bias;
@@ -113,12 +119,15 @@ struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding 
 // fmt 2 (p3): the stream of R2L_PREC_FP16X3_ASM -- per row tile its KS hi fragments, then its KS lo fragments, of W x 2^k with
 // max|w| 2^k in [2^12, 2^13) over the layer's main and embedding columns (lo = the fp16 rounding residual: a normal number thanks
 // to the factor); the bias x act_scale x 2^k; at the scale bytes' place 2^-k as a float for the epilogue
+// fmt 4 (p3a): fmt 2 without the view branch (kChainP3A): nine layers, the last one the alpha row with its own 2^k
 // fmt 3 (mix): the stream of R2L_PREC_FP16_MIX -- fmt 0 with layers L1 .. L<NERF_MIX_K> packed as in fmt 2 (hi | lo fragments of
 // W x 2^k, 2^-k at the scale bytes' place) and 1.0f there for L0, whose epilogue hands L1 hi + lo sets with the three-pass form
 int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img, int fmt = 0) {
-    const bool mix = fmt == 3;
-    const bool x1 = fmt != 0 && !mix, all_p3 = fmt == 2;
-    const size_t stream_bytes = mix ? NERF_CHAINM_STREAM_BYTES : all_p3 ? NERF_CHAINP3_STREAM_BYTES : (x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
+    const bool mix = fmt == 3, alpha_only = fmt == 4;
+    const bool x1 = fmt == 1, all_p3 = fmt == 2 || alpha_only;
+    const size_t stream_bytes = alpha_only ? NERF_CHAINP3A_STREAM_BYTES : mix ? NERF_CHAINM_STREAM_BYTES : all_p3 ? NERF_CHAINP3_STREAM_BYTES
+                                : (x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
+    const int n_layers = alpha_only ? 9 : 11;
     img.assign(stream_bytes + NERF_CHAIN_AUX_BYTES, 0);
     auto mat = [&](int ti, int ncol, int col0) {
         const float* p = w[ti].data();
@@ -138,12 +147,16 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
         src[8] = {[=](int r, int k) -> float { return r < 256 ? fw[(size_t)r * 256 + k] : aw[k]; }, nullptr,
                   [=](int r) -> float { return r < 256 ? fb[r] : ab[0]; }, true};
     }
+    if (alpha_only) {
+        const float *aw = w[T_ALPHA_W].data(), *ab = w[T_ALPHA_B].data();
+        src[8] = {[=](int, int k) -> float { return aw[k]; }, nullptr, [=](int) -> float { return ab[0]; }, true};
+    }
     src[9] = {mat(T_VIEWS_W, 283, 0), mat(T_VIEWS_W, 283, 256), vec(T_VIEWS_B), false};  // cat([feature, views]) (:390)
     src[10] = {mat(T_RGB_W, 128, 0), nullptr, vec(T_RGB_B), true};
     size_t chunk_off = 0;
     uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + stream_bytes);
-    for (int li = 0; li < 11; ++li) {
-        const ChainLayer& L = (all_p3 ? kChainP3 : (x1 ? kChainX : kChain))[li];
+    for (int li = 0; li < n_layers; ++li) {
+        const ChainLayer& L = (alpha_only ? kChainP3A : all_p3 ? kChainP3 : (x1 ? kChainX : kChain))[li];
         const ChainSrc& S = src[li];
         const bool p3 = all_p3 || (mix && li >= 1 && li <= NERF_MIX_K);      // this layer's main k-steps run three fp16 passes
         const int nj = (x1 || p3) ? 0 : L.ks / 2, K = L.ks * 32;
@@ -238,6 +251,7 @@ struct nerf_ctx {
     int H, W, N_samples, N_importance, white_bkgd, mode, n_cu;
     int mode_net[2] = {0, 0};   // precision of the coarse / the fine network's MLP launches (nerf_set_precision: both; nerf_set_precision_pair)
     int ndc = 0;            // render() projects the rays to NDC first (main.py:160-162)
+    bool skip_rgb0 = false;    // nerf_set_skip_rgb0: the coarse pass of the render pipeline without its view branch when it runs fp16x3_asm
     bool split_scans = false;  // nerf_debug_set_split_scans: raw2outputs / sample_pdf / merge as three launches (A/B, parity tests)
     int x1_col_tiles = 4;      // nerf_debug_set_x1_col_tiles: 16-point column tiles per wave of the fp16-only chain (3 or 2 for the A/B)
     bool x1_stream_embed = true;   // nerf_debug_set_x1_stream_embed: the four-tile chain with its embedding in the stream (nerf_chain_emb_kernel)
@@ -352,6 +366,8 @@ void nerf_destroy(nerf_ctx* c) {
     for (auto& n : c->net)
         for (int m = 0; m < 8; ++m)
             if (n.d_img[m]) (void)hipFree(n.d_img[m]);
+    for (auto& n : c->net)
+        if (n.d_img_alpha) (void)hipFree(n.d_img_alpha);
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_zmid) (void)hipFree(c->d_zmid);
     if (c->d_u) (void)hipFree(c->d_u);
@@ -462,9 +478,19 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
             (void)hipFree(net.d_img[m]);
             net.d_img[m] = nullptr;
         }
+    if (net.d_img_alpha) {
+        (void)hipFree(net.d_img_alpha);
+        net.d_img_alpha = nullptr;
+    }
     int rc = build_net(c, net, c->mode_net[which]);
     if (rc) return rc;
     net.loaded = true;
+    return R2L_OK;
+}
+
+int nerf_set_skip_rgb0(nerf_ctx* c, int on) {
+    if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
+    c->skip_rgb0 = on != 0;
     return R2L_OK;
 }
 
@@ -491,12 +517,22 @@ int nerf_set_precision_pair(nerf_ctx* c, int coarse_mode, int fine_mode) {
 }
 
 static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* rays_d, const float* z, int z_stride,
-                   int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr) {
+                   int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr, bool alpha_only = false) {
     NerfMlpParams p;
     memset(&p, 0, sizeof p);
     p.viewdirs = viewdirs;
     const int mode = c->mode_net[which];
-    p.wimg = c->net[which].d_img[mode];
+    alpha_only = alpha_only && mode == R2L_PREC_FP16X3_ASM;
+    if (alpha_only && !c->net[which].d_img_alpha) {      // packed on first use: the stream without the view branch (pack_chain fmt 4)
+        std::vector<char> img;
+        int rc = pack_chain(c->net[which].host_w, c->act_scale, img, 4);
+        if (rc) return rc;
+        hipError_t e = hipMalloc((void**)&c->net[which].d_img_alpha, img.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(c->net[which].d_img_alpha, img.data(), img.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);      // `img` is a local
+        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "the coarse network's stream without its view branch: %s", hipGetErrorString(e));
+    }
+    p.wimg = alpha_only ? c->net[which].d_img_alpha : c->net[which].d_img[mode];
     p.raw = raw;
     p.rays_o = rays_o;
     p.rays_d = rays_d;
@@ -541,7 +577,7 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
         c->ev_used += 2;
         (void)hipEventRecord(e0, s);
     }
-    hipError_t e = nerf_launch_mlp(p, mode, grid, s, x1_nc, stream_embed);
+    hipError_t e = nerf_launch_mlp(p, mode, grid, s, x1_nc, stream_embed, alpha_only);
     if (c->timing) (void)hipEventRecord(e1, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
     return R2L_OK;
@@ -601,7 +637,8 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
     }
     const float* zc = o.z_coarse ? o.z_coarse : c->d_zc;
     const int zc_stride = o.z_coarse ? S0 : 0;
-    int rc = run_mlp(c, 0, rays_o, rays_d, zc, zc_stride, S0, n, c->d_raw0, s, vd);  // coarse network_fn
+    // coarse network_fn; with nerf_set_skip_rgb0 without its view branch: raw0 = (0, 0, 0, sigma), sigma bit for bit the full chain's
+    int rc = run_mlp(c, 0, rays_o, rays_d, zc, zc_stride, S0, n, c->d_raw0, s, vd, c->skip_rgb0);
     if (rc) return rc;
     if (!o.u && !c->split_scans) {
         // deterministic test path: raw2outputs(coarse) + sample_pdf + merge as ONE launch (nerf_coarse_scan_kernel: the weights,
@@ -735,6 +772,8 @@ int nerf_copy_extras(nerf_ctx* c, int n, float* rgb0_dev, float* z_samples_dev, 
     if (n < 0 || n > c->cap) return r2l_set_error(R2L_EINVAL, "n=%d exceeds the last render (%d rays)", n, c->cap);
     const int S1 = c->N_samples + c->N_importance;
     hipStream_t s = (hipStream_t)stream;
+    if (rgb0_dev && c->skip_rgb0 && c->mode_net[0] == R2L_PREC_FP16X3_ASM)
+        return r2l_set_error(R2L_ESTATE, "rgb0 was not computed: nerf_set_skip_rgb0 is on (the coarse pass ran without its view branch)");
     struct { float* dst; const float* src; size_t numel; } cp[] = {
         {rgb0_dev, c->d_rgb0, (size_t)n * 3}, {z_samples_dev, c->d_zs, (size_t)n * c->N_importance},
         {z_vals_dev, c->d_zall, (size_t)n * S1}, {raw_dev, c->d_raw, (size_t)n * S1 * 4}};
@@ -768,7 +807,7 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 
 // run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
 long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, int fmt, char* out, long long cap, long long* offs) {
-    if (fmt < 0 || fmt > 3) return r2l_set_error(R2L_EINVAL, "chain stream format %d (0 fp16 + bf6 terms, 1 fp16 only, 2 hi | lo, 3 mix)", fmt);
+    if (fmt < 0 || fmt > 4) return r2l_set_error(R2L_EINVAL, "chain stream format %d (0 fp16 + bf6 terms, 1 fp16 only, 2 hi | lo, 3 mix, 4 hi | lo without the view branch)", fmt);
     if (!tensors || n_tensors != 24) return r2l_set_error(R2L_EINVAL, "expected 24 tensors");
     std::vector<std::vector<float>> w;
     for (int i = 0; i < 24; ++i) {
@@ -778,7 +817,7 @@ long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors,
     std::vector<char> img;
     int rc = pack_chain(w, 16.0f, img, fmt);
     if (rc) return rc;
-    if (offs) offs[0] = fmt == 3 ? NERF_CHAINM_STREAM_BYTES : fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
+    if (offs) offs[0] = fmt == 4 ? NERF_CHAINP3A_STREAM_BYTES : fmt == 3 ? NERF_CHAINM_STREAM_BYTES : fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
 }

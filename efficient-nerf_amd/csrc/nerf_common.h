@@ -38,6 +38,8 @@
 #define NERF_CHAINP3_STREAM_BYTES 2433024
 // R2L_PREC_FP16_MIX (gen/nerf_gen.py NERF_GEN_FMT=mix): the bf6 chain with trunk layers L1 .. L<NERF_MIX_K> in three fp16 passes (their
 // chunks in the hi | lo layout of the p3 stream, W x 2^k): 80 chunks as the bf6 stream, 2 x 8 of them 32 KiB instead of 28
+// the three-pass chain without its view branch (gen/nerf_gen.py NERF_GEN_FMT=f16p3a): trunk + the alpha row (+ one all-zero row tile), 68 chunks
+#define NERF_CHAINP3A_STREAM_BYTES 1998848
 #define NERF_MIX_K 2
 #define NERF_CHAINM_STREAM_BYTES 2232320
 #define NERF_CHAIN_AUX_BYTES 16384

@@ -313,8 +313,12 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // MIX = true (NC = 2) is R2L_PREC_FP16_MIX (round 6): the bf6 chain with trunk layers L1 .. L<NERF_MIX_K> in three fp16 passes
 // (NERF_GEN_FMT=mix -> nerf_mlpm_*.inc): for the FINE pass of trained teachers, whose sharp tail amplifies what the early layers get wrong
 // (profiles/r06_teacher_mixed_study.txt); lo(a) of those layers' sources in AGPRs the bf6 chain leaves free (a176-a255).
-template <bool X1, int NC, bool P3 = false, bool MIX = false>
+// ALPHA = true (P3 only; round 6): the three-pass chain WITHOUT the view branch (NERF_GEN_FMT=f16p3a -> nerf_mlpp3a_*.inc): raw = (0, 0, 0, sigma).
+// The coarse pass of a render whose caller does not take rgb0 (nerf_set_skip_rgb0): sample_pdf and the fine pass see the coarse network
+// through its densities only (main.py:716-733), which this build computes bit for bit as the full chain does; 17 % fewer MACs.
+template <bool X1, int NC, bool P3 = false, bool MIX = false, bool ALPHA = false>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
+    static_assert(!ALPHA || P3, "the chain without its view branch exists for the three-pass format");
     static_assert(NC == 2 || (X1 && (NC == 3 || NC == 4)), "three / four column tiles exist for the fp16-only chain");
     static_assert(!P3 || (!X1 && NC == 2), "the three-pass chain is a two-column-tile build");
     static_assert(!MIX || (!X1 && !P3 && NC == 2), "the mixed chain is a two-column-tile build of the bf6 chain");
@@ -322,12 +326,20 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     {   // resident table: per layer 272 f32 bias (act_scale domain) | E8M0 weight scales (nerf_common.h)
-        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (MIX ? NERF_CHAINM_STREAM_BYTES : P3 ? NERF_CHAINP3_STREAM_BYTES : (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES)));
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (ALPHA ? NERF_CHAINP3A_STREAM_BYTES : MIX ? NERF_CHAINM_STREAM_BYTES : P3 ? NERF_CHAINP3_STREAM_BYTES : (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES)));
         uint4* dst = reinterpret_cast<uint4*>(nerf_chain_lds + NERF_CHAIN_RING_BYTES);
         for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    if constexpr (MIX) {
+    if constexpr (ALPHA) {
+        asm volatile(
+#include "nerf_mlpp3a_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpp3a_pro_clobbers.inc"
+        );
+    } else if constexpr (MIX) {
         asm volatile(
 #include "nerf_mlpm_pro_asm.inc"
             :
@@ -401,7 +413,15 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
             : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),             \
               [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),       \
               [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
-        if constexpr (MIX) {
+        if constexpr (ALPHA) {
+            asm volatile(
+#include "nerf_mlpp3a_asm.inc"
+                NERF_CHAIN_OUT2
+                NERF_CHAIN_IN2
+                :
+#include "nerf_mlpp3a_clobbers.inc"
+            );
+        } else if constexpr (MIX) {
             asm volatile(
 #include "nerf_mlpm_asm.inc"
                 NERF_CHAIN_OUT2
@@ -1017,8 +1037,10 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
     return hipGetLastError();
 }
 
-hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles, bool stream_embed) {
-    static std::atomic<bool> attr_set[8][64];  // zero-initialised; the opt-in call itself is idempotent
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles, bool stream_embed, bool alpha_only) {
+    static std::atomic<bool> attr_set[9][64];  // zero-initialised; the opt-in call itself is idempotent
+    if (alpha_only && mode == R2L_PREC_FP16X3_ASM)
+        return launch_big_lds(&nerf_chain_kernel<false, 2, true, false, true>, attr_set[8], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16_MIX) return launch_big_lds(&nerf_chain_kernel<false, 2, false, true>, attr_set[7], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X3_ASM) return launch_big_lds(&nerf_chain_kernel<false, 2, true>, attr_set[6], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16X1 && x1_col_tiles == 4 && stream_embed)

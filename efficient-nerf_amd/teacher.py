@@ -316,6 +316,20 @@ class NeRFEngine:
             check(lib().nerf_set_precision(self._ctx, int(precision)))
         self.precision = self.precision_coarse = int(precision)
 
+    def set_skip_rgb0(self, on=True):
+        """nerf_set_skip_rgb0 (include/r2l_hip.h): the render pipeline's coarse pass without its view branch whenever the coarse network runs
+        fp16x3_asm -- rgb0 is not computed (render(..., extras=True) then returns no 'rgb0'), every other output is bit for bit what it
+        was.  For callers that drop render()'s extras, as main.py:277-282 and utils/create_data.py:824-831 do (frontend.render_path and
+        create_data.create_rand switch it on)."""
+        with torch.cuda.device(self.device):
+            check(lib().nerf_set_skip_rgb0(self._ctx, int(bool(on))))
+        self.skip_rgb0 = bool(on)
+        return self
+
+    def _rgb0_skipped(self):
+        from ._lib import PREC_FP16X3_ASM
+        return getattr(self, 'skip_rgb0', False) and self.precision_coarse == PREC_FP16X3_ASM
+
     def set_precision_pair(self, coarse, fine):
         """one mode per network (include/r2l_hip.h nerf_set_precision_pair): the coarse pass decides where the fine samples go
         (sample_pdf), which on rays that graze an object depends on weights at the 1e-4 level -- a trained teacher needs it at
@@ -383,6 +397,8 @@ class NeRFEngine:
         The choice is not final: spot_check / step_down keep watching what is rendered afterwards (create_data per save group,
         render_path every few frames).  Synchronous, once per weight load."""
         from ._lib import PREC_FP16_FP8
+        if getattr(self, 'skip_rgb0', False):
+            self.set_skip_rgb0(False)           # the measurements below compare the coarse maps too; the render loops switch it on again
         max_diff = self.AUTO_MAX_DIFF if max_diff is None else float(max_diff)
         max_diff_x1 = self.AUTO_MAX_DIFF_X1 if max_diff_x1 is None else float(max_diff_x1)
         sets = [(rays_o, rays_d)] if rays_d is not None else list(rays_o)
@@ -531,12 +547,19 @@ class NeRFEngine:
         idx = self._strided(ro.shape[0], int(n_rays or self.WATCH_RAYS), ro.device)
         if cur == PREC_FP16X3_ASM:        # two fp32-grade modes: coarse maps, then the fine pass at the same sample positions (_x3_pair)
             ro_s, rd_s = ro[idx].contiguous(), rd[idx].contiguous()
+            skipped = getattr(self, 'skip_rgb0', False)
+            if skipped:
+                self.set_skip_rgb0(False)       # the comparison of the coarse maps includes rgb0
             self.set_precision(PREC_FP16X3)
             try:
                 ref = {k: v.clone() for k, v in self.render_rays(ro_s, rd_s, extras=True).items()}
             finally:
                 self.set_precision(cur)
-            d, good = self._x3_pair(ro_s, rd_s, ref)
+            try:
+                d, good = self._x3_pair(ro_s, rd_s, ref)
+            finally:
+                if skipped:
+                    self.set_skip_rgb0(True)
             self.watch_checks = getattr(self, 'watch_checks', 0) + 1
             return good, d
         lim = self._limits(self.AUTO_MAX_DIFF_X1 if cur == PREC_FP16X1 else self.AUTO_MAX_DIFF_MIX if cur == PREC_FP16_MIX else self.AUTO_MAX_DIFF)
@@ -591,7 +614,7 @@ class NeRFEngine:
     def _extras(self, n):
         S1 = self.N_samples + self.N_importance
         dev = self.device
-        rgb0 = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        rgb0 = None if self._rgb0_skipped() else torch.empty((n, 3), dtype=torch.float32, device=dev)
         zs = torch.empty((n, self.N_importance), dtype=torch.float32, device=dev)
         zv = torch.empty((n, S1), dtype=torch.float32, device=dev)
         raw = torch.empty((n, S1, 4), dtype=torch.float32, device=dev)
@@ -599,7 +622,10 @@ class NeRFEngine:
         disp0, acc0, z_std = (torch.empty((n,), dtype=torch.float32, device=dev) for _ in range(3))
         check(lib().nerf_copy_extras0(self._ctx, n, dptr(disp0), dptr(acc0), dptr(z_std), current_stream()))
         # main.py:743-750: rgb0, disp0, acc0, z_std (+ raw with retraw); z_samples / z_vals for the parity tests
-        return {'rgb0': rgb0, 'disp0': disp0, 'acc0': acc0, 'z_std': z_std, 'z_samples': zs, 'z_vals': zv, 'raw': raw}
+        ret = {'disp0': disp0, 'acc0': acc0, 'z_std': z_std, 'z_samples': zs, 'z_vals': zv, 'raw': raw}
+        if rgb0 is not None:            # (set_skip_rgb0: the coarse pass ran without its view branch)
+            ret['rgb0'] = rgb0
+        return ret
 
     def render(self, c2w, rows=None, extras=False):
         """render(H, W, focal, c2w=c2w[:3,:4]) of main.py:107-186 for rows [r0,r1):

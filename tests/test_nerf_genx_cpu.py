@@ -187,7 +187,7 @@ def cxx_pack_fmt(tensors, fmt):
     assert n > 0, L.r2l_last_error()
     buf = np.zeros(n, dtype=np.uint8)
     assert L.nerf_debug_pack_chain_host(arr, len(keep), fmt, C.c_void_p(buf.ctypes.data), n, offs) == n
-    assert L.nerf_debug_pack_chain_host(arr, len(keep), 4, None, 0, offs) < 0          # the format is an argument, not process state
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), 5, None, 0, offs) < 0          # the format is an argument, not process state
     return buf, int(offs[0])
 
 
@@ -320,3 +320,42 @@ def test_emulated_mixed_chain_on_the_trained_like_fine_network():
         rel[name] = (d[:, 3] / np.maximum(1., np.abs(ref[:, 3])))[ref[:, 3] > 1].max()
         print('%-4s raw L_inf rgb %.3g sigma %.3g; sigma relative (sigma > 1) %.3g' % (name, d[:, :3].max(), d[:, 3].max(), rel[name]))
     assert rel['mix'] <= 0.3 * rel['bf6'] and rel['p3'] <= 0.3 * rel['mix'] and rel['mix'] < 2e-4
+
+
+# ---- f16p3a: the three-pass chain without its view branch (the coarse pass of renders whose caller drops rgb0: nerf_set_skip_rgb0) ----
+GA = _load_x('f16p3a')
+
+
+def test_alpha_only_chain_layout_packer_and_committed_text(tmp_path):
+    assert GA.ALPHA and GA.P3 and GA.NC == 2 and len(GA.CHAIN) == 9 and GA.CHAIN[-1].epi == 'alpha' and GA.CHAIN[-1].rt == 2 and GA.CHAIN[-1].fan_out == 1
+    assert GA.NCH == 68 and GA.NCH % GA.NSLOT == 0 and GA.STREAM_BYTES == 1998848        # NERF_CHAINP3A_STREAM_BYTES (csrc/nerf_common.h)
+    # the view branch's MFMAs are gone: 15 of FA's 17 row tiles, V, RGB
+    assert GA.N_ANCH == GP.N_ANCH - (15 * 48 + 8 * (48 + 6) + 24) == 5856
+    for seed, gain in ((5, 1.0), (6, 40.0)):
+        t = T.make_tensors(seed=seed, gain=gain)
+        buf, aux_off = cxx_pack_fmt(t, 4)
+        img, aux = GA.pack_teacher(t)
+        assert aux_off == img.size == GA.STREAM_BYTES and buf.size == img.size + aux.size
+        assert np.array_equal(buf[:aux_off], img) and np.array_equal(buf[aux_off:], aux)
+    GA.emit(str(tmp_path), GA.Opts())
+    for name in ('nerf_mlpp3a_asm.inc', 'nerf_mlpp3a_pro_asm.inc', 'nerf_mlpp3a_clobbers.inc', 'nerf_mlpp3a_pro_clobbers.inc'):
+        built = os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)
+        assert open(os.path.join(str(tmp_path), name)).read() == open(built).read(), name
+
+
+@pytest.mark.parametrize('wave,n_tiles,gain', [(0, 1, 1.0), (3, 2, 1.5)])
+def test_emulated_alpha_only_chain_gives_the_full_chains_density_bit_for_bit(wave, n_tiles, gain):
+    """the density of the chain without its view branch IS the three-pass chain's (same instruction sequence for the trunk and the alpha
+    row; its own power-of-two weight scale changes nothing), the colour outputs are zero"""
+    t = T.make_tensors(seed=wave, gain=gain)
+    rng = np.random.default_rng(10 + wave)
+    pts = rng.uniform(-2.5, 2.5, size=(32, 3)).astype(np.float32)
+    vd = rng.normal(size=(32, 3))
+    vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
+    ref, e, v = T.ref_mlp(t, pts, vd)
+    ba, oa = cxx_pack_fmt(t, 4)
+    bp, op = cxx_pack_fmt(t, 2)
+    a = _run_tile(GA, ba, oa, e, v, wave, n_tiles)
+    p = _run_tile(GP, bp, op, e, v, wave, n_tiles)
+    assert np.array_equal(a[:, 3], p[:, 3]) and not a[:, :3].any()
+    assert np.abs(a[:, 3] - ref[:, 3]).max() < 1e-6 * max(1.0, np.abs(ref).max())

@@ -156,3 +156,47 @@ def test_rebalanced_fine_network_is_the_same_function_and_fits_the_bf6_range(pkg
     assert d3 <= 2e-6 and torch.equal(same['z_samples'], ref['z_samples'])
     assert after <= max(before, 3e-5) and after <= 5e-5
     eng.close()
+
+
+@pytest.mark.parametrize('mode', ['fp16x3_asm', 'fp16_mix'])
+def test_coarse_pass_without_its_view_branch_changes_nothing_but_rgb0(pkg, mode):
+    """nerf_set_skip_rgb0 (round 6): with the coarse network in fp16x3_asm the render pipeline runs it without feature_linear /
+    views_linears.0 / rgb_linear (model/nerf_raybased.py:391-398) -- the coarse densities, hence z_samples, hence every map of the fine
+    pass, and acc0 / disp0 / z_std are BITWISE what they were; rgb0 is gone (and asked for through the C-ABI: refused); the frame is
+    faster; nerf_run_network still evaluates the whole coarse network; a coarse mode without that build is unaffected"""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    from efficient_nerf_amd._lib import R2LError
+    from oracle import whole_frame as WF
+    sds = WF.load_teacher()
+    H = WF.H
+    eng = NeRFEngine(H, H, WF.focal(), precision=PRECISIONS[mode]).load_state_dicts(*sds)
+    pose = WF.pose(1)
+
+    def timed():
+        eng.render(pose)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.render(pose)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3
+    full = {k: v.clone() for k, v in eng.render(pose, extras=True).items()}
+    t_full = timed()
+    ro, rd = (t.reshape(-1, 3)[:4096].contiguous() for t in __import__('efficient_nerf_amd').teacher.get_rays(H, H, WF.focal(), pose[:3, :4], device=eng.device))
+    raw0 = eng.run_network(0, ro, rd, eng.z_coarse.cuda()).clone()
+    eng.set_skip_rgb0(True)
+    got = eng.render(pose, extras=True)
+    t_skip = timed()
+    assert 'rgb0' not in got and set(got) == set(full) - {'rgb0'}
+    for k in got:          # bit patterns: disp of an empty ray is 0 / 0 = NaN in the reference too (main.py:609-610)
+        assert torch.equal(got[k].view(torch.int32), full[k].view(torch.int32)), k
+    assert torch.equal(eng.run_network(0, ro, rd, eng.z_coarse.cuda()), raw0) and float(raw0[..., :3].abs().max()) > 0
+    with pytest.raises(R2LError, match='rgb0 was not computed'):
+        from efficient_nerf_amd._lib import lib, check, dptr, current_stream
+        buf = torch.empty((16, 3), device='cuda')
+        check(lib().nerf_copy_extras(eng._ctx, 16, dptr(buf), None, None, None, current_stream()))
+    print(f'{mode}: {t_full * 1e3:.1f} ms per 400 x 400 frame, without the coarse view branch {t_skip * 1e3:.1f} ms ({(1 - t_skip / t_full) * 100:.1f} % less)')
+    assert t_skip < 0.975 * t_full
+    eng.set_precision(PRECISIONS['fp16x3'])              # the compiler-scheduled mode has no such build: nothing is skipped, rgb0 is there
+    assert 'rgb0' in eng.render(pose, extras=True)
+    eng.close()
