@@ -437,7 +437,7 @@ class NeRFEngine:
                 idx = self._strided(ro.shape[0], self.MIX_PROBE_RAYS, ro.device)
                 big.append((ro[idx].contiguous(), rd[idx].contiguous()))
             self.set_precision(PREC_FP16X3_ASM)
-            if self.AUTO_REBALANCE:
+            if self.AUTO_REBALANCE and not self.ndc:      # (NDC renders: the points the fine network sees are not ro + rd z of the given rays)
                 # the fine network's activations on the probes' own fine sample positions -> exact rescaling into the bf6 chain's range
                 # (measured on the trained-like teacher: worst rgb difference over whole frames 4.3e-5 -> 3.0e-5)
                 zs, rs = [], []
