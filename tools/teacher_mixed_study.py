@@ -84,7 +84,7 @@ def make_lin_half(which, cal=False):
     return lin
 
 
-def forward(lin_main, k_x3=0, stats=None, lin_lead=None):
+def forward(lin_main, k_x3=0, stats=None, lin_lead=None, x3_set=None):
     """teacher_forward with `lin_main` on the 256- / 128-wide sources of the layers behind the first k_x3 trunk layers; embedding
     columns always x3"""
     def f(sd, x, input_ch=63, skips=(4,), dtype=torch.float32):
@@ -96,7 +96,8 @@ def forward(lin_main, k_x3=0, stats=None, lin_lead=None):
         def main(h, Wm, li):
             if stats is not None:
                 stats[li] = max(stats.get(li, 0.), float(h.abs().max()))
-            return ((lin_lead or lin_x3) if li < k_x3 else lin_main)(h, Wm, torch.zeros(()))
+            exact = (li in x3_set) if x3_set is not None else li < k_x3
+            return ((lin_lead or lin_x3) if exact else lin_main)(h, Wm, torch.zeros(()))
         h = F.relu(lin_x3(pts, W('pts_linears.0'), Bv('pts_linears.0')))
         for i in range(1, 8):
             Wi = W(f'pts_linears.{i}')
@@ -146,6 +147,13 @@ def main():
     sd_reb = {k: v.to(dev) for k, v in rebalanced_state({k: v.cpu() for k, v in sds[1].items()}, MX)[0].items()}
     for k in (3,):
         cands.append((f'split {k} + bf6 fixed, rebalanced', fixed, k))
+    # ... and three-pass layers elsewhere than in front (layer numbers: 1-7 trunk, 8 feature | alpha, 9 views, 10 rgb)
+    sets = {}
+    for name, ls in (('L1 L2 FA', (1, 2, 8)), ('L1 L2 L7 FA', (1, 2, 7, 8)), ('L1 L2 FA V RGB', (1, 2, 8, 9, 10)), ('L1 FA', (1, 8)), ('L1 L2 L3 FA', (1, 2, 3, 8)),
+                     ('L1 L2 RGB', (1, 2, 10)), ('L1 L2 V', (1, 2, 9))):
+        tag = f'x3 in {name} + bf6 fixed'
+        cands.append((tag, fixed, 0))
+        sets[tag] = set(ls)
     only = os.environ.get('STUDY_ONLY')          # comma list of substrings: those candidates only (x3 always)
     if only:
         cands = [c for c in cands if c[0] == 'x3' or any(o in c[0] for o in only.split(','))]
@@ -168,7 +176,7 @@ def main():
                 vd = rd / torch.norm(rd, dim=-1, keepdim=True)
                 x3rgb = None
                 for tag, lin, k in cands:
-                    O.teacher_forward = forward(lin, k, stats if tag in ('bf6 cal', 'x3') else None, lead.get(tag))
+                    O.teacher_forward = forward(lin, k, stats if tag in ('bf6 cal', 'x3') else None, lead.get(tag), sets.get(tag))
                     raw = O.run_network(sd_reb if 'rebalanced' in tag else sds[1], pts, vd, netchunk=1 << 22)
                     rgb = O.raw2outputs(raw, z_all, rd, True)[0]
                     if tag == 'x3':

@@ -34,14 +34,25 @@ LIGHT = torch.tensor([0.4, 0.3, 0.85]) / torch.tensor([0.4, 0.3, 0.85]).norm()
 SPHERES = [((-0.55, 0.15, 0.10), 0.50, (0.85, 0.15, 0.12), 0.0), ((0.50, -0.45, 0.25), 0.38, (0.15, 0.65, 0.20), 0.5),
            ((0.05, -0.10, -0.55), 0.30, (0.90, 0.80, 0.15), 0.0)]        # centre, radius, colour, specular weight
 BOX = ((0.25, 0.60, -0.20), (0.35, 0.28, 0.30), (0.15, 0.25, 0.85))      # centre, half size, colour
+MORE_BOXES = []                 # variant 2: thin bars
 SEEDS = {'teacher': (11, 12), 'teacher_rs': 7, 'student': 21, 'student_rs': 9}
 
 
 def use_variant(v):
     """--variant 1: a second scene (two large overlapping spheres, one shiny, a flat slab, a small bright sphere) and other seeds for
     every network and sampler -- is what the committed fixture shows a property of trained weights or of that one run?"""
-    global SPHERES, BOX, LIGHT
+    global SPHERES, BOX, LIGHT, MORE_BOXES
     if v == 0:
+        return
+    if v == 2:
+        # round 6: a third scene made of THIN structures (three crossing bars 0.08-0.12 thick, a thin plate, one small shiny sphere): many
+        # rays graze an edge -- the regime in which sample_pdf is discontinuous and the density tail sharpest
+        SPHERES = [((0.35, -0.40, 0.30), 0.24, (0.90, 0.20, 0.25), 0.6)]
+        BOX = ((0.00, 0.00, -0.60), (0.90, 0.90, 0.04), (0.60, 0.62, 0.58))
+        MORE_BOXES = [((0.00, 0.00, 0.05), (0.85, 0.05, 0.05), (0.15, 0.45, 0.85)), ((-0.20, 0.10, 0.00), (0.04, 0.80, 0.06), (0.90, 0.70, 0.10)),
+                      ((0.30, 0.25, -0.10), (0.06, 0.06, 0.55), (0.20, 0.75, 0.30))]
+        LIGHT = torch.tensor([0.3, -0.4, 0.85]) / torch.tensor([0.3, -0.4, 0.85]).norm()
+        SEEDS.update(teacher=(51, 52), teacher_rs=27, student=61, student_rs=29)
         return
     assert v == 1, v
     SPHERES = [((-0.20, -0.30, 0.00), 0.62, (0.20, 0.35, 0.85), 0.6), ((0.45, 0.35, 0.15), 0.45, (0.90, 0.55, 0.10), 0.0),
@@ -79,14 +90,15 @@ def scene_rgb(ro, rd):
         t = (-b - disc.clamp(min=0.).sqrt()) / (2. * a)
         p = ro + t[:, None] * rd
         shade((disc > 0) & (t > 0), t, (p - torch.tensor(cen, device=dev)) / r, base, spec)
-    cen, half, base = (torch.tensor(v, device=dev) for v in BOX)
     inv = 1. / rd
-    t0, t1 = (cen - half - ro) * inv, (cen + half - ro) * inv
-    tmin, tmax = torch.minimum(t0, t1), torch.maximum(t0, t1)
-    tn, axis = tmin.max(-1)
-    tf = tmax.min(-1)[0]
-    normal = -torch.sign(rd.gather(1, axis[:, None])) * torch.nn.functional.one_hot(axis, 3).float()
-    shade((tn < tf) & (tn > 0), tn, normal, tuple(float(v) for v in base), 0.)
+    for box in [BOX] + MORE_BOXES:
+        cen, half, base = (torch.tensor(v, device=dev) for v in box)
+        t0, t1 = (cen - half - ro) * inv, (cen + half - ro) * inv
+        tmin, tmax = torch.minimum(t0, t1), torch.maximum(t0, t1)
+        tn, axis = tmin.max(-1)
+        tf = tmax.min(-1)[0]
+        normal = -torch.sign(rd.gather(1, axis[:, None])) * torch.nn.functional.one_hot(axis, 3).float()
+        shade((tn < tf) & (tn > 0), tn, normal, tuple(float(v) for v in base), 0.)
     return col
 
 
@@ -289,7 +301,7 @@ def main():
     ap.add_argument('--student-steps', type=int, default=6000)
     ap.add_argument('--files', type=int, default=4, help='shards of 4,096 rays per student batch (the reference: --N_rand 20)')
     ap.add_argument('--measure-only', action='store_true', help='load the three .npz from --out and measure')
-    ap.add_argument('--variant', type=int, default=0, help='0: the committed fixture\'s scene and seeds; 1: a second scene, other seeds')
+    ap.add_argument('--variant', type=int, default=0, help='0: the committed fixture\'s scene and seeds; 1: a second scene, other seeds; 2: a scene of thin bars (round 6)')
     ap.add_argument('--lr-scale', type=float, default=1.0, help='peak learning rate of both fits x this')
     ap.add_argument('--teacher-from', default='', help='directory with teacher_coarse.npz / teacher_fine.npz to distil from (skips the teacher fit)')
     args = ap.parse_args()
