@@ -45,14 +45,14 @@ def use_variant(v):
     if v == 0:
         return
     if v == 2:
-        # round 6: a third scene made of THIN structures (three crossing bars 0.08-0.12 thick, a thin plate, one small shiny sphere): many
+        # round 6: a third scene made of THIN structures (three crossing bars 0.16-0.20 thick, a thin plate, one shiny sphere): many
         # rays graze an edge -- the regime in which sample_pdf is discontinuous and the density tail sharpest
-        SPHERES = [((0.35, -0.40, 0.30), 0.24, (0.90, 0.20, 0.25), 0.6)]
-        BOX = ((0.00, 0.00, -0.60), (0.90, 0.90, 0.04), (0.60, 0.62, 0.58))
-        MORE_BOXES = [((0.00, 0.00, 0.05), (0.85, 0.05, 0.05), (0.15, 0.45, 0.85)), ((-0.20, 0.10, 0.00), (0.04, 0.80, 0.06), (0.90, 0.70, 0.10)),
-                      ((0.30, 0.25, -0.10), (0.06, 0.06, 0.55), (0.20, 0.75, 0.30))]
+        SPHERES = [((0.40, -0.45, 0.30), 0.30, (0.90, 0.20, 0.25), 0.6)]
+        BOX = ((0.00, 0.00, -0.60), (0.90, 0.90, 0.06), (0.60, 0.62, 0.58))
+        MORE_BOXES = [((0.00, 0.00, 0.05), (0.85, 0.09, 0.09), (0.15, 0.45, 0.85)), ((-0.25, 0.10, 0.00), (0.08, 0.80, 0.10), (0.90, 0.70, 0.10)),
+                      ((0.30, 0.30, -0.05), (0.10, 0.10, 0.55), (0.20, 0.75, 0.30))]
         LIGHT = torch.tensor([0.3, -0.4, 0.85]) / torch.tensor([0.3, -0.4, 0.85]).norm()
-        SEEDS.update(teacher=(51, 52), teacher_rs=27, student=61, student_rs=29)
+        SEEDS.update(teacher=(13, 14), teacher_rs=27, student=61, student_rs=29)
         return
     assert v == 1, v
     SPHERES = [((-0.20, -0.30, 0.00), 0.62, (0.20, 0.35, 0.85), 0.6), ((0.45, 0.35, 0.15), 0.45, (0.90, 0.55, 0.10), 0.0),
