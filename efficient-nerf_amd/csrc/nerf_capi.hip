@@ -273,6 +273,8 @@ struct nerf_ctx {
     int ev_used = 0;
 };
 
+static int ensure_alpha_img(nerf_ctx* c);
+
 static void free_tmp(nerf_ctx* c) {
     float** ps[] = {&c->d_rays_o, &c->d_rays_d, &c->d_raw0, &c->d_w0, &c->d_zs, &c->d_zall, &c->d_raw,
                     &c->d_rgb0, &c->d_disp0, &c->d_acc0, &c->d_ndc_o, &c->d_ndc_d, &c->d_vdir, &c->d_zsort};
@@ -485,13 +487,13 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
     int rc = build_net(c, net, c->mode_net[which]);
     if (rc) return rc;
     net.loaded = true;
-    return R2L_OK;
+    return which == 0 ? ensure_alpha_img(c) : R2L_OK;
 }
 
 int nerf_set_skip_rgb0(nerf_ctx* c, int on) {
     if (!c) return r2l_set_error(R2L_EINVAL, "NULL ctx");
     c->skip_rgb0 = on != 0;
-    return R2L_OK;
+    return ensure_alpha_img(c);
 }
 
 int nerf_set_precision(nerf_ctx* c, int mode) {
@@ -513,6 +515,19 @@ int nerf_set_precision_pair(nerf_ctx* c, int coarse_mode, int fine_mode) {
         c->mode_net[which] = modes[which];
     }
     c->mode = fine_mode;
+    return ensure_alpha_img(c);
+}
+
+// nerf_set_skip_rgb0: the coarse network's three-pass stream without its view branch (pack_chain fmt 4), packed outside the render path
+static int ensure_alpha_img(nerf_ctx* c) {
+    PackedNet& n = c->net[0];
+    if (!c->skip_rgb0 || !n.loaded || n.d_img_alpha || c->mode_net[0] != R2L_PREC_FP16X3_ASM) return R2L_OK;
+    std::vector<char> img;
+    int rc = pack_chain(n.host_w, c->act_scale, img, 4);
+    if (rc) return rc;
+    hipError_t e = hipMalloc((void**)&n.d_img_alpha, img.size());
+    if (e == hipSuccess) e = hipMemcpy(n.d_img_alpha, img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "the coarse network's stream without its view branch: %s", hipGetErrorString(e));
     return R2L_OK;
 }
 
@@ -522,16 +537,9 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     memset(&p, 0, sizeof p);
     p.viewdirs = viewdirs;
     const int mode = c->mode_net[which];
-    alpha_only = alpha_only && mode == R2L_PREC_FP16X3_ASM;
-    if (alpha_only && !c->net[which].d_img_alpha) {      // packed on first use: the stream without the view branch (pack_chain fmt 4)
-        std::vector<char> img;
-        int rc = pack_chain(c->net[which].host_w, c->act_scale, img, 4);
-        if (rc) return rc;
-        hipError_t e = hipMalloc((void**)&c->net[which].d_img_alpha, img.size());
-        if (e == hipSuccess) e = hipMemcpyAsync(c->net[which].d_img_alpha, img.data(), img.size(), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);      // `img` is a local
-        if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "the coarse network's stream without its view branch: %s", hipGetErrorString(e));
-    }
+    // (the stream without the view branch is packed when the flag, the weights or the mode are set -- ensure_alpha_img --, never here:
+    // a render allocates nothing and does not synchronise; without it the full kernel runs)
+    alpha_only = alpha_only && mode == R2L_PREC_FP16X3_ASM && c->net[which].d_img_alpha != nullptr;
     p.wimg = alpha_only ? c->net[which].d_img_alpha : c->net[which].d_img[mode];
     p.raw = raw;
     p.rays_o = rays_o;

@@ -37,6 +37,33 @@ def test_r2l_render_in_a_hip_graph(pkg, prec):
     eng.close()
 
 
+def test_teacher_mixed_rung_with_the_skipped_coarse_view_branch_in_a_hip_graph(pkg):
+    """round 6: the rung trained teachers get (coarse fp16x3_asm without its view branch, fine fp16_mix) captures and replays as well: the
+    stream without the view branch is packed when nerf_set_skip_rgb0 / the weights / the mode are set, not inside a render"""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    H = 32
+    eng = NeRFEngine(H, H, O.focal_from_angle(H), precision=PRECISIONS['fp16_mix']).load_state_dicts(O.make_teacher_state(1), O.make_teacher_state(2))
+    eng.set_skip_rgb0(True)
+    ro, rd = O.get_rays(H, H, eng.focal, O.pose_spherical(25., -40., 4.)[:3, :4])
+    ro, rd = ro.reshape(-1, 3).float().contiguous().cuda(), rd.reshape(-1, 3).float().contiguous().cuda()
+    want = {k: v.clone() for k, v in eng.render_rays(ro, rd).items()}           # warm-up: temporaries allocated
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.render_rays(ro, rd)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = eng.render_rays(ro, rd)
+    for k in got:
+        got[k].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in ('rgb_map', 'acc_map', 'depth_map'):
+        assert torch.equal(got[k], want[k]), k
+    eng.close()
+
+
 def test_teacher_render_rays_in_a_hip_graph(pkg):
     """coarse + fine networks, raw2outputs, sample_pdf, merge: eight launches, one graph"""
     from efficient_nerf_amd import NeRFEngine, PREC_FP16_FP8
