@@ -12,7 +12,13 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'r0
 out = ['# the trained-like family through `--precision auto` (round 6, VERDICT r5 next 4): tools/train_like.py at other points of its recipe;',
        '# reports only (weights not committed).  Contract: L_inf <= 1e-4 on rgb against the CPU oracle (teacher: 1,020 strided rays per frame x 3 poses;',
        '# student: 80,000 rays per frame x 3 poses at 800 x 800).  Committed fixture for comparison: v0, teacher 4,000 steps, student 6,000 steps, lr x 1:',
-       '# teacher sigma <= 200 -> fp16_mix (fp16x3_asm before round 6), student max|a| 126 -> fp16_split8 at block 0-2.', '']
+       '# teacher sigma <= 206 -> fp16_mix (fp16x3_asm before round 6), student max|a| 126 -> fp16_split8 at block 0-2.',
+       '# Teacher times are plain NeRFEngine.render calls (the coarse view branch is NOT skipped here; render_path / create_rand skip it: another -4.8 %).',
+       '# Summary: 11 students, every one on a measured split rung (8 x e4m3 terms, 3 x bf6 terms, split 0-9), L_inf 1.5e-5 ... 6.1e-5; 4 distinct teachers:',
+       '# v0 (sigma 206) and v1 (sigma 83-123) get fp16_mix at 2.2-3.0e-5, v0 fitted three times longer (sigma 268) and the thin-bar scene v2 (sigma 276) miss its',
+       '# 5e-5 check at 7.2-7.4e-5 and render in three passes.', '']
+NOTES = {'v1_s12k': 'measured BEFORE the far-plane tie rule (teacher.FAR_TIE): one probe ray whose far sample sits at sigma_raw = +-1e-6 read acc 0.82 / depth 4.9 '
+                    'with rgb unchanged and rejected the rung; the same scene and recipe after the rule: point v1 (fp16_mix at 2.2e-5)'}
 worst_t = worst_s = 0.
 for f in sorted(glob.glob(os.path.join(src, '*.json'))):
     r = json.load(open(f))
@@ -39,6 +45,11 @@ for f in sorted(glob.glob(os.path.join(src, '*.json'))):
     if 'ms_per_frame_fp16x3_asm' in s:
         line += f' (three passes everywhere: {s["ms_per_frame_fp16x3_asm"]:.2f} ms)'
     out.append(line)
+    if 'fp16_mix' not in t['probe_diffs'] and t['auto_precision'] == 'fp16x3_asm':
+        out.append('(teacher measured before the fp16_mix rung existed: the same teacher as point v0_s48k / v1, where `auto` gives fp16_mix)' if rc.get('teacher_from') or rc['variant'] == 1
+                   else '(teacher measured before the fp16_mix rung existed)')
+    if name in NOTES:
+        out.append('(' + NOTES[name] + ')')
     out.append('')
 out.append(f'== worst L_inf against the CPU oracle over the family: teacher {worst_t:.1e}, student {worst_s:.1e} (contract 1e-4)')
 text = '\n'.join(out) + '\n'
