@@ -62,6 +62,7 @@ S_NEG1, S_M0SAVE = 43, 44
 S_G = 46                      # 46,47 LDS-DMA source
 S_WPW = 48                    # 48..55: wave * PW * 1024 for PW = 1..8
 N_SGPR_LO, N_SGPR_HI = 40, 56
+S_CUT = 56                    # f16p3s / mixs: 56..59 the second exit's masks and flag (N_SGPR_HI = 60 there)
 
 SLOT = 32768
 NSLOT = 4
@@ -87,7 +88,7 @@ ACT_EXP, RES_EXP = B.ACT_EXP, B.RES_EXP
 # that computed the embedding between two blocks while the matrix pipe idled (2.3 ms of a 33.4 ms frame, -DNERF_SKIP_EMBED) is gone.
 # The arithmetic per point is that of nerf_tile_embed (csrc/nerf_kernels.hip), operation for operation: bitwise-equal results.
 FMT = os.environ.get('NERF_GEN_FMT', 'bf6')
-assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3', 'f16p3a', 'mix'), FMT
+assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3', 'f16p3a', 'f16p3s', 'mix', 'mixs'), FMT
 # NERF_GEN_FMT=mix (round 6): the bf6 chain with its FIRST trunk layers in three fp16 passes -- layers L1 .. L<MIXK> as in f16p3 (hi / lo
 # fragments of both operands, W x 2^k in the stream), everything behind them with bf6 terms.  For the FINE pass of trained teachers: the
 # early layers' error is what the sharp tail of such a network amplifies (tools/teacher_mixed_study.py on whole frames of the trained-like
@@ -104,6 +105,17 @@ assert FMT in ('bf6', 'f16', 'f16c3', 'f16c4', 'f16c4e', 'f16p3', 'f16p3a', 'mix
 ALPHA = FMT == 'f16p3a'
 if ALPHA:
     FMT = 'f16p3'
+# NERF_GEN_FMT=f16p3s / mixs (round 6): the chain with a SECOND EXIT behind the density.  A sample whose raw density is <= 0 has alpha = 0 and
+# weight 0 exactly (main.py:600-606): its colour cannot reach rgb_map.  The feature | alpha layer is split -- layer A: the alpha row alone,
+# FIRST; layer F: the 256 feature rows -- and behind A's epilogue the four waves of the workgroup agree (an OR through an LDS word, one
+# barrier) whether ANY of the tile's 128 points has a positive density.  If none: the feature rows, the views layer and the rgb layer are dead
+# work -- the block waits for the LDS-DMA pieces in flight, re-primes the ring with the next tile's first three chunks and leaves with
+# raw = (0, 0, 0, sigma).  rgb / disp / acc / depth are bit for bit what the full chain gives (0 x sigmoid(c) = 0 either way); `raw` shows
+# zeros for the colours of such tiles.  For renders whose caller drops the extras (nerf_set_skip_rgb0) and adds no density noise.
+SKIPV = FMT in ('f16p3s', 'mixs')
+if SKIPV:
+    FMT = FMT[:-1]
+    N_SGPR_HI = 60
 MIX = FMT == 'mix'
 MIXK = int(os.environ.get('NERF_GEN_MIX_K', '2')) if MIX else 0
 assert 0 <= MIXK <= 7
@@ -117,7 +129,7 @@ EMB = FMT == 'f16c4e'
 # a normal fp16 number, the epilogue takes the factor out (one v_fma_mix per value does it together with the conversion to fp16).
 P3 = FMT == 'f16p3'
 NC = {'f16c3': 3, 'f16c4': 4, 'f16c4e': 4}.get(FMT, 2)          # column tiles (16 points each) per wave
-SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e', 'f16p3': 'p3', 'mix': 'm'}[FMT] + ('a' if ALPHA else '')     # nerf_mlpx_asm.inc ...
+SUFFIX = {'bf6': '', 'f16': 'x', 'f16c3': 'x3', 'f16c4': 'x4', 'f16c4e': 'x4e', 'f16p3': 'p3', 'mix': 'm'}[FMT] + ('a' if ALPHA else '') + ('s' if SKIPV else '')     # nerf_mlpx_asm.inc ...
 # passes of an embedding k-step: hi(W) hi(E), hi(W) lo(E), lo(W) hi(E).  The fp16-only chains drop the third (their 256-wide layers
 # carry no lo(W) term either; measured over whole frames, three seed pairs x three poses: rgb 6.5e-6 .. 1.9e-5 from fp16x3 with two
 # passes against 6.4e-6 .. 1.6e-5 with three, -4.4 % time; ONE pass -- no lo(E), i.e. fp16-rounded coordinates -- reads 1.3 .. 2.8e-5
@@ -213,6 +225,11 @@ def chain():
     L.append(Layer('L7', 'Q', 'P', 8, [], 16, 'relu', r_std, 256))
     if ALPHA:       # the alpha row alone (row tile 0, row 0) + an all-zero row tile (chunk count = 0 mod 4); no view branch
         L.append(Layer('FA', 'P', None, 8, [], 2, 'alpha', 1, 1))
+    elif SKIPV:     # the alpha row first (one row tile: one chunk), then the cut, then the feature rows (8 chunks: 9 as the unsplit layer)
+        L.append(Layer('A', 'P', None, 8, [], 1, 'alpha', 1, 1))
+        L.append(Layer('F', 'P', 'Q', 8, [], 16, 'feat', r_std, 256))
+        L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', r_v, 128))
+        L.append(Layer('RGB', 'P', None, 4, [], 1, 'rgb', 1, 3))
     else:
         L.append(Layer('FA', 'P', 'Q', 8, [], 17, 'feat', r_std, 257))
         L.append(Layer('V', 'Q', 'P', 8, [('V', 0)], 8, 'relu', r_v, 128))
@@ -223,6 +240,10 @@ def chain():
             l.set_p3(1 <= li <= MIXK)
             if l.p3:
                 l.rt_per_chunk = {'L5': 1}.get(l.name, 2)
+    for li, l in enumerate(L):
+        # exp_group: layers whose bf6 terms share one weight exponent (A and F: that of the unsplit feature | alpha layer, so that the split
+        # chain computes bit for bit what the unsplit one does)
+        l.exp_group = ('A', 'F') if l.name in ('A', 'F') else (l.name,)
     for li, l in enumerate(L):
         # lo_out: the epilogue hands its consumer hi + lo fp16 sets (the consumer runs three passes); scaled: its accumulators carry the
         # 2^k of a three-pass stream; uses_inv: its epilogue multiplies by the f32 in the layer's scale registers (1 / 2^k; L0 of mix: 1.0)
@@ -334,7 +355,11 @@ def layer_matrices(t):
     if ALPHA:
         out.append((W(20, 1, 256), None, t[21].reshape(-1)))
         return out
-    out.append((np.concatenate([W(18, 256, 256), W(20, 1, 256)], 0), None, np.concatenate([t[19].reshape(-1), t[21].reshape(-1)])))
+    if SKIPV:
+        out.append((W(20, 1, 256), None, t[21].reshape(-1)))
+        out.append((W(18, 256, 256), None, t[19].reshape(-1)))
+    else:
+        out.append((np.concatenate([W(18, 256, 256), W(20, 1, 256)], 0), None, np.concatenate([t[19].reshape(-1), t[21].reshape(-1)])))
     wv = W(16, 128, 283)                                                   # cat([feature, input_views]) (:390)
     out.append((np.ascontiguousarray(wv[:, :256]), np.ascontiguousarray(wv[:, 256:]), t[17]))
     out.append((W(22, 3, 128), None, t[23]))
@@ -358,7 +383,8 @@ def pack_teacher(tensors, act_scale=16.0):
             for qq in range(4):
                 aux[a0 + AUX_SCALES // 4 + 4 * qq] = np.array([1.0], dtype=np.float32).view(np.uint32)[0]
         if L.p3:    # W x 2^k with max|w| 2^k in [2^12, 2^13) over everything that accumulates into this layer's rows (r2l_pow2_scale)
-            mx = max(float(np.abs(m).max()) for m in (Wm, We) if m is not None)
+            grp = [m for j, l2 in enumerate(CHAIN) if l2.name in L.exp_group for m in mats[j][:2] if m is not None]    # (A, F: the unsplit layer's)
+            mx = max(float(np.abs(m).max()) for m in grp)
             sw = np.float32(2.0 ** (12 - int(np.floor(np.log2(mx)))) if mx > 0 and np.isfinite(mx) else 1.0)
             aux[a0:a0 + len(bias)] = (bias.astype(np.float64) * act_scale * float(sw)).astype(np.float32).view(np.uint32)
             for qq in range(4):
@@ -368,7 +394,8 @@ def pack_teacher(tensors, act_scale=16.0):
         if Wm is not None:
             hi = Wm.astype(np.float16)
         if Wm is not None and not X1 and not L.p3:       # the E8M0 scale bytes of the bf6 terms
-            el, ew = weight_exps(layer_exponent(Wm))
+            grp = [mats[j][0] for j, l2 in enumerate(CHAIN) if l2.name in L.exp_group]
+            el, ew = weight_exps(max(layer_exponent(g) for g in grp))
             for qq in range(4):
                 aux[a0 + AUX_SCALES // 4 + 4 * qq] = 0x01010101 * (127 + el)
                 aux[a0 + AUX_SCALES // 4 + 4 * qq + 1] = 0x01010101 * (127 + ew)
@@ -660,6 +687,8 @@ def epilogue_ops(T, c):
     if L.epi == 'alpha':     # f16p3a: sigma from row 0 of row tile 0, zeros for the colours nobody computed; the padding row tile: nothing
         if u != 0:
             return []
+        if SKIPV:            # the colours come from the rgb layer, or as zeros from the second exit
+            return [(v_mov_out(c * 4 + 3, acc, inv), None)]
         return [(v_mov_out(c * 4 + 3, acc, inv), None)] + [(v_zero_out(c * 4 + k), None) for k in range(3)]
     if L.epi == 'rgb':
         return [(v_mov_out(c * 4 + k, acc + k, inv), None) for k in range(3)]
@@ -1282,6 +1311,8 @@ def build_fillers(opts):
     # ---- epilogue of tile T-1 under tile T -------------------------------------------------------------
     for T in range(1, NT):
         tp = TILES[T - 1]
+        if SKIPV and tp.layer.name == 'A':
+            continue                        # the density's epilogue runs AT the cut (cut_ops), in front of the decision
         for c in range(NC):
             e0 = afirst(T) + 2 + c          # two further MFMAs behind the last writer of its accumulator
             for ins, cons in epilogue_ops(T - 1, c):
@@ -1339,6 +1370,58 @@ def build_fillers(opts):
             F.append(Filler(ins, a_c, N_ANCH + 1, ch))
         opts.a_emb = a_e
     return F, bufmap
+
+
+def cut_ops(T_A):
+    """f16p3s / mixs: behind the last MFMA of layer A (tile T_A) -- its epilogue (sigma into the output operands), then the decision: does any
+    of the workgroup's 128 points have a positive density?  Row 0 of the tile's accumulators is sigma x act_scale (x 2^k): lanes 0..15
+    of register 0 (the other rows of the tile have zero weights and zero bias: never > 0).  The wave's answer goes into this tile's LDS
+    word (%[fl]: the HIP code alternates between two words, the other one is cleared here for the next tile: every wave has read it
+    before this tile's entry barrier), one barrier, every wave reads the OR back and takes the same exit."""
+    acc = [ACC(T_A & 1, c) for c in range(NC)]
+    t0 = TMP(0)
+    v_any, v_addr, v_addr2, v_zero = t0 + 6, t0 + 7, t0 + 8, t0 + 9
+    m0s, m1s, sf = S_CUT, S_CUT + 2, S_CUT + 2
+    ops = [s_nop(15), s_nop(15)]
+    if TILES[T_A].layer.uses_inv:
+        ops.append(('need', ('scale', TILES[T_A].li)))
+    for c in range(NC):
+        ops += [ins for ins, _ in epilogue_ops(T_A, c)]
+
+    def decide(st):
+        anyp = False
+        for c in range(NC):
+            anyp = anyp or bool((st.f32('v', acc[c]) > 0).any())
+        st.skip = not anyp
+    ops.append(valu('v_cmp_lt_f32_e64 %s, 0, %s' % (sreg(m0s, 2), vreg(acc[0])), vr(acc[0]), [], decide))
+    ops.append(valu('v_cmp_lt_f32_e64 %s, 0, %s' % (sreg(m1s, 2), vreg(acc[1])), vr(acc[1]), [], None))
+    ops.append(s_nop(4))
+    ops.append(salu('s_or_b64 %s, %s, %s' % (sreg(m0s, 2), sreg(m0s, 2), sreg(m1s, 2))))
+    ops.append(salu('s_cselect_b32 %s, 1, 0' % sreg(sf)))
+    ops.append(valu('v_mov_b32 %s, %s' % (vreg(v_any), sreg(sf)), [], vr(v_any), None))
+    ops.append(valu('v_mov_b32 %s, %%[fl]' % vreg(v_addr), [], vr(v_addr), None))
+    ops.append(valu('v_xor_b32 %s, 4, %s' % (vreg(v_addr2), vreg(v_addr)), vr(v_addr), vr(v_addr2), None))
+    ops.append(valu('v_mov_b32 %s, 0' % vreg(v_zero), [], vr(v_zero), None))
+    ops.append(Ins('ds_write_b32 %s, %s' % (vreg(v_addr2), vreg(v_zero)), 'salu'))       # (kind: outside the scheduler's LDS-read accounting;
+    ops.append(Ins('ds_max_u32 %s, %s' % (vreg(v_addr), vreg(v_any)), 'salu'))           #  the waits around them are lgkmcnt(0))
+    ops.append(waitcnt_lgkm(0))
+    ops.append(barrier())
+    ops.append(Ins('ds_read_b32 %s, %s' % (vreg(v_any), vreg(v_addr)), 'salu'))
+    ops.append(waitcnt_lgkm(0))
+    ops.append(salu('v_readfirstlane_b32 %s, %s' % (sreg(sf), vreg(v_any))))
+    ops.append(salu('s_cmp_eq_u32 %s, 0' % sreg(sf)))
+    ops.append(Ins('s_cbranch_scc1 L_skip_%=', 'salu', tag='cut'))
+    return ops
+
+
+def skip_tail_ops():
+    """the second exit: nothing of the feature rows / views / rgb layers runs.  LDS-DMA pieces of chunks behind the cut are in flight and
+    fragment reads may be: wait for both, one barrier (every wave's pieces have landed, nobody reads a slot any more), then the next tile's
+    chunks 0..2 into slots 0..2 as the full path's last refills do, and zeros for the colours"""
+    ops = [waitcnt_vm(0), waitcnt_lgkm(0), barrier()] + prologue_ops()
+    for c in range(NC):
+        ops += [v_zero_out(c * 4 + k) for k in range(3)]
+    return ops
 
 
 class Sched:
@@ -1400,6 +1483,7 @@ def schedule(opts):
             break
         issue(r[0])
     T = 0
+    a_cut = afirst(TILE_OF[([l.name for l in CHAIN].index('F'), 0)]) if SKIPV else -1
     for a in range(N_ANCH):
         while True:
             r = [f for f in ready(a - 1) if f.deadline <= a]
@@ -1408,6 +1492,14 @@ def schedule(opts):
             issue(r[0])
         while a >= ABASE[T + 1]:
             T += 1
+        if a == a_cut:          # the second exit sits between layer A's last MFMA and layer F's first
+            for ins in cut_ops(T - 1):
+                if isinstance(ins, tuple):
+                    sch.need(ins[1])
+                else:
+                    sch.emit(ins)
+                    if ins.kind == 'wait' and 'lgkmcnt(0)' in ins.text:
+                        sch.ds_done = sch.ds_issued
         t = TILES[T]
         L = t.layer
         kind, k, c, p = ANCH[T][a - ABASE[T]]
@@ -1521,9 +1613,16 @@ def tail_ops():
 
 
 def block_stream(opts):
+    """f16p3s / mixs: the full path (the branch of the cut is an instruction of it, tagged 'cut': split_at_cut / skip_tail_ops)"""
     if EMB:      # ... and the block ends with the stores of its own tile's raw
         return [vm_wait(0), barrier()] + schedule(opts) + tail_ops() + raw_store_ops()
     return [waitcnt_vm(0), barrier()] + schedule(opts) + tail_ops()
+
+
+def split_at_cut(body):
+    """(instructions up to and including the cut's branch, the rest of the full path)"""
+    i = next(k for k, ins in enumerate(body) if ins.tag == 'cut')
+    return body[:i + 1], body[i + 1:]
 
 
 # ---- f16c4e: the kernel around the block (one asm statement: setup, ring prologue, first tile's embedding, tile loop) --------------
@@ -1684,7 +1783,10 @@ def emit(dirname, opts):
     with open(os.path.join(dirname, 'nerf_mlp%s_asm.inc' % SUFFIX), 'w') as f:
         f.write('// GENERATED by gen/nerf_gen.py -- do not edit.  One 128-point tile of the teacher MLP: %s\n' %
                 ', '.join('%s %d' % kv for kv in sorted(n.items())))
-        for line in setup + [i.text for i in body] + ['s_mov_b32 m0, %s' % sreg(S_M0SAVE)]:
+        lines = setup + [i.text for i in body]
+        if SKIPV:
+            lines += ['s_branch L_done_%=', 'L_skip_%=:'] + [i.text for i in skip_tail_ops()] + ['L_done_%=:']
+        for line in lines + ['s_mov_b32 m0, %s' % sreg(S_M0SAVE)]:
             f.write('"%s\\n\\t"\n' % line)
     with open(os.path.join(dirname, 'nerf_mlp%s_pro_asm.inc' % SUFFIX), 'w') as f:
         f.write('// GENERATED by gen/nerf_gen.py -- do not edit.  Ring prologue: chunks 0..2 of the stream\n')
@@ -1716,15 +1818,26 @@ def emulate_tile(opts, img, aux, frags, wave=0, n_tiles=1, check_hazards=True, b
     for name, reg in INPUT_NAMES:
         st.A[reg:reg + 4] = frags[name]
     st.run(prologue_ops())
+    st.skipped = []
     for _ in range(n_tiles):
         st.out = {}
-        st.run(body)
+        if SKIPV:        # the emulated wave decides alone (the kernel ORs four waves): up to the branch, then one of the two exits
+            pre, post = split_at_cut(body)
+            st.run(pre)
+            st.skipped.append(bool(st.skip))
+            st.run(skip_tail_ops() if st.skip else post)
+        else:
+            st.run(body)
     errs = list(st.errors)
     if st.pend_ds:
         errs.append('%d LDS reads never waited for' % len(st.pend_ds))
     if check_hazards:
         errs += check_hazards_stream(body)
+        if SKIPV:
+            errs += check_hazards_stream(split_at_cut(body)[0] + skip_tail_ops())
     out = np.stack([st.out[k] for k in range(4 * NC)]).view(np.float32)
+    if SKIPV:
+        return out, errs, st.skipped
     return out, errs
 
 

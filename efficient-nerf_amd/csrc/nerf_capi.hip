@@ -19,6 +19,8 @@ struct PackedNet {
     char* d_img[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [precision mode]
     float inv_scale[8][NERF_N_SCALES];
     char* d_img_alpha = nullptr;             // the three-pass stream without the view branch (coarse network, nerf_set_skip_rgb0)
+    char* d_img_exit = nullptr;              // the fine network's stream with the second exit behind the density (fp16x3_asm or fp16_mix), and
+    int exit_mode = -1;                      // the mode it was packed for
     std::vector<std::vector<float>> host_w;  // 24 tensors, state_dict order
     bool loaded = false;
 };
@@ -109,6 +111,13 @@ const ChainLayer kChainP3[11] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 
 const ChainLayer kChainP3A[9] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256},
                                  {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 2, 1, 1}};
 
+// the chains with a second exit behind the density (NERF_GEN_FMT=f16p3s / mixs): layer 8 = the alpha row (one row tile, one chunk), layer 9 =
+// the 256 feature rows, then views and rgb: 12 layers
+const ChainLayer kChainP3S[12] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256},
+                                  {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 1, 1, 1},   {8, 0, 16, 2, 256}, {8, 1, 8, 1, 128},  {4, 0, 1, 1, 3}};
+const ChainLayer kChainS[12] = {{0, 2, 16, 8, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 2, 16, 1, 256},
+                                {8, 0, 16, 2, 256}, {8, 0, 16, 2, 256}, {8, 0, 1, 1, 1},   {8, 0, 16, 2, 256}, {8, 1, 8, 2, 128},  {4, 0, 1, 1, 3}};
+
 struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding column), bias(row); rows < fan_out
     std::function<float(int, int)> main, emb;
     std::function<float(int)> bias;
@@ -119,15 +128,19 @@ struct ChainSrc {   // one layer's parameters: main(row, k), emb(row, embedding 
 // fmt 2 (p3): the stream of R2L_PREC_FP16X3_ASM -- per row tile its KS hi fragments, then its KS lo fragments, of W x 2^k with
 // max|w| 2^k in [2^12, 2^13) over the layer's main and embedding columns (lo = the fp16 rounding residual: a normal number thanks
 // to the factor); the bias x act_scale x 2^k; at the scale bytes' place 2^-k as a float for the epilogue
+// fmt 5 (p3s) / 6 (mixs): fmt 2 / 3 with the feature | alpha layer split (kChainP3S / kChainS: the alpha row first); the two halves' bf6 terms
+// keep the unsplit layer's weight exponent, so that the split chain computes bit for bit what the unsplit one does
 // fmt 4 (p3a): fmt 2 without the view branch (kChainP3A): nine layers, the last one the alpha row with its own 2^k
 // fmt 3 (mix): the stream of R2L_PREC_FP16_MIX -- fmt 0 with layers L1 .. L<NERF_MIX_K> packed as in fmt 2 (hi | lo fragments of
 // W x 2^k, 2^-k at the scale bytes' place) and 1.0f there for L0, whose epilogue hands L1 hi + lo sets with the three-pass form
 int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<char>& img, int fmt = 0) {
-    const bool mix = fmt == 3, alpha_only = fmt == 4;
-    const bool x1 = fmt == 1, all_p3 = fmt == 2 || alpha_only;
-    const size_t stream_bytes = alpha_only ? NERF_CHAINP3A_STREAM_BYTES : mix ? NERF_CHAINM_STREAM_BYTES : all_p3 ? NERF_CHAINP3_STREAM_BYTES
+    const bool split = fmt == 5 || fmt == 6;
+    const bool mix = fmt == 3 || fmt == 6, alpha_only = fmt == 4;
+    const bool x1 = fmt == 1, all_p3 = fmt == 2 || alpha_only || fmt == 5;
+    const size_t stream_bytes = fmt == 5 ? NERF_CHAINP3S_STREAM_BYTES : fmt == 6 ? NERF_CHAINMS_STREAM_BYTES : alpha_only ? NERF_CHAINP3A_STREAM_BYTES
+                                : mix ? NERF_CHAINM_STREAM_BYTES : all_p3 ? NERF_CHAINP3_STREAM_BYTES
                                 : (x1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
-    const int n_layers = alpha_only ? 9 : 11;
+    const int n_layers = alpha_only ? 9 : split ? 12 : 11;
     img.assign(stream_bytes + NERF_CHAIN_AUX_BYTES, 0);
     auto mat = [&](int ti, int ncol, int col0) {
         const float* p = w[ti].data();
@@ -137,7 +150,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
         const float* p = w[ti].data();
         return [p](int r) -> float { return p[r]; };
     };
-    ChainSrc src[11];
+    ChainSrc src[12];
     src[0] = {nullptr, mat(0, 63, 0), vec(1), true};
     const int plain[6] = {1, 2, 3, 4, 6, 7};
     for (int li : plain) src[li] = {mat(2 * li, 256, 0), nullptr, vec(2 * li + 1), true};
@@ -153,10 +166,24 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
     }
     src[9] = {mat(T_VIEWS_W, 283, 0), mat(T_VIEWS_W, 283, 256), vec(T_VIEWS_B), false};  // cat([feature, views]) (:390)
     src[10] = {mat(T_RGB_W, 128, 0), nullptr, vec(T_RGB_B), true};
+    int fa_exp = 0;          // split chains: the weight exponent of the unsplit feature | alpha layer, shared by its two halves' bf6 terms,
+    float fa_max = 0.f;      // and its max|w| (the three-pass halves' common 2^k): the split chain computes bit for bit what the unsplit one does
+    if (split) {
+        std::vector<float> all((size_t)257 * 256);
+        for (int r = 0; r < 257; ++r)
+            for (int k = 0; k < 256; ++k) all[(size_t)r * 256 + k] = src[8].main(r, k);
+        fa_exp = r2l_layer_exponent(all.data(), all.size());
+        for (float v : all) fa_max = fmaxf(fa_max, fabsf(v));
+        const float *aw = w[T_ALPHA_W].data(), *ab = w[T_ALPHA_B].data();
+        src[11] = src[10];
+        src[10] = src[9];
+        src[9] = {mat(T_FEAT_W, 256, 0), nullptr, vec(T_FEAT_B), true};
+        src[8] = {[=](int, int k) -> float { return aw[k]; }, nullptr, [=](int) -> float { return ab[0]; }, true};
+    }
     size_t chunk_off = 0;
     uint32_t* aux = reinterpret_cast<uint32_t*>(img.data() + stream_bytes);
     for (int li = 0; li < n_layers; ++li) {
-        const ChainLayer& L = (alpha_only ? kChainP3A : all_p3 ? kChainP3 : (x1 ? kChainX : kChain))[li];
+        const ChainLayer& L = (fmt == 5 ? kChainP3S : fmt == 6 ? kChainS : alpha_only ? kChainP3A : all_p3 ? kChainP3 : (x1 ? kChainX : kChain))[li];
         const ChainSrc& S = src[li];
         const bool p3 = all_p3 || (mix && li >= 1 && li <= NERF_MIX_K);      // this layer's main k-steps run three fp16 passes
         const int nj = (x1 || p3) ? 0 : L.ks / 2, K = L.ks * 32;
@@ -169,6 +196,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
                 for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(S.main(r, k)));
                 for (int k = 0; k < n_emb; ++k) mx = fmaxf(mx, fabsf(S.emb(r, k)));
             }
+            if (split && (li == 8 || li == 9)) mx = fa_max;        // the two halves of the feature | alpha layer keep the unsplit layer's 2^k
             sw = (mx > 0.f && isfinite(mx)) ? r2l_pow2_scale(&mx, 1) : 1.0f;
         }
         const size_t chunk_bytes = (size_t)((pieces + 3) / 4) * 4096;
@@ -186,7 +214,7 @@ int pack_chain(const std::vector<std::vector<float>>& w, float Sa, std::vector<c
             std::vector<float> all((size_t)L.fan_out * K);
             for (int r = 0; r < L.fan_out; ++r)
                 for (int k = 0; k < K; ++k) all[(size_t)r * K + k] = S.main(r, k);
-            const int e = r2l_layer_exponent(all.data(), all.size());
+            const int e = (split && (li == 8 || li == 9)) ? fa_exp : r2l_layer_exponent(all.data(), all.size());
             if (e < -12 || e > 6)
                 return r2l_set_error(R2L_EINVAL, "teacher layer %d: max|w| = 2^%d is outside the range the fp16 + bf6 weight "
                                      "split covers (2^-12 .. 2^6); use R2L_PREC_FP16X3", li, e);
@@ -368,8 +396,10 @@ void nerf_destroy(nerf_ctx* c) {
     for (auto& n : c->net)
         for (int m = 0; m < 8; ++m)
             if (n.d_img[m]) (void)hipFree(n.d_img[m]);
-    for (auto& n : c->net)
+    for (auto& n : c->net) {
         if (n.d_img_alpha) (void)hipFree(n.d_img_alpha);
+        if (n.d_img_exit) (void)hipFree(n.d_img_exit);
+    }
     if (c->d_zc) (void)hipFree(c->d_zc);
     if (c->d_zmid) (void)hipFree(c->d_zmid);
     if (c->d_u) (void)hipFree(c->d_u);
@@ -484,10 +514,15 @@ int nerf_load_weights(nerf_ctx* c, int which, const float* const* tensors, int n
         (void)hipFree(net.d_img_alpha);
         net.d_img_alpha = nullptr;
     }
+    if (net.d_img_exit) {
+        (void)hipFree(net.d_img_exit);
+        net.d_img_exit = nullptr;
+        net.exit_mode = -1;
+    }
     int rc = build_net(c, net, c->mode_net[which]);
     if (rc) return rc;
     net.loaded = true;
-    return which == 0 ? ensure_alpha_img(c) : R2L_OK;
+    return ensure_alpha_img(c);
 }
 
 int nerf_set_skip_rgb0(nerf_ctx* c, int on) {
@@ -520,6 +555,22 @@ int nerf_set_precision_pair(nerf_ctx* c, int coarse_mode, int fine_mode) {
 
 // nerf_set_skip_rgb0: the coarse network's three-pass stream without its view branch (pack_chain fmt 4), packed outside the render path
 static int ensure_alpha_img(nerf_ctx* c) {
+    if (c->skip_rgb0) {      // ... and the fine network's stream with the second exit, for the mode it runs in
+        PackedNet& f = c->net[1];
+        const int fm = c->mode_net[1];
+        if (f.loaded && (fm == R2L_PREC_FP16X3_ASM || fm == R2L_PREC_FP16_MIX) && f.exit_mode != fm) {
+            std::vector<char> img;
+            int rc = pack_chain(f.host_w, c->act_scale, img, fm == R2L_PREC_FP16_MIX ? 6 : 5);
+            if (rc) return rc;
+            if (f.d_img_exit) (void)hipFree(f.d_img_exit);
+            f.d_img_exit = nullptr;
+            f.exit_mode = -1;
+            hipError_t e = hipMalloc((void**)&f.d_img_exit, img.size());
+            if (e == hipSuccess) e = hipMemcpy(f.d_img_exit, img.data(), img.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "the fine network's stream with the second exit: %s", hipGetErrorString(e));
+            f.exit_mode = fm;
+        }
+    }
     PackedNet& n = c->net[0];
     if (!c->skip_rgb0 || !n.loaded || n.d_img_alpha || c->mode_net[0] != R2L_PREC_FP16X3_ASM) return R2L_OK;
     std::vector<char> img;
@@ -532,7 +583,7 @@ static int ensure_alpha_img(nerf_ctx* c) {
 }
 
 static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* rays_d, const float* z, int z_stride,
-                   int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr, bool alpha_only = false) {
+                   int S, int n, float* raw, hipStream_t s, const float* viewdirs = nullptr, bool alpha_only = false, bool second_exit = false) {
     NerfMlpParams p;
     memset(&p, 0, sizeof p);
     p.viewdirs = viewdirs;
@@ -540,7 +591,9 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
     // (the stream without the view branch is packed when the flag, the weights or the mode are set -- ensure_alpha_img --, never here:
     // a render allocates nothing and does not synchronise; without it the full kernel runs)
     alpha_only = alpha_only && mode == R2L_PREC_FP16X3_ASM && c->net[which].d_img_alpha != nullptr;
-    p.wimg = alpha_only ? c->net[which].d_img_alpha : c->net[which].d_img[mode];
+    // the second exit behind the density (fine network of a render whose caller drops the extras, no density noise): same rule
+    second_exit = second_exit && !alpha_only && c->net[which].d_img_exit != nullptr && c->net[which].exit_mode == mode;
+    p.wimg = alpha_only ? c->net[which].d_img_alpha : second_exit ? c->net[which].d_img_exit : c->net[which].d_img[mode];
     p.raw = raw;
     p.rays_o = rays_o;
     p.rays_d = rays_d;
@@ -585,7 +638,7 @@ static int run_mlp(nerf_ctx* c, int which, const float* rays_o, const float* ray
         c->ev_used += 2;
         (void)hipEventRecord(e0, s);
     }
-    hipError_t e = nerf_launch_mlp(p, mode, grid, s, x1_nc, stream_embed, alpha_only);
+    hipError_t e = nerf_launch_mlp(p, mode, grid, s, x1_nc, stream_embed, alpha_only, second_exit);
     if (c->timing) (void)hipEventRecord(e1, s);
     if (e != hipSuccess) return r2l_set_error(R2L_EHIP, "nerf_mlp launch: %s", hipGetErrorString(e));
     return R2L_OK;
@@ -672,7 +725,9 @@ static int render_rays_dev(nerf_ctx* c, const float* rays_o, const float* rays_d
         }
         HIPCHK(nerf_launch_merge(zc, zc_stride, S0, zs_sorted, NI, n, c->d_zall, s), "merge");
     }
-    rc = run_mlp(c, 1, rays_o, rays_d, c->d_zall, S1, S1, n, c->d_raw, s, vd);   // network_fine
+    // network_fine; with nerf_set_skip_rgb0 and no density noise on the chain with the second exit: the colours of workgroup tiles without a
+    // positive density (weight 0 exactly) are not computed -- raw shows zeros there, every map is bit for bit the same
+    rc = run_mlp(c, 1, rays_o, rays_d, c->d_zall, S1, S1, n, c->d_raw, s, vd, false, c->skip_rgb0 && !o.noise1);
     if (rc) return rc;
     HIPCHK(nerf_launch_raw2outputs(c->d_raw, c->d_zall, S1, rays_d, n, S1, c->white_bkgd, rgb, disp, acc, nullptr,
                                    depth, s, o.noise1), "raw2outputs(fine)");
@@ -815,7 +870,9 @@ int nerf_get_rays(int H, int W, double focal, const float* c2w_host, int row_beg
 
 // run_network (main.py:65-87) on explicit z values: raw [n, S, 4]
 long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors, int fmt, char* out, long long cap, long long* offs) {
-    if (fmt < 0 || fmt > 4) return r2l_set_error(R2L_EINVAL, "chain stream format %d (0 fp16 + bf6 terms, 1 fp16 only, 2 hi | lo, 3 mix, 4 hi | lo without the view branch)", fmt);
+    if (fmt < 0 || fmt > 6)
+        return r2l_set_error(R2L_EINVAL, "chain stream format %d (0 fp16 + bf6 terms, 1 fp16 only, 2 hi | lo, 3 mix, 4 hi | lo without the view branch, "
+                             "5 / 6: 2 / 3 with the second exit behind the density)", fmt);
     if (!tensors || n_tensors != 24) return r2l_set_error(R2L_EINVAL, "expected 24 tensors");
     std::vector<std::vector<float>> w;
     for (int i = 0; i < 24; ++i) {
@@ -825,7 +882,7 @@ long long nerf_debug_pack_chain_host(const float* const* tensors, int n_tensors,
     std::vector<char> img;
     int rc = pack_chain(w, 16.0f, img, fmt);
     if (rc) return rc;
-    if (offs) offs[0] = fmt == 4 ? NERF_CHAINP3A_STREAM_BYTES : fmt == 3 ? NERF_CHAINM_STREAM_BYTES : fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
+    if (offs) offs[0] = fmt == 6 ? NERF_CHAINMS_STREAM_BYTES : fmt == 5 ? NERF_CHAINP3S_STREAM_BYTES : fmt == 4 ? NERF_CHAINP3A_STREAM_BYTES : fmt == 3 ? NERF_CHAINM_STREAM_BYTES : fmt == 2 ? NERF_CHAINP3_STREAM_BYTES : (fmt == 1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES);
     if (out && cap > 0) memcpy(out, img.data(), (size_t)(cap < (long long)img.size() ? cap : (long long)img.size()));
     return (long long)img.size();
 }

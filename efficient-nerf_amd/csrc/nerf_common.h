@@ -40,6 +40,10 @@
 // chunks in the hi | lo layout of the p3 stream, W x 2^k): 80 chunks as the bf6 stream, 2 x 8 of them 32 KiB instead of 28
 // the three-pass chain without its view branch (gen/nerf_gen.py NERF_GEN_FMT=f16p3a): trunk + the alpha row (+ one all-zero row tile), 68 chunks
 #define NERF_CHAINP3A_STREAM_BYTES 1998848
+// the chains with a second exit behind the density (gen/nerf_gen.py NERF_GEN_FMT=f16p3s / mixs): the feature | alpha layer split into layer A
+// (the alpha row, one chunk) and layer F (the feature rows, 8 chunks): 12 layers, 16 KiB less stream than the unsplit chains
+#define NERF_CHAINP3S_STREAM_BYTES 2416640
+#define NERF_CHAINMS_STREAM_BYTES 2220032
 #define NERF_MIX_K 2
 #define NERF_CHAINM_STREAM_BYTES 2232320
 #define NERF_CHAIN_AUX_BYTES 16384
@@ -47,6 +51,7 @@
 #define NERF_CHAIN_AUX_SCALES 1152
 #define NERF_CHAIN_RING_BYTES (4 * 32768)
 #define NERF_CHAIN_LDS (NERF_CHAIN_RING_BYTES + NERF_CHAIN_AUX_BYTES)
+#define NERF_CHAIN_LDS_SKIP (NERF_CHAIN_LDS + 16)   // + the two LDS words the second exit's OR alternates between (at byte NERF_CHAIN_LDS)
 #define NERF_N_SCALES 12  // L0..L7, FA, V, RGB (+1 spare)
 #define NERF_PTS_PER_WAVE 32
 #define NERF_TILE_PTS 128

@@ -27,7 +27,7 @@ struct NerfMlpParams {
 // stream_embed (FP16X1, four column tiles, no given view directions): nerf_chain_emb_kernel, the chain as one statement that loads its
 // rays, computes the next tile's embedding under the MFMAs and stores raw itself (needs p.div_* and n_pts < 2^28)
 hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles = 2, bool stream_embed = false,
-                           bool alpha_only = false);
+                           bool alpha_only = false, bool second_exit = false);
 
 // rays of rows [row_begin,row_end) of one frame (utils/run_nerf_raybased_helpers.py:231-257)
 hipError_t nerf_launch_get_rays(const float* c2w12_host, int W, float half_w, float half_h, float focal,

@@ -316,9 +316,14 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_kernel(NerfMlpParams p) {
 // ALPHA = true (P3 only; round 6): the three-pass chain WITHOUT the view branch (NERF_GEN_FMT=f16p3a -> nerf_mlpp3a_*.inc): raw = (0, 0, 0, sigma).
 // The coarse pass of a render whose caller does not take rgb0 (nerf_set_skip_rgb0): sample_pdf and the fine pass see the coarse network
 // through its densities only (main.py:716-733), which this build computes bit for bit as the full chain does; 17 % fewer MACs.
-template <bool X1, int NC, bool P3 = false, bool MIX = false, bool ALPHA = false>
+// SKIPV = true (P3 or MIX; round 6): the chain with a second exit behind the density (NERF_GEN_FMT=f16p3s / mixs -> nerf_mlpp3s_*.inc /
+// nerf_mlpms_*.inc): the alpha row is computed first; when none of the workgroup tile's 128 points has a positive density -- alpha = 0,
+// weight 0 exactly, the colour cannot reach rgb_map (main.py:600-606) -- the feature rows, the views layer and the rgb layer are skipped
+// and raw = (0, 0, 0, sigma).  The four waves agree through one of two LDS words (alternating per tile) and a barrier.
+template <bool X1, int NC, bool P3 = false, bool MIX = false, bool ALPHA = false, bool SKIPV = false>
 __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     static_assert(!ALPHA || P3, "the chain without its view branch exists for the three-pass format");
+    static_assert(!SKIPV || ((P3 || MIX) && !ALPHA && NC == 2), "the second exit exists for the three-pass and the mixed chain");
     static_assert(NC == 2 || (X1 && (NC == 3 || NC == 4)), "three / four column tiles exist for the fp16-only chain");
     static_assert(!P3 || (!X1 && NC == 2), "the three-pass chain is a two-column-tile build");
     static_assert(!MIX || (!X1 && !P3 && NC == 2), "the mixed chain is a two-column-tile build of the bf6 chain");
@@ -326,12 +331,30 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     {   // resident table: per layer 272 f32 bias (act_scale domain) | E8M0 weight scales (nerf_common.h)
-        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (ALPHA ? NERF_CHAINP3A_STREAM_BYTES : MIX ? NERF_CHAINM_STREAM_BYTES : P3 ? NERF_CHAINP3_STREAM_BYTES : (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES)));
+        const uint4* src = reinterpret_cast<const uint4*>(p.wimg + (SKIPV ? (MIX ? NERF_CHAINMS_STREAM_BYTES : NERF_CHAINP3S_STREAM_BYTES) : ALPHA ? NERF_CHAINP3A_STREAM_BYTES : MIX ? NERF_CHAINM_STREAM_BYTES : P3 ? NERF_CHAINP3_STREAM_BYTES : (X1 ? NERF_CHAINX_STREAM_BYTES : NERF_CHAIN_STREAM_BYTES)));
         uint4* dst = reinterpret_cast<uint4*>(nerf_chain_lds + NERF_CHAIN_RING_BYTES);
         for (int i = threadIdx.x; i < NERF_CHAIN_AUX_BYTES / 16; i += 256) dst[i] = src[i];
+        if constexpr (SKIPV)
+            if (threadIdx.x < 4) reinterpret_cast<unsigned*>(nerf_chain_lds + NERF_CHAIN_LDS)[threadIdx.x] = 0u;     // the second exit's two words
     }
     __syncthreads();
-    if constexpr (ALPHA) {
+    if constexpr (SKIPV && MIX) {
+        asm volatile(
+#include "nerf_mlpms_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpms_pro_clobbers.inc"
+        );
+    } else if constexpr (SKIPV) {
+        asm volatile(
+#include "nerf_mlpp3s_pro_asm.inc"
+            :
+            : [wimg] "s"(p.wimg), [wave] "s"(wave)
+            :
+#include "nerf_mlpp3s_pro_clobbers.inc"
+        );
+    } else if constexpr (ALPHA) {
         asm volatile(
 #include "nerf_mlpp3a_pro_asm.inc"
             :
@@ -394,6 +417,7 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
     constexpr bool VD = NC != 4;
     NerfTileRawT<NC, VD> raw;
     if ((int)blockIdx.x < p.n_tiles) nerf_tile_load<NC, VD>(p, blockIdx.x, wave, lane, raw);
+    int fl_parity = 0;
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         f16x8 Eh[2][NC], El[2][NC], Vh[2][NC], Vl[2][NC];
 #ifdef NERF_SKIP_EMBED      // diagnostics only (wrong results): what the un-overlapped embedding prologue costs (tools/build_teacher_variant.sh)
@@ -413,7 +437,26 @@ __global__ __launch_bounds__(256, 1) void nerf_chain_kernel(NerfMlpParams p) {
             : [wimg] "s"(p.wimg), [wave] "s"(wave), [eh00] "a"(Eh[0][0]), [eh01] "a"(Eh[0][1]), [eh10] "a"(Eh[1][0]),             \
               [eh11] "a"(Eh[1][1]), [el00] "a"(El[0][0]), [el01] "a"(El[0][1]), [el10] "a"(El[1][0]), [el11] "a"(El[1][1]),       \
               [vh0] "a"(Vh[0][0]), [vh1] "a"(Vh[0][1]), [vl0] "a"(Vl[0][0]), [vl1] "a"(Vl[0][1])
-        if constexpr (ALPHA) {
+        // the second exit's LDS word of this tile (its OR lives there; the other word is cleared for the next tile)
+        const int fl = NERF_CHAIN_LDS + 4 * fl_parity;
+        fl_parity ^= 1;
+        if constexpr (SKIPV && MIX) {
+            asm volatile(
+#include "nerf_mlpms_asm.inc"
+                NERF_CHAIN_OUT2
+                NERF_CHAIN_IN2, [fl] "s"(fl)
+                :
+#include "nerf_mlpms_clobbers.inc"
+            );
+        } else if constexpr (SKIPV) {
+            asm volatile(
+#include "nerf_mlpp3s_asm.inc"
+                NERF_CHAIN_OUT2
+                NERF_CHAIN_IN2, [fl] "s"(fl)
+                :
+#include "nerf_mlpp3s_clobbers.inc"
+            );
+        } else if constexpr (ALPHA) {
             asm volatile(
 #include "nerf_mlpp3a_asm.inc"
                 NERF_CHAIN_OUT2
@@ -1037,8 +1080,13 @@ static hipError_t launch_big_lds(K kernel, std::atomic<bool>* attr_set, int lds,
     return hipGetLastError();
 }
 
-hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles, bool stream_embed, bool alpha_only) {
-    static std::atomic<bool> attr_set[9][64];  // zero-initialised; the opt-in call itself is idempotent
+hipError_t nerf_launch_mlp(const NerfMlpParams& p, int mode, int grid, hipStream_t stream, int x1_col_tiles, bool stream_embed, bool alpha_only,
+                           bool second_exit) {
+    static std::atomic<bool> attr_set[11][64];  // zero-initialised; the opt-in call itself is idempotent
+    if (second_exit && mode == R2L_PREC_FP16X3_ASM)
+        return launch_big_lds(&nerf_chain_kernel<false, 2, true, false, false, true>, attr_set[9], NERF_CHAIN_LDS_SKIP, p, grid, stream);
+    if (second_exit && mode == R2L_PREC_FP16_MIX)
+        return launch_big_lds(&nerf_chain_kernel<false, 2, false, true, false, true>, attr_set[10], NERF_CHAIN_LDS_SKIP, p, grid, stream);
     if (alpha_only && mode == R2L_PREC_FP16X3_ASM)
         return launch_big_lds(&nerf_chain_kernel<false, 2, true, false, true>, attr_set[8], NERF_CHAIN_LDS, p, grid, stream);
     if (mode == R2L_PREC_FP16_MIX) return launch_big_lds(&nerf_chain_kernel<false, 2, false, true>, attr_set[7], NERF_CHAIN_LDS, p, grid, stream);

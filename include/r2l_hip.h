@@ -303,12 +303,16 @@ int nerf_set_precision(nerf_ctx* ctx, int precision_mode);
  * the pdf is decided by differences at the 1e-4 level, so a trained teacher needs the coarse pass at fp32 grade (FP16X3) whatever
  * the fine pass runs in (profiles/r05_trained_like.txt). */
 int nerf_set_precision_pair(nerf_ctx* ctx, int coarse_mode, int fine_mode);
-/* on != 0: the render pipeline (nerf_render / nerf_render_rays[_ex]) runs the COARSE network without its view branch (feature_linear,
- * views_linears.0, rgb_linear: model/nerf_raybased.py:391-398) whenever that network's mode is R2L_PREC_FP16X3_ASM: sample_pdf and every
- * map of the fine pass depend on the coarse network through its densities only (main.py:716-733), which are computed bit for bit as
- * before -- rgb / disp / acc / depth and disp0 / acc0 / z_samples / z_std are unchanged, rgb0 (main.py:743) is NOT computed and
- * nerf_copy_extras refuses to return it.  For callers that drop render()'s extras, as the reference's own do (main.py:277-282,
- * utils/create_data.py:824-831): 17 % fewer MACs in the coarse pass.  nerf_run_network always evaluates the whole network.  Default: off. */
+/* on != 0: for callers that drop render()'s extras, as the reference's own do (main.py:277-282, utils/create_data.py:824-831) -- the render
+ * pipeline (nerf_render / nerf_render_rays[_ex]) leaves out work whose results only the extras rgb0 / raw would show:
+ *   - the COARSE network runs without its view branch (feature_linear, views_linears.0, rgb_linear: model/nerf_raybased.py:391-398) whenever
+ *     its mode is R2L_PREC_FP16X3_ASM: sample_pdf and every map of the fine pass depend on it through its densities only (main.py:716-733),
+ *     which are computed bit for bit as before; rgb0 (main.py:743) is NOT computed and nerf_copy_extras refuses to return it;
+ *   - the FINE network (mode R2L_PREC_FP16X3_ASM or R2L_PREC_FP16_MIX, no density noise) computes the alpha row first and skips the feature
+ *     rows, the views layer and the rgb layer for workgroup tiles (128 consecutive points) none of whose densities is positive: alpha = 0,
+ *     weight 0 exactly (main.py:600-606), so their colours cannot reach rgb_map; `raw` shows zeros for them.
+ * rgb / disp / acc / depth, disp0 / acc0 / z_samples / z_std are bit for bit what they are without the flag.  nerf_run_network always evaluates
+ * the whole network.  Default: off. */
 int nerf_set_skip_rgb0(nerf_ctx* ctx, int on);
 /* Override the coarse depths z_vals[N_samples] (main.py:676-678) and/or the inverse-CDF
  * abscissae u[N_importance] = torch.linspace(0,1,N) (helpers:293) with the tensors the

@@ -187,7 +187,7 @@ def cxx_pack_fmt(tensors, fmt):
     assert n > 0, L.r2l_last_error()
     buf = np.zeros(n, dtype=np.uint8)
     assert L.nerf_debug_pack_chain_host(arr, len(keep), fmt, C.c_void_p(buf.ctypes.data), n, offs) == n
-    assert L.nerf_debug_pack_chain_host(arr, len(keep), 5, None, 0, offs) < 0          # the format is an argument, not process state
+    assert L.nerf_debug_pack_chain_host(arr, len(keep), 7, None, 0, offs) < 0          # the format is an argument, not process state
     return buf, int(offs[0])
 
 
@@ -359,3 +359,64 @@ def test_emulated_alpha_only_chain_gives_the_full_chains_density_bit_for_bit(wav
     p = _run_tile(GP, bp, op, e, v, wave, n_tiles)
     assert np.array_equal(a[:, 3], p[:, 3]) and not a[:, :3].any()
     assert np.abs(a[:, 3] - ref[:, 3]).max() < 1e-6 * max(1.0, np.abs(ref).max())
+
+
+# ---- f16p3s / mixs: the chains with a second exit behind the density (tiles without a positive density skip the view branch) ----
+GS3 = _load_x('f16p3s')
+GSM = _load_x('mixs')
+
+
+@pytest.mark.parametrize('G,fmt,base,stream', [(GS3, 5, 'p3', 2416640), (GSM, 6, 'm', 2220032)])
+def test_second_exit_chains_layout_packer_and_committed_text(tmp_path, G, fmt, base, stream):
+    assert G.SKIPV and [l.name for l in G.CHAIN] == ['L0', 'L1', 'L2', 'L3', 'L4', 'L5', 'L6', 'L7', 'A', 'F', 'V', 'RGB']
+    assert G.CHAIN[8].rt == 1 and G.CHAIN[8].fan_out == 1 and G.CHAIN[9].rt == 16 and G.NCH % G.NSLOT == 0 and G.STREAM_BYTES == stream
+    B_ = {'p3': GP, 'm': GM}[base]
+    assert G.N_ANCH == B_.N_ANCH and G.NCH == B_.NCH and G.N_SGPR_HI == 60          # the same MFMAs, the alpha row first
+    for seed, gain in ((5, 1.0), (6, 40.0)):
+        t = T.make_tensors(seed=seed, gain=gain)
+        buf, aux_off = cxx_pack_fmt(t, fmt)
+        img, aux = G.pack_teacher(t)
+        assert aux_off == img.size == G.STREAM_BYTES and buf.size == img.size + aux.size
+        assert np.array_equal(buf[:aux_off], img) and np.array_equal(buf[aux_off:], aux)
+    G.emit(str(tmp_path), G.Opts())
+    for kind in ('asm', 'pro_asm', 'clobbers', 'pro_clobbers'):
+        name = 'nerf_mlp%ss_%s.inc' % (base, kind)
+        assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', name)).read(), name
+    text = open(os.path.join(ROOT, 'efficient-nerf_amd', 'csrc', 'nerf_mlp%ss_asm.inc' % base)).read()
+    assert text.count('s_cbranch_scc1 L_skip_%=') == 1 and text.count('L_skip_%=:') == 1 and text.count('L_done_%=:') == 1 and '%[fl]' in text
+    # every wave passes the same barriers whichever exit the workgroup takes: the cut's own barrier in front of the branch, then either the
+    # rest of the full path or the second exit's single one
+    body = G.block_stream(G.Opts())
+    pre, post = G.split_at_cut(body)
+    nb = lambda L: sum(1 for i in L if i.kind == 'barrier')
+    assert nb(pre) + nb(post) == nb(B_.block_stream(B_.Opts())) + 1 and nb(G.skip_tail_ops()) == 1
+    assert [i.text for i in pre[-3:]] == ['v_readfirstlane_b32 s58, v218', 's_cmp_eq_u32 s58, 0', 's_cbranch_scc1 L_skip_%=']
+
+
+@pytest.mark.parametrize('G,fmt,B_,bfmt', [(GS3, 5, GP, 2), (GSM, 6, GM, 3)])
+def test_emulated_second_exit_is_taken_only_without_a_positive_density_and_changes_no_density(G, fmt, B_, bfmt):
+    """two tiles in a row per case (the ring must be primed for the next tile by either exit): with positive densities the full path runs
+    and every output is the unsplit chain's bit for bit; with alpha_linear.bias = -100 the second exit is taken, the densities are still
+    the unsplit chain's bit for bit and the colours are zero; no hazard, no unwaited LDS read on either path"""
+    for wave, shift in ((0, 0.0), (1, -100.0)):
+        t = [x.copy() for x in T.make_tensors(seed=wave, gain=1.0)]
+        t[21] = t[21] + np.float32(shift)
+        rng = np.random.default_rng(10 + wave)
+        pts = rng.uniform(-2.5, 2.5, size=(32, 3)).astype(np.float32)
+        vd = rng.normal(size=(32, 3))
+        vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
+        ref, e, v = T.ref_mlp(t, pts, vd)
+        buf, off = cxx_pack_fmt(t, fmt)
+        out, errs, skipped = G.emulate_tile(G.Opts(), buf[:off], buf[off:], T.make_frags(e, v, 16.0), wave=wave, n_tiles=2)
+        assert not errs, errs[:10]
+        bb, boff = cxx_pack_fmt(t, bfmt)
+        want = _run_tile(B_, bb, boff, e, v, wave, 2)
+        got = np.zeros((32, 4))
+        for c in range(2):
+            for k in range(4):
+                got[c * 16:(c + 1) * 16, k] = out[c * 4 + k][:16] / 16.0
+        assert skipped == [shift < 0] * 2 and np.array_equal(got[:, 3], want[:, 3])
+        if shift < 0:
+            assert (ref[:, 3] < 0).all() and not got[:, :3].any()
+        else:
+            assert (ref[:, 3] > 0).any() and np.array_equal(got, want)

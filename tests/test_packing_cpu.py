@@ -245,7 +245,7 @@ def test_host_packers_under_asan_ubsan(pkg, built_lib, tmp_path):
         assert got[('pack_body', str(fmt))] == [str(size), _fnv(bytes(buf)), str(offs[0]), str(offs[1])], fmt
     L.r2l_debug_pack_body_format(0)
     tkeep, tarr = _lib.host_ptrs([tsd[n] for n in tnames])
-    for fmt in (0, 1, 2, 3, 4):   # the chain streams: bf6 terms, one fp16 pass, three passes (the p3 hi | lo layout: ADVICE r5), mix (round 6)
+    for fmt in (0, 1, 2, 3, 4, 5, 6):   # (5, 6: with the second exit) the chain streams: bf6 terms, one fp16 pass, three passes (the p3 hi | lo layout: ADVICE r5), mix (round 6)
         off = (C.c_longlong * 1)()
         size = L.nerf_debug_pack_chain_host(tarr, 24, fmt, None, 0, off)
         buf = (C.c_char * size)()

@@ -189,7 +189,9 @@ def test_coarse_pass_without_its_view_branch_changes_nothing_but_rgb0(pkg, mode)
     t_skip = timed()
     assert 'rgb0' not in got and set(got) == set(full) - {'rgb0'}
     for k in got:          # bit patterns: disp of an empty ray is 0 / 0 = NaN in the reference too (main.py:609-610)
-        assert torch.equal(got[k].view(torch.int32), full[k].view(torch.int32)), k
+        if k != 'raw':     # (the fine network's second exit leaves zero colours in raw where no density is positive: the next test)
+            assert torch.equal(got[k].view(torch.int32), full[k].view(torch.int32)), k
+    assert torch.equal(got['raw'][..., 3], full['raw'][..., 3])
     assert torch.equal(eng.run_network(0, ro, rd, eng.z_coarse.cuda()), raw0) and float(raw0[..., :3].abs().max()) > 0
     with pytest.raises(R2LError, match='rgb0 was not computed'):
         from efficient_nerf_amd._lib import lib, check, dptr, current_stream
@@ -199,4 +201,54 @@ def test_coarse_pass_without_its_view_branch_changes_nothing_but_rgb0(pkg, mode)
     assert t_skip < 0.975 * t_full
     eng.set_precision(PRECISIONS['fp16x3'])              # the compiler-scheduled mode has no such build: nothing is skipped, rgb0 is there
     assert 'rgb0' in eng.render(pose, extras=True)
+    eng.close()
+
+
+@pytest.mark.parametrize('mode', ['fp16x3_asm', 'fp16_mix'])
+def test_second_exit_behind_the_density_changes_no_map(pkg, mode):
+    """nerf_set_skip_rgb0, fine network (round 6): the chain with the alpha row first and a second exit for workgroup tiles without a
+    positive density (NERF_GEN_FMT=f16p3s / mixs).  On the trained-like teacher (three quarters of the rays see nothing) every map and
+    extra is BITWISE what the full chain gives -- a sample with density <= 0 has weight 0 exactly (main.py:600-606) --, `raw` keeps every
+    density and shows zero colours exactly on tiles without a positive one, and the frame is faster.  With density noise the full chain
+    runs (the noise can lift a density above zero)."""
+    from efficient_nerf_amd import NeRFEngine, PRECISIONS
+    from oracle import whole_frame as WF
+    sds = WF.load_teacher()
+    H = WF.H
+    eng = NeRFEngine(H, H, WF.focal(), precision=PRECISIONS[mode]).load_state_dicts(*sds)
+
+    def timed(pose):
+        eng.render(pose)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.render(pose)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3
+    for pi in (0, 1):
+        pose = WF.pose(pi)
+        eng.set_skip_rgb0(False)
+        full = {k: v.clone() for k, v in eng.render(pose, extras=True).items()}
+        t_full = timed(pose)
+        eng.set_skip_rgb0(True)
+        got = eng.render(pose, extras=True)
+        t_skip = timed(pose)
+        for k in got:
+            if k != 'raw':
+                assert torch.equal(got[k].view(torch.int32), full[k].view(torch.int32)), k
+        raw, raw_f = got['raw'].reshape(-1, 4), full['raw'].reshape(-1, 4)
+        assert torch.equal(raw[:, 3], raw_f[:, 3])                                   # every density as before
+        n = raw.shape[0] // 128 * 128
+        dead = ~(raw_f[:n, 3] > 0).reshape(-1, 128).any(-1)                          # workgroup tiles of the fine launch without a positive density
+        tiles, tiles_f = raw[:n, :3].reshape(-1, 128, 3), raw_f[:n, :3].reshape(-1, 128, 3)
+        assert not tiles[dead].any() and torch.equal(tiles[~dead], tiles_f[~dead])   # zero colours exactly there, the full chain's everywhere else
+        print(f'{mode} pose {pi}: {float(dead.float().mean()):.3f} of the fine launch\'s {dead.numel()} tiles take the second exit; '
+              f'{t_full * 1e3:.1f} -> {t_skip * 1e3:.1f} ms per frame ({(1 - t_skip / t_full) * 100:.1f} % less, incl. the coarse view branch)')
+        assert float(dead.float().mean()) > 0.4 and t_skip < 0.95 * t_full
+    # density noise: the full chain
+    ro, rd = (t.reshape(-1, 3)[:8192].contiguous() for t in __import__('efficient_nerf_amd').teacher.get_rays(H, H, WF.focal(), WF.pose(0)[:3, :4], device=eng.device))
+    a = eng.render_rays(ro, rd, extras=True, raw_noise_std=1.0, pytest=True)['raw']
+    eng.set_skip_rgb0(False)
+    b = eng.render_rays(ro, rd, extras=True, raw_noise_std=1.0, pytest=True)['raw']
+    assert torch.equal(a, b)
     eng.close()

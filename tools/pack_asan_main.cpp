@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
         printf("pack_body %d %lld %016llx %lld %lld\n", fmt, n, (unsigned long long)fnv(out), offs[0], offs[1]);
     }
     r2l_debug_pack_body_format(0);
-    for (int fmt : {0, 1, 2, 3, 4}) {              // the teacher's chain streams: bf6 terms, one fp16 pass, three fp16 passes (hi | lo pieces), mix, three passes without the view branch
+    for (int fmt : {0, 1, 2, 3, 4, 5, 6}) {            // the teacher's chain streams: bf6 terms, one fp16 pass, three fp16 passes (hi | lo pieces), mix, three passes without the view branch
         long long off = 0;
         long long n = nerf_debug_pack_chain_host(p.data() + n_r2l, 24, fmt, nullptr, 0, &off);
         if (n <= 0) {
