@@ -239,6 +239,9 @@ def trained_like_leg(torch, O, cpu):
     teng.set_skip_rgb0(True)
     t['coarse_view_branch'] = ('not executed (nerf_set_skip_rgb0: rgb0 is not produced; every other output bit for bit the same): 13.07 of the '
                                '303.82 algorithmic MFLOP per ray' if teng._rgb0_skipped() else 'executed')
+    t['fine_second_exit'] = ('on (nerf_set_skip_rgb0): workgroup tiles of 128 fine samples without a positive density -- weight 0 exactly, main.py:600-606 -- '
+                             'skip the feature rows, the views layer and the rgb layer (up to 39.2 of the 303.82 MFLOP per ray; every map bit for bit the same, '
+                             'raw shows zero colours there)' if teng.precision_name in ('fp16_mix', 'fp16x3_asm') else 'this mode has no such build')
     teng.render(poses[0])
     teng.timing(True)
     teng.kernel_time_ms(reset=True)
