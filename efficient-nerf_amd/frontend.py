@@ -628,7 +628,8 @@ def render_path(render_poses, hwf, kind, eng, gt_imgs=None, savedir=None, log=pr
         # that build (fp16x3_asm, the coarse mode of every trained teacher) -- bit for bit the same frames, 17 % fewer coarse MACs
         eng.set_skip_rgb0(True)
         if rank == 0 and eng._rgb0_skipped():
-            log('[precision] the coarse pass runs without its view branch (rgb0 is not produced; rgb / disp / acc are bit for bit the same)')
+            log('[precision] rgb only: the coarse pass runs without its view branch and fine-pass tiles without a positive density skip theirs '
+                '(rgb0 is not produced; rgb / disp / acc are bit for bit the same)')
 
     def watched(i, ro, rd, got):
         from .teacher import get_rays
