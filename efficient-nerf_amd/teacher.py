@@ -130,8 +130,9 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
 
 def rebalanced_state(sd, maxima, keep=2, target=8.0):
     """An exact reparametrisation of NeRF(D=8, W=256, use_viewdirs) (model/nerf_raybased.py:377-401) that brings the inputs of its layers
-    into the range the bf6 layer chain converts them with (fixed exponents: |a| <= 14 for the values, <= 8 for their fp16 residuals;
-    csrc/gen/isa.py ACT_EXP / RES_EXP): relu is positively homogeneous and feature_linear is linear, so the output of trunk layer i
+    to the range the bf6 layer chain converts them with (fixed exponents: |a| <= 14 for the values, <= 8 for their fp16 residuals;
+    csrc/gen/isa.py ACT_EXP / RES_EXP; which `target` serves that best is measured: NeRFEngine.REBALANCE_TARGET): relu is positively
+    homogeneous and feature_linear is linear, so the output of trunk layer i
     divided by 2^s_i, feature by 2^s_f and the view layer's output by 2^s_v -- with the consumers' weight columns multiplied back -- is the
     same function, and every factor a power of two makes it the same function in float32 arithmetic too (no rounding: each weight and
     bias is scaled exactly).  `maxima`: {'h0' .. 'h7', 'feature', 'views': largest |value| measured on the job's own points
@@ -292,13 +293,21 @@ class NeRFEngine:
             l.close()
         return mx
 
-    def rebalance_fine(self, rays_o, rays_d, z_vals):
-        """Re-pack the fine network from an exact power-of-two reparametrisation whose hidden activations fit the bf6 chain's fixed
-        conversion exponents on these points (rebalanced_state): the calibration of R2L_PREC_FP16_MIX / _FP16_FP8 without a kernel
-        change.  The function the network computes is unchanged bit for bit in float32; three passes render the same image.  Returns
-        the shifts {activation: s} (also kept in `fine_shifts`)."""
+    # The largest value of every rescaled activation lands in (REBALANCE_TARGET / 2, REBALANCE_TARGET].  Measured, not derived
+    # (tools/rebalance_sweep.py, profiles/r06_rebalance_sweep.txt: targets 2 .. 80 on two trained teachers, fp16_mix against three passes
+    # over three whole frames): the worst ray falls from 1.1e-4 / 2.2e-4 at target 2 to a flat minimum at 28 .. 40 (2.4e-5 / 4.4-5.0e-5;
+    # 8, the chain's nominal range, gives 2.9e-5 / 6.4e-5) and rises again from 56.  Trained activations are heavy-tailed: at 32 the bulk sits
+    # two binades further inside bf6's seven-binade normal range, and the few values beyond the conversion's largest number saturate in the
+    # CORRECTION terms only (the fp16 pass carries them whole) -- an error of the size of a bf6 rounding step on those terms.
+    REBALANCE_TARGET = 32.0
+
+    def rebalance_fine(self, rays_o, rays_d, z_vals, target=None):
+        """Re-pack the fine network from an exact power-of-two reparametrisation whose hidden activations suit the bf6 chain's fixed
+        conversion exponents on these points (rebalanced_state, REBALANCE_TARGET): the calibration of R2L_PREC_FP16_MIX / _FP16_FP8 without
+        a kernel change.  The function the network computes is unchanged bit for bit in float32; three passes render the same image.
+        Returns the shifts {activation: s} (also kept in `fine_shifts`)."""
         mx = self.fine_activation_maxima(rays_o, rays_d, z_vals)
-        sd, sh = rebalanced_state(self._fine_state, mx)
+        sd, sh = rebalanced_state(self._fine_state, mx, target=self.REBALANCE_TARGET if target is None else float(target))
         try:
             self._load(1, sd)
         except R2LError as e:          # a rescaled layer outside what the chain's weight split packs (max|w| beyond 2^-12 .. 2^6): as loaded
@@ -439,7 +448,7 @@ class NeRFEngine:
             self.set_precision(PREC_FP16X3_ASM)
             if self.AUTO_REBALANCE and not self.ndc:      # (NDC renders: the points the fine network sees are not ro + rd z of the given rays)
                 # the fine network's activations on the probes' own fine sample positions -> exact rescaling into the bf6 chain's range
-                # (measured on the trained-like teacher: worst rgb difference over whole frames 4.3e-5 -> 3.0e-5)
+                # (measured on the trained-like teacher: worst rgb difference over whole frames 4.1e-5 -> 2.4e-5)
                 zs, rs = [], []
                 for ro, rd in probes:
                     zs.append(self.render_rays(ro, rd, extras=True)['z_vals'].clone())

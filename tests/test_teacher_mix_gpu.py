@@ -107,7 +107,8 @@ def test_synthetic_teacher_keeps_its_single_pass(pkg):
 def test_rebalanced_fine_network_is_the_same_function_and_fits_the_bf6_range(pkg):
     """NeRFEngine.rebalance_fine: the activation maxima of the fine network measured with the library's fp32 layer kernels agree with the
     CPU oracle's, the power-of-two reparametrisation renders the same image in three passes (the same function in float32), every
-    rescaled activation lies in (4, 8], and the mixed chain is closer to three passes on the rebalanced network than on the original"""
+    rescaled activation lies in (target / 2, target] (NeRFEngine.REBALANCE_TARGET), and the mixed chain is
+    closer to three passes on the rebalanced network than on the original"""
     from efficient_nerf_amd import NeRFEngine, PRECISIONS
     from efficient_nerf_amd.teacher import get_rays, rebalanced_state
     from oracle import whole_frame as WF
@@ -143,10 +144,10 @@ def test_rebalanced_fine_network_is_the_same_function_and_fits_the_bf6_range(pkg
     before = (eng.render_rays(ros, rds)['rgb_map'] - ref['rgb_map']).abs().max().item()
     sh = eng.rebalance_fine(ros, rds, ref['z_vals'])
     print('shifts:', sh)
-    assert sh is not None and sh['h0'] == sh['h1'] == 0 and sh['views'] >= 3 and sh['h7'] >= 1
+    assert sh is not None and sh['h0'] == sh['h1'] == 0 and sh['views'] >= 2 and sh['h2'] < 0        # the tail down, the small front layers up
     for k, v in eng.fine_maxima.items():
         if k not in ('h0', 'h1'):
-            assert 4.0 < v / 2.0 ** sh[k] <= 8.0, (k, v, sh[k])
+            assert eng.REBALANCE_TARGET / 2 < v / 2.0 ** sh[k] <= eng.REBALANCE_TARGET, (k, v, sh[k])
     after = (eng.render_rays(ros, rds)['rgb_map'] - ref['rgb_map']).abs().max().item()
     eng.set_precision(PRECISIONS['fp16x3_asm'])
     same = eng.render_rays(ros, rds, extras=True)
