@@ -26,7 +26,8 @@ n_pose = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 focal = O.focal_from_angle(H)
 prec = os.environ.get("CD_PREC", "fp16x1")
-sds = WF.load_teacher() if os.environ.get("CD_TEACHER") == "trained" else (O.make_teacher_state(1), O.make_teacher_state(2))
+sds = (WF.load_teacher(os.environ["CD_TEACHER_DIR"]) if os.environ.get("CD_TEACHER_DIR") else      # any directory with teacher_{coarse,fine}.npz
+       WF.load_teacher() if os.environ.get("CD_TEACHER") == "trained" else (O.make_teacher_state(1), O.make_teacher_state(2)))
 eng = NeRFEngine(H, H, focal, precision=PRECISIONS['fp16x3' if prec == 'auto' else prec]).load_state_dicts(*sds)
 if prec == 'auto':
     prec = choose_precision_for_rand(eng, H, H, focal)
